@@ -1,0 +1,93 @@
+"""Deterministic synthetic chessboard frames (integer-only, torch).
+
+Inputs for tests/ and bench.py: the same bytes come out on the CPU here and on
+the GPU box because every step is int64 arithmetic (no libm, no floats).
+
+Board geometry follows the reference's own generator
+(generate-chessboard-fig.py:103-134): gridn+3 cells per side, the outer ring
+of cells merged into double-size squares, so exactly gridn x gridn interior
+X-corners.  Rendering: cell = 0.8*H/(gridn+3) px,
+centred, in-plane rotation 0.1 rad, dark/light 30/220 on background 200, 4x4
+supersampling, per-pixel pseudo-noise (sigma ~2.3), then the 3x3 box blur the
+reference CLI applies before the detector (mrgingham-from-image.cc:106-111,
+(sum+4)/9, reflect-101 border).
+"""
+import torch
+
+_COS_Q16 = 65209  # round(cos(0.1) * 2^16)
+_SIN_Q16 = 6543   # round(sin(0.1) * 2^16)
+
+
+def _mix(h):
+    """32-bit integer hash on int64 tensors (xorshift-multiply)."""
+    m = 0xFFFFFFFF
+    h = h & m
+    h = ((h ^ (h >> 16)) * 0x45D9F3B) & m
+    h = ((h ^ (h >> 16)) * 0x45D9F3B) & m
+    return h ^ (h >> 16)
+
+
+def box_blur3(img):
+    """(sum of 3x3 + 4) // 9 with reflect-101 borders; img int64 [H,W]."""
+    p = torch.cat([img[1:2], img, img[-2:-1]], dim=0)
+    p = torch.cat([p[:, 1:2], p, p[:, -2:-1]], dim=1)
+    H, W = img.shape
+    s = torch.zeros_like(img)
+    for dy in range(3):
+        for dx in range(3):
+            s += p[dy:dy + H, dx:dx + W]
+    return (s + 4) // 9
+
+
+def board_frame(W, H, gridn=10, seed=0, noise=True, blur=True, device="cpu"):
+    """One uint8 [H,W] frame.  `seed` moves the board by a sub-pixel offset and
+    reseeds the noise, so a batch is `seed = frame index`."""
+    dev = torch.device(device)
+    ncell = gridn + 3
+    cell = (8 * 65536 * 8 * H) // (10 * ncell)      # cell edge, units of 2^-16 * (1/8 px)
+    half = (ncell * cell) // 2
+    s = int(_mix(torch.tensor(seed * 7919 + 13, dtype=torch.int64)).item())
+    ox, oy = s & 63, (s >> 6) & 63                      # offset, 1/8 px units (< 8 px)
+
+    ys = torch.arange(H, dtype=torch.int64, device=dev).view(H, 1)
+    xs = torch.arange(W, dtype=torch.int64, device=dev).view(1, W)
+    acc = torch.zeros((H, W), dtype=torch.int64, device=dev)
+    for j in range(4):
+        dy = 8 * ys + (2 * j + 1) - 4 * H - oy
+        for i in range(4):
+            dx = 8 * xs + (2 * i + 1) - 4 * W - ox
+            bu = _COS_Q16 * dx + _SIN_Q16 * dy + half
+            bv = -_SIN_Q16 * dx + _COS_Q16 * dy + half
+            cx = torch.div(bu, cell, rounding_mode="floor")
+            cy = torch.div(bv, cell, rounding_mode="floor")
+            inside = (cx >= 0) & (cx < ncell) & (cy >= 0) & (cy < ncell)
+            par = (cx.clamp(1, ncell - 2) + cy.clamp(1, ncell - 2)) & 1
+            val = torch.where(par == 1, 30, 220)
+            acc += torch.where(inside, val, 200)
+    img = (acc + 8) >> 4
+    if noise:
+        h = _mix((ys * W + xs) * 2654435761 + (seed + 1) * 40503)
+        n = (h & 7) + ((h >> 3) & 7) + ((h >> 6) & 7) + ((h >> 9) & 7) - 14
+        img = (img + (n >> 1)).clamp(0, 255)
+    if blur:
+        img = box_blur3(img)
+    return img.to(torch.uint8)
+
+
+def board_batch(B, W, H, gridn=10, seed0=0, noise=True, blur=True, device="cpu"):
+    out = torch.empty((B, H, W), dtype=torch.uint8, device=device)
+    for b in range(B):
+        out[b] = board_frame(W, H, gridn, seed0 + b, noise, blur, device)
+    return out
+
+
+def noise_frame(W, H, seed=0, smooth=0, device="cpu"):
+    """Pseudo-random uint8 frame (optionally box-blurred `smooth` times): the
+    adversarial input for the connected-component rules."""
+    dev = torch.device(device)
+    ys = torch.arange(H, dtype=torch.int64, device=dev).view(H, 1)
+    xs = torch.arange(W, dtype=torch.int64, device=dev).view(1, W)
+    img = _mix((ys * W + xs) * 2246822519 + (seed + 1) * 3266489917) & 255
+    for _ in range(smooth):
+        img = box_blur3(img)
+    return img.to(torch.uint8)

@@ -1,0 +1,224 @@
+"""CPU checks of the oracle itself (no GPU).
+
+ * the ChESS restatement against the known-answer vectors produced by the REAL
+   upstream ChESS.c (tests/golden/chess_kat.npz), and against oracle/_ref live
+   when that build is present;
+ * the connected-component / decimation restatement against its own committed
+   regression vectors and against hand-derived expectations of the reference's
+   rules (find_chessboard_corners.cc citations inline).
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from mrgingham_amd import synth
+from oracle import oracle
+
+FILL = -32768
+
+
+def _kat_cases(golden_dir):
+    z = np.load(os.path.join(golden_dir, "chess_kat.npz"))
+    names = [k[3:] for k in z.files if k.startswith("in_") and not k.endswith("_buf")]
+    return z, names
+
+
+def test_chess_restatement_matches_reference_kats(golden_dir):
+    z, names = _kat_cases(golden_dir)
+    assert len(names) >= 12
+    for n in names:
+        img = z["in_" + n]
+        got = oracle.chess_response_5(img, fill=FILL)
+        assert np.array_equal(got, z["out_" + n]), n
+    buf = z["in_strided77_64x48_buf"]
+    got = oracle.chess_response_5(buf[:, :64], fill=FILL)
+    assert np.array_equal(got, z["out_strided77_64x48"])
+
+
+def test_chess_kat_border_untouched_and_tiny_images(golden_dir):
+    z, _ = _kat_cases(golden_dir)
+    out = z["out_rand0_64x48"]
+    assert (out[:7] == FILL).all() and (out[-7:] == FILL).all()
+    assert (out[:, :7] == FILL).all() and (out[:, -7:] == FILL).all()
+    assert (out[7:-7, 7:-7] != FILL).all()
+    assert (z["out_none_14x14"] == FILL).all()                 # ChESS.c:62-63: no interior
+    assert (z["out_single_15x15"] != FILL).sum() == 1           # exactly one interior pixel
+
+
+@pytest.mark.skipif(not oracle.have_reference_build(), reason="oracle/_ref not built")
+def test_chess_restatement_matches_live_reference_build():
+    rng = np.random.RandomState(123)
+    for (h, w) in [(15, 15), (31, 47), (97, 130), (240, 320)]:
+        img = rng.randint(0, 256, size=(h, w)).astype(np.uint8)
+        assert np.array_equal(oracle.chess_response_5(img, FILL), oracle.ref_chess_response_5(img, FILL))
+    f = synth.board_frame(640, 480, 10, 3).numpy()
+    assert np.array_equal(oracle.chess_response_5(f, FILL), oracle.ref_chess_response_5(f, FILL))
+
+
+def test_chess_value_range():
+    # ChESS.c:88-104: sum,diff <= 2040, mean,local_mean <= 4080 -> [-6120, 2040]
+    img = (np.random.RandomState(5).randint(0, 2, size=(64, 64)) * 255).astype(np.uint8)
+    r = oracle.chess_response_5(img)
+    assert r.min() >= -6120 and r.max() <= 2040
+
+
+def test_level_dims_and_decimate():
+    assert oracle.level_dims(4096, 3072, 3) == (512, 384)
+    assert oracle.level_dims(1001, 999, 1) == (500, 500)      # cvRound: half to even
+    assert oracle.level_dims(1003, 1005, 1) == (502, 502)
+    with pytest.raises(ValueError):
+        oracle.level_dims(64, 64, 11)
+    rng = np.random.RandomState(0)
+    img = rng.randint(0, 256, size=(48, 64)).astype(np.uint8)
+    for L in (1, 2, 3):
+        s = 1 << L
+        o = s // 2 - 1
+        a = img[o::s, o::s].astype(np.int32)[: 48 // s, : 64 // s]
+        b = img[o::s, o + 1::s].astype(np.int32)[: 48 // s, : 64 // s]
+        c = img[o + 1::s, o::s].astype(np.int32)[: 48 // s, : 64 // s]
+        d = img[o + 1::s, o + 1::s].astype(np.int32)[: 48 // s, : 64 // s]
+        assert np.array_equal(oracle.decimate(img, L), ((a + b + c + d + 2) >> 2).astype(np.uint8)), L
+    assert np.array_equal(oracle.decimate(img, 0), img)
+    # strided input honoured (cv::resize reads through the Mat step)
+    buf = rng.randint(0, 256, size=(48, 80)).astype(np.uint8)
+    assert np.array_equal(oracle.decimate(buf[:, :64], 2), oracle.decimate(np.ascontiguousarray(buf[:, :64]), 2))
+    # ragged sizes run and give the rounded dims
+    for (h, w) in [(37, 53), (41, 66), (50, 51)]:
+        im = rng.randint(0, 256, size=(h, w)).astype(np.uint8)
+        for L in (1, 2, 3):
+            ow, oh = oracle.level_dims(w, h, L)
+            assert oracle.decimate(im, L).shape == (oh, ow)
+
+
+def test_box_blur():
+    rng = np.random.RandomState(1)
+    img = rng.randint(0, 256, size=(20, 31)).astype(np.uint8)
+    p = np.pad(img.astype(np.int32), 1, mode="reflect")
+    s = sum(p[dy:dy + 20, dx:dx + 31] for dy in range(3) for dx in range(3))
+    assert np.array_equal(oracle.box_blur(img, 1), ((s + 4) // 9).astype(np.uint8))
+    import torch
+    assert np.array_equal(synth.box_blur3(torch.from_numpy(img.astype(np.int64))).numpy().astype(np.uint8),
+                          oracle.box_blur(img, 1))
+
+
+def test_synth_frames_are_stable(golden_dir):
+    z = np.load(os.path.join(golden_dir, "corners_golden.npz"))
+    f = synth.board_frame(640, 480, 10, 0).numpy()
+    assert hashlib.sha256(f.tobytes()).digest() == z["sha_board10_640x480_s0"].tobytes()
+    n = synth.noise_frame(320, 240, 0).numpy()
+    assert hashlib.sha256(n.tobytes()).digest() == z["sha_noise_320x240_s0"].tobytes()
+
+
+def test_detect_and_chain_regression(golden_dir):
+    z = np.load(os.path.join(golden_dir, "corners_golden.npz"))
+    frames = {
+        "board10_640x480_s0": synth.board_frame(640, 480, 10, 0).numpy(),
+        "board14_800x600_s1": synth.board_frame(800, 600, 14, 1).numpy(),
+        "noise_320x240_s1_smooth1": synth.noise_frame(320, 240, 1, smooth=1).numpy(),
+        "noise_333x251_s2_smooth2": synth.noise_frame(333, 251, 2, smooth=2).numpy(),
+    }
+    for name, img in frames.items():
+        for L in range(4):
+            assert np.array_equal(oracle.find_corners(img, L), z[f"detect_L{L}_{name}"]), (name, L)
+        pts, lv = oracle.chain(img, 3)
+        assert np.array_equal(pts, z[f"chain3_pts_{name}"]) and np.array_equal(lv, z[f"chain3_lv_{name}"])
+    assert len(z["detect_L0_board10_640x480_s0"]) == 100
+    assert len(z["detect_L1_board14_800x600_s1"]) == 196
+
+
+def test_detect_error_paths():
+    img = synth.board_frame(160, 120, 10, 0).numpy()
+    assert oracle.find_corners(img, -1) is None            # find_chessboard_corners.cc:433-441
+    assert oracle.find_corners(img, 11) is None
+    wide = np.zeros((120, 200), np.uint8)
+    wide[:, :160] = img
+    assert oracle.find_corners(wide[:, :160], 0) is None   # :461-466 non-continuous at level 0
+    assert oracle.find_corners(wide[:, :160], 1) is not None  # resize output is continuous
+    assert len(oracle.find_corners(np.zeros((10, 10), np.uint8), 0)) == 0
+
+
+# ---- hand-built responses exercising the fill rules ------------------------
+
+def _flat_img(h, w, var=True):
+    img = np.zeros((h, w), np.uint8)
+    if var:
+        img[:, ::2] = 255          # every 21x21 window has variance ~ 127^2 > 400
+    return img
+
+
+def test_cc_rules_on_handbuilt_responses():
+    h, w = 48, 64
+    img = _flat_img(h, w)
+
+    def run(d, image=img):
+        return oracle.cc_detect_on_response(d, image)
+
+    # single pixel: N < 2 rejected (find_chessboard_corners.cc:205)
+    d = np.zeros((h, w), np.int16); d[20, 20] = 500
+    assert len(run(d)) == 0
+    # two pixels, peak > 120: accepted, weighted centroid (:262-263), *1000 rounding (:350-351)
+    d = np.zeros((h, w), np.int16); d[20, 20] = 300; d[20, 21] = 100
+    out = run(d)
+    assert out.tolist() == [[int(0.5 + (300 * 20 + 100 * 21) / 400 * 1000), 20000]]
+    # peak must be strictly > 120 (:206)
+    d = np.zeros((h, w), np.int16); d[20, 20] = 120; d[20, 21] = 100
+    assert len(run(d)) == 0
+    d[20, 20] = 121
+    assert len(run(d)) == 1
+    # responses <= 15 neither seed nor extend (:169)
+    d = np.zeros((h, w), np.int16); d[20, 20] = 300; d[20, 21] = 15; d[20, 22] = 300
+    assert len(run(d)) == 0                                 # two isolated single pixels
+    d[20, 21] = 16                                          # > 15 but not > 300>>4 = 18 (:27)
+    assert len(run(d)) == 0
+    d[20, 20] = 300; d[20, 21] = 19; d[20, 22] = 300
+    assert len(run(d)) == 1
+    # low variance window rejects (:207, :50-88)
+    d = np.zeros((h, w), np.int16); d[20, 20] = 300; d[20, 21] = 100
+    assert len(run(d, _flat_img(h, w, var=False))) == 0
+    # window leaving the image rejects (:52-57): peak at x = 9 < 10
+    d = np.zeros((h, w), np.int16); d[20, 9] = 300; d[20, 10] = 100
+    assert len(run(d)) == 0
+    d = np.zeros((h, w), np.int16); d[20, 10] = 300; d[20, 11] = 100
+    assert len(run(d)) == 1
+    # touching the margin invalidates but still consumes (:216-221, :259)
+    d = np.zeros((h, w), np.int16); d[20, 7] = 300; d[20, 8] = 300; d[20, 9] = 300; d[20, 10] = 300; d[20, 11] = 300
+    assert len(run(d)) == 0
+    # ratio-of-max rule is order dependent (:27, :170): seed 100 first, then 2000 raises the bar
+    d = np.zeros((h, w), np.int16)
+    d[20, 20] = 100; d[20, 21] = 2000; d[21, 20] = 100
+    # raster seed (20,20): push (21,20),(19,20),(20,21),(20,19) -> pops (20,21)... order of pops:
+    # y-1 first (zero), then y+1 = (21,20)? no: LIFO of +x,-x,+y,-y -> pops -y,+y,-x,+x.
+    # (20,21) is x=21,y=20 = +x, popped LAST, so (x=20,y=21) [+y] is accumulated at max=100.
+    out = run(d)
+    sw = 100 + 100 + 2000
+    assert out.tolist() == [[int(0.5 + (100 * 20 + 100 * 20 + 2000 * 21) / sw * 1000),
+                             int(0.5 + (100 * 20 + 100 * 21 + 2000 * 20) / sw * 1000)]]
+    # now make the big one pop first: put it at -y of the seed; then the 100s are below 2000>>4=125
+    d = np.zeros((h, w), np.int16)
+    d[20, 20] = 130; d[19, 20] = 0; d[21, 20] = 2000; d[20, 21] = 100
+    # pops: -y (0, skipped: not pushed), +y (2000) accumulated -> max 2000, threshold 125;
+    # its neighbours pushed; later (21,20)=100 <= 125 zeroed without being accumulated.
+    out = run(d)
+    sw = 130 + 2000
+    assert out.tolist() == [[20000, int(0.5 + (130 * 20 + 2000 * 21) / sw * 1000)]]
+
+
+def test_refine_rules():
+    h, w = 48, 64
+    img = _flat_img(h, w)
+    d = np.zeros((h, w), np.int16); d[20, 20] = 300; d[20, 21] = 100
+    pts = np.array([[20.2, 19.8], [100.0, 60.0]])   # full-resolution coordinates (:367-372)
+    # refine at level 0 only touches points whose level is 1 (:362)
+    p2, lv, n = oracle.cc_refine_on_response(pts, np.array([1, 2], np.int8), d, img, 0)
+    assert n == 1 and lv.tolist() == [0, 2]
+    assert p2[0, 0] == (300 * 20 + 100 * 21) / 400 and p2[0, 1] == 20.0
+    assert p2[1].tolist() == [100.0, 60.0]
+    # seed neighbourhood is 3x3 around the rounded point (:371-382): 2 px away finds nothing
+    p3, lv3, n3 = oracle.cc_refine_on_response(np.array([[23.0, 20.0]]), np.array([1], np.int8), d, img, 0)
+    assert n3 == 0 and lv3.tolist() == [1] and p3.tolist() == [[23.0, 20.0]]
+    # the response buffer mutates between points (:358-396): second identical point finds nothing
+    p4, lv4, n4 = oracle.cc_refine_on_response(np.array([[20.0, 20.0], [20.0, 20.0]]), np.array([1, 1], np.int8),
+                                               d, img, 0)
+    assert n4 == 1 and lv4.tolist() == [0, 1]
