@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X corner-candidate path (contract: see the task brief).
+
+  python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic frames that
+already live in HBM: for each of B = 64 frames of 4096x3072 (10x10 board, the
+size BASELINE.json's metric is quoted on) the reference's found-frame schedule
+for image_pyramid_level < 0 -- detect at pyramid level 3, then refine through
+levels 2, 1, 0 (mrgingham.cc:50, :81-99; 1.328*W*H ChESS pixels per frame) --
+ending with the corner list on the device (and, for N > 1, ONE gather of the
+corner lists to rank 0 over RCCL).  Weak scaling: every rank owns its own B
+frames.  Rank 0 prints ONE JSON line.
+
+  roofline      dominant kernel = the level-0 ChESS response kernel; achieved =
+                algorithmic bytes per launch (3 B/px: u8 read once + int16
+                written once) / average launch duration measured
+                with hipEvents on the stream each launch ran on.
+  cpu_baseline  the C oracle (a port of the reference's algorithm) running the
+                same schedule on a bounded sample of the same frames, one frame
+                per host thread at a time like the reference CLI's --jobs.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (W, H, gridn, start_level, batch)
+    "c3_4096x3072_chain": (4096, 3072, 10, 3, 64),
+    "c2_1920x1080_level0": (1920, 1080, 10, 0, 64),
+    "c1_640x480_chain": (640, 480, 10, 3, 64),
+}
+
+
+def cpu_baseline(frames_host, start_level, budget_s=20.0):
+    """Oracle (kind "port") on the host cores, frame-parallel threads."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle
+    oracle.lib()
+    ncores = os.cpu_count() or 1
+    n = len(frames_host)
+    t0 = time.perf_counter()
+    oracle.chain(frames_host[0], start_level)               # one frame sizes the sample
+    t1 = time.perf_counter() - t0
+    nsample = int(max(ncores, min(n, ncores * max(1, int(budget_s / max(t1, 1e-3))))))
+    nsample = min(nsample, n)
+    idx = list(range(nsample))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=ncores) as ex:      # ctypes releases the GIL
+        list(ex.map(lambda i: oracle.chain(frames_host[i], start_level), idx))
+    dt = time.perf_counter() - t0
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": nsample / dt, "unit": "frames/s", "cores": min(ncores, nsample), "kind": "port",
+            "sample": f"{nsample} of the batch's frames, full detect(L{start_level})+refine chain, "
+                      f"{min(ncores, nsample)} threads x 1 frame each at a time; cpu: {model}; "
+                      f"1 frame on 1 thread: {t1 * 1e3:.0f} ms"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3_4096x3072_chain", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="frames per GPU per step (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--max-points", type=int, default=256)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: mrgingham_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import mrgingham_amd
+    from mrgingham_amd import parallel, synth
+
+    W, H, gridn, start_level, batch = WORKLOADS[args.workload]
+    if args.batch > 0:
+        batch = args.batch
+    dev = torch.device("cuda", local_rank)
+    # every rank renders its own shard of the global batch (seed = global frame index)
+    lo, _ = parallel.shard_range(world * batch, rank, world)
+    frames = synth.board_batch(batch, W, H, gridn=gridn, seed0=lo, device=dev)
+    det = mrgingham_amd.Detector(local_rank)
+    P = args.max_points
+    out = (torch.empty((batch, P, 2), dtype=torch.float64, device=dev),
+           torch.empty((batch, P), dtype=torch.int8, device=dev),
+           torch.empty((batch,), dtype=torch.int32, device=dev))
+    torch.cuda.synchronize()
+
+    def step():
+        pts, lv, npts = det.chain(frames, start_level=start_level, max_points=P, out=out, sync=True)
+        if world > 1:
+            parallel.gather_corner_lists(pts, lv, npts, dst=0)
+        return npts
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    det.set_kernel_timing(True)
+    det.chess_kernel_ms()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        npts = step()
+    fence()
+    dt = time.perf_counter() - t0
+    det.set_kernel_timing(False)
+    kern_ms, nlaunch = det.chess_kernel_ms()
+
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    found = int((npts >= gridn * gridn).sum().item())
+    if rank == 0:
+        total_frames = world * batch * args.steps
+        # level-0 ChESS launches per step = number of stream chunks; frames per launch follows
+        launches_per_step = max(1, nlaunch // max(1, args.steps))
+        frames_per_launch = batch / launches_per_step
+        alg_bytes = frames_per_launch * W * H * 3.0
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        res = {
+            "metric": "frames/sec, 4096x3072 10x10 board, corner-candidate path (ChESS + level decimation + "
+                      "connected components), frames resident in HBM",
+            "value": total_frames / dt,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8->int16 (ChESS), int64/f64 (centroids)",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {batch} frames/GPU of {W}x{H} u8, {gridn}x{gridn} board, "
+                                   f"detect at level {start_level} + refine to level 0, corner lists "
+                                   f"{'gathered to rank 0' if world > 1 else 'left on the device'}",
+                       "frames_per_gpu": batch, "width": W, "height": H, "gridn": gridn,
+                       "start_level": start_level, "parallelism": f"frames sharded x{world}",
+                       "frames_with_full_grid_last_step": found},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "level-0 ChESS response (+clamp +hot-pixel compaction)",
+                         "bytes_model": "3 B/px (u8 read once + int16 written once)",
+                         "bytes_per_launch": alg_bytes, "avg_launch_ms": kern_ms,
+                         "launches_timed": nlaunch},
+        }
+        if not args.no_cpu_baseline:
+            nhost = min(batch, 2 * (os.cpu_count() or 1))
+            res["cpu_baseline"] = cpu_baseline(frames[:nhost].cpu().numpy(), start_level)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

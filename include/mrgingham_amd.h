@@ -1,0 +1,175 @@
+/*
+ * mrgingham_amd.h -- C-ABI of the MI355X-native chessboard-corner candidate path.
+ *
+ * One shared library (mrgingham_amd/libmrgingham_amd.so, HIP for gfx950) exports
+ *
+ *   (1) the reference's own C symbols for this path, same names, arguments and
+ *       error behaviour, so the reference's callers bind to it unchanged;
+ *   (2) a batch API over frames that already live in HBM, which is what the
+ *       single-frame symbols are thin wrappers of, and what bench.py measures.
+ *
+ * Plain pointers and sizes only: no torch, OpenCV or C++ types cross this
+ * boundary.  INTEGRATION.md shows the reference-side bindings.  "file:line"
+ * citations are into the upstream dkogan/mrgingham tree.
+ *
+ * There is no CPU fallback anywhere behind this header: with no usable HIP
+ * device every entry point fails loudly (message on stderr, false / 0 / NULL /
+ * negative status), it never computes on the host.
+ */
+#pragma once
+#include <stdbool.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRGINGHAM_AMD_ABI_VERSION 1
+
+/* ------------------------------------------------------------------------ */
+/* (1) Reference symbols                                                    */
+/* ------------------------------------------------------------------------ */
+
+/* Replaces mrgingham_ChESS_response_5 (ChESS.h:31-34, ChESS.c:55-106).
+ * HOST pointers, caller-owned.  `image` is w x h bytes with `stride` bytes per
+ * row, `response` is a dense w x h int16 image.  Exactly like the reference,
+ * only the interior [7,w-7) x [7,h-7) is written; the 7-pixel frame of
+ * `response` is left untouched.  No return value; a device failure prints a
+ * message on stderr and leaves `response` unwritten. */
+void mrgingham_ChESS_response_5(int16_t* response, const uint8_t* image, int w, int h, int stride);
+
+/* Replaces find_chessboard_corners_from_image_array_C
+ * (mrgingham_pywrap_cplusplus_bridge.h:10-23, .cc:28-70), the extern "C" face
+ * of mrgingham::find_chessboard_corners_from_image_array
+ * (find_chessboard_corners.hh:12-30, .cc:568-587).
+ * HOST image buffer (Nrows x Ncols bytes, `stride` bytes per row).  On success
+ * calls add_points(xy, N, 1/1000., cookie) once with N > 0 interleaved
+ * (x,y)*1000 ints in the reference's order (valid only during the callback)
+ * and returns its result.  Returns false without calling add_points when
+ * nothing was found or on an error (message on stderr):
+ *   - image_pyramid_level outside [0,10]            (find_chessboard_corners.cc:433-441)
+ *   - level 0 and stride != Ncols (non-continuous)  (find_chessboard_corners.cc:461-466)
+ *   - doblobs: the blob detector (find_blobs.cc) is outside this library's
+ *     path; always false, with a message. */
+bool find_chessboard_corners_from_image_array_C(int Nrows, int Ncols, int stride, char* imagebuffer,
+                                                int image_pyramid_level, bool doblobs, bool debug,
+                                                bool (*add_points)(int* xy, int N, double scale, void* cookie),
+                                                void* cookie);
+
+/* C face of mrgingham::refine_chessboard_corners_from_image_array
+ * (find_chessboard_corners.hh:51-72, .cc:591-619), which the reference only
+ * exposes with std::vector / cv::Mat arguments.  points_xy: Npoints interleaved
+ * doubles (full-resolution pixel coordinates), updated in place; level[i] is
+ * the pyramid level point i was computed at and is lowered to
+ * image_pyramid_level for each point that gets refined.  Returns the number of
+ * refined points (0 on error, like the reference). */
+int refine_chessboard_corners_from_image_array_C(int Nrows, int Ncols, int stride, char* imagebuffer,
+                                                 double* points_xy, signed char* level, int Npoints,
+                                                 int image_pyramid_level, bool debug);
+
+/* ------------------------------------------------------------------------ */
+/* (2) Batch API over device-resident frames                                */
+/* ------------------------------------------------------------------------ */
+
+typedef struct mrgingham_amd_ctx mrgingham_amd_ctx;
+
+/* A batch of equally-sized 8-bit frames in DEVICE memory:
+ * frame f, row y starts at frames + f*frame_pitch + y*stride. */
+typedef struct {
+    const uint8_t* frames;
+    int64_t frame_pitch; /* bytes between consecutive frames */
+    int nframes;
+    int width, height;
+    int stride; /* bytes between consecutive rows */
+} mrgingham_amd_frames;
+
+enum {
+    MRGINGHAM_AMD_OK = 0,
+    MRGINGHAM_AMD_ERR_ARG = -1,      /* bad argument (level, sizes, NULL) */
+    MRGINGHAM_AMD_ERR_DEVICE = -2,   /* HIP error; see mrgingham_amd_last_error */
+    MRGINGHAM_AMD_ERR_CAPACITY = -3, /* an output capacity given by the caller was too small */
+};
+
+/* One context = one device, a small pool of HIP streams and the scratch
+ * buffers (level images, responses, component tables) that are grown on
+ * demand and reused.  Not thread-safe: use one context per host thread. */
+mrgingham_amd_ctx* mrgingham_amd_create(int device_ordinal);
+void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx);
+const char* mrgingham_amd_last_error(const mrgingham_amd_ctx* ctx);
+int mrgingham_amd_abi_version(void);
+
+/* Size of pyramid level `level` of a width x height frame: what
+ * cv::resize(.., 1/2^level, 1/2^level) produces (find_chessboard_corners.cc:449-450). */
+int mrgingham_amd_level_dims(int width, int height, int level, int* w, int* h);
+
+/* Dense ChESS response of every frame at pyramid level `level` (0 = the frame
+ * itself): d_response receives nframes dense w_L x h_L int16 images back to
+ * back.  clamp = 0: the raw reference response in the interior (ChESS.c:104),
+ * zeros in the 7-pixel frame.  clamp = 1: negatives replaced by 0, i.e. the
+ * buffer the reference's component search starts from
+ * (find_chessboard_corners.cc:506-529).  `stream` is a hipStream_t (NULL =
+ * the context's own stream); the call is asynchronous on it. */
+int mrgingham_amd_chess_response_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* frames, int level,
+                                       int clamp, int16_t* d_response, void* stream);
+
+/* Pyramid level images alone (find_chessboard_corners.cc:445-452): d_out
+ * receives nframes dense w_L x h_L byte images. */
+int mrgingham_amd_decimate_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* frames, int level,
+                                 uint8_t* d_out, void* stream);
+
+/* 3x3.. box blur the reference CLI applies before detection
+ * (mrgingham-from-image.cc:106-111): d_out receives nframes dense byte images. */
+int mrgingham_amd_box_blur_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* frames, int radius,
+                                 uint8_t* d_out, void* stream);
+
+/* find_chessboard_corners_from_image_array for every frame of the batch at one
+ * pyramid level.  Device outputs: d_xy holds nframes blocks of
+ * capacity_per_frame interleaved (x,y)*1000 int pairs in the reference's
+ * order, d_counts[f] the number of candidates of frame f (may exceed
+ * capacity_per_frame: then only the first capacity_per_frame were stored).
+ * Asynchronous on the context's streams; mrgingham_amd_sync() waits. */
+int mrgingham_amd_detect_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* frames, int level,
+                               int32_t* d_xy, int capacity_per_frame, int32_t* d_counts);
+
+/* refine_chessboard_corners_from_image_array for every frame at one level.
+ * d_points: nframes blocks of points_pitch interleaved (x,y) doubles;
+ * d_levels: nframes blocks of points_pitch signed chars; d_npoints[f] points
+ * are live in frame f.  Updated in place; d_nrefined[f] (may be NULL) receives
+ * the reference's return value. */
+int mrgingham_amd_refine_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* frames, int level,
+                               double* d_points, signed char* d_levels, const int32_t* d_npoints,
+                               int points_pitch, int32_t* d_nrefined);
+
+/* The reference's found-frame schedule for image_pyramid_level < 0 with the
+ * grid finder left on the host (mrgingham.cc:50, :81-99): detect at
+ * start_level, take every candidate as a corner ((double)x/1000,
+ * find_grid.cc:353-354), then refine through start_level-1 .. 0.  Outputs as
+ * mrgingham_amd_refine_batch; d_npoints[f] receives the candidate count. */
+int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* frames, int start_level,
+                              double* d_points, signed char* d_levels, int32_t* d_npoints, int points_pitch);
+
+/* Tunables outside the reference's surface.  Known names:
+ *   "hot_capacity_shift"  per-frame capacity of the hot-pixel / component tables is
+ *                         (width*height) >> shift entries (default 3; 0 = one per pixel)
+ *   "streams"             HIP streams a batch is spread over (default 4, max 8)
+ *   "chess_v0"            1 = use the plain reference-shaped ChESS kernel (cross-check) */
+int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value);
+
+/* Wait for everything queued on the context's streams; returns the first
+ * asynchronous error.  MRGINGHAM_AMD_ERR_CAPACITY here means a frame had more
+ * hot pixels than the component tables hold (adversarial texture): lower
+ * "hot_capacity_shift" and re-run the batch.  The reference-symbol wrappers in
+ * section (1) do that retry themselves. */
+int mrgingham_amd_sync(mrgingham_amd_ctx* ctx);
+
+/* Average duration in milliseconds of the dominant kernel (the level-0 ChESS
+ * response kernel) over the launches issued since the last call, measured with
+ * hipEvents on the streams the kernel ran on; the number of launches is stored
+ * in *nlaunches.  Timing is off by default: enable with
+ * mrgingham_amd_set_kernel_timing(ctx, 1). */
+void mrgingham_amd_set_kernel_timing(mrgingham_amd_ctx* ctx, int enable);
+double mrgingham_amd_chess_kernel_ms(mrgingham_amd_ctx* ctx, int* nlaunches);
+
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,86 @@
+"""ctypes binding of libmrgingham_amd.so (the C-ABI in include/mrgingham_amd.h).
+
+The library is HIP-only.  If it is missing or cannot be loaded this module
+raises -- there is no CPU implementation to fall back to.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmrgingham_amd.so")
+
+ADD_POINTS_INT = ctypes.CFUNCTYPE(ctypes.c_bool, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_double,
+                                  ctypes.c_void_p)
+
+
+class Frames(ctypes.Structure):
+    """mrgingham_amd_frames"""
+    _fields_ = [("frames", ctypes.c_void_p), ("frame_pitch", ctypes.c_int64), ("nframes", ctypes.c_int),
+                ("width", ctypes.c_int), ("height", ctypes.c_int), ("stride", ctypes.c_int)]
+
+
+# every symbol include/mrgingham_amd.h declares
+EXPORTS = [
+    "mrgingham_ChESS_response_5", "find_chessboard_corners_from_image_array_C",
+    "refine_chessboard_corners_from_image_array_C", "mrgingham_amd_create", "mrgingham_amd_destroy",
+    "mrgingham_amd_last_error", "mrgingham_amd_abi_version", "mrgingham_amd_level_dims",
+    "mrgingham_amd_chess_response_batch", "mrgingham_amd_decimate_batch", "mrgingham_amd_box_blur_batch",
+    "mrgingham_amd_detect_batch", "mrgingham_amd_refine_batch", "mrgingham_amd_chain_batch",
+    "mrgingham_amd_set_option", "mrgingham_amd_sync", "mrgingham_amd_set_kernel_timing",
+    "mrgingham_amd_chess_kernel_ms",
+]
+
+
+def build(force=False):
+    """hipcc --offload-arch=gfx950 build of the shared library, in-tree."""
+    src = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-s", "-C", src, "clean"])
+    subprocess.check_call(["make", "-s", "-C", src, "-j4", "all"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C mrgingham_amd/csrc` "
+                           "(hipcc, gfx950).  mrgingham_amd has no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    c_int, c_vp, c_bool = ctypes.c_int, ctypes.c_void_p, ctypes.c_bool
+    FP = ctypes.POINTER(Frames)
+    L.mrgingham_ChESS_response_5.argtypes = [c_vp, c_vp, c_int, c_int, c_int]
+    L.mrgingham_ChESS_response_5.restype = None
+    L.find_chessboard_corners_from_image_array_C.argtypes = [c_int, c_int, c_int, c_vp, c_int, c_bool, c_bool,
+                                                             ADD_POINTS_INT, c_vp]
+    L.find_chessboard_corners_from_image_array_C.restype = c_bool
+    L.refine_chessboard_corners_from_image_array_C.argtypes = [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_int,
+                                                               c_bool]
+    L.refine_chessboard_corners_from_image_array_C.restype = c_int
+    L.mrgingham_amd_create.argtypes = [c_int]
+    L.mrgingham_amd_create.restype = c_vp
+    L.mrgingham_amd_destroy.argtypes = [c_vp]
+    L.mrgingham_amd_destroy.restype = None
+    L.mrgingham_amd_last_error.argtypes = [c_vp]
+    L.mrgingham_amd_last_error.restype = ctypes.c_char_p
+    L.mrgingham_amd_abi_version.restype = c_int
+    L.mrgingham_amd_level_dims.argtypes = [c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
+    L.mrgingham_amd_chess_response_batch.argtypes = [c_vp, FP, c_int, c_int, c_vp, c_vp]
+    L.mrgingham_amd_decimate_batch.argtypes = [c_vp, FP, c_int, c_vp, c_vp]
+    L.mrgingham_amd_box_blur_batch.argtypes = [c_vp, FP, c_int, c_vp, c_vp]
+    L.mrgingham_amd_detect_batch.argtypes = [c_vp, FP, c_int, c_vp, c_int, c_vp]
+    L.mrgingham_amd_refine_batch.argtypes = [c_vp, FP, c_int, c_vp, c_vp, c_vp, c_int, c_vp]
+    L.mrgingham_amd_chain_batch.argtypes = [c_vp, FP, c_int, c_vp, c_vp, c_vp, c_int]
+    L.mrgingham_amd_set_option.argtypes = [c_vp, ctypes.c_char_p, c_int]
+    L.mrgingham_amd_sync.argtypes = [c_vp]
+    L.mrgingham_amd_set_kernel_timing.argtypes = [c_vp, c_int]
+    L.mrgingham_amd_set_kernel_timing.restype = None
+    L.mrgingham_amd_chess_kernel_ms.argtypes = [c_vp, ctypes.POINTER(c_int)]
+    L.mrgingham_amd_chess_kernel_ms.restype = ctypes.c_double
+    _lib = L
+    return L

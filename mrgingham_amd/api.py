@@ -1,0 +1,237 @@
+"""Python face of the C-ABI.
+
+Single-image functions mirror the reference module (names, arguments, error
+behaviour: mrgingham_pywrap.c:40-112 ChESS_response_5, :128-212 find_points).
+`Detector` is the batch interface over device-resident torch tensors.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+def level_dims(width, height, level):
+    """Size (w, h) of pyramid level `level` (find_chessboard_corners.cc:449-450)."""
+    w, h = ctypes.c_int(), ctypes.c_int()
+    if _lib.lib().mrgingham_amd_level_dims(width, height, level, ctypes.byref(w), ctypes.byref(h)) != 0:
+        raise RuntimeError(f"Got an unreasonable image_pyramid_level = {level}")
+    return w.value, h.value
+
+
+def _check_image(image, exact_2d):
+    image = np.asarray(image) if not isinstance(image, np.ndarray) else image
+    # same checks, same messages as mrgingham_pywrap.c:53-68 / :163-178
+    if exact_2d and image.ndim != 2:
+        raise RuntimeError("The input image array must have exactly 2 dims (broadcasting not supported here); "
+                           f"got {image.ndim}")
+    if not exact_2d and image.ndim < 2:
+        raise RuntimeError("The input image array must have at least 2 dims (extra ones will be broadcasted); "
+                           f"got {image.ndim}")
+    if image.dtype != np.uint8:
+        raise RuntimeError("The input image array must contain 8-bit unsigned data")
+    if image.shape[-1] > 1 and image.strides[-1] != 1:
+        raise RuntimeError("Image rows must live in contiguous memory")
+    return image
+
+
+def ChESS_response_5(image):
+    """int16 ChESS response, broadcasting over leading dims (mrgingham_pywrap.c:40-112).
+
+    Like the reference, only the interior [7,W-7) x [7,H-7) of each slice is
+    computed; the reference leaves the 7-pixel frame uninitialised, here it is 0.
+    """
+    image = _check_image(image, exact_2d=False)
+    L = _lib.lib()
+    out = np.zeros(image.shape, dtype=np.int16)
+    H, W = image.shape[-2:]
+    lead = image.shape[:-2]
+    for idx in np.ndindex(*lead):
+        src = image[idx]
+        dst = out[idx]
+        stride = src.strides[0] if H > 1 else W
+        L.mrgingham_ChESS_response_5(dst.ctypes.data, src.ctypes.data, W, H, stride)
+    return out
+
+
+def find_points(image, image_pyramid_level=0, blobs=False, debug=False):
+    """Unordered corner candidates, float64 (N,2); (0,2) when none (mrgingham_pywrap.c:128-212)."""
+    if blobs and image_pyramid_level != 0:
+        raise RuntimeError("blob detector requires that image_pyramid_level == 0")
+    image = _check_image(image, exact_2d=True)
+    result = []
+
+    @_lib.ADD_POINTS_INT
+    def add_points(xy, n, scale, cookie):  # add_points__find_points, mrgingham_pywrap.c:115-127
+        a = np.ctypeslib.as_array(xy, shape=(2 * n,)).astype(np.float64)
+        result.append((a * scale).reshape(n, 2))
+        return True
+
+    H, W = image.shape
+    stride = image.strides[0] if H > 1 else W
+    ok = _lib.lib().find_chessboard_corners_from_image_array_C(H, W, stride, image.ctypes.data,
+                                                              int(image_pyramid_level), bool(blobs), bool(debug),
+                                                              add_points, None)
+    if not ok:
+        if not result:
+            return np.zeros((0, 2), dtype=np.float64)
+        raise RuntimeError("find_chessboard_corners_from_image_array_C() failed")
+    return result[0]
+
+
+find_chessboard_corners = find_points  # compatibility alias, mrgingham_pywrap.c:365
+
+
+def refine_points(points, levels, image, image_pyramid_level):
+    """refine_chessboard_corners_from_image_array (find_chessboard_corners.hh:51-72):
+    returns (points', levels', Nrefined); inputs are not modified."""
+    image = _check_image(image, exact_2d=True)
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 2).copy()
+    lv = np.ascontiguousarray(levels, dtype=np.int8).copy()
+    assert len(lv) == len(pts)
+    H, W = image.shape
+    stride = image.strides[0] if H > 1 else W
+    n = _lib.lib().refine_chessboard_corners_from_image_array_C(H, W, stride, image.ctypes.data, pts.ctypes.data,
+                                                                lv.ctypes.data, len(lv), int(image_pyramid_level),
+                                                                False)
+    return pts, lv, n
+
+
+def find_board(image, image_pyramid_level=-1, gridn=10, blobs=False, debug=False, debug_sequence=None):
+    """Needs the grid finder (find_grid.cc), which stays on the host in the
+    reference and is outside this library's hot path: not provided."""
+    raise NotImplementedError("find_board needs mrgingham's host-side grid finder (find_grid.cc); mrgingham_amd "
+                              "covers the corner-candidate path only.  Use mrgingham.find_grid_from_points on "
+                              "find_points()/Detector.chain() output.")
+
+
+find_chessboard = find_board  # compatibility alias, mrgingham_pywrap.c:366
+
+
+class Detector:
+    """Batch interface: frames are a uint8 torch tensor [B,H,W] already on the GPU.
+
+    Wraps one mrgingham_amd_ctx (streams + scratch).  All results stay on the
+    device until the caller moves them.
+    """
+
+    def __init__(self, device=None):
+        import torch
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("mrgingham_amd.Detector needs a HIP device; there is no CPU path")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.L = _lib.lib()
+        self.ctx = self.L.mrgingham_amd_create(self.device.index)
+        if not self.ctx:
+            raise RuntimeError("mrgingham_amd_create failed")
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.L.mrgingham_amd_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, name, value):
+        if self.L.mrgingham_amd_set_option(self.ctx, name.encode(), int(value)) != 0:
+            raise ValueError(f"bad option {name}={value}")
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"mrgingham_amd error {rc}: {self.L.mrgingham_amd_last_error(self.ctx).decode()}")
+
+    def _frames(self, frames):
+        t = self.torch
+        assert frames.dtype == t.uint8 and frames.is_cuda and frames.dim() == 3 and frames.stride(2) == 1
+        B, H, W = frames.shape
+        fr = _lib.Frames(frames.data_ptr(), frames.stride(0) if B > 1 else H * frames.stride(1), B, W, H,
+                         frames.stride(1) if H > 1 else W)
+        return fr, B, H, W
+
+    def sync(self):
+        self._check(self.L.mrgingham_amd_sync(self.ctx))
+
+    def chess_response(self, frames, level=0, clamp=False, out=None):
+        """Dense int16 response [B,h,w] (border zero).  Runs on torch's current stream."""
+        t = self.torch
+        fr, B, H, W = self._frames(frames)
+        w, h = level_dims(W, H, level)
+        if out is None:
+            out = t.empty((B, h, w), dtype=t.int16, device=frames.device)
+        stream = t.cuda.current_stream(frames.device).cuda_stream
+        self._check(self.L.mrgingham_amd_chess_response_batch(self.ctx, ctypes.byref(fr), level, int(clamp),
+                                                              out.data_ptr(), stream))
+        return out
+
+    def decimate(self, frames, level):
+        t = self.torch
+        fr, B, H, W = self._frames(frames)
+        w, h = level_dims(W, H, level)
+        out = t.empty((B, h, w), dtype=t.uint8, device=frames.device)
+        stream = t.cuda.current_stream(frames.device).cuda_stream
+        self._check(self.L.mrgingham_amd_decimate_batch(self.ctx, ctypes.byref(fr), level, out.data_ptr(), stream))
+        return out
+
+    def box_blur(self, frames, radius=1):
+        t = self.torch
+        fr, B, H, W = self._frames(frames)
+        out = t.empty((B, H, W), dtype=t.uint8, device=frames.device)
+        stream = t.cuda.current_stream(frames.device).cuda_stream
+        self._check(self.L.mrgingham_amd_box_blur_batch(self.ctx, ctypes.byref(fr), radius, out.data_ptr(), stream))
+        return out
+
+    def detect(self, frames, level, capacity=4096, sync=True):
+        """-> (xy int32 [B,capacity,2], counts int32 [B]) on the device."""
+        t = self.torch
+        fr, B, H, W = self._frames(frames)
+        xy = t.empty((B, capacity, 2), dtype=t.int32, device=frames.device)
+        counts = t.empty((B,), dtype=t.int32, device=frames.device)
+        t.cuda.current_stream(frames.device).synchronize()  # inputs/outputs ready before the ctx streams run
+        self._check(self.L.mrgingham_amd_detect_batch(self.ctx, ctypes.byref(fr), level, xy.data_ptr(), capacity,
+                                                      counts.data_ptr()))
+        if sync:
+            self.sync()
+        return xy, counts
+
+    def refine(self, frames, level, points, levels, npoints, sync=True):
+        """In-place refine of points f64 [B,P,2], levels int8 [B,P], npoints int32 [B]; -> nrefined int32 [B]."""
+        t = self.torch
+        fr, B, H, W = self._frames(frames)
+        assert points.dtype == t.float64 and points.is_contiguous() and levels.dtype == t.int8
+        P = points.shape[1]
+        nref = t.empty((B,), dtype=t.int32, device=frames.device)
+        t.cuda.current_stream(frames.device).synchronize()
+        self._check(self.L.mrgingham_amd_refine_batch(self.ctx, ctypes.byref(fr), level, points.data_ptr(),
+                                                      levels.data_ptr(), npoints.data_ptr(), P, nref.data_ptr()))
+        if sync:
+            self.sync()
+        return nref
+
+    def chain(self, frames, start_level=3, max_points=1024, out=None, sync=True):
+        """detect at start_level, refine down to 0 -> (points f64 [B,P,2], levels int8 [B,P], npoints int32 [B])."""
+        t = self.torch
+        fr, B, H, W = self._frames(frames)
+        if out is None:
+            out = (t.empty((B, max_points, 2), dtype=t.float64, device=frames.device),
+                   t.empty((B, max_points), dtype=t.int8, device=frames.device),
+                   t.empty((B,), dtype=t.int32, device=frames.device))
+            t.cuda.current_stream(frames.device).synchronize()
+        pts, lv, npts = out
+        self._check(self.L.mrgingham_amd_chain_batch(self.ctx, ctypes.byref(fr), start_level, pts.data_ptr(),
+                                                     lv.data_ptr(), npts.data_ptr(), pts.shape[1]))
+        if sync:
+            self.sync()
+        return pts, lv, npts
+
+    def set_kernel_timing(self, enable):
+        self.L.mrgingham_amd_set_kernel_timing(self.ctx, int(enable))
+
+    def chess_kernel_ms(self):
+        n = ctypes.c_int()
+        ms = self.L.mrgingham_amd_chess_kernel_ms(self.ctx, ctypes.byref(n))
+        return ms, n.value

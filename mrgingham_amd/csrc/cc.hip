@@ -1,0 +1,507 @@
+// Exact, order-preserving connected-component search on the GPU (gfx950).
+//
+// The reference (find_chessboard_corners.cc:159-267, :284-397) walks the clamped
+// response in raster order and flood-fills with a LIFO whose running-maximum
+// threshold makes the result depend on visiting order.  It is reproduced
+// bit-exactly, in parallel, from two facts:
+//
+//  (1) only "hot" pixels (response > 15) are ever accumulated or expanded: a
+//      pixel in (0,15] that gets pushed is popped, found invalid and zeroed with
+//      no other effect (:243-247), so it can simply not be pushed;
+//  (2) a fill never leaves the 4-connected region of hot pixels that contains
+//      its seed (a "super-component"), responses only ever decrease to 0, and
+//      the margin flag depends only on coordinates (:216-221).  Super-components
+//      are therefore independent of each other; only WITHIN one must the
+//      reference's sequence (raster order of seeds, push order +x,-x,+y,-y,
+//      first-maximum-wins) be replayed, and that is done by a single lane.
+//
+// One 1024-thread workgroup owns one frame, so every hand-off between the
+// phases below is a workgroup barrier (no cross-XCD traffic, no grid sync):
+//   P1 union-find over the hot list (left/up neighbours)        -> forest
+//   P2 flatten; per-root pixel count and bounding box
+//   P3 one lane per root: scan its box in raster order, replay the fills
+//      (detect)  |  group the points that share super-components, one lane per
+//      group replays them in index order (refine)
+//   P4 one wave per surviving component: 21x21 variance test (:50-88)
+//   P5 order by seed raster index (detect: bitonic sort) and emit coordinates.
+//
+// Floating point: centroid, level rescaling and the *1000 rounding are the
+// reference's exact double expressions (:262-263, :278-279, :350-351); the file
+// is compiled with -ffp-contract=off so no FMA changes a truncation.
+#include "common.h"
+#include "kernels.h"
+
+namespace mrg {
+
+constexpr int CC_THREADS = 1024;
+constexpr int CC_WAVES = CC_THREADS / 64;
+
+__device__ __forceinline__ int aload(const int32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ int uf_root(const int32_t* parent, int i) {
+    int p = aload(parent + i);
+    while (p != i) {
+        i = p;
+        p = aload(parent + i);
+    }
+    return i;
+}
+
+// Lock-free union by minimum index.  A failed atomicMin (the target stopped
+// being a root meanwhile) still leaves the forest connected: continue with the
+// displaced parent.
+__device__ __forceinline__ void uf_unite(int32_t* parent, int a, int b) {
+    while (true) {
+        a = uf_root(parent, a);
+        b = uf_root(parent, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(parent + a, b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+struct FrameView {
+    int w, h, n;  // level size, number of hot pixels
+    const uint8_t* img;
+    int img_stride;
+    int16_t* d;
+    int32_t *hot_pix, *parent, *comp_cnt, *roots, *lidx;
+    int4* comp_box;
+    uint32_t* arena;
+    long long arena_cap;
+    Cand* cand;
+    int cand_cap;
+    unsigned long long* sortkeys;
+    int sort_cap;
+    int32_t* status;
+};
+
+__device__ __forceinline__ FrameView make_view(const LevelBatch& lb, const CompTables& t, int frame) {
+    FrameView v;
+    v.w = lb.w;
+    v.h = lb.h;
+    v.img = lb.img + (long long)frame * lb.img_pitch;
+    v.img_stride = lb.img_stride;
+    v.d = lb.resp + (long long)frame * lb.resp_pitch;
+    const long long e = (long long)frame * t.cap;
+    v.hot_pix = t.hot_pix + e;
+    v.parent = t.parent + e;
+    v.comp_cnt = t.comp_cnt + e;
+    v.roots = t.roots + e;
+    v.comp_box = t.comp_box + e;
+    v.lidx = t.lidx + (long long)frame * t.lidx_pitch;
+    v.arena = t.arena + (long long)frame * t.arena_cap;
+    v.arena_cap = t.arena_cap;
+    v.cand = t.cand + (long long)frame * t.cand_cap;
+    v.cand_cap = t.cand_cap;
+    v.sortkeys = t.sortkeys + (long long)frame * t.sort_cap;
+    v.sort_cap = t.sort_cap;
+    v.status = t.status + frame;
+    const int cnt = t.hot_cnt[frame];
+    v.n = cnt < t.cap ? cnt : t.cap;
+    return v;
+}
+
+// P1 + P2.  Ends with a barrier; afterwards parent[i] is the root of i.
+__device__ void build_super_components(const FrameView& v) {
+    const int w = v.w;
+    for (int i = threadIdx.x; i < v.n; i += CC_THREADS) {
+        const int p = v.hot_pix[i];
+        const int y = p / w, x = p - y * w;
+        if (x > kMargin && v.d[p - 1] > kRespMin) uf_unite(v.parent, i, v.lidx[p - 1]);
+        if (y > kMargin && v.d[p - w] > kRespMin) uf_unite(v.parent, i, v.lidx[p - w]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < v.n; i += CC_THREADS) {
+        const int r = uf_root(v.parent, i);
+        __hip_atomic_store(v.parent + i, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int p = v.hot_pix[i];
+        const int y = p / w, x = p - y * w;
+        int* box = reinterpret_cast<int*>(v.comp_box + r);
+        atomicMin(box + 0, x);
+        atomicMin(box + 1, y);
+        atomicMax(box + 2, x);
+        atomicMax(box + 3, y);
+        atomicAdd(v.comp_cnt + r, 1);
+    }
+    __syncthreads();
+}
+
+struct Blob {
+    unsigned long long srx, sry, sr;
+    int npix, rmax, xpk, ypk;
+    bool touched;
+};
+
+// Drains the LIFO exactly like follow_connected_component (:236-256).
+__device__ __forceinline__ void drain_lifo(int16_t* d, int w, int h, uint32_t* stk, int sp, Blob& b) {
+    b.srx = b.sry = b.sr = 0;
+    b.npix = 0;
+    b.rmax = 0;
+    b.xpk = b.ypk = 0;
+    b.touched = false;
+    while (sp > 0) {
+        const uint32_t e = stk[--sp];
+        const int x = (int)(e & 0xffffu), y = (int)(e >> 16);
+        const int q = y * w + x;
+        const int v = d[q];
+        d[q] = 0;                                              // :245 / :250
+        if (!(v > kRespMin && v > (b.rmax >> 4))) continue;    // :159-171 with :27
+        if (v > b.rmax) { b.rmax = v; b.xpk = x; b.ypk = y; }  // :176-181, first maximum wins
+        b.srx += (unsigned long long)(v * x);
+        b.sry += (unsigned long long)(v * y);
+        b.sr += (unsigned long long)v;
+        b.npix++;
+        // :252-255 then :216-226 (only hot pixels are worth pushing, see (1) above)
+        if (x + 1 >= w - kMargin) b.touched = true;
+        else if (d[q + 1] > kRespMin) stk[sp++] = e + 1u;
+        if (x - 1 < kMargin) b.touched = true;
+        else if (d[q - 1] > kRespMin) stk[sp++] = e - 1u;
+        if (y + 1 >= h - kMargin) b.touched = true;
+        else if (d[q + w] > kRespMin) stk[sp++] = e + 0x10000u;
+        if (y - 1 < kMargin) b.touched = true;
+        else if (d[q - w] > kRespMin) stk[sp++] = e - 0x10000u;
+    }
+}
+
+__device__ __forceinline__ bool blob_passes_cheap_tests(const Blob& b) {
+    return !b.touched && b.npix >= kBlobMinPixels && b.rmax > kPeakMin;  // :259, :205-206
+}
+
+// P4: the 21x21 window test of high_variance (:50-88), one wave per candidate.
+__device__ void variance_stage(const FrameView& v, int ncand) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int R = kVarWindowR, D = 2 * R + 1, NPIX = D * D;  // 441
+    for (int c = wave; c < ncand; c += CC_WAVES) {
+        const int x = v.cand[c].x_peak, y = v.cand[c].y_peak;
+        int ok = 0;
+        if (!(x - R < 0 || x + R >= v.w || y - R < 0 || y + R >= v.h)) {  // :52-57
+            int vals[7];
+            int sum = 0;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                const int idx = lane + 64 * k;
+                int val = 0;
+                if (idx < NPIX) {
+                    const int dy = idx / D - R, dx = idx % D - R;
+                    val = v.img[(long long)(y + dy) * v.img_stride + x + dx];
+                }
+                vals[k] = val;
+                sum += val;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            const int mean = sum / NPIX;  // :69-70
+            int ssd = 0;
+#pragma unroll
+            for (int k = 0; k < 7; ++k)
+                if (lane + 64 * k < NPIX) {
+                    const int dev = vals[k] - mean;
+                    ssd += dev * dev;
+                }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ssd += __shfl_xor(ssd, o);
+            ok = (ssd / NPIX) > kVarMin;  // :80-87
+        }
+        if (lane == 0) v.cand[c].ok = ok;
+    }
+}
+
+// (p + 0.5) * scale - 0.5, find_chessboard_corners.cc:278-279
+__device__ __forceinline__ double rescale_coord(double p, double scale) { return (p + 0.5) * scale - 0.5; }
+
+// Block-wide bitonic sort of n_pad (power of two) 64-bit keys in global memory.
+__device__ void bitonic_sort(unsigned long long* keys, int n_pad) {
+    for (int k = 2; k <= n_pad; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n_pad; i += CC_THREADS) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = keys[i], b = keys[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+// ---------------------------------------------------------------------------
+// Detect: process_connected_components, points_scaled_out branch (:330-355)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(CC_THREADS) void cc_detect_kernel(LevelBatch lb, CompTables t, int level,
+                                                               DetectOut out, int frame0) {
+    __shared__ int s_nroots, s_ncand, s_nvalid;
+    __shared__ unsigned long long s_arena_top;
+    const int frame = frame0 + blockIdx.x;
+    if (t.hot_cnt[frame] > t.cap) {  // table overflow: report, produce nothing
+        if (threadIdx.x == 0) {
+            atomicOr(t.status + frame, kStatusHotOverflow);
+            out.counts[frame] = -1;
+        }
+        return;
+    }
+    const FrameView v = make_view(lb, t, frame);
+    if (threadIdx.x == 0) { s_nroots = 0; s_ncand = 0; s_nvalid = 0; s_arena_top = 0; }
+    build_super_components(v);
+
+    // P3a: compact the roots
+    for (int i = threadIdx.x; i < v.n; i += CC_THREADS)
+        if (aload(v.parent + i) == i) v.roots[atomicAdd(&s_nroots, 1)] = i;
+    __syncthreads();
+    const int nroots = s_nroots;
+
+    // P3b: one lane per super-component replays the reference's sequence
+    const int w = v.w, h = v.h;
+    for (int k = threadIdx.x; k < nroots; k += CC_THREADS) {
+        const int r = v.roots[k];
+        const int4 box = v.comp_box[r];
+        const int cnt = v.comp_cnt[r];
+        const unsigned long long off = atomicAdd(&s_arena_top, (unsigned long long)(4 * cnt + 1));
+        uint32_t* stk = v.arena + off;
+        // seeds live in [8, w-8) x [8, h-8) (:332-333)
+        const int ylo = max(box.y, kMargin + 1), yhi = min(box.w, h - kMargin - 2);
+        const int xlo = max(box.x, kMargin + 1), xhi = min(box.z, w - kMargin - 2);
+        for (int y = ylo; y <= yhi; ++y)
+            for (int x = xlo; x <= xhi; ++x) {
+                const int p = y * w + x;
+                if (!(v.d[p] > kRespMin)) continue;          // is_valid(.., NULL), :335
+                if (v.parent[v.lidx[p]] != r) continue;      // someone else's super-component
+                stk[0] = (uint32_t)x | ((uint32_t)y << 16);  // :338
+                Blob b;
+                drain_lifo(v.d, w, h, stk, 1, b);
+                if (!blob_passes_cheap_tests(b)) continue;
+                const int c = atomicAdd(&s_ncand, 1);
+                if (c < v.cand_cap) {
+                    Cand cd;
+                    cd.sum_rx = b.srx; cd.sum_ry = b.sry; cd.sum_r = b.sr;
+                    cd.seed = p;
+                    cd.x_peak = (uint16_t)b.xpk; cd.y_peak = (uint16_t)b.ypk;
+                    cd.ok = 0; cd.pad = 0;
+                    v.cand[c] = cd;
+                }
+            }
+    }
+    __syncthreads();
+    if (s_ncand > v.cand_cap) {
+        if (threadIdx.x == 0) { atomicOr(v.status, kStatusCandOverflow); out.counts[frame] = -1; }
+        return;
+    }
+    const int ncand = s_ncand;
+
+    variance_stage(v, ncand);
+    __syncthreads();
+
+    // P5: order by seed raster index = the reference's output order (:332-353)
+    for (int c = threadIdx.x; c < ncand; c += CC_THREADS)
+        if (v.cand[c].ok) {
+            const int k = atomicAdd(&s_nvalid, 1);
+            v.sortkeys[k] = ((unsigned long long)(uint32_t)v.cand[c].seed << 32) | (uint32_t)c;
+        }
+    __syncthreads();
+    const int nvalid = s_nvalid;
+    int n_pad = 1;
+    while (n_pad < nvalid) n_pad <<= 1;
+    for (int i = nvalid + threadIdx.x; i < n_pad; i += CC_THREADS) v.sortkeys[i] = ~0ull;
+    __syncthreads();
+    bitonic_sort(v.sortkeys, n_pad);
+
+    const double scale = (double)(uint16_t)(1u << level);  // :319
+    int32_t* oxy = out.xy + (long long)frame * out.capacity * 2;
+    const int nout = nvalid < out.capacity ? nvalid : out.capacity;
+    for (int k = threadIdx.x; k < nout; k += CC_THREADS) {
+        const Cand& cd = v.cand[(uint32_t)(v.sortkeys[k] & 0xffffffffu)];
+        const double cx = (double)cd.sum_rx / (double)cd.sum_r;  // :262-263
+        const double cy = (double)cd.sum_ry / (double)cd.sum_r;
+        const double px = rescale_coord(cx, scale), py = rescale_coord(cy, scale);  // :346
+        oxy[2 * k + 0] = (int)(0.5 + px * kGridScale);  // :350-351
+        oxy[2 * k + 1] = (int)(0.5 + py * kGridScale);
+    }
+    if (threadIdx.x == 0) out.counts[frame] = nvalid;
+}
+
+void launch_cc_detect(const LevelBatch& lb, const CompTables& t, int level, const DetectOut& out, int frame0,
+                      int nframes, hipStream_t s) {
+    if (nframes <= 0) return;
+    hipLaunchKernelGGL(cc_detect_kernel, dim3(nframes), dim3(CC_THREADS), 0, s, lb, t, level, out, frame0);
+}
+
+// ---------------------------------------------------------------------------
+// Refine: process_connected_components, points_refinement branch (:356-397)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, CompTables t, int level,
+                                                               RefineIO io, int frame0) {
+    __shared__ int s_ncand, s_changed, s_nref;
+    __shared__ unsigned long long s_arena_top;
+    const int frame = frame0 + blockIdx.x;
+    if (t.hot_cnt[frame] > t.cap) {
+        if (threadIdx.x == 0) {
+            atomicOr(t.status + frame, kStatusHotOverflow);
+            if (io.nrefined) io.nrefined[frame] = -1;
+        }
+        return;
+    }
+    const FrameView v = make_view(lb, t, frame);
+    if (threadIdx.x == 0) { s_ncand = 0; s_changed = 0; s_nref = 0; s_arena_top = 0; }
+    build_super_components(v);  // v.roots[] was preset to INT_MAX by the ChESS kernel: the claim table
+
+    const int w = v.w, h = v.h;
+    const int npts = min(io.npoints[frame], io.pitch);
+    const long long pb = (long long)frame * io.pitch;
+    double* pts = io.points + 2 * pb;
+    signed char* lv = io.levels + pb;
+    int32_t* leader = io.leader + pb;
+    int32_t* need = io.need + pb;
+    int32_t* nseeds = io.nseeds + pb;
+    uint32_t* seeds = io.seeds + 9 * pb;
+    const uint16_t coord_scale = (uint16_t)(1u << level);
+
+    // R1: seeds of every refinable point (:362-382), in the reference's push order
+    for (int i = threadIdx.x; i < npts; i += CC_THREADS) {
+        int ns = -1;  // -1: not refinable at this level
+        if (lv[i] == level + 1) {
+            ns = 0;
+            const double lx = rescale_coord(pts[2 * i + 0], 1.0 / coord_scale);  // :369
+            const double ly = rescale_coord(pts[2 * i + 1], 1.0 / coord_scale);
+            const int x = (int)(lx + 0.5), y = (int)(ly + 0.5);  // :371-372
+            for (int dx = -1; dx <= 1; ++dx)
+                for (int dy = -1; dy <= 1; ++dy) {
+                    const int sx = (int16_t)(x + dx), sy = (int16_t)(y + dy);  // is_valid takes int16_t
+                    if (sx < 0 || sx >= w || sy < 0 || sy >= h) continue;
+                    if (!(v.d[sy * w + sx] > kRespMin)) continue;
+                    seeds[9 * i + ns++] = (uint32_t)sx | ((uint32_t)sy << 16);
+                }
+        }
+        nseeds[i] = ns;
+        leader[i] = i;
+        need[i] = 0;
+    }
+    __syncthreads();
+
+    // R2: points whose seeds share a super-component must be replayed in index
+    // order by one lane; label-propagate the minimum point index over the
+    // bipartite graph points <-> super-components until nothing changes.
+    while (true) {
+        for (int i = threadIdx.x; i < npts; i += CC_THREADS) {
+            const int ns = nseeds[i];
+            if (ns <= 0) continue;
+            int m = leader[i];
+            for (int k = 0; k < ns; ++k) {
+                const uint32_t e = seeds[9 * i + k];
+                const int r = v.parent[v.lidx[(int)(e >> 16) * w + (int)(e & 0xffffu)]];
+                m = min(m, aload(v.roots + r));
+            }
+            for (int k = 0; k < ns; ++k) {
+                const uint32_t e = seeds[9 * i + k];
+                const int r = v.parent[v.lidx[(int)(e >> 16) * w + (int)(e & 0xffffu)]];
+                atomicMin(v.roots + r, m);
+            }
+            if (m < leader[i]) { leader[i] = m; s_changed = 1; }
+        }
+        __syncthreads();
+        const int changed = s_changed;
+        __syncthreads();
+        if (!changed) break;
+        if (threadIdx.x == 0) s_changed = 0;
+        __syncthreads();
+    }
+
+    // R3: stack demand of each group = 4 * (hot pixels of its super-components), counted once
+    for (int i = threadIdx.x; i < npts; i += CC_THREADS) {
+        const int ns = nseeds[i];
+        for (int k = 0; k < ns; ++k) {
+            const uint32_t e = seeds[9 * i + k];
+            const int r = v.parent[v.lidx[(int)(e >> 16) * w + (int)(e & 0xffffu)]];
+            const int old = atomicOr(v.comp_cnt + r, (int)0x80000000);
+            if (old >= 0) atomicAdd(need + leader[i], 4 * old);
+        }
+    }
+    __syncthreads();
+
+    // R4: one lane per group, members in index order (:358)
+    for (int i = threadIdx.x; i < npts; i += CC_THREADS) {
+        if (nseeds[i] < 0 || leader[i] != i) continue;
+        const unsigned long long off = atomicAdd(&s_arena_top, (unsigned long long)(need[i] + 10));
+        uint32_t* stk = v.arena + off;
+        for (int j = i; j < npts; ++j) {
+            if (nseeds[j] < 0 || leader[j] != i) continue;
+            const int ns = nseeds[j];
+            for (int k = 0; k < ns; ++k) stk[k] = seeds[9 * j + k];
+            Blob b;
+            drain_lifo(v.d, w, h, stk, ns, b);
+            if (!blob_passes_cheap_tests(b)) continue;
+            const int c = atomicAdd(&s_ncand, 1);
+            if (c < v.cand_cap) {
+                Cand cd;
+                cd.sum_rx = b.srx; cd.sum_ry = b.sry; cd.sum_r = b.sr;
+                cd.seed = j;  // point index
+                cd.x_peak = (uint16_t)b.xpk; cd.y_peak = (uint16_t)b.ypk;
+                cd.ok = 0; cd.pad = 0;
+                v.cand[c] = cd;
+            }
+        }
+    }
+    __syncthreads();
+    if (s_ncand > v.cand_cap) {
+        if (threadIdx.x == 0) { atomicOr(v.status, kStatusCandOverflow); if (io.nrefined) io.nrefined[frame] = -1; }
+        return;
+    }
+    const int ncand = s_ncand;
+    variance_stage(v, ncand);
+    __syncthreads();
+
+    for (int c = threadIdx.x; c < ncand; c += CC_THREADS) {
+        const Cand& cd = v.cand[c];
+        if (!cd.ok) continue;
+        const int j = cd.seed;
+        const double cx = (double)cd.sum_rx / (double)cd.sum_r;
+        const double cy = (double)cd.sum_ry / (double)cd.sum_r;
+        pts[2 * j + 0] = rescale_coord(cx, (double)coord_scale);  // :390
+        pts[2 * j + 1] = rescale_coord(cy, (double)coord_scale);
+        lv[j] = (signed char)level;  // :393
+        atomicAdd(&s_nref, 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && io.nrefined) io.nrefined[frame] = s_nref;
+}
+
+void launch_cc_refine(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io, int frame0,
+                      int nframes, hipStream_t s) {
+    if (nframes <= 0) return;
+    hipLaunchKernelGGL(cc_refine_kernel, dim3(nframes), dim3(CC_THREADS), 0, s, lb, t, level, io, frame0);
+}
+
+// Candidate ints -> corner doubles, find_grid.cc:353-354 ((double)x / 1000.),
+// with every point tagged with the level it was detected at (mrgingham.cc:81-85).
+__global__ void points_from_candidates_kernel(const int32_t* xy, int capacity, const int32_t* counts,
+                                              double* points, signed char* levels, int32_t* npoints, int pitch,
+                                              int level, int frame0) {
+    const int frame = frame0 + blockIdx.y;
+    int n = counts[frame];
+    n = n < 0 ? 0 : (n < capacity ? n : capacity);
+    n = n < pitch ? n : pitch;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) npoints[frame] = n;
+    if (i >= n) return;
+    const int32_t* src = xy + ((long long)frame * capacity + i) * 2;
+    double* dst = points + ((long long)frame * pitch + i) * 2;
+    dst[0] = (double)src[0] / kGridScale;
+    dst[1] = (double)src[1] / kGridScale;
+    levels[(long long)frame * pitch + i] = (signed char)level;
+}
+
+void launch_points_from_candidates(const int32_t* xy, int capacity, const int32_t* counts, double* points,
+                                   signed char* levels, int32_t* npoints, int pitch, int level, int frame0,
+                                   int nframes, hipStream_t s) {
+    if (nframes <= 0) return;
+    const int m = capacity < pitch ? capacity : pitch;
+    dim3 grid((m + 255) / 256 > 0 ? (m + 255) / 256 : 1, nframes);
+    hipLaunchKernelGGL(points_from_candidates_kernel, grid, dim3(256), 0, s, xy, capacity, counts, points, levels,
+                       npoints, pitch, level, frame0);
+}
+
+}  // namespace mrg

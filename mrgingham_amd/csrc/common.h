@@ -1,0 +1,73 @@
+// Shared definitions of the HIP implementation (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct mrgingham_amd_ctx;
+
+namespace mrg {
+
+int fail_hip(mrgingham_amd_ctx* ctx, hipError_t e, const char* what, const char* file, int line);
+
+// Detector constants: compile-time in the reference as well
+// (find_chessboard_corners.cc:18-44, :559-564; mrgingham-internal.h:3).
+constexpr int kRespMin = 15;         // RESPONSE_MIN_THRESHOLD
+constexpr int kPeakMin = 120;        // RESPONSE_MIN_PEAK_THRESHOLD
+constexpr int kBlobMinPixels = 2;    // CONNECTED_COMPONENT_MIN_SIZE
+constexpr int kVarWindowR = 10;      // CONSTANCY_WINDOW_R
+constexpr int kVarMin = 20 * 20;     // STDEV_THRESHOLD^2
+constexpr int kMargin = 7;           // ChESS ring radius 5 + blur border 2 (ChESS.c:61)
+constexpr double kGridScale = 1000.; // FIND_GRID_SCALE
+
+// One pyramid level of a batch, as every kernel of the level sees it.
+struct LevelBatch {
+    int nframes;
+    int w, h;                 // level image size
+    const uint8_t* img;       // level images (the caller's frames at level 0)
+    long long img_pitch;      // bytes between frames
+    int img_stride;           // bytes between rows
+    int16_t* resp;            // dense w*h int16 per frame
+    long long resp_pitch;     // elements between frames
+};
+
+// Per-frame tables of the component search, all of capacity `cap` entries per
+// frame unless noted.  "hot" pixels are those with response > kRespMin: the
+// only pixels that can seed, join or extend a component.
+struct CompTables {
+    int cap;                  // hot-pixel capacity per frame
+    int32_t* hot_cnt;         // [nframes]     number of hot pixels found (may exceed cap)
+    int32_t* hot_pix;         // [nframes*cap] linear pixel index y*w+x
+    int32_t* parent;          // [nframes*cap] union-find forest over hot-list indices
+    int32_t* comp_cnt;        // [nframes*cap] hot pixels per super-component (at its root)
+    int4* comp_box;           // [nframes*cap] (xmin, ymin, xmax, ymax) at the root
+    int32_t* roots;           // [nframes*cap] compacted root list / claim table (refine)
+    int32_t* lidx;            // [nframes*w0*h0] pixel -> hot-list index (sparse writes)
+    long long lidx_pitch;     // elements between frames
+    uint32_t* arena;          // [nframes*arena_cap] DFS stacks
+    long long arena_cap;      // entries per frame
+    int cand_cap;             // candidate capacity per frame
+    struct Cand* cand;        // [nframes*cand_cap]
+    unsigned long long* sortkeys; // [nframes*cand_cap_pow2]
+    int sort_cap;             // power of two >= cand_cap
+    int32_t* status;          // [nframes] bit 0: hot table overflow, bit 1: candidate overflow
+};
+
+// A component that passed the size / peak / margin tests and waits for the
+// variance test and the ordering by seed (find_chessboard_corners.cc:193-209).
+struct Cand {
+    unsigned long long sum_rx, sum_ry, sum_r;
+    int32_t seed;             // raster index of the seed pixel (output order key)
+    uint16_t x_peak, y_peak;
+    int32_t ok;               // set by the variance stage
+    int32_t pad;
+};
+
+enum : int { kStatusHotOverflow = 1, kStatusCandOverflow = 2 };
+
+#define MRG_HIP_CHECK(expr)                                                                          \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess) return ::mrg::fail_hip(ctx, _e, #expr, __FILE__, __LINE__);            \
+    } while (0)
+
+}  // namespace mrg

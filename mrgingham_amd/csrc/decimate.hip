@@ -1,0 +1,107 @@
+// Pyramid level images and the caller-side box blur, for gfx950.
+//
+// decimate: what find_chessboard_corners.cc:445-452 asks of
+//   cv::resize(src, dst, Size(), 1/2^L, 1/2^L, INTER_LINEAR) on CV_8UC1:
+//   every level is cut from the FULL-RESOLUTION frame (not cascaded).
+//   L = 1 -> OpenCV's 2x2 area-fast path, (a+b+c+d+2)>>2, with the partial-cell
+//            average (round half to even) at a ragged right/bottom edge;
+//   L >= 2 -> 11-bit fixed-point bilinear whose sample point is the cell centre:
+//            the four pixels at (s/2-1, s/2) of each s x s cell, weights 1/4,
+//            right column / bottom row replicated when they fall off the frame.
+//   (OpenCV arithmetic, not vendored by the reference: parity unpinned.)
+// box blur: cv::blur((2r+1)^2), BORDER_REFLECT_101, (sum + area/2)/area
+//   (mrgingham-from-image.cc:106-111).
+#include "common.h"
+#include "kernels.h"
+
+namespace mrg {
+
+__device__ __forceinline__ int clipi(int v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); }
+
+__global__ __launch_bounds__(256) void decimate_kernel(FrameBatch in, int level, uint8_t* out, int ow, int oh,
+                                                       int frame0) {
+    const int frame = frame0 + blockIdx.z;
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= ow || dy >= oh) return;
+    const uint8_t* src = in.frames + (long long)frame * in.frame_pitch;
+    const int W = in.width, H = in.height, st = in.stride;
+    int v;
+    if (level == 1) {
+        const int sx0 = 2 * dx, sy0 = 2 * dy;
+        if (sy0 >= H) {
+            v = 0;
+        } else if (sy0 + 2 <= H && dx < W / 2) {
+            const uint8_t* r0 = src + (long long)sy0 * st + sx0;
+            v = (r0[0] + r0[1] + r0[st] + r0[st + 1] + 2) >> 2;
+        } else {
+            int sum = 0, count = 0;
+            for (int sy = 0; sy < 2 && sy0 + sy < H; ++sy)
+                for (int sx = 0; sx < 2 && sx0 + sx < W; ++sx) {
+                    sum += src[(long long)(sy0 + sy) * st + sx0 + sx];
+                    ++count;
+                }
+            if (count == 0) {
+                v = 0;
+            } else {  // cvRound((float)sum/count): count is 1, 2 or 4, ties to even
+                int q = sum / count;
+                const int rem = sum - q * count;
+                if (2 * rem > count || (2 * rem == count && (q & 1))) ++q;
+                v = q;
+            }
+        }
+    } else {
+        const int s = 1 << level;
+        int sx = s * dx + s / 2 - 1;
+        int a0 = 1024, a1 = 1024;
+        if (sx >= W - 1) { sx = W - 1; a0 = 2048; a1 = 0; }
+        const int sx1 = sx + 1 < W ? sx + 1 : sx;
+        const int sy = s * dy + s / 2 - 1;
+        const uint8_t* r0 = src + (long long)clipi(sy, H) * st;
+        const uint8_t* r1 = src + (long long)clipi(sy + 1, H) * st;
+        const int S0 = r0[sx] * a0 + r0[sx1] * a1;
+        const int S1 = r1[sx] * a0 + r1[sx1] * a1;
+        v = (((1024 * (S0 >> 4)) >> 16) + ((1024 * (S1 >> 4)) >> 16) + 2) >> 2;
+    }
+    out[((long long)frame * oh + dy) * ow + dx] = (uint8_t)v;
+}
+
+void launch_decimate(const FrameBatch& in, int level, uint8_t* out, int ow, int oh, int frame0, int nframes,
+                     hipStream_t s) {
+    if (ow <= 0 || oh <= 0 || nframes <= 0) return;
+    dim3 grid((ow + 63) / 64, (oh + 3) / 4, nframes);
+    hipLaunchKernelGGL(decimate_kernel, grid, dim3(256), 0, s, in, level, out, ow, oh, frame0);
+}
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) {
+        if (i < 0) i = -i;
+        if (i >= n) i = 2 * (n - 1) - i;
+    }
+    return i;
+}
+
+__global__ __launch_bounds__(256) void box_blur_kernel(FrameBatch in, int radius, uint8_t* out, int frame0) {
+    const int frame = frame0 + blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int W = in.width, H = in.height;
+    if (x >= W || y >= H) return;
+    const uint8_t* src = in.frames + (long long)frame * in.frame_pitch;
+    const int area = (2 * radius + 1) * (2 * radius + 1);
+    int sum = 0;
+    for (int dy = -radius; dy <= radius; ++dy) {
+        const uint8_t* row = src + (long long)reflect101(y + dy, H) * in.stride;
+        for (int dx = -radius; dx <= radius; ++dx) sum += row[reflect101(x + dx, W)];
+    }
+    out[((long long)frame * H + y) * W + x] = (uint8_t)((sum + area / 2) / area);
+}
+
+void launch_box_blur(const FrameBatch& in, int radius, uint8_t* out, int frame0, int nframes, hipStream_t s) {
+    if (in.width <= 0 || in.height <= 0 || nframes <= 0) return;
+    dim3 grid((in.width + 63) / 64, (in.height + 3) / 4, nframes);
+    hipLaunchKernelGGL(box_blur_kernel, grid, dim3(256), 0, s, in, radius, out, frame0);
+}
+
+}  // namespace mrg

@@ -1,0 +1,49 @@
+// Launchers of the HIP kernels (host side declarations).
+#pragma once
+#include "common.h"
+
+namespace mrg {
+
+// chess.hip
+void launch_chess_v0(const LevelBatch& lb, const CompTables& t, int frame0, int nframes, bool clamp, bool hot,
+                     hipStream_t s);
+void launch_chess(const LevelBatch& lb, const CompTables& t, int frame0, int nframes, bool clamp, bool hot,
+                  hipStream_t s);
+
+// decimate.hip
+struct FrameBatch {
+    const uint8_t* frames;
+    long long frame_pitch;
+    int width, height, stride;
+};
+void launch_decimate(const FrameBatch& in, int level, uint8_t* out, int ow, int oh, int frame0, int nframes,
+                     hipStream_t s);
+void launch_box_blur(const FrameBatch& in, int radius, uint8_t* out, int frame0, int nframes, hipStream_t s);
+
+// cc.hip
+struct DetectOut {
+    int32_t* xy;      // [nframes*capacity*2]
+    int capacity;
+    int32_t* counts;  // [nframes]
+};
+struct RefineIO {
+    double* points;          // [nframes*pitch*2]
+    signed char* levels;     // [nframes*pitch]
+    const int32_t* npoints;  // [nframes]
+    int pitch;
+    int32_t* nrefined;       // [nframes] or NULL
+    // scratch, per frame `pitch` entries unless noted
+    int32_t* leader;
+    int32_t* need;
+    int32_t* nseeds;
+    uint32_t* seeds;         // [nframes*pitch*9]
+};
+void launch_cc_detect(const LevelBatch& lb, const CompTables& t, int level, const DetectOut& out, int frame0,
+                      int nframes, hipStream_t s);
+void launch_cc_refine(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io, int frame0,
+                      int nframes, hipStream_t s);
+void launch_points_from_candidates(const int32_t* xy, int capacity, const int32_t* counts, double* points,
+                                   signed char* levels, int32_t* npoints, int pitch, int level, int frame0,
+                                   int nframes, hipStream_t s);
+
+}  // namespace mrg

@@ -1,0 +1,39 @@
+"""Frame sharding across GPUs and the one collective of the path.
+
+Frames are independent (the reference already parallelises per image,
+mrgingham-from-image.cc:50, :374-379), so each rank runs the whole path on its
+own contiguous shard with no data-path communication.  The only exchange is the
+gather of the (tiny) corner lists to rank 0: per-frame counts plus fixed-pitch
+point blocks, one torch.distributed gather each (backend "nccl" = RCCL over
+xGMI on the GPU box, "gloo" in the CPU tests).  Output order on rank 0 is
+frame-major, and within a frame the reference's order.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(nframes, rank, world):
+    """Contiguous block [lo, hi) of frames owned by `rank`."""
+    per, extra = divmod(nframes, world)
+    lo = rank * per + min(rank, extra)
+    return lo, lo + per + (1 if rank < extra else 0)
+
+
+def gather_corner_lists(points, levels, npoints, dst=0, group=None):
+    """points f64 [B,P,2], levels int8 [B,P], npoints int32 [B] (same B,P on every
+    rank) -> on `dst`: the three tensors concatenated over ranks along dim 0
+    ([world*B, ...]); None elsewhere."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return points, levels, npoints
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    outs = []
+    for t in (points, levels, npoints):
+        t = t.contiguous()
+        # int8 is not a NCCL reduction type but gather only moves bytes; view as uint8 for safety
+        payload = t.view(torch.uint8) if t.dtype == torch.int8 else t
+        bufs = [torch.empty_like(payload) for _ in range(world)] if rank == dst else None
+        dist.gather(payload, bufs, dst=dst, group=group)
+        if rank == dst:
+            cat = torch.cat(bufs, dim=0)
+            outs.append(cat.view(torch.int8) if t.dtype == torch.int8 else cat)
+    return tuple(outs) if rank == dst else None

@@ -1,0 +1,71 @@
+"""CPU checks of the boundary: the C-ABI library loads, exports every symbol
+include/mrgingham_amd.h declares, and refuses to compute without a device."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from mrgingham_amd import _lib
+from oracle import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "mrgingham_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", src)
+    skip = {"defined", "add_points", "C", "bool", "int", "void", "double"}
+    out = []
+    for n in names:
+        if n in skip or n.startswith("__") or n in out:
+            continue
+        out.append(n)
+    return out
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    declared = _declared_symbols()
+    assert "mrgingham_ChESS_response_5" in declared
+    assert "find_chessboard_corners_from_image_array_C" in declared
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/mrgingham_amd.h but not exported"
+    assert sorted(declared) == sorted(_lib.EXPORTS)
+    assert L.mrgingham_amd_abi_version() == 1
+
+
+def test_level_dims_match_oracle():
+    L = _lib.lib()
+    w, h = ctypes.c_int(), ctypes.c_int()
+    for (W, H) in [(4096, 3072), (1920, 1080), (640, 480), (1001, 999), (1003, 1005), (37, 53), (15, 15), (6, 2)]:
+        for level in range(0, 5):
+            assert L.mrgingham_amd_level_dims(W, H, level, ctypes.byref(w), ctypes.byref(h)) == 0
+            assert (w.value, h.value) == oracle.level_dims(W, H, level), (W, H, level)
+    assert L.mrgingham_amd_level_dims(64, 64, 11, ctypes.byref(w), ctypes.byref(h)) != 0
+    assert L.mrgingham_amd_level_dims(64, 64, -1, ctypes.byref(w), ctypes.byref(h)) != 0
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    L = _lib.lib()
+    assert L.mrgingham_amd_create(0) is None            # fails loudly, no host path
+    import mrgingham_amd
+    with pytest.raises(RuntimeError):
+        mrgingham_amd.Detector()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "mrgingham_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                for pat in ("import oracle", "from oracle", "liboracle", "mrgingham_oracle", "oracle/", "oracle."):
+                    assert pat not in text, f"{f} references the oracle ({pat})"

@@ -1,0 +1,308 @@
+"""GPU parity tests proper: the HIP path, called through the C-ABI, against
+ * the known-answer vectors of the REAL upstream ChESS.c (tests/golden/chess_kat.npz),
+ * the CPU oracle on the same seeded inputs (bit-exact: everything on this path
+   is integer / index work; the refined doubles are compared for equality and
+   the 1e-4 px tolerance of the north star is asserted as the outer bound),
+ * the committed golden corner lists,
+ * size-independent properties at BASELINE's full frame size.
+Nothing here reads /root/reference.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import mrgingham_amd
+from mrgingham_amd import synth
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+FILL = -32768
+TOL_PX = 1e-4   # north_star: sub-pixel refined coordinates within 1e-4 px
+
+
+@pytest.fixture(scope="module")
+def det():
+    d = mrgingham_amd.Detector(0)
+    yield d
+    d.close()
+
+
+def _cuda(frames_np):
+    return torch.from_numpy(np.ascontiguousarray(frames_np)).cuda()
+
+
+# ----------------------------------------------------------------------------- ChESS
+
+def test_chess_kats_through_reference_symbol(golden_dir):
+    """mrgingham_ChESS_response_5 (host pointers) vs vectors made by the upstream ChESS.c."""
+    z = np.load(os.path.join(golden_dir, "chess_kat.npz"))
+    names = [k[3:] for k in z.files if k.startswith("in_") and not k.endswith("_buf")]
+    L = mrgingham_amd._lib.lib()
+    for n in names:
+        img = np.ascontiguousarray(z["in_" + n])
+        h, w = img.shape
+        out = np.full((h, w), FILL, np.int16)
+        L.mrgingham_ChESS_response_5(out.ctypes.data, img.ctypes.data, w, h, w)
+        assert np.array_equal(out, z["out_" + n]), n   # interior bit-exact AND frame left untouched
+    buf = np.ascontiguousarray(z["in_strided77_64x48_buf"])
+    out = np.full((48, 64), FILL, np.int16)
+    L.mrgingham_ChESS_response_5(out.ctypes.data, buf.ctypes.data, 64, 48, 77)
+    assert np.array_equal(out, z["out_strided77_64x48"])
+
+
+def test_chess_python_mirror_broadcasts():
+    rng = np.random.RandomState(3)
+    imgs = rng.randint(0, 256, size=(2, 3, 40, 52)).astype(np.uint8)
+    r = mrgingham_amd.ChESS_response_5(imgs)
+    assert r.shape == imgs.shape and r.dtype == np.int16
+    for i in range(2):
+        for j in range(3):
+            assert np.array_equal(r[i, j], oracle.chess_response_5(imgs[i, j], fill=0))
+    with pytest.raises(RuntimeError):
+        mrgingham_amd.ChESS_response_5(imgs.astype(np.float32))
+    with pytest.raises(RuntimeError):
+        mrgingham_amd.ChESS_response_5(np.zeros(5, np.uint8))
+
+
+@pytest.mark.parametrize("shape", [(15, 15), (16, 80), (97, 130), (240, 333), (480, 640), (1080, 1920)])
+def test_chess_batch_raw_and_clamped(det, shape):
+    h, w = shape
+    rng = np.random.RandomState(h * 7 + w)
+    frames = rng.randint(0, 256, size=(3, h, w)).astype(np.uint8)
+    frames[1] = synth.board_frame(w, h, 10, 1).numpy() if h >= 240 else frames[1]
+    d = _cuda(frames)
+    raw = det.chess_response(d, 0, clamp=False).cpu().numpy()
+    cl = det.chess_response(d, 0, clamp=True).cpu().numpy()
+    for f in range(3):
+        ref = oracle.chess_response_5(frames[f], fill=0)
+        assert np.array_equal(raw[f], ref), (shape, f)
+        assert np.array_equal(cl[f], np.maximum(ref, 0)), (shape, f)
+
+
+def test_chess_strided_device_frames(det):
+    rng = np.random.RandomState(5)
+    big = rng.randint(0, 256, size=(2, 100, 200)).astype(np.uint8)
+    d = _cuda(big)[:, 10:90, 16:150]          # non-dense rows and frames
+    r = det.chess_response(d, 0).cpu().numpy()
+    for f in range(2):
+        assert np.array_equal(r[f], oracle.chess_response_5(np.ascontiguousarray(big[f, 10:90, 16:150]), fill=0))
+
+
+def test_chess_v0_cross_check(det):
+    """The plain reference-shaped kernel and the tuned kernel agree on the device."""
+    frames = _cuda(np.stack([synth.board_frame(640, 480, 10, s).numpy() for s in range(2)] +
+                            [synth.noise_frame(640, 480, 3).numpy()]))
+    a = det.chess_response(frames, 0).cpu()
+    det.set_option("chess_v0", 1)
+    try:
+        b = det.chess_response(frames, 0).cpu()
+    finally:
+        det.set_option("chess_v0", 0)
+    assert torch.equal(a, b)
+
+
+# ----------------------------------------------------------------------------- decimate / blur
+
+@pytest.mark.parametrize("shape", [(48, 64), (480, 640), (37, 53), (41, 66), (50, 51), (1001, 999)])
+def test_decimate_levels(det, shape):
+    h, w = shape
+    rng = np.random.RandomState(h + w)
+    frames = rng.randint(0, 256, size=(2, h, w)).astype(np.uint8)
+    d = _cuda(frames)
+    for level in (0, 1, 2, 3):
+        got = det.decimate(d, level).cpu().numpy()
+        for f in range(2):
+            assert np.array_equal(got[f], oracle.decimate(frames[f], level)), (shape, level)
+
+
+def test_box_blur(det):
+    rng = np.random.RandomState(9)
+    frames = rng.randint(0, 256, size=(2, 61, 83)).astype(np.uint8)
+    for r in (1, 2):
+        got = det.box_blur(_cuda(frames), r).cpu().numpy()
+        for f in range(2):
+            assert np.array_equal(got[f], oracle.box_blur(frames[f], r))
+
+
+# ----------------------------------------------------------------------------- detect
+
+def _frames_small():
+    return {
+        "board10_640x480_s0": synth.board_frame(640, 480, 10, 0).numpy(),
+        "board10_640x480_s5": synth.board_frame(640, 480, 10, 5).numpy(),
+        "board14_800x600_s1": synth.board_frame(800, 600, 14, 1).numpy(),
+        "board10_clean_648x486": synth.board_frame(648, 486, 10, 2, noise=False).numpy(),
+        "noise_320x240_s0": synth.noise_frame(320, 240, 0).numpy(),
+        "noise_320x240_s1_smooth1": synth.noise_frame(320, 240, 1, smooth=1).numpy(),
+        "noise_333x251_s2_smooth2": synth.noise_frame(333, 251, 2, smooth=2).numpy(),
+    }
+
+
+def _as_int(pts):
+    return np.round(pts * 1000).astype(np.int64)
+
+
+def test_find_points_matches_oracle_and_golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, "corners_golden.npz"))
+    for name, img in _frames_small().items():
+        for level in range(4):
+            got = mrgingham_amd.find_points(img, image_pyramid_level=level)
+            want = oracle.find_corners(img, level)
+            assert got.dtype == np.float64 and got.shape == (len(want), 2), (name, level)
+            assert np.array_equal(_as_int(got), want.astype(np.int64)), (name, level)    # values AND order
+            assert np.array_equal(want, z[f"detect_L{level}_{name}"]), (name, level)
+            # the callback scale is exactly 1/1000. (bridge.cc:66-69)
+            assert np.array_equal(got, want.astype(np.float64) * (1. / 1000.))
+
+
+def test_find_points_error_and_empty_paths():
+    img = synth.board_frame(160, 120, 10, 0).numpy()
+    assert mrgingham_amd.find_points(img, image_pyramid_level=-1).shape == (0, 2)   # :433-441 -> no points
+    assert mrgingham_amd.find_points(img, image_pyramid_level=11).shape == (0, 2)
+    wide = np.zeros((120, 200), np.uint8)
+    wide[:, :160] = img
+    assert mrgingham_amd.find_points(wide[:, :160], 0).shape == (0, 2)              # :461-466 non-continuous
+    a = mrgingham_amd.find_points(wide[:, :160], 1)
+    assert np.array_equal(_as_int(a), oracle.find_corners(wide[:, :160], 1))
+    assert mrgingham_amd.find_points(np.zeros((10, 10), np.uint8)).shape == (0, 2)  # no interior at all
+    assert mrgingham_amd.find_points(np.zeros((64, 64), np.uint8)).shape == (0, 2)  # nothing found
+    assert mrgingham_amd.find_points(img, blobs=True).shape == (0, 2)               # blob path not provided
+    with pytest.raises(RuntimeError):
+        mrgingham_amd.find_points(img, image_pyramid_level=1, blobs=True)           # mrgingham_pywrap.c:153-157
+    with pytest.raises(RuntimeError):
+        mrgingham_amd.find_points(np.zeros((4, 64, 64), np.uint8))
+    with pytest.raises(RuntimeError):
+        mrgingham_amd.find_points(np.zeros((64, 64), np.uint16))
+
+
+def test_detect_adversarial_textures():
+    """Dense corner textures overflow the default component tables; the
+    reference-symbol wrapper retries with full tables and must still be exact."""
+    yy, xx = np.arange(240).reshape(-1, 1), np.arange(320).reshape(1, -1)
+    for cell in (3, 7):
+        img = (((yy // cell + xx // cell) & 1) * 255).astype(np.uint8)
+        got = mrgingham_amd.find_points(img, 0)
+        want = oracle.find_corners(img, 0)
+        assert len(want) > 1000
+        assert np.array_equal(_as_int(got), want.astype(np.int64)), cell
+    # ramps / constant images: nothing
+    assert mrgingham_amd.find_points(np.tile(np.arange(256, dtype=np.uint8), (200, 1))).shape == (0, 2)
+
+
+def test_detect_batch_mixed_content(det):
+    frames = np.stack([synth.board_frame(640, 480, 10, 0).numpy(), synth.noise_frame(640, 480, 1).numpy(),
+                       synth.board_frame(640, 480, 14, 2).numpy(), np.zeros((480, 640), np.uint8),
+                       synth.noise_frame(640, 480, 4, smooth=1).numpy(), synth.board_frame(640, 480, 10, 9).numpy(),
+                       synth.noise_frame(640, 480, 6, smooth=2).numpy()])
+    d = _cuda(frames)
+    for level in (0, 1, 3):
+        xy, counts = det.detect(d, level, capacity=8192)
+        xy, counts = xy.cpu().numpy(), counts.cpu().numpy()
+        for f in range(len(frames)):
+            want = oracle.find_corners(frames[f], level)
+            assert counts[f] == len(want), (level, f)
+            assert np.array_equal(xy[f, :counts[f]], want), (level, f)
+    # capacity smaller than the count: count is still reported, the first `capacity` stored in order
+    xy, counts = det.detect(d, 0, capacity=16)
+    want = oracle.find_corners(frames[1], 0)
+    assert counts[1].item() == len(want) and np.array_equal(xy[1].cpu().numpy(), want[:16])
+
+
+# ----------------------------------------------------------------------------- refine / chain
+
+def test_refine_symbol_matches_oracle():
+    for name, img in _frames_small().items():
+        for start in (3, 2, 1):
+            cand = oracle.find_corners(img, start)
+            pts = cand.astype(np.float64) / 1000.0
+            lv = np.full(len(pts), start, np.int8)
+            for level in range(start - 1, -1, -1):
+                wp, wl, wn = oracle.refine_corners(pts, lv, img, level)
+                gp, gl, gn = mrgingham_amd.refine_points(pts, lv, img, level)
+                assert gn == wn, (name, start, level)
+                assert np.array_equal(gl, wl), (name, start, level)
+                assert np.abs(gp - wp).max(initial=0.) <= TOL_PX
+                assert np.array_equal(gp, wp), (name, start, level)       # in fact bit-identical doubles
+                pts, lv = wp, wl
+
+
+def test_refine_shared_blobs_and_odd_points():
+    """Points that seed from the same blob must be processed in index order on the
+    mutating response (find_chessboard_corners.cc:358-396); junk points are ignored."""
+    img = synth.board_frame(640, 480, 10, 0).numpy()
+    cand = oracle.find_corners(img, 1).astype(np.float64) / 1000.0
+    pts = np.concatenate([cand[:20], cand[:20] + 0.4, cand[5:10] - 0.6, [[-50., -50.], [1e6, 1e6], [3., 3.]], cand[20:40]])
+    lv = np.full(len(pts), 1, np.int8)
+    lv[7] = 2
+    lv[33] = 0
+    wp, wl, wn = oracle.refine_corners(pts, lv, img, 0)
+    gp, gl, gn = mrgingham_amd.refine_points(pts, lv, img, 0)
+    assert gn == wn and np.array_equal(gl, wl) and np.array_equal(gp, wp)
+    assert 20 <= wn < len(pts)
+
+
+def test_chain_batch_matches_oracle(det, golden_dir):
+    z = np.load(os.path.join(golden_dir, "corners_golden.npz"))
+    frames = np.stack([synth.board_frame(640, 480, 10, s).numpy() for s in (0, 5, 7)] +
+                      [synth.noise_frame(640, 480, 1, smooth=1).numpy(), synth.board_frame(640, 480, 14, 3).numpy()])
+    d = _cuda(frames)
+    for start in (3, 2, 0):
+        pts, lv, npts = det.chain(d, start_level=start, max_points=2048)
+        pts, lv, npts = pts.cpu().numpy(), lv.cpu().numpy(), npts.cpu().numpy()
+        for f in range(len(frames)):
+            wp, wl = oracle.chain(frames[f], start)
+            n = npts[f]
+            assert n == len(wp), (start, f)
+            assert np.array_equal(lv[f, :n], wl), (start, f)
+            assert np.abs(pts[f, :n] - wp).max(initial=0.) <= TOL_PX
+            assert np.array_equal(pts[f, :n], wp), (start, f)
+    assert np.array_equal(oracle.chain(frames[0], 3)[0], z["chain3_pts_board10_640x480_s0"])
+
+
+def test_streams_option_does_not_change_results(det):
+    frames = _cuda(np.stack([synth.board_frame(640, 480, 10, s).numpy() for s in range(6)]))
+    ref = [t.clone() for t in det.chain(frames, 3, 512)]
+    for ns in (1, 3, 8):
+        det.set_option("streams", ns)
+        got = det.chain(frames, 3, 512)
+        n = got[2]
+        assert torch.equal(n, ref[2])
+        for f in range(6):
+            k = int(n[f])
+            assert torch.equal(got[0][f, :k], ref[0][f, :k]) and torch.equal(got[1][f, :k], ref[1][f, :k])
+    det.set_option("streams", 4)
+
+
+# ----------------------------------------------------------------------------- full size
+
+def test_full_size_frames_bit_exact_and_properties(det):
+    """BASELINE size 4096x3072: two frames bit-exact against the oracle end to end,
+    plus properties that need no oracle."""
+    W, H = 4096, 3072
+    frames = synth.board_batch(2, W, H, gridn=10, seed0=11, device="cuda")
+    host = frames.cpu().numpy()
+    r = det.chess_response(frames, 0, clamp=False)
+    assert np.array_equal(r[0].cpu().numpy(), oracle.chess_response_5(host[0], fill=0))
+    # frame is zero, interior range bound (ChESS.c:88-104)
+    assert int(r[:, :7].abs().max()) == 0 and int(r[:, :, -7:].abs().max()) == 0
+    assert int(r.min()) >= -6120 and int(r.max()) <= 2040
+    # translation covariance: shifting the image shifts the response
+    shifted = torch.roll(frames, shifts=(5, 9), dims=(1, 2))
+    rs = det.chess_response(shifted, 0, clamp=False)
+    assert torch.equal(rs[:, 20:-20, 20:-20], torch.roll(r, shifts=(5, 9), dims=(1, 2))[:, 20:-20, 20:-20])
+    for level in (0, 3):
+        xy, counts = det.detect(frames, level, capacity=4096)
+        for f in range(2):
+            want = oracle.find_corners(host[f], level)
+            assert counts[f].item() == len(want) and np.array_equal(xy[f, :len(want)].cpu().numpy(), want)
+    pts, lv, npts = det.chain(frames, 3, 1024)
+    again = det.chain(frames, 3, 1024)
+    for f in range(2):
+        wp, wl = oracle.chain(host[f], 3)
+        n = int(npts[f])
+        assert n == len(wp) and np.array_equal(pts[f, :n].cpu().numpy(), wp) and np.array_equal(lv[f, :n].cpu().numpy(), wl)
+        assert torch.equal(again[0][f, :n], pts[f, :n])                  # deterministic re-run
+        assert int((lv[f, :n] == 0).sum()) >= 100                        # the 10x10 grid reaches level 0

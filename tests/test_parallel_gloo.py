@@ -1,0 +1,61 @@
+"""world_size-2 gloo run of the multi-GPU host logic (shards + the one gather)."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    from mrgingham_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, P = 3, 8
+    lo, hi = parallel.shard_range(world * B, rank, world)
+    assert hi - lo == B
+    pts = torch.arange(B * P * 2, dtype=torch.float64).reshape(B, P, 2) + 1000 * rank
+    lv = (torch.arange(B * P, dtype=torch.int64).reshape(B, P) % 4).to(torch.int8) - rank
+    npts = torch.tensor([rank + 1, rank + 2, rank + 3], dtype=torch.int32)
+    out = parallel.gather_corner_lists(pts, lv, npts, dst=0)
+    if rank == 0:
+        gp, gl, gn = out
+        ok = gp.shape == (world * B, P, 2) and gl.dtype == torch.int8
+        for r in range(world):
+            ok &= bool(torch.equal(gp[r * B:(r + 1) * B], torch.arange(B * P * 2, dtype=torch.float64).reshape(B, P, 2) + 1000 * r))
+            ok &= bool(torch.equal(gl[r * B:(r + 1) * B], (torch.arange(B * P, dtype=torch.int64).reshape(B, P) % 4).to(torch.int8) - r))
+            ok &= gn[r * B:(r + 1) * B].tolist() == [r + 1, r + 2, r + 3]
+        ret.put(ok)
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_covers_everything():
+    sys.path.insert(0, ROOT)
+    from mrgingham_amd import parallel
+    for n in (0, 1, 7, 64, 2048):
+        for world in (1, 2, 3, 8):
+            spans = [parallel.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def test_gather_corner_lists_world2_gloo():
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok = ret.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok
