@@ -107,8 +107,8 @@ int mrgingham_amd_level_dims(int width, int height, int level, int* w, int* h);
  * back.  clamp = 0: the raw reference response in the interior (ChESS.c:104),
  * zeros in the 7-pixel frame.  clamp = 1: negatives replaced by 0, i.e. the
  * buffer the reference's component search starts from
- * (find_chessboard_corners.cc:506-529).  `stream` is a hipStream_t (NULL =
- * the context's own stream); the call is asynchronous on it. */
+ * (find_chessboard_corners.cc:506-529).  `stream` is a hipStream_t, used as given
+ * (NULL = HIP's default stream); the call is asynchronous on it. */
 int mrgingham_amd_chess_response_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* frames, int level,
                                        int clamp, int16_t* d_response, void* stream);
 

@@ -48,6 +48,9 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch first: it brings its own libamdhip64, and device pointers / streams are
+    # shared between torch and this library, so both must sit on ONE HIP runtime.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C mrgingham_amd/csrc` "
                            "(hipcc, gfx950).  mrgingham_amd has no CPU fallback.")

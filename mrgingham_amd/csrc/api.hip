@@ -198,13 +198,18 @@ static LevelBatch queue_level_response(mrgingham_amd_ctx* ctx, const mrgingham_a
         lb.img_stride = fr->stride;
     } else {
         FrameBatch fb{fr->frames, fr->frame_pitch, fr->width, fr->height, fr->stride};
-        launch_decimate(fb, level, (uint8_t*)ctx->level_img.p, w, h, f0, n, s);
+        // scratch slices are per frame and level-independent: chunks on different
+        // streams may be at different levels at the same time
+        int w1, h1;
+        level_dims(fr->width, fr->height, 1, &w1, &h1);
+        const long long pitch = (long long)w1 * h1;
+        launch_decimate(fb, level, (uint8_t*)ctx->level_img.p, pitch, w, h, f0, n, s);
         lb.img = (const uint8_t*)ctx->level_img.p;
-        lb.img_pitch = (long long)w * h;
+        lb.img_pitch = pitch;
         lb.img_stride = w;
     }
     lb.resp = resp_override ? resp_override : (int16_t*)ctx->resp.p;
-    lb.resp_pitch = (long long)w * h;
+    lb.resp_pitch = resp_override ? (long long)w * h : (long long)fr->width * fr->height;
     CompTables t = tables_of(ctx);
     if (hot) {
         hipMemsetAsync((int32_t*)ctx->hot_cnt.p + f0, 0, sizeof(int32_t) * n, s);
@@ -385,7 +390,7 @@ int mrgingham_amd_chess_response_batch(mrgingham_amd_ctx* ctx, const mrgingham_a
         level_dims(fr->width, fr->height, 1, &w1, &h1);
         if ((rc = ensure(ctx, ctx->level_img, (size_t)fr->nframes * w1 * h1 + 16))) return rc;
     }
-    hipStream_t s = stream ? (hipStream_t)stream : ctx->streams[0];
+    hipStream_t s = (hipStream_t)stream;  // used as given: NULL is HIP's default stream
     queue_level_response(ctx, fr, level, 0, fr->nframes, clamp != 0, false, d_response, s, level == 0);
     MRG_HIP_CHECK(hipGetLastError());
     return 0;
@@ -400,7 +405,7 @@ int mrgingham_amd_decimate_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_fra
         return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "bad level %d or NULL output", level);
     if (fr->nframes == 0) return 0;
     MRG_HIP_CHECK(hipSetDevice(ctx->device));
-    hipStream_t s = stream ? (hipStream_t)stream : ctx->streams[0];
+    hipStream_t s = (hipStream_t)stream;  // used as given: NULL is HIP's default stream
     if (level == 0) {
         for (int f = 0; f < fr->nframes; ++f)
             MRG_HIP_CHECK(hipMemcpy2DAsync(d_out + (size_t)f * w * h, w, fr->frames + (size_t)f * fr->frame_pitch,
@@ -408,7 +413,7 @@ int mrgingham_amd_decimate_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_fra
         return 0;
     }
     FrameBatch fb{fr->frames, fr->frame_pitch, fr->width, fr->height, fr->stride};
-    launch_decimate(fb, level, d_out, w, h, 0, fr->nframes, s);
+    launch_decimate(fb, level, d_out, (long long)w * h, w, h, 0, fr->nframes, s);
     MRG_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -420,7 +425,7 @@ int mrgingham_amd_box_blur_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_fra
     if (radius < 0 || radius > 64 || !d_out) return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "bad blur radius or output");
     if (fr->nframes == 0) return 0;
     MRG_HIP_CHECK(hipSetDevice(ctx->device));
-    hipStream_t s = stream ? (hipStream_t)stream : ctx->streams[0];
+    hipStream_t s = (hipStream_t)stream;  // used as given: NULL is HIP's default stream
     FrameBatch fb{fr->frames, fr->frame_pitch, fr->width, fr->height, fr->stride};
     launch_box_blur(fb, radius, d_out, 0, fr->nframes, s);
     MRG_HIP_CHECK(hipGetLastError());
@@ -542,8 +547,10 @@ static int upload_frame(mrgingham_amd_ctx* ctx, const void* host, int rows, int 
                         mrgingham_amd_frames* fr) {
     int rc;
     if ((rc = ensure(ctx, ctx->io_frame, (size_t)rows * cols + 64))) return rc;
+    // stream-ordered on streams[0]: the kernels that read it are queued on the same stream
     if (rows > 0 && cols > 0)
-        MRG_HIP_CHECK(hipMemcpy2D(ctx->io_frame.p, cols, host, stride, cols, rows, hipMemcpyHostToDevice));
+        MRG_HIP_CHECK(hipMemcpy2DAsync(ctx->io_frame.p, cols, host, stride, cols, rows, hipMemcpyHostToDevice,
+                                       ctx->streams[0]));
     fr->frames = (const uint8_t*)ctx->io_frame.p;
     fr->frame_pitch = (int64_t)rows * cols;
     fr->nframes = 1;
@@ -564,16 +571,14 @@ void mrgingham_ChESS_response_5(int16_t* response, const uint8_t* image, int w, 
     mrgingham_amd_frames fr;
     if (upload_frame(ctx, image, h, w, stride, &fr)) return;
     if (ensure(ctx, ctx->io_out, (size_t)w * h * 2 + 64)) return;
-    if (mrgingham_amd_chess_response_batch(ctx, &fr, 0, 0, (int16_t*)ctx->io_out.p, nullptr)) return;
-    if (hipStreamSynchronize(ctx->streams[0]) != hipSuccess) {
-        fprintf(stderr, "mrgingham_amd: ChESS kernel failed: %s\n", hipGetErrorString(hipGetLastError()));
-        return;
-    }
+    if (mrgingham_amd_chess_response_batch(ctx, &fr, 0, 0, (int16_t*)ctx->io_out.p, ctx->streams[0])) return;
     // interior only, like the reference: the 7-pixel frame of `response` is not touched
     const size_t off = (size_t)kMargin * w + kMargin;
-    hipError_t e = hipMemcpy2D(response + off, (size_t)w * 2, (const int16_t*)ctx->io_out.p + off, (size_t)w * 2,
-                               (size_t)(w - 2 * kMargin) * 2, h - 2 * kMargin, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) fprintf(stderr, "mrgingham_amd: response download failed: %s\n", hipGetErrorString(e));
+    hipError_t e = hipMemcpy2DAsync(response + off, (size_t)w * 2, (const int16_t*)ctx->io_out.p + off,
+                                    (size_t)w * 2, (size_t)(w - 2 * kMargin) * 2, h - 2 * kMargin,
+                                    hipMemcpyDeviceToHost, ctx->streams[0]);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->streams[0]);
+    if (e != hipSuccess) fprintf(stderr, "mrgingham_amd: ChESS response failed: %s\n", hipGetErrorString(e));
 }
 
 // Common checks of apply_image_pyramid_scaling (find_chessboard_corners.cc:433-473).
@@ -659,9 +664,11 @@ int refine_chessboard_corners_from_image_array_C(int Nrows, int Ncols, int strid
         if (ensure(ctx, ctx->io_out, o_nr + 8)) break;
         char* base = (char*)ctx->io_out.p;
         const int32_t np = Npoints;
-        if (hipMemcpy(base, points_xy, (size_t)Npoints * 16, hipMemcpyHostToDevice) != hipSuccess) break;
-        if (hipMemcpy(base + o_lv, level, (size_t)Npoints, hipMemcpyHostToDevice) != hipSuccess) break;
-        if (hipMemcpy(base + o_np, &np, 4, hipMemcpyHostToDevice) != hipSuccess) break;
+        hipStream_t s0 = ctx->streams[0];
+        if (hipMemcpyAsync(base, points_xy, (size_t)Npoints * 16, hipMemcpyHostToDevice, s0) != hipSuccess) break;
+        if (hipMemcpyAsync(base + o_lv, level, (size_t)Npoints, hipMemcpyHostToDevice, s0) != hipSuccess) break;
+        if (hipMemcpyAsync(base + o_np, &np, 4, hipMemcpyHostToDevice, s0) != hipSuccess) break;
+        if (hipStreamSynchronize(s0) != hipSuccess) break;  // `np` lives on this stack frame
         if (mrgingham_amd_refine_batch(ctx, &fr, image_pyramid_level, (double*)base, (signed char*)(base + o_lv),
                                        (const int32_t*)(base + o_np), Npoints, (int32_t*)(base + o_nr)))
             break;

@@ -395,12 +395,14 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, Co
                 const int r = v.parent[v.lidx[(int)(e >> 16) * w + (int)(e & 0xffffu)]];
                 m = min(m, aload(v.roots + r));
             }
+            bool changed = m < leader[i];
             for (int k = 0; k < ns; ++k) {
                 const uint32_t e = seeds[9 * i + k];
                 const int r = v.parent[v.lidx[(int)(e >> 16) * w + (int)(e & 0xffffu)]];
-                atomicMin(v.roots + r, m);
+                if (atomicMin(v.roots + r, m) > m) changed = true;
             }
-            if (m < leader[i]) { leader[i] = m; s_changed = 1; }
+            leader[i] = m;
+            if (changed) s_changed = 1;
         }
         __syncthreads();
         const int changed = s_changed;

@@ -18,8 +18,8 @@ namespace mrg {
 
 __device__ __forceinline__ int clipi(int v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); }
 
-__global__ __launch_bounds__(256) void decimate_kernel(FrameBatch in, int level, uint8_t* out, int ow, int oh,
-                                                       int frame0) {
+__global__ __launch_bounds__(256) void decimate_kernel(FrameBatch in, int level, uint8_t* out, long long out_pitch,
+                                                       int ow, int oh, int frame0) {
     const int frame = frame0 + blockIdx.z;
     const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -63,14 +63,14 @@ __global__ __launch_bounds__(256) void decimate_kernel(FrameBatch in, int level,
         const int S1 = r1[sx] * a0 + r1[sx1] * a1;
         v = (((1024 * (S0 >> 4)) >> 16) + ((1024 * (S1 >> 4)) >> 16) + 2) >> 2;
     }
-    out[((long long)frame * oh + dy) * ow + dx] = (uint8_t)v;
+    out[(long long)frame * out_pitch + (long long)dy * ow + dx] = (uint8_t)v;
 }
 
-void launch_decimate(const FrameBatch& in, int level, uint8_t* out, int ow, int oh, int frame0, int nframes,
-                     hipStream_t s) {
+void launch_decimate(const FrameBatch& in, int level, uint8_t* out, long long out_pitch, int ow, int oh, int frame0,
+                     int nframes, hipStream_t s) {
     if (ow <= 0 || oh <= 0 || nframes <= 0) return;
     dim3 grid((ow + 63) / 64, (oh + 3) / 4, nframes);
-    hipLaunchKernelGGL(decimate_kernel, grid, dim3(256), 0, s, in, level, out, ow, oh, frame0);
+    hipLaunchKernelGGL(decimate_kernel, grid, dim3(256), 0, s, in, level, out, out_pitch, ow, oh, frame0);
 }
 
 __device__ __forceinline__ int reflect101(int i, int n) {

@@ -16,8 +16,8 @@ struct FrameBatch {
     long long frame_pitch;
     int width, height, stride;
 };
-void launch_decimate(const FrameBatch& in, int level, uint8_t* out, int ow, int oh, int frame0, int nframes,
-                     hipStream_t s);
+void launch_decimate(const FrameBatch& in, int level, uint8_t* out, long long out_pitch, int ow, int oh, int frame0,
+                     int nframes, hipStream_t s);
 void launch_box_blur(const FrameBatch& in, int radius, uint8_t* out, int frame0, int nframes, hipStream_t s);
 
 // cc.hip
