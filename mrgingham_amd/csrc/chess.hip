@@ -116,10 +116,266 @@ void launch_chess_v0(const LevelBatch& lb, const CompTables& t, int frame0, int 
         hipLaunchKernelGGL((chess_v0_kernel<false, false>), grid, dim3(256), 0, s, lb, t, frame0);
 }
 
-// Production entry point.  (The tuned kernel replaces this forwarding.)
+// ---------------------------------------------------------------------------
+// v1: the production kernel.  HBM-bound design for gfx950 (wave64):
+//
+//  * a 256-thread workgroup owns a vertical strip SW = 256 pixels wide and SEG
+//    rows tall and ROLLS down it 8 rows at a time, so every input row is
+//    fetched from HBM once (plus a 32-px horizontal and 10-row per-segment halo)
+//    and every output row is written once: ~3.3 B/px of traffic for 3 B/px of
+//    algorithmic bytes;
+//  * rows are staged through registers into an LDS ring of 32 rows as TWO
+//    planes of packed u16 pixel pairs: P0 holds (I[2m], I[2m+1]), P1 holds
+//    (I[2m+1], I[2m+2]).  Every ring sample at an even dx is then a whole-dword
+//    offset in P0 and every odd dx (+-5, +-1) a whole-dword offset in P1: the
+//    per-lane operands are picked by register renaming out of three aligned,
+//    conflict-free ds_read_b128 per (plane,row), never by byte shuffles;
+//  * each lane produces 8 adjacent pixels as 4 packed pairs with 16-bit packed
+//    VALU ops (v_pk_max_u16, 32-bit adds of non-overflowing halves) using the
+//    max-identities in the file header: 42 VALU ops per pixel PAIR;
+//  * the group of 8 rows for the iteration after next is prefetched into
+//    registers before the math and written to the ring after it, one barrier per
+//    iteration; results leave as one 16-byte store per lane.
+// ---------------------------------------------------------------------------
+constexpr int V1_SW = 256;                    // strip width, output pixels
+constexpr int V1_HL = 16;                     // left halo in the LDS window (16 keeps global loads 16-B aligned)
+constexpr int V1_WIN = V1_SW + 2 * V1_HL;     // 288 window pixels per row
+constexpr int V1_NCH = V1_WIN / 16;           // 18 staging chunks of 16 pixels per row
+constexpr int V1_ROWB = V1_WIN * 2;           // 576 bytes per row per plane
+constexpr int V1_NR = 32;                     // ring rows
+constexpr int V1_RB = 8;                      // rows per iteration (4 waves x 2 rows)
+constexpr int V1_PLANE = V1_NR * V1_ROWB;     // 18432 bytes
+
+using u16x2 = unsigned short __attribute__((ext_vector_type(2)));
+using i16x2 = short __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a),
+                                                                  __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a),
+                                                                  __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, (i16x2)(__builtin_bit_cast(i16x2, a) - __builtin_bit_cast(i16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_add_i16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, (i16x2)(__builtin_bit_cast(i16x2, a) + __builtin_bit_cast(i16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, a),
+                                                                  __builtin_bit_cast(i16x2, b)));
+}
+
+struct StageRegs {
+    uint4 g;        // 16 pixels
+    uint32_t next;  // byte 0 = the pixel after them
+};
+
+// Global -> registers for one 16-pixel chunk of window row `r` (clamped: pixels
+// outside the image read as 0; they only ever feed non-interior outputs).
+__device__ __forceinline__ StageRegs stage_load(const uint8_t* img, int stride, int w, int h, int r, int gx) {
+    StageRegs s;
+    s.g = make_uint4(0, 0, 0, 0);
+    s.next = 0;
+    if (r < 0 || r >= h) return s;
+    const uint8_t* row = img + (long long)r * stride;
+    if (gx >= 0 && gx + 16 <= w) {
+        __builtin_memcpy(&s.g, row + gx, 16);
+        if (gx + 16 < w) s.next = row[gx + 16];
+    } else if (gx + 16 > 0 && gx < w) {
+        uint32_t v[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 16; ++i) {
+            const int x = gx + i;
+            if (x >= 0 && x < w) v[i >> 2] |= (uint32_t)row[x] << (8 * (i & 3));
+        }
+        s.g = make_uint4(v[0], v[1], v[2], v[3]);
+        if (gx + 16 >= 0 && gx + 16 < w) s.next = row[gx + 16];
+    }
+    return s;
+}
+
+// Registers -> both LDS planes (packed u16 pairs).
+__device__ __forceinline__ void stage_store(char* lds, int slot, int ch, const StageRegs& s) {
+    const uint32_t g0 = s.g.x, g1 = s.g.y, g2 = s.g.z, g3 = s.g.w;
+    constexpr uint32_t S01 = 0x0c010c00u, S23 = 0x0c030c02u;  // (b0,b1) / (b2,b3) of the low operand
+    constexpr uint32_t S12 = 0x0c020c01u, S34 = 0x0c040c03u;  // (b1,b2) / (b3, b0 of the high operand)
+    uint4 a, b, c, d;
+    a.x = __builtin_amdgcn_perm(g0, g0, S01); a.y = __builtin_amdgcn_perm(g0, g0, S23);
+    a.z = __builtin_amdgcn_perm(g1, g1, S01); a.w = __builtin_amdgcn_perm(g1, g1, S23);
+    b.x = __builtin_amdgcn_perm(g2, g2, S01); b.y = __builtin_amdgcn_perm(g2, g2, S23);
+    b.z = __builtin_amdgcn_perm(g3, g3, S01); b.w = __builtin_amdgcn_perm(g3, g3, S23);
+    c.x = __builtin_amdgcn_perm(g0, g0, S12); c.y = __builtin_amdgcn_perm(g1, g0, S34);
+    c.z = __builtin_amdgcn_perm(g1, g1, S12); c.w = __builtin_amdgcn_perm(g2, g1, S34);
+    d.x = __builtin_amdgcn_perm(g2, g2, S12); d.y = __builtin_amdgcn_perm(g3, g2, S34);
+    d.z = __builtin_amdgcn_perm(g3, g3, S12); d.w = __builtin_amdgcn_perm(s.next, g3, S34);
+    char* p = lds + slot * V1_ROWB + ch * 32;
+    *reinterpret_cast<uint4*>(p) = a;
+    *reinterpret_cast<uint4*>(p + 16) = b;
+    *reinterpret_cast<uint4*>(p + V1_PLANE) = c;
+    *reinterpret_cast<uint4*>(p + V1_PLANE + 16) = d;
+}
+
+// 12 dwords D[-4..7] around the lane's 4 dwords of one (plane,row).
+// The empty asm statements make each 16-byte value opaque, so hipcc keeps the
+// aligned, bank-conflict-free ds_read_b128 instead of narrowing it to the few
+// dwords that are used (at a 16-byte lane stride those narrow reads are 2- to
+// 4-way bank conflicted).
+using u32x4 = uint32_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 lds_read_b128(const char* p) {
+    u32x4 v = *reinterpret_cast<const u32x4*>(p);
+    asm("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ void load12(uint32_t (&R)[12], const char* p) {
+    const u32x4 a = lds_read_b128(p);
+    const u32x4 b = lds_read_b128(p + 16);
+    const u32x4 c = lds_read_b128(p + 32);
+    R[0] = a.x; R[1] = a.y; R[2] = a.z; R[3] = a.w;
+    R[4] = b.x; R[5] = b.y; R[6] = b.z; R[7] = b.w;
+    R[8] = c.x; R[9] = c.y; R[10] = c.z; R[11] = c.w;
+}
+
+template <bool CLAMP, bool HOT>
+__global__ __launch_bounds__(256) void chess_v1_kernel(LevelBatch lb, CompTables t, int frame0, int seg) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int frame = frame0 + blockIdx.z;
+    const int w = lb.w, h = lb.h, stride = lb.img_stride;
+    const uint8_t* img = lb.img + (long long)frame * lb.img_pitch;
+    int16_t* resp = lb.resp + (long long)frame * lb.resp_pitch;
+    const int strip_x = blockIdx.x * V1_SW;
+    const int ys = blockIdx.y * seg;
+    const int ye = min(ys + seg, h);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6, half = lane >> 5, lx = lane & 31;
+    // staging role: 8 rows x 18 chunks = 144 threads
+    const bool stager = tid < V1_RB * V1_NCH;
+    const int st_row = tid / V1_NCH, st_ch = tid - st_row * V1_NCH;
+    const int st_gx = strip_x - V1_HL + 16 * st_ch;
+
+    // prologue: row groups G0..G2 = rows ys-5 .. ys+18
+    if (stager) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const int r = ys - 5 + V1_RB * g + st_row;
+            const StageRegs s = stage_load(img, stride, w, h, r, st_gx);
+            stage_store(lds, (r + 64) & (V1_NR - 1), st_ch, s);
+        }
+    }
+    __syncthreads();
+
+    // per-lane constants
+    const int x0 = strip_x + 8 * lx;
+    uint32_t xmask[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int xa = x0 + 2 * k, xb = xa + 1;
+        xmask[k] = ((xa >= kMargin && xa < w - kMargin) ? 0x0000ffffu : 0u) |
+                   ((xb >= kMargin && xb < w - kMargin) ? 0xffff0000u : 0u);
+    }
+    const char* lane_base = lds + 16 + 16 * lx;  // address of D[-4] in a row of plane 0
+
+    int grp = 3;
+    for (int y = ys; y < ye; y += V1_RB, ++grp) {
+        // prefetch the group needed two iterations from now (rows y+19 .. y+26)
+        StageRegs pre;
+        const int pr = ys - 5 + V1_RB * grp + st_row;
+        if (stager) pre = stage_load(img, stride, w, h, pr, st_gx);
+
+        const int yy = y + 2 * wv + half;
+        auto rowp = [&](int dy) { return lane_base + ((yy + dy + 64) & (V1_NR - 1)) * V1_ROWB; };
+        uint32_t m5[12], p5[12], m4[12], p4[12], m2[12], p2[12], z1[12];
+        load12(m5, rowp(-5));
+        load12(p5, rowp(+5));
+        load12(m4, rowp(-4));
+        load12(p4, rowp(+4));
+        load12(m2, rowp(-2) + V1_PLANE);
+        load12(p2, rowp(+2) + V1_PLANE);
+        load12(z1, rowp(0) + V1_PLANE);
+        const u32x4 z0v = lds_read_b128(rowp(0) + 16);
+        const uint32_t z0[4] = {z0v.x, z0v.y, z0v.z, z0v.w};
+
+        const bool row_interior = yy >= kMargin && yy < h - kMargin;
+        uint32_t out[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = 4 + k;
+            // quadruples (a,b,c,d) = (s[i], s[i+4], s[i+8], s[i+12]); ring offsets from ChESS.c:68-83
+            const uint32_t a0 = m5[c + 1], c0 = p5[c - 1], b0 = m2[c - 3], d0 = p2[c + 2];
+            const uint32_t a1 = m5[c], c1 = p5[c], b1 = z1[c - 3], d1 = z1[c + 2];
+            const uint32_t a2 = m5[c - 1], c2 = p5[c + 1], b2 = p2[c - 3], d2 = m2[c + 2];
+            const uint32_t a3 = m4[c - 2], c3 = p4[c + 2], b3 = p4[c - 2], d3 = m4[c + 2];
+            // halves never overflow 16 bits (sums <= 4080), so plain 32-bit adds act on both pixels
+            const uint32_t t10 = a0 + c0, t20 = b0 + d0, t11 = a1 + c1, t21 = b1 + d1;
+            const uint32_t t12 = a2 + c2, t22 = b2 + d2, t13 = a3 + c3, t23 = b3 + d3;
+            const uint32_t M = (t10 + t20 + t11) + (t21 + t12 + t22) + (t13 + t23);
+            const uint32_t Y = (pk_max_u16(t10, t20) + pk_max_u16(t11, t21)) +
+                               (pk_max_u16(t12, t22) + pk_max_u16(t13, t23));
+            const uint32_t X = (pk_max_u16(a0, c0) + pk_max_u16(b0, d0) + pk_max_u16(a1, c1)) +
+                               (pk_max_u16(b1, d1) + pk_max_u16(a2, c2) + pk_max_u16(b2, d2)) +
+                               (pk_max_u16(a3, c3) + pk_max_u16(b3, d3));
+            // local_mean = (I[x-1]+I[x]+I[x+1])*16/3, truncating (ChESS.c:86): floor(16n/3) = (n*349536)>>16, n <= 765
+            const uint32_t n = z1[c - 1] + z0[k] + z1[c];
+            const uint32_t lm_lo = __umul24(n & 0xffffu, 349536u);
+            const uint32_t lm_hi = __umul24(n >> 16, 349536u);
+            const uint32_t LM = __builtin_amdgcn_perm(lm_hi, lm_lo, 0x07060302u);
+            const uint32_t dev = pk_sub_i16(pk_max_u16(M, LM), pk_min_u16(M, LM));  // |M - LM|
+            const uint32_t yx = pk_sub_i16(Y, X);
+            uint32_t r = pk_sub_i16(pk_add_i16(yx, yx), dev);  // ChESS.c:104
+            if (CLAMP) r = pk_max_i16(r, 0u);
+            out[k] = row_interior ? (r & xmask[k]) : 0u;
+        }
+
+        if (yy < ye && x0 < w) {
+            int16_t* dst = resp + (long long)yy * w + x0;
+            if (x0 + 8 <= w) {
+                const uint4 v = make_uint4(out[0], out[1], out[2], out[3]);
+                __builtin_memcpy(dst, &v, 16);
+            } else {
+                for (int i = 0; i < w - x0; ++i) dst[i] = (int16_t)(out[i >> 1] >> (16 * (i & 1)));
+            }
+        }
+        if (HOT) {
+            // responses are clamped here, so "> 15" is "any bit above bit 3"
+            const uint32_t any = (out[0] | out[1] | out[2] | out[3]) & 0xfff0fff0u;
+            if (__ballot(any != 0 && yy < ye) != 0ull) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int v = (int)((out[i >> 1] >> (16 * (i & 1))) & 0xffffu);
+                    append_hot(v > kRespMin && yy < ye, yy * w + x0 + i, t, frame);
+                }
+            }
+        }
+
+        if (stager) stage_store(lds, (pr + 64) & (V1_NR - 1), st_ch, pre);
+        __syncthreads();
+    }
+}
+
+static int pick_segment(int w, int h, int nframes) {
+    // tall segments amortise the 10-row halo; short ones fill the 256 CUs when the batch is small
+    const long long strips = (w + V1_SW - 1) / V1_SW;
+    for (int seg : {256, 128, 64, 32}) {
+        const long long blocks = strips * ((h + seg - 1) / seg) * nframes;
+        if (blocks >= 2048 || seg == 32) return seg;
+    }
+    return 32;
+}
+
+// Production entry point.
 void launch_chess(const LevelBatch& lb, const CompTables& t, int frame0, int nframes, bool clamp, bool hot,
                   hipStream_t s) {
-    launch_chess_v0(lb, t, frame0, nframes, clamp, hot, s);
+    const int seg = pick_segment(lb.w, lb.h, nframes);
+    dim3 grid((lb.w + V1_SW - 1) / V1_SW, (lb.h + seg - 1) / seg, nframes);
+    const size_t lds = 2 * V1_PLANE;
+    if (hot)
+        hipLaunchKernelGGL((chess_v1_kernel<true, true>), grid, dim3(256), lds, s, lb, t, frame0, seg);
+    else if (clamp)
+        hipLaunchKernelGGL((chess_v1_kernel<true, false>), grid, dim3(256), lds, s, lb, t, frame0, seg);
+    else
+        hipLaunchKernelGGL((chess_v1_kernel<false, false>), grid, dim3(256), lds, s, lb, t, frame0, seg);
 }
 
 }  // namespace mrg

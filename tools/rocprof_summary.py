@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 --kernel-trace run (rocpd .db) for this repo's kernels.
+
+    python tools/rocprof_summary.py gpurun_out/<run>/<name>_results.db > profiles/<round>_<what>.txt
+
+One row per (kernel, grid): calls, average / min / max duration, registers, LDS.
+Only `mrg::` kernels are listed in detail; everything else (torch's synthetic
+frame generator, memsets, copies) is folded into one line.
+"""
+import sqlite3
+import sys
+
+
+def main(path):
+    c = sqlite3.connect(path)
+    rows = c.execute("select name, grid_x, grid_y, grid_z, workgroup_x, duration, vgpr_count, sgpr_count, lds_size "
+                     "from kernels").fetchall()
+    groups, other = {}, [0, 0.0]
+    for name, gx, gy, gz, wx, dur, vg, sg, lds in rows:
+        if "mrg::" not in name:
+            other[0] += 1
+            other[1] += dur
+            continue
+        short = name.split("(")[0].replace("void ", "")
+        groups.setdefault((short, gx, gy, gz, wx, vg, sg, lds), []).append(dur)
+    print(f"# {path}")
+    print(f"# {'kernel':58s} {'grid(threads)':>22s} {'wg':>5s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} "
+          f"{'max_us':>10s} {'total_ms':>9s} {'vgpr':>5s} {'sgpr':>5s} {'lds':>6s}")
+    tot = 0.0
+    for key, d in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
+        short, gx, gy, gz, wx, vg, sg, lds = key
+        tot += sum(d)
+        print(f"  {short:58s} {f'{gx}x{gy}x{gz}':>22s} {wx:5d} {len(d):6d} {sum(d) / len(d) / 1e3:10.1f} "
+              f"{min(d) / 1e3:10.1f} {max(d) / 1e3:10.1f} {sum(d) / 1e6:9.2f} {vg:5d} {sg:5d} {lds:6d}")
+    print(f"# mrg:: kernels total {tot / 1e6:.2f} ms; other kernels (synthetic-frame generator, fills, copies): "
+          f"{other[0]} calls, {other[1] / 1e6:.2f} ms")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
