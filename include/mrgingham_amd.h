@@ -90,9 +90,11 @@ enum {
     MRGINGHAM_AMD_ERR_CAPACITY = -3, /* an output capacity given by the caller was too small */
 };
 
-/* One context = one device, a small pool of HIP streams and the scratch
- * buffers (level images, responses, component tables) that are grown on
- * demand and reused.  Not thread-safe: use one context per host thread. */
+/* One context = one device, two HIP streams (the HBM-bound pixel kernels of a
+ * batch run back to back on one, the latency-bound component kernels underneath
+ * them on the other) and the per-level scratch buffers (level images, responses,
+ * component tables), grown on demand and reused.  Not thread-safe: use one
+ * context per host thread. */
 mrgingham_amd_ctx* mrgingham_amd_create(int device_ordinal);
 void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx);
 const char* mrgingham_amd_last_error(const mrgingham_amd_ctx* ctx);
@@ -151,7 +153,6 @@ int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames
 /* Tunables outside the reference's surface.  Known names:
  *   "hot_capacity_shift"  per-frame capacity of the hot-pixel / component tables is
  *                         (width*height) >> shift entries (default 3; 0 = one per pixel)
- *   "streams"             HIP streams a batch is spread over (default 4, max 8)
  *   "chess_v0"            1 = use the plain reference-shaped ChESS kernel (cross-check) */
 int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value);
 

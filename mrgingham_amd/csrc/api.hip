@@ -15,31 +15,43 @@
 
 namespace mrg {
 
-constexpr int kMaxStreams = 8;
+constexpr int kMaxLevel = 10;  // find_chessboard_corners.cc:433-436
 
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
 };
 
+// Scratch of one pyramid level: level images, the dense response and the
+// component tables.  Levels have their own scratch because the pixel kernels of
+// level L-1 run while the component search of level L is still working.
+struct LevelScratch {
+    int w = 0, h = 0, nframes = 0, cap = 0, cand_cap = 0, sort_cap = 0, pitch = 0, shift = -1;
+    long long arena_cap = 0;
+    DevBuf img, resp, lidx, hot_cnt, status, hot_pix, parent, comp_cnt, roots, comp_box, arena, cand, sortkeys;
+};
+
 }  // namespace mrg
 
 struct mrgingham_amd_ctx {
     int device = 0;
-    int nstreams = 4;
-    hipStream_t streams[mrg::kMaxStreams] = {};
+    // Two HIP streams per context: `pix` runs the HBM-bound pixel kernels
+    // (pyramid, ChESS) back to back, each over the whole batch; `cc` runs the
+    // latency-bound component kernels, which only occupy one workgroup per frame,
+    // underneath them.  Events order cc(L) after pix(L).
+    hipStream_t pix = nullptr, cc = nullptr;
+    hipEvent_t ev_pix[mrg::kMaxLevel + 1] = {};
+    hipEvent_t ev_cc_done = nullptr;
+    bool cc_pending = false;
     std::string err;
-    int cap_shift = 3;        // hot-pixel table capacity = pixels >> cap_shift per frame
-    bool use_v0 = false;      // reference-shaped ChESS kernel instead of the tuned one
-    bool async_error = false; // a queued batch could not be issued
+    int cap_shift = 3;    // hot-pixel table capacity = level pixels >> cap_shift per frame
+    bool use_v0 = false;  // reference-shaped ChESS kernel instead of the tuned one
 
-    // scratch
-    mrg::DevBuf level_img, resp, lidx, hot_cnt, status, hot_pix, parent, comp_cnt, roots, comp_box, arena, cand,
-        sortkeys, leader, need, nseeds, seeds, cand_xy, cand_counts, io_frame, io_out;
-    // what the scratch was sized for
-    int active_nframes = 0;   // frames of the batches queued since the last sync
-    int s_nframes = 0, s_w = 0, s_h = 0, s_pitch = 0, s_cap = 0, s_cand_cap = 0, s_sort_cap = 0, s_shift = -1;
-    long long s_arena_cap = 0;
+    mrg::LevelScratch lv[mrg::kMaxLevel + 1];
+    mrg::DevBuf leader, need, nseeds, seeds, cand_xy, cand_counts, aux_img, io_frame, io_out;
+    int pts_nframes = 0, pts_pitch = 0;
+    // levels (and frame counts) whose status words must be checked at the next sync
+    int pending_frames[mrg::kMaxLevel + 1] = {};
 
     // dominant-kernel timing
     bool timing = false;
@@ -80,8 +92,8 @@ static int ensure(mrgingham_amd_ctx* ctx, DevBuf& b, size_t bytes) {
 }
 
 static int level_dims(int W, int H, int level, int* w, int* h) {
-    if (level < 0 || level > 10) return -1;  // find_chessboard_corners.cc:433-441
-    auto rnd = [level](int v) {              // cvRound(v / 2^level): ties to even
+    if (level < 0 || level > kMaxLevel) return -1;  // find_chessboard_corners.cc:433-441
+    auto rnd = [level](int v) {                     // cvRound(v / 2^level): ties to even
         const int s = 1 << level;
         int q = v >> level;
         const int rem = v & (s - 1), half = s >> 1;
@@ -103,14 +115,17 @@ static int validate_frames(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* f
     return 0;
 }
 
-// Scratch for a batch of nframes W x H frames with up to `pitch` points per frame.
-static int ensure_scratch(mrgingham_amd_ctx* ctx, int nframes, int W, int H, int pitch) {
-    if (nframes <= ctx->s_nframes && W == ctx->s_w && H == ctx->s_h && pitch <= ctx->s_pitch &&
-        ctx->s_shift == ctx->cap_shift)
-        return 0;
-    nframes = nframes > ctx->s_nframes ? nframes : ctx->s_nframes;
-    pitch = pitch > ctx->s_pitch ? pitch : ctx->s_pitch;
-    const long long px = (long long)W * H;
+// Scratch of level `level` for a batch of nframes W x H frames and up to `pitch` points per frame.
+static int ensure_level(mrgingham_amd_ctx* ctx, int level, int nframes, int W, int H, int pitch) {
+    LevelScratch& L = ctx->lv[level];
+    int w, h;
+    level_dims(W, H, level, &w, &h);
+    if (nframes <= L.nframes && w == L.w && h == L.h && pitch <= L.pitch && L.shift == ctx->cap_shift) return 0;
+    if (w == L.w && h == L.h) {
+        nframes = nframes > L.nframes ? nframes : L.nframes;
+        pitch = pitch > L.pitch ? pitch : L.pitch;
+    }
+    const long long px = (long long)w * h;
     long long cap = px >> ctx->cap_shift;
     if (cap < 4096) cap = 4096;
     if (cap > px) cap = px > 0 ? px : 1;
@@ -120,101 +135,73 @@ static int ensure_scratch(mrgingham_amd_ctx* ctx, int nframes, int W, int H, int
     long long sort_cap = 1;
     while (sort_cap < cand_cap) sort_cap <<= 1;
     const long long arena_cap = 5 * cap + 16LL * (pitch > 1024 ? pitch : 1024);
-    int w1 = 0, h1 = 0;
-    level_dims(W, H, 1, &w1, &h1);
     const size_t nf = (size_t)nframes;
     int rc = 0;
-    if ((rc = ensure(ctx, ctx->level_img, nf * (size_t)w1 * (size_t)h1 + 16))) return rc;
-    if ((rc = ensure(ctx, ctx->resp, nf * (size_t)px * 2 + 16))) return rc;
-    if ((rc = ensure(ctx, ctx->lidx, nf * (size_t)px * 4 + 16))) return rc;
-    if (nf * 4 > ctx->status.bytes) {
-        if ((rc = ensure(ctx, ctx->hot_cnt, nf * 4))) return rc;
-        if ((rc = ensure(ctx, ctx->status, nf * 4))) return rc;
-        MRG_HIP_CHECK(hipMemset(ctx->hot_cnt.p, 0, ctx->hot_cnt.bytes));
-        MRG_HIP_CHECK(hipMemset(ctx->status.p, 0, ctx->status.bytes));
+    if (level > 0 && (rc = ensure(ctx, L.img, nf * (size_t)px + 16))) return rc;
+    if ((rc = ensure(ctx, L.resp, nf * (size_t)px * 2 + 16))) return rc;
+    if ((rc = ensure(ctx, L.lidx, nf * (size_t)px * 4 + 16))) return rc;
+    if (nf * 4 > L.status.bytes) {
+        if ((rc = ensure(ctx, L.hot_cnt, nf * 4))) return rc;
+        if ((rc = ensure(ctx, L.status, nf * 4))) return rc;
+        MRG_HIP_CHECK(hipMemset(L.hot_cnt.p, 0, L.hot_cnt.bytes));
+        MRG_HIP_CHECK(hipMemset(L.status.p, 0, L.status.bytes));
     }
-    if ((rc = ensure(ctx, ctx->hot_pix, nf * (size_t)cap * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->parent, nf * (size_t)cap * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->comp_cnt, nf * (size_t)cap * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->roots, nf * (size_t)cap * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->comp_box, nf * (size_t)cap * 16))) return rc;
-    if ((rc = ensure(ctx, ctx->arena, nf * (size_t)arena_cap * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->cand, nf * (size_t)cand_cap * sizeof(Cand)))) return rc;
-    if ((rc = ensure(ctx, ctx->sortkeys, nf * (size_t)sort_cap * 8))) return rc;
-    const size_t np = nf * (size_t)(pitch > 0 ? pitch : 1);
+    if ((rc = ensure(ctx, L.hot_pix, nf * (size_t)cap * 4))) return rc;
+    if ((rc = ensure(ctx, L.parent, nf * (size_t)cap * 4))) return rc;
+    if ((rc = ensure(ctx, L.comp_cnt, nf * (size_t)cap * 4))) return rc;
+    if ((rc = ensure(ctx, L.roots, nf * (size_t)cap * 4))) return rc;
+    if ((rc = ensure(ctx, L.comp_box, nf * (size_t)cap * 16))) return rc;
+    if ((rc = ensure(ctx, L.arena, nf * (size_t)arena_cap * 4))) return rc;
+    if ((rc = ensure(ctx, L.cand, nf * (size_t)cand_cap * sizeof(Cand)))) return rc;
+    if ((rc = ensure(ctx, L.sortkeys, nf * (size_t)sort_cap * 8))) return rc;
+    L.w = w; L.h = h; L.nframes = nframes; L.pitch = pitch;
+    L.cap = (int)cap; L.cand_cap = (int)cand_cap; L.sort_cap = (int)sort_cap; L.arena_cap = arena_cap;
+    L.shift = ctx->cap_shift;
+    return 0;
+}
+
+// Per-batch point scratch shared by the levels (the component kernels of the
+// levels of one batch run one after the other on the cc stream).
+static int ensure_points(mrgingham_amd_ctx* ctx, int nframes, int pitch) {
+    if (nframes <= ctx->pts_nframes && pitch <= ctx->pts_pitch) return 0;
+    nframes = nframes > ctx->pts_nframes ? nframes : ctx->pts_nframes;
+    pitch = pitch > ctx->pts_pitch ? pitch : ctx->pts_pitch;
+    const size_t np = (size_t)nframes * (size_t)(pitch > 0 ? pitch : 1);
+    int rc = 0;
     if ((rc = ensure(ctx, ctx->leader, np * 4))) return rc;
     if ((rc = ensure(ctx, ctx->need, np * 4))) return rc;
     if ((rc = ensure(ctx, ctx->nseeds, np * 4))) return rc;
     if ((rc = ensure(ctx, ctx->seeds, np * 9 * 4))) return rc;
     if ((rc = ensure(ctx, ctx->cand_xy, np * 8))) return rc;
-    if ((rc = ensure(ctx, ctx->cand_counts, nf * 4))) return rc;
-    ctx->s_nframes = nframes;
-    ctx->s_w = W;
-    ctx->s_h = H;
-    ctx->s_pitch = pitch;
-    ctx->s_cap = (int)cap;
-    ctx->s_cand_cap = (int)cand_cap;
-    ctx->s_sort_cap = (int)sort_cap;
-    ctx->s_arena_cap = arena_cap;
-    ctx->s_shift = ctx->cap_shift;
+    if ((rc = ensure(ctx, ctx->cand_counts, (size_t)nframes * 4))) return rc;
+    ctx->pts_nframes = nframes;
+    ctx->pts_pitch = pitch;
     return 0;
 }
 
-static CompTables tables_of(mrgingham_amd_ctx* ctx) {
+static CompTables tables_of(const LevelScratch& L) {
     CompTables t;
-    t.cap = ctx->s_cap;
-    t.hot_cnt = (int32_t*)ctx->hot_cnt.p;
-    t.hot_pix = (int32_t*)ctx->hot_pix.p;
-    t.parent = (int32_t*)ctx->parent.p;
-    t.comp_cnt = (int32_t*)ctx->comp_cnt.p;
-    t.comp_box = (int4*)ctx->comp_box.p;
-    t.roots = (int32_t*)ctx->roots.p;
-    t.lidx = (int32_t*)ctx->lidx.p;
-    t.lidx_pitch = (long long)ctx->s_w * ctx->s_h;
-    t.arena = (uint32_t*)ctx->arena.p;
-    t.arena_cap = ctx->s_arena_cap;
-    t.cand_cap = ctx->s_cand_cap;
-    t.cand = (Cand*)ctx->cand.p;
-    t.sortkeys = (unsigned long long*)ctx->sortkeys.p;
-    t.sort_cap = ctx->s_sort_cap;
-    t.status = (int32_t*)ctx->status.p;
+    t.cap = L.cap;
+    t.hot_cnt = (int32_t*)L.hot_cnt.p;
+    t.hot_pix = (int32_t*)L.hot_pix.p;
+    t.parent = (int32_t*)L.parent.p;
+    t.comp_cnt = (int32_t*)L.comp_cnt.p;
+    t.comp_box = (int4*)L.comp_box.p;
+    t.roots = (int32_t*)L.roots.p;
+    t.lidx = (int32_t*)L.lidx.p;
+    t.lidx_pitch = (long long)L.w * L.h;
+    t.arena = (uint32_t*)L.arena.p;
+    t.arena_cap = L.arena_cap;
+    t.cand_cap = L.cand_cap;
+    t.cand = (Cand*)L.cand.p;
+    t.sortkeys = (unsigned long long*)L.sortkeys.p;
+    t.sort_cap = L.sort_cap;
+    t.status = (int32_t*)L.status.p;
     return t;
 }
 
-// Level image + response of frames [f0, f0+n) at `level`, queued on `s`.
-// Returns the LevelBatch the later kernels of the level use.
-static LevelBatch queue_level_response(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int level, int f0,
-                                       int n, bool clamp, bool hot, int16_t* resp_override, hipStream_t s,
-                                       bool time_it) {
-    LevelBatch lb;
-    int w, h;
-    level_dims(fr->width, fr->height, level, &w, &h);
-    lb.nframes = fr->nframes;
-    lb.w = w;
-    lb.h = h;
-    if (level == 0) {
-        lb.img = fr->frames;
-        lb.img_pitch = fr->frame_pitch;
-        lb.img_stride = fr->stride;
-    } else {
-        FrameBatch fb{fr->frames, fr->frame_pitch, fr->width, fr->height, fr->stride};
-        // scratch slices are per frame and level-independent: chunks on different
-        // streams may be at different levels at the same time
-        int w1, h1;
-        level_dims(fr->width, fr->height, 1, &w1, &h1);
-        const long long pitch = (long long)w1 * h1;
-        launch_decimate(fb, level, (uint8_t*)ctx->level_img.p, pitch, w, h, f0, n, s);
-        lb.img = (const uint8_t*)ctx->level_img.p;
-        lb.img_pitch = pitch;
-        lb.img_stride = w;
-    }
-    lb.resp = resp_override ? resp_override : (int16_t*)ctx->resp.p;
-    lb.resp_pitch = resp_override ? (long long)w * h : (long long)fr->width * fr->height;
-    CompTables t = tables_of(ctx);
-    if (hot) {
-        hipMemsetAsync((int32_t*)ctx->hot_cnt.p + f0, 0, sizeof(int32_t) * n, s);
-        hipMemsetAsync((int32_t*)ctx->status.p + f0, 0, sizeof(int32_t) * n, s);
-    }
+static void launch_chess_any(mrgingham_amd_ctx* ctx, const LevelBatch& lb, const CompTables& t, int n, bool clamp,
+                             bool hot, hipStream_t s, bool time_it) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (time_it && ctx->timing) {
         auto get = [ctx]() {
@@ -227,23 +214,67 @@ static LevelBatch queue_level_response(mrgingham_amd_ctx* ctx, const mrgingham_a
         e1 = get();
         hipEventRecord(e0, s);
     }
-    if (w > 0 && h > 0) {
-        if (ctx->use_v0) launch_chess_v0(lb, t, f0, n, clamp, hot, s);
-        else launch_chess(lb, t, f0, n, clamp, hot, s);
+    if (lb.w > 0 && lb.h > 0 && n > 0) {
+        if (ctx->use_v0) launch_chess_v0(lb, t, 0, n, clamp, hot, s);
+        else launch_chess(lb, t, 0, n, clamp, hot, s);
     }
     if (e0) {
         hipEventRecord(e1, s);
         ctx->events.emplace_back(e0, e1);
     }
-    return lb;
 }
 
-static void chunk_of(const mrgingham_amd_ctx* ctx, int nframes, int c, int* f0, int* n) {
-    const int per = (nframes + ctx->nstreams - 1) / ctx->nstreams;
-    *f0 = c * per;
-    int e = *f0 + per;
-    if (e > nframes) e = nframes;
-    *n = e > *f0 ? e - *f0 : 0;
+// Every detect / refine / chain call starts here: the pixel stream must not
+// overwrite level scratch the component stream of the previous call still reads.
+static void begin_op(mrgingham_amd_ctx* ctx) {
+    if (ctx->cc_pending) hipStreamWaitEvent(ctx->pix, ctx->ev_cc_done, 0);
+}
+static void end_op(mrgingham_amd_ctx* ctx) {
+    hipEventRecord(ctx->ev_cc_done, ctx->cc);
+    ctx->cc_pending = true;
+}
+
+// Level images of levels [1, max_level] of the batch into the level scratch, on the pixel stream.
+static void queue_level_images(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int max_level) {
+    const FrameBatch fb{fr->frames, fr->frame_pitch, fr->width, fr->height, fr->stride};
+    PyramidOut po{};
+    int top = max_level < 3 ? max_level : 3;
+    for (int L = 1; L <= top; ++L) {
+        po.out[L - 1] = (uint8_t*)ctx->lv[L].img.p;
+        po.w[L - 1] = ctx->lv[L].w;
+        po.h[L - 1] = ctx->lv[L].h;
+    }
+    if (top >= 1) launch_pyramid(fb, po, top, fr->nframes, ctx->pix);
+    for (int L = 4; L <= max_level; ++L)
+        launch_decimate(fb, L, (uint8_t*)ctx->lv[L].img.p, (long long)ctx->lv[L].w * ctx->lv[L].h, ctx->lv[L].w,
+                        ctx->lv[L].h, 0, fr->nframes, ctx->pix);
+}
+
+// ChESS response (+ hot list) of one level for the whole batch on the pixel
+// stream; records ev_pix[level].  Level images of levels > 0 must already be queued.
+static LevelBatch queue_level_chess(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int level) {
+    LevelScratch& L = ctx->lv[level];
+    LevelBatch lb;
+    lb.nframes = fr->nframes;
+    lb.w = L.w;
+    lb.h = L.h;
+    if (level == 0) {
+        lb.img = fr->frames;
+        lb.img_pitch = fr->frame_pitch;
+        lb.img_stride = fr->stride;
+    } else {
+        lb.img = (const uint8_t*)L.img.p;
+        lb.img_pitch = (long long)L.w * L.h;
+        lb.img_stride = L.w;
+    }
+    lb.resp = (int16_t*)L.resp.p;
+    lb.resp_pitch = (long long)L.w * L.h;
+    hipMemsetAsync(L.hot_cnt.p, 0, sizeof(int32_t) * fr->nframes, ctx->pix);
+    hipMemsetAsync(L.status.p, 0, sizeof(int32_t) * fr->nframes, ctx->pix);
+    launch_chess_any(ctx, lb, tables_of(L), fr->nframes, true, true, ctx->pix, level == 0);
+    hipEventRecord(ctx->ev_pix[level], ctx->pix);
+    if (fr->nframes > ctx->pending_frames[level]) ctx->pending_frames[level] = fr->nframes;
+    return lb;
 }
 
 }  // namespace mrg
@@ -274,19 +305,18 @@ mrgingham_amd_ctx* mrgingham_amd_create(int device_ordinal) {
     if (hipSetDevice(device_ordinal) != hipSuccess) return nullptr;
     mrgingham_amd_ctx* ctx = new mrgingham_amd_ctx();
     ctx->device = device_ordinal;
-    const char* ns = getenv("MRGINGHAM_AMD_STREAMS");
-    if (ns) {
-        const int v = atoi(ns);
-        if (v >= 1 && v <= kMaxStreams) ctx->nstreams = v;
-    }
     const char* v0 = getenv("MRGINGHAM_AMD_CHESS_V0");
     ctx->use_v0 = v0 && atoi(v0) != 0;
-    for (int i = 0; i < ctx->nstreams; ++i)
-        if (hipStreamCreateWithFlags(&ctx->streams[i], hipStreamNonBlocking) != hipSuccess) {
-            fprintf(stderr, "mrgingham_amd: hipStreamCreate failed\n");
-            delete ctx;
-            return nullptr;
-        }
+    bool ok = hipStreamCreateWithFlags(&ctx->pix, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&ctx->cc, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&ctx->ev_cc_done, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i <= kMaxLevel; ++i)
+        ok = hipEventCreateWithFlags(&ctx->ev_pix[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        fprintf(stderr, "mrgingham_amd: could not create HIP streams/events\n");
+        mrgingham_amd_destroy(ctx);
+        return nullptr;
+    }
     return ctx;
 }
 
@@ -294,16 +324,23 @@ void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
-    DevBuf* bufs[] = {&ctx->level_img, &ctx->resp, &ctx->lidx, &ctx->hot_cnt, &ctx->status, &ctx->hot_pix,
-                      &ctx->parent, &ctx->comp_cnt, &ctx->roots, &ctx->comp_box, &ctx->arena, &ctx->cand,
-                      &ctx->sortkeys, &ctx->leader, &ctx->need, &ctx->nseeds, &ctx->seeds, &ctx->cand_xy,
-                      &ctx->cand_counts, &ctx->io_frame, &ctx->io_out};
+    for (LevelScratch& L : ctx->lv) {
+        DevBuf* bufs[] = {&L.img, &L.resp, &L.lidx, &L.hot_cnt, &L.status, &L.hot_pix, &L.parent,
+                          &L.comp_cnt, &L.roots, &L.comp_box, &L.arena, &L.cand, &L.sortkeys};
+        for (DevBuf* b : bufs)
+            if (b->p) hipFree(b->p);
+    }
+    DevBuf* bufs[] = {&ctx->leader, &ctx->need, &ctx->nseeds, &ctx->seeds, &ctx->cand_xy, &ctx->cand_counts,
+                      &ctx->aux_img, &ctx->io_frame, &ctx->io_out};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     for (auto& pr : ctx->events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : ctx->event_pool) hipEventDestroy(e);
-    for (int i = 0; i < ctx->nstreams; ++i)
-        if (ctx->streams[i]) hipStreamDestroy(ctx->streams[i]);
+    for (hipEvent_t e : ctx->ev_pix)
+        if (e) hipEventDestroy(e);
+    if (ctx->ev_cc_done) hipEventDestroy(ctx->ev_cc_done);
+    if (ctx->pix) hipStreamDestroy(ctx->pix);
+    if (ctx->cc) hipStreamDestroy(ctx->cc);
     delete ctx;
 }
 
@@ -322,15 +359,6 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
         return 0;
     }
     if (!strcmp(name, "chess_v0")) { ctx->use_v0 = value != 0; return 0; }
-    if (!strcmp(name, "streams")) {
-        if (value < 1 || value > kMaxStreams) return MRGINGHAM_AMD_ERR_ARG;
-        hipSetDevice(ctx->device);
-        for (int i = ctx->nstreams; i < value; ++i)
-            if (!ctx->streams[i] && hipStreamCreateWithFlags(&ctx->streams[i], hipStreamNonBlocking) != hipSuccess)
-                return MRGINGHAM_AMD_ERR_DEVICE;
-        ctx->nstreams = value;
-        return 0;
-    }
     return MRGINGHAM_AMD_ERR_ARG;
 }
 
@@ -355,25 +383,28 @@ double mrgingham_amd_chess_kernel_ms(mrgingham_amd_ctx* ctx, int* nlaunches) {
 int mrgingham_amd_sync(mrgingham_amd_ctx* ctx) {
     if (!ctx) return MRGINGHAM_AMD_ERR_ARG;
     MRG_HIP_CHECK(hipSetDevice(ctx->device));
-    for (int i = 0; i < ctx->nstreams; ++i) MRG_HIP_CHECK(hipStreamSynchronize(ctx->streams[i]));
+    MRG_HIP_CHECK(hipStreamSynchronize(ctx->pix));
+    MRG_HIP_CHECK(hipStreamSynchronize(ctx->cc));
+    ctx->cc_pending = false;
     MRG_HIP_CHECK(hipGetLastError());
-    if (ctx->async_error) { ctx->async_error = false; return MRGINGHAM_AMD_ERR_DEVICE; }
-    const int nact = ctx->active_nframes;
-    ctx->active_nframes = 0;
-    if (nact > 0 && ctx->status.p) {
+    int rc = MRGINGHAM_AMD_OK;
+    for (int level = 0; level <= kMaxLevel; ++level) {
+        const int nact = ctx->pending_frames[level];
+        ctx->pending_frames[level] = 0;
+        if (nact <= 0 || !ctx->lv[level].status.p) continue;
         ctx->host_status.resize(nact);
-        MRG_HIP_CHECK(hipMemcpy(ctx->host_status.data(), ctx->status.p, sizeof(int32_t) * nact,
+        MRG_HIP_CHECK(hipMemcpy(ctx->host_status.data(), ctx->lv[level].status.p, sizeof(int32_t) * nact,
                                 hipMemcpyDeviceToHost));
-        for (int f = 0; f < nact; ++f)
+        for (int f = 0; f < nact && rc == MRGINGHAM_AMD_OK; ++f)
             if (ctx->host_status[f]) {
-                MRG_HIP_CHECK(hipMemset(ctx->status.p, 0, sizeof(int32_t) * nact));
-                return fail(ctx, MRGINGHAM_AMD_ERR_CAPACITY,
-                            "frame %d: component tables overflowed (status %d); lower \"hot_capacity_shift\" "
-                            "(now %d) with mrgingham_amd_set_option and re-run",
-                            f, ctx->host_status[f], ctx->cap_shift);
+                MRG_HIP_CHECK(hipMemset(ctx->lv[level].status.p, 0, sizeof(int32_t) * nact));
+                rc = fail(ctx, MRGINGHAM_AMD_ERR_CAPACITY,
+                          "frame %d, level %d: component tables overflowed (status %d); lower "
+                          "\"hot_capacity_shift\" (now %d) with mrgingham_amd_set_option and re-run",
+                          f, level, ctx->host_status[f], ctx->cap_shift);
             }
     }
-    return MRGINGHAM_AMD_OK;
+    return rc;
 }
 
 int mrgingham_amd_chess_response_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int level,
@@ -385,13 +416,26 @@ int mrgingham_amd_chess_response_batch(mrgingham_amd_ctx* ctx, const mrgingham_a
         return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "bad level %d or NULL response", level);
     if (fr->nframes == 0) return 0;
     MRG_HIP_CHECK(hipSetDevice(ctx->device));
-    if (level > 0) {
-        int w1, h1;
-        level_dims(fr->width, fr->height, 1, &w1, &h1);
-        if ((rc = ensure(ctx, ctx->level_img, (size_t)fr->nframes * w1 * h1 + 16))) return rc;
-    }
     hipStream_t s = (hipStream_t)stream;  // used as given: NULL is HIP's default stream
-    queue_level_response(ctx, fr, level, 0, fr->nframes, clamp != 0, false, d_response, s, level == 0);
+    LevelBatch lb;
+    lb.nframes = fr->nframes;
+    lb.w = w;
+    lb.h = h;
+    if (level == 0) {
+        lb.img = fr->frames;
+        lb.img_pitch = fr->frame_pitch;
+        lb.img_stride = fr->stride;
+    } else {
+        if ((rc = ensure(ctx, ctx->aux_img, (size_t)fr->nframes * w * h + 16))) return rc;
+        const FrameBatch fb{fr->frames, fr->frame_pitch, fr->width, fr->height, fr->stride};
+        launch_decimate(fb, level, (uint8_t*)ctx->aux_img.p, (long long)w * h, w, h, 0, fr->nframes, s);
+        lb.img = (const uint8_t*)ctx->aux_img.p;
+        lb.img_pitch = (long long)w * h;
+        lb.img_stride = w;
+    }
+    lb.resp = d_response;
+    lb.resp_pitch = (long long)w * h;
+    launch_chess_any(ctx, lb, CompTables{}, fr->nframes, clamp != 0, false, s, level == 0);
     MRG_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -412,8 +456,18 @@ int mrgingham_amd_decimate_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_fra
                                            fr->stride, w, h, hipMemcpyDeviceToDevice, s));
         return 0;
     }
-    FrameBatch fb{fr->frames, fr->frame_pitch, fr->width, fr->height, fr->stride};
-    launch_decimate(fb, level, d_out, (long long)w * h, w, h, 0, fr->nframes, s);
+    const FrameBatch fb{fr->frames, fr->frame_pitch, fr->width, fr->height, fr->stride};
+    if (level <= 3) {
+        // the one-pass pyramid kernel, restricted to the requested level (same arithmetic, tested against
+        // the single-level kernel)
+        PyramidOut po{};
+        po.out[level - 1] = d_out;
+        po.w[level - 1] = w;
+        po.h[level - 1] = h;
+        launch_pyramid(fb, po, level, fr->nframes, s);
+    } else {
+        launch_decimate(fb, level, d_out, (long long)w * h, w, h, 0, fr->nframes, s);
+    }
     MRG_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -442,18 +496,18 @@ int mrgingham_amd_detect_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frame
     if (!d_xy || !d_counts || capacity_per_frame < 0) return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "NULL outputs");
     if (fr->nframes == 0) return 0;
     MRG_HIP_CHECK(hipSetDevice(ctx->device));
-    if ((rc = ensure_scratch(ctx, fr->nframes, fr->width, fr->height, 0))) return rc;
-    if (fr->nframes > ctx->active_nframes) ctx->active_nframes = fr->nframes;
-    const CompTables t = tables_of(ctx);
-    const DetectOut out{d_xy, capacity_per_frame, d_counts};
-    for (int c = 0; c < ctx->nstreams; ++c) {
-        int f0, n;
-        chunk_of(ctx, fr->nframes, c, &f0, &n);
-        if (n <= 0) continue;
-        hipStream_t s = ctx->streams[c];
-        const LevelBatch lb = queue_level_response(ctx, fr, level, f0, n, true, true, nullptr, s, level == 0);
-        launch_cc_detect(lb, t, level, out, f0, n, s);
+    if ((rc = ensure_level(ctx, level, fr->nframes, fr->width, fr->height, 0))) return rc;
+    begin_op(ctx);
+    if (level > 0) {
+        const FrameBatch fb{fr->frames, fr->frame_pitch, fr->width, fr->height, fr->stride};
+        launch_decimate(fb, level, (uint8_t*)ctx->lv[level].img.p, (long long)w * h, w, h, 0, fr->nframes,
+                        ctx->pix);
     }
+    const LevelBatch lb = queue_level_chess(ctx, fr, level);
+    MRG_HIP_CHECK(hipStreamWaitEvent(ctx->cc, ctx->ev_pix[level], 0));
+    launch_cc_detect(lb, tables_of(ctx->lv[level]), level, DetectOut{d_xy, capacity_per_frame, d_counts}, 0,
+                     fr->nframes, ctx->cc);
+    end_op(ctx);
     MRG_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -470,19 +524,20 @@ int mrgingham_amd_refine_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frame
         return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "NULL point buffers");
     if (fr->nframes == 0) return 0;
     MRG_HIP_CHECK(hipSetDevice(ctx->device));
-    if ((rc = ensure_scratch(ctx, fr->nframes, fr->width, fr->height, points_pitch))) return rc;
-    if (fr->nframes > ctx->active_nframes) ctx->active_nframes = fr->nframes;
-    const CompTables t = tables_of(ctx);
+    if ((rc = ensure_level(ctx, level, fr->nframes, fr->width, fr->height, points_pitch))) return rc;
+    if ((rc = ensure_points(ctx, fr->nframes, points_pitch))) return rc;
+    begin_op(ctx);
+    if (level > 0) {
+        const FrameBatch fb{fr->frames, fr->frame_pitch, fr->width, fr->height, fr->stride};
+        launch_decimate(fb, level, (uint8_t*)ctx->lv[level].img.p, (long long)w * h, w, h, 0, fr->nframes,
+                        ctx->pix);
+    }
+    const LevelBatch lb = queue_level_chess(ctx, fr, level);
     RefineIO io{d_points, d_levels, d_npoints, points_pitch, d_nrefined, (int32_t*)ctx->leader.p,
                 (int32_t*)ctx->need.p, (int32_t*)ctx->nseeds.p, (uint32_t*)ctx->seeds.p};
-    for (int c = 0; c < ctx->nstreams; ++c) {
-        int f0, n;
-        chunk_of(ctx, fr->nframes, c, &f0, &n);
-        if (n <= 0) continue;
-        hipStream_t s = ctx->streams[c];
-        const LevelBatch lb = queue_level_response(ctx, fr, level, f0, n, true, true, nullptr, s, level == 0);
-        launch_cc_refine(lb, t, level, io, f0, n, s);
-    }
+    MRG_HIP_CHECK(hipStreamWaitEvent(ctx->cc, ctx->ev_pix[level], 0));
+    launch_cc_refine(lb, tables_of(ctx->lv[level]), level, io, 0, fr->nframes, ctx->cc);
+    end_op(ctx);
     MRG_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -498,26 +553,28 @@ int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames
         return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "NULL point buffers");
     if (fr->nframes == 0) return 0;
     MRG_HIP_CHECK(hipSetDevice(ctx->device));
-    if ((rc = ensure_scratch(ctx, fr->nframes, fr->width, fr->height, points_pitch))) return rc;
-    if (fr->nframes > ctx->active_nframes) ctx->active_nframes = fr->nframes;
-    const CompTables t = tables_of(ctx);
+    for (int L = 0; L <= start_level; ++L)
+        if ((rc = ensure_level(ctx, L, fr->nframes, fr->width, fr->height, points_pitch))) return rc;
+    if ((rc = ensure_points(ctx, fr->nframes, points_pitch))) return rc;
     const DetectOut out{(int32_t*)ctx->cand_xy.p, points_pitch, (int32_t*)ctx->cand_counts.p};
     RefineIO io{d_points, d_levels, d_npoints, points_pitch, nullptr, (int32_t*)ctx->leader.p,
                 (int32_t*)ctx->need.p, (int32_t*)ctx->nseeds.p, (uint32_t*)ctx->seeds.p};
-    for (int c = 0; c < ctx->nstreams; ++c) {
-        int f0, n;
-        chunk_of(ctx, fr->nframes, c, &f0, &n);
-        if (n <= 0) continue;
-        hipStream_t s = ctx->streams[c];
-        LevelBatch lb = queue_level_response(ctx, fr, start_level, f0, n, true, true, nullptr, s, start_level == 0);
-        launch_cc_detect(lb, t, start_level, out, f0, n, s);                       // mrgingham.cc:50
-        launch_points_from_candidates(out.xy, out.capacity, out.counts, d_points,  // find_grid.cc:353-354
-                                      d_levels, d_npoints, points_pitch, start_level, f0, n, s);
-        for (int L = start_level - 1; L >= 0; --L) {                               // mrgingham.cc:87-99
-            lb = queue_level_response(ctx, fr, L, f0, n, true, true, nullptr, s, L == 0);
-            launch_cc_refine(lb, t, L, io, f0, n, s);
-        }
+    begin_op(ctx);
+    // pixel stream: every level image in one pass over the frames, then the responses top-down
+    queue_level_images(ctx, fr, start_level);
+    LevelBatch lbs[kMaxLevel + 1];
+    for (int L = start_level; L >= 0; --L) lbs[L] = queue_level_chess(ctx, fr, L);
+    // component stream: detect at the top (mrgingham.cc:50), candidates -> corners
+    // (find_grid.cc:353-354), then refine level by level (mrgingham.cc:87-99)
+    MRG_HIP_CHECK(hipStreamWaitEvent(ctx->cc, ctx->ev_pix[start_level], 0));
+    launch_cc_detect(lbs[start_level], tables_of(ctx->lv[start_level]), start_level, out, 0, fr->nframes, ctx->cc);
+    launch_points_from_candidates(out.xy, out.capacity, out.counts, d_points, d_levels, d_npoints, points_pitch,
+                                  start_level, 0, fr->nframes, ctx->cc);
+    for (int L = start_level - 1; L >= 0; --L) {
+        MRG_HIP_CHECK(hipStreamWaitEvent(ctx->cc, ctx->ev_pix[L], 0));
+        launch_cc_refine(lbs[L], tables_of(ctx->lv[L]), L, io, 0, fr->nframes, ctx->cc);
     }
+    end_op(ctx);
     MRG_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -537,7 +594,6 @@ static mrgingham_amd_ctx* thread_ctx() {
     if (!h.ctx) {
         const char* d = getenv("MRGINGHAM_AMD_DEVICE");
         h.ctx = mrgingham_amd_create(d ? atoi(d) : 0);
-        if (h.ctx) mrgingham_amd_set_option(h.ctx, "streams", 1);
     }
     return h.ctx;
 }
@@ -550,7 +606,7 @@ static int upload_frame(mrgingham_amd_ctx* ctx, const void* host, int rows, int 
     // stream-ordered on streams[0]: the kernels that read it are queued on the same stream
     if (rows > 0 && cols > 0)
         MRG_HIP_CHECK(hipMemcpy2DAsync(ctx->io_frame.p, cols, host, stride, cols, rows, hipMemcpyHostToDevice,
-                                       ctx->streams[0]));
+                                       ctx->pix));
     fr->frames = (const uint8_t*)ctx->io_frame.p;
     fr->frame_pitch = (int64_t)rows * cols;
     fr->nframes = 1;
@@ -571,13 +627,13 @@ void mrgingham_ChESS_response_5(int16_t* response, const uint8_t* image, int w, 
     mrgingham_amd_frames fr;
     if (upload_frame(ctx, image, h, w, stride, &fr)) return;
     if (ensure(ctx, ctx->io_out, (size_t)w * h * 2 + 64)) return;
-    if (mrgingham_amd_chess_response_batch(ctx, &fr, 0, 0, (int16_t*)ctx->io_out.p, ctx->streams[0])) return;
+    if (mrgingham_amd_chess_response_batch(ctx, &fr, 0, 0, (int16_t*)ctx->io_out.p, ctx->pix)) return;
     // interior only, like the reference: the 7-pixel frame of `response` is not touched
     const size_t off = (size_t)kMargin * w + kMargin;
     hipError_t e = hipMemcpy2DAsync(response + off, (size_t)w * 2, (const int16_t*)ctx->io_out.p + off,
                                     (size_t)w * 2, (size_t)(w - 2 * kMargin) * 2, h - 2 * kMargin,
-                                    hipMemcpyDeviceToHost, ctx->streams[0]);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->streams[0]);
+                                    hipMemcpyDeviceToHost, ctx->pix);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->pix);
     if (e != hipSuccess) fprintf(stderr, "mrgingham_amd: ChESS response failed: %s\n", hipGetErrorString(e));
 }
 
@@ -616,8 +672,9 @@ bool find_chessboard_corners_from_image_array_C(int Nrows, int Ncols, int stride
     for (int attempt = 0; attempt < 2; ++attempt) {
         mrgingham_amd_frames fr;
         if (upload_frame(ctx, imagebuffer, Nrows, Ncols, stride, &fr)) break;
-        if (ensure_scratch(ctx, 1, Ncols, Nrows, 0)) break;
-        const int cap = ctx->s_cand_cap;
+        if (ensure_level(ctx, image_pyramid_level, 1, Ncols, Nrows, 0)) break;
+        if (ensure_points(ctx, 1, 1)) break;
+        const int cap = ctx->lv[image_pyramid_level].cand_cap;
         if (ensure(ctx, ctx->io_out, (size_t)cap * 8 + 64)) break;
         if (mrgingham_amd_detect_batch(ctx, &fr, image_pyramid_level, (int32_t*)ctx->io_out.p, cap,
                                        (int32_t*)ctx->cand_counts.p))
@@ -658,13 +715,12 @@ int refine_chessboard_corners_from_image_array_C(int Nrows, int Ncols, int strid
     for (int attempt = 0; attempt < 2; ++attempt) {
         mrgingham_amd_frames fr;
         if (upload_frame(ctx, imagebuffer, Nrows, Ncols, stride, &fr)) break;
-        if (ensure_scratch(ctx, 1, Ncols, Nrows, Npoints)) break;
         // layout of io_out: points | levels | npoints | nrefined
         const size_t o_lv = (size_t)Npoints * 16, o_np = o_lv + (((size_t)Npoints + 7) & ~(size_t)7), o_nr = o_np + 8;
         if (ensure(ctx, ctx->io_out, o_nr + 8)) break;
         char* base = (char*)ctx->io_out.p;
         const int32_t np = Npoints;
-        hipStream_t s0 = ctx->streams[0];
+        hipStream_t s0 = ctx->pix;
         if (hipMemcpyAsync(base, points_xy, (size_t)Npoints * 16, hipMemcpyHostToDevice, s0) != hipSuccess) break;
         if (hipMemcpyAsync(base + o_lv, level, (size_t)Npoints, hipMemcpyHostToDevice, s0) != hipSuccess) break;
         if (hipMemcpyAsync(base + o_np, &np, 4, hipMemcpyHostToDevice, s0) != hipSuccess) break;

@@ -328,15 +328,6 @@ __global__ __launch_bounds__(256) void chess_v1_kernel(LevelBatch lb, CompTables
             out[k] = row_interior ? (r & xmask[k]) : 0u;
         }
 
-        if (yy < ye && x0 < w) {
-            int16_t* dst = resp + (long long)yy * w + x0;
-            if (x0 + 8 <= w) {
-                const uint4 v = make_uint4(out[0], out[1], out[2], out[3]);
-                __builtin_memcpy(dst, &v, 16);
-            } else {
-                for (int i = 0; i < w - x0; ++i) dst[i] = (int16_t)(out[i >> 1] >> (16 * (i & 1)));
-            }
-        }
         if (HOT) {
             // responses are clamped here, so "> 15" is "any bit above bit 3"
             const uint32_t any = (out[0] | out[1] | out[2] | out[3]) & 0xfff0fff0u;
@@ -349,8 +340,22 @@ __global__ __launch_bounds__(256) void chess_v1_kernel(LevelBatch lb, CompTables
             }
         }
 
+        // ring first, results second: the wait for the prefetched rows must not also
+        // wait for this iteration's output stores (loads and stores share vmcnt)
         if (stager) stage_store(lds, (pr + 64) & (V1_NR - 1), st_ch, pre);
-        __syncthreads();
+        if (yy < ye && x0 < w) {
+            int16_t* dst = resp + (long long)yy * w + x0;
+            if (x0 + 8 <= w) {
+                const uint4 v = make_uint4(out[0], out[1], out[2], out[3]);
+                __builtin_memcpy(dst, &v, 16);
+            } else {
+                for (int i = 0; i < w - x0; ++i) dst[i] = (int16_t)(out[i >> 1] >> (16 * (i & 1)));
+            }
+        }
+        // LDS-only workgroup barrier: the output stores stay in flight across it
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     }
 }
 

@@ -18,6 +18,40 @@ namespace mrg {
 
 __device__ __forceinline__ int clipi(int v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); }
 
+// One output pixel of pyramid level `level` (>= 1).
+__device__ __forceinline__ int decimate_pixel(const uint8_t* src, int W, int H, int st, int level, int dx, int dy) {
+    if (level == 1) {
+        const int sx0 = 2 * dx, sy0 = 2 * dy;
+        if (sy0 >= H) return 0;
+        if (sy0 + 2 <= H && dx < W / 2) {
+            const uint8_t* r0 = src + (long long)sy0 * st + sx0;
+            return (r0[0] + r0[1] + r0[st] + r0[st + 1] + 2) >> 2;
+        }
+        int sum = 0, count = 0;
+        for (int sy = 0; sy < 2 && sy0 + sy < H; ++sy)
+            for (int sx = 0; sx < 2 && sx0 + sx < W; ++sx) {
+                sum += src[(long long)(sy0 + sy) * st + sx0 + sx];
+                ++count;
+            }
+        if (count == 0) return 0;
+        int q = sum / count;  // cvRound((float)sum/count): count is 1, 2 or 4, ties to even
+        const int rem = sum - q * count;
+        if (2 * rem > count || (2 * rem == count && (q & 1))) ++q;
+        return q;
+    }
+    const int s = 1 << level;
+    int sx = s * dx + s / 2 - 1;
+    int a0 = 1024, a1 = 1024;
+    if (sx >= W - 1) { sx = W - 1; a0 = 2048; a1 = 0; }
+    const int sx1 = sx + 1 < W ? sx + 1 : sx;
+    const int sy = s * dy + s / 2 - 1;
+    const uint8_t* r0 = src + (long long)clipi(sy, H) * st;
+    const uint8_t* r1 = src + (long long)clipi(sy + 1, H) * st;
+    const int S0 = r0[sx] * a0 + r0[sx1] * a1;
+    const int S1 = r1[sx] * a0 + r1[sx1] * a1;
+    return (((1024 * (S0 >> 4)) >> 16) + ((1024 * (S1 >> 4)) >> 16) + 2) >> 2;
+}
+
 __global__ __launch_bounds__(256) void decimate_kernel(FrameBatch in, int level, uint8_t* out, long long out_pitch,
                                                        int ow, int oh, int frame0) {
     const int frame = frame0 + blockIdx.z;
@@ -25,44 +59,7 @@ __global__ __launch_bounds__(256) void decimate_kernel(FrameBatch in, int level,
     const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (dx >= ow || dy >= oh) return;
     const uint8_t* src = in.frames + (long long)frame * in.frame_pitch;
-    const int W = in.width, H = in.height, st = in.stride;
-    int v;
-    if (level == 1) {
-        const int sx0 = 2 * dx, sy0 = 2 * dy;
-        if (sy0 >= H) {
-            v = 0;
-        } else if (sy0 + 2 <= H && dx < W / 2) {
-            const uint8_t* r0 = src + (long long)sy0 * st + sx0;
-            v = (r0[0] + r0[1] + r0[st] + r0[st + 1] + 2) >> 2;
-        } else {
-            int sum = 0, count = 0;
-            for (int sy = 0; sy < 2 && sy0 + sy < H; ++sy)
-                for (int sx = 0; sx < 2 && sx0 + sx < W; ++sx) {
-                    sum += src[(long long)(sy0 + sy) * st + sx0 + sx];
-                    ++count;
-                }
-            if (count == 0) {
-                v = 0;
-            } else {  // cvRound((float)sum/count): count is 1, 2 or 4, ties to even
-                int q = sum / count;
-                const int rem = sum - q * count;
-                if (2 * rem > count || (2 * rem == count && (q & 1))) ++q;
-                v = q;
-            }
-        }
-    } else {
-        const int s = 1 << level;
-        int sx = s * dx + s / 2 - 1;
-        int a0 = 1024, a1 = 1024;
-        if (sx >= W - 1) { sx = W - 1; a0 = 2048; a1 = 0; }
-        const int sx1 = sx + 1 < W ? sx + 1 : sx;
-        const int sy = s * dy + s / 2 - 1;
-        const uint8_t* r0 = src + (long long)clipi(sy, H) * st;
-        const uint8_t* r1 = src + (long long)clipi(sy + 1, H) * st;
-        const int S0 = r0[sx] * a0 + r0[sx1] * a1;
-        const int S1 = r1[sx] * a0 + r1[sx1] * a1;
-        v = (((1024 * (S0 >> 4)) >> 16) + ((1024 * (S1 >> 4)) >> 16) + 2) >> 2;
-    }
+    const int v = decimate_pixel(src, in.width, in.height, in.stride, level, dx, dy);
     out[(long long)frame * out_pitch + (long long)dy * ow + dx] = (uint8_t)v;
 }
 
@@ -71,6 +68,43 @@ void launch_decimate(const FrameBatch& in, int level, uint8_t* out, long long ou
     if (ow <= 0 || oh <= 0 || nframes <= 0) return;
     dim3 grid((ow + 63) / 64, (oh + 3) / 4, nframes);
     hipLaunchKernelGGL(decimate_kernel, grid, dim3(256), 0, s, in, level, out, out_pitch, ow, oh, frame0);
+}
+
+// Levels 1..3 in ONE pass over the frame: the thread grid is the level-1 image;
+// the thread of every 2nd / 4th level-1 pixel also produces the level-2 / level-3
+// pixel of its cell, whose four source pixels its neighbours have just pulled
+// through the vector cache.  HBM traffic: the frame once + the three level images.
+__global__ __launch_bounds__(256) void pyramid_kernel(FrameBatch in, PyramidOut po, int top) {
+    const int frame = blockIdx.z;
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const uint8_t* src = in.frames + (long long)frame * in.frame_pitch;
+    const int W = in.width, H = in.height, st = in.stride;
+    if (po.out[0] && dx < po.w[0] && dy < po.h[0])
+        po.out[0][((long long)frame * po.h[0] + dy) * po.w[0] + dx] = (uint8_t)decimate_pixel(src, W, H, st, 1, dx, dy);
+    if (top >= 2 && po.out[1] && !(dx & 1) && !(dy & 1)) {
+        const int X = dx >> 1, Y = dy >> 1;
+        if (X < po.w[1] && Y < po.h[1])
+            po.out[1][((long long)frame * po.h[1] + Y) * po.w[1] + X] = (uint8_t)decimate_pixel(src, W, H, st, 2, X, Y);
+    }
+    if (top >= 3 && po.out[2] && !(dx & 3) && !(dy & 3)) {
+        const int X = dx >> 2, Y = dy >> 2;
+        if (X < po.w[2] && Y < po.h[2])
+            po.out[2][((long long)frame * po.h[2] + Y) * po.w[2] + X] = (uint8_t)decimate_pixel(src, W, H, st, 3, X, Y);
+    }
+}
+
+void launch_pyramid(const FrameBatch& in, const PyramidOut& po, int top, int nframes, hipStream_t s) {
+    if (nframes <= 0 || top < 1) return;
+    int gw = 0, gh = 0;  // thread grid in level-1 pixels, large enough for every requested level
+    for (int L = 1; L <= top && L <= 3; ++L)
+        if (po.out[L - 1]) {
+            gw = max(gw, po.w[L - 1] << (L - 1));
+            gh = max(gh, po.h[L - 1] << (L - 1));
+        }
+    if (gw <= 0 || gh <= 0) return;
+    dim3 grid((gw + 63) / 64, (gh + 3) / 4, nframes);
+    hipLaunchKernelGGL(pyramid_kernel, grid, dim3(256), 0, s, in, po, top);
 }
 
 __device__ __forceinline__ int reflect101(int i, int n) {

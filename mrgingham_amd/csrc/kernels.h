@@ -18,6 +18,11 @@ struct FrameBatch {
 };
 void launch_decimate(const FrameBatch& in, int level, uint8_t* out, long long out_pitch, int ow, int oh, int frame0,
                      int nframes, hipStream_t s);
+struct PyramidOut {
+    uint8_t* out[3];  // dense level images of levels 1..3 (NULL = not wanted), frames back to back
+    int w[3], h[3];
+};
+void launch_pyramid(const FrameBatch& in, const PyramidOut& po, int top, int nframes, hipStream_t s);
 void launch_box_blur(const FrameBatch& in, int radius, uint8_t* out, int frame0, int nframes, hipStream_t s);
 
 // cc.hip

@@ -262,18 +262,25 @@ def test_chain_batch_matches_oracle(det, golden_dir):
     assert np.array_equal(oracle.chain(frames[0], 3)[0], z["chain3_pts_board10_640x480_s0"])
 
 
-def test_streams_option_does_not_change_results(det):
-    frames = _cuda(np.stack([synth.board_frame(640, 480, 10, s).numpy() for s in range(6)]))
-    ref = [t.clone() for t in det.chain(frames, 3, 512)]
-    for ns in (1, 3, 8):
-        det.set_option("streams", ns)
-        got = det.chain(frames, 3, 512)
-        n = got[2]
-        assert torch.equal(n, ref[2])
+def test_back_to_back_batches_without_sync(det):
+    """Queued calls reuse the level scratch: the pixel stream of call N+1 must wait for the
+    component stream of call N (results equal the synchronous ones)."""
+    fa = _cuda(np.stack([synth.board_frame(640, 480, 10, s).numpy() for s in range(6)]))
+    fb = _cuda(np.stack([synth.noise_frame(640, 480, s, smooth=1).numpy() for s in range(6)]))
+    ref_a = [t.clone() for t in det.chain(fa, 3, 512)]
+    ref_b = [t.clone() for t in det.chain(fb, 3, 512)]
+    out_a = det.chain(fa, 3, 512, sync=False)
+    out_b = det.chain(fb, 3, 512, sync=False)
+    xy, counts = det.detect(fa, 0, capacity=512, sync=False)
+    det.sync()
+    for got, ref in ((out_a, ref_a), (out_b, ref_b)):
+        assert torch.equal(got[2], ref[2])
         for f in range(6):
-            k = int(n[f])
+            k = int(ref[2][f])
             assert torch.equal(got[0][f, :k], ref[0][f, :k]) and torch.equal(got[1][f, :k], ref[1][f, :k])
-    det.set_option("streams", 4)
+    for f in range(6):
+        want = oracle.find_corners(fa[f].cpu().numpy(), 0)
+        assert int(counts[f]) == len(want) and np.array_equal(xy[f, :len(want)].cpu().numpy(), want)
 
 
 # ----------------------------------------------------------------------------- full size
