@@ -237,6 +237,47 @@ __device__ __forceinline__ void load12(uint32_t (&R)[12], const char* p) {
     R[8] = c.x; R[9] = c.y; R[10] = c.z; R[11] = c.w;
 }
 
+// Hot pixels of a workgroup are collected in LDS and appended to the frame's
+// list with ONE global atomic per workgroup: per-pixel (even per-wave) returning
+// atomics on the frame counter serialise and were costing more than the response
+// itself on the small pyramid levels.
+constexpr int V1_HOTBUF = 768;  // entries; overflow falls back to direct appends
+
+__device__ __forceinline__ void write_hot_entry(const CompTables& t, int frame, int idx, int p) {
+    if (idx >= t.cap) return;
+    const long long e = (long long)frame * t.cap + idx;
+    t.hot_pix[e] = p;
+    t.parent[e] = idx;
+    t.comp_cnt[e] = 0;
+    t.comp_box[e] = make_int4(0x7fffffff, 0x7fffffff, -1, -1);
+    t.roots[e] = 0x7fffffff;
+    t.lidx[(long long)frame * t.lidx_pitch + p] = idx;
+}
+
+// All lanes of the wave call this; `bits` has bit i set when pixel p0+i of the lane is hot.
+__device__ __forceinline__ void collect_hot(uint32_t bits, int p0, int* hotbuf, int* hotcnt, const CompTables& t,
+                                            int frame) {
+    const int cnt = __popc(bits);  // 0..8
+    int prefix = 0, total = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const unsigned long long m = __ballot((cnt >> b) & 1);
+        prefix += (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0)) << b;
+        total += __popcll(m) << b;
+    }
+    int base = 0;
+    if (__lane_id() == 0) base = atomicAdd(hotcnt, total);  // LDS atomic
+    base = __builtin_amdgcn_readfirstlane(base);
+    int k = base + prefix;
+    while (bits) {
+        const int i = __ffs(bits) - 1;
+        bits &= bits - 1;
+        if (k < V1_HOTBUF) hotbuf[k] = p0 + i;
+        else write_hot_entry(t, frame, atomicAdd(t.hot_cnt + frame, 1), p0 + i);  // rare: buffer full
+        ++k;
+    }
+}
+
 template <bool CLAMP, bool HOT>
 __global__ __launch_bounds__(256) void chess_v1_kernel(LevelBatch lb, CompTables t, int frame0, int seg) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -250,6 +291,9 @@ __global__ __launch_bounds__(256) void chess_v1_kernel(LevelBatch lb, CompTables
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6, half = lane >> 5, lx = lane & 31;
+    int* hotbuf = reinterpret_cast<int*>(lds + 2 * V1_PLANE);
+    int* hotcnt = hotbuf + V1_HOTBUF;
+    if (HOT && tid == 0) *hotcnt = 0;
     // staging role: 8 rows x 18 chunks = 144 threads
     const bool stager = tid < V1_RB * V1_NCH;
     const int st_row = tid / V1_NCH, st_ch = tid - st_row * V1_NCH;
@@ -330,13 +374,16 @@ __global__ __launch_bounds__(256) void chess_v1_kernel(LevelBatch lb, CompTables
 
         if (HOT) {
             // responses are clamped here, so "> 15" is "any bit above bit 3"
+            const bool live = yy < ye;
             const uint32_t any = (out[0] | out[1] | out[2] | out[3]) & 0xfff0fff0u;
-            if (__ballot(any != 0 && yy < ye) != 0ull) {
+            if (__ballot(any != 0 && live) != 0ull) {
+                uint32_t bits = 0;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int v = (int)((out[i >> 1] >> (16 * (i & 1))) & 0xffffu);
-                    append_hot(v > kRespMin && yy < ye, yy * w + x0 + i, t, frame);
+                    bits |= (uint32_t)(v > kRespMin && live) << i;
                 }
+                collect_hot(bits, yy * w + x0, hotbuf, hotcnt, t, frame);
             }
         }
 
@@ -357,6 +404,18 @@ __global__ __launch_bounds__(256) void chess_v1_kernel(LevelBatch lb, CompTables
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     }
+    if (HOT) {
+        // flush the workgroup's hot pixels: one global atomic, then coalesced table writes
+        __syncthreads();
+        const int n = min(*hotcnt, V1_HOTBUF);
+        if (n > 0) {
+            __syncthreads();
+            if (tid == 0) *hotcnt = atomicAdd(t.hot_cnt + frame, n);
+            __syncthreads();
+            const int gbase = *hotcnt;
+            for (int i = tid; i < n; i += 256) write_hot_entry(t, frame, gbase + i, hotbuf[i]);
+        }
+    }
 }
 
 static int pick_segment(int w, int h, int nframes) {
@@ -374,7 +433,7 @@ void launch_chess(const LevelBatch& lb, const CompTables& t, int frame0, int nfr
                   hipStream_t s) {
     const int seg = pick_segment(lb.w, lb.h, nframes);
     dim3 grid((lb.w + V1_SW - 1) / V1_SW, (lb.h + seg - 1) / seg, nframes);
-    const size_t lds = 2 * V1_PLANE;
+    const size_t lds = 2 * V1_PLANE + (hot ? (V1_HOTBUF + 4) * sizeof(int) : 0);
     if (hot)
         hipLaunchKernelGGL((chess_v1_kernel<true, true>), grid, dim3(256), lds, s, lb, t, frame0, seg);
     else if (clamp)

@@ -94,8 +94,72 @@ __global__ __launch_bounds__(256) void pyramid_kernel(FrameBatch in, PyramidOut 
     }
 }
 
+// Fast path of the pyramid for frames whose width is a multiple of 16 and height
+// a multiple of 8 (every BASELINE size): one thread owns a 16 x 8 source block,
+// pulls it in with eight 16-byte loads and emits 8x4 level-1, 4x2 level-2 and
+// 2x1 level-3 pixels with 8- / 4- / 2-byte stores.  Same arithmetic as
+// decimate_pixel (whole cells only, so every level is (a+b+c+d+2)>>2).
+__global__ __launch_bounds__(256) void pyramid_fast_kernel(FrameBatch in, PyramidOut po, int top) {
+    const int frame = blockIdx.z;
+    const int bx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int by = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int W = in.width, H = in.height, st = in.stride;
+    if (bx * 16 >= W || by * 8 >= H) return;
+    const uint8_t* src = in.frames + (long long)frame * in.frame_pitch + (long long)(by * 8) * st + bx * 16;
+    uint32_t r[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) __builtin_memcpy(r[i], src + (long long)i * st, 16);
+    auto px = [&](int row, int col) -> uint32_t { return (r[row][col >> 2] >> (8 * (col & 3))) & 0xffu; };
+
+    if (po.out[0]) {
+        uint8_t* o = po.out[0] + ((long long)frame * po.h[0] + by * 4) * po.w[0] + bx * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t packed[2];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                // byte pairs of both rows summed as two u16 lanes: (b0+b1, b2+b3)
+                const uint32_t a = r[2 * j][d], b = r[2 * j + 1][d];
+                uint32_t v = (a & 0x00ff00ffu) + ((a >> 8) & 0x00ff00ffu) + (b & 0x00ff00ffu) + ((b >> 8) & 0x00ff00ffu);
+                v = ((v + 0x00020002u) >> 2) & 0x00ff00ffu;
+                const uint32_t two = (v | (v >> 8)) & 0xffffu;  // two level-1 pixels
+                if (d & 1) packed[d >> 1] |= two << 16; else packed[d >> 1] = two;
+            }
+            __builtin_memcpy(o + (long long)j * po.w[0], packed, 8);
+        }
+    }
+    if (top >= 2 && po.out[1]) {
+        uint8_t* o = po.out[1] + ((long long)frame * po.h[1] + by * 2) * po.w[1] + bx * 4;
+#pragma unroll
+        for (int Y = 0; Y < 2; ++Y) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int X = 0; X < 4; ++X) {
+                const int c = 4 * X + 1, rr = 4 * Y + 1;
+                v |= ((px(rr, c) + px(rr, c + 1) + px(rr + 1, c) + px(rr + 1, c + 1) + 2) >> 2) << (8 * X);
+            }
+            __builtin_memcpy(o + (long long)Y * po.w[1], &v, 4);
+        }
+    }
+    if (top >= 3 && po.out[2]) {
+        uint8_t* o = po.out[2] + ((long long)frame * po.h[2] + by) * po.w[2] + bx * 2;
+        uint16_t v = 0;
+#pragma unroll
+        for (int X = 0; X < 2; ++X) {
+            const int c = 8 * X + 3;
+            v |= (uint16_t)(((px(3, c) + px(3, c + 1) + px(4, c) + px(4, c + 1) + 2) >> 2) << (8 * X));
+        }
+        __builtin_memcpy(o, &v, 2);
+    }
+}
+
 void launch_pyramid(const FrameBatch& in, const PyramidOut& po, int top, int nframes, hipStream_t s) {
     if (nframes <= 0 || top < 1) return;
+    if (in.width % 16 == 0 && in.height % 8 == 0 && in.width > 0 && in.height > 0) {
+        dim3 grid((in.width / 16 + 63) / 64, (in.height / 8 + 3) / 4, nframes);
+        hipLaunchKernelGGL(pyramid_fast_kernel, grid, dim3(256), 0, s, in, po, top);
+        return;
+    }
     int gw = 0, gh = 0;  // thread grid in level-1 pixels, large enough for every requested level
     for (int L = 1; L <= top && L <= 3; ++L)
         if (po.out[L - 1]) {
