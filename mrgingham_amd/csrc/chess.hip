@@ -281,12 +281,25 @@ __device__ __forceinline__ void collect_hot(uint32_t bits, int p0, int* hotbuf, 
 template <bool CLAMP, bool HOT>
 __global__ __launch_bounds__(256) void chess_v1_kernel(LevelBatch lb, CompTables t, int frame0, int seg) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int frame = frame0 + blockIdx.z;
+    // XCD-aware work order: workgroup b is dispatched to XCD b % 8 (observed, used
+    // for speed only).  Give each XCD a contiguous run of work items, strips
+    // fastest, so the 32-pixel column halo and the 10-row segment halo a
+    // workgroup shares with its neighbours is found in that XCD's L2 instead of
+    // being fetched from HBM once per neighbour.
+    const int nstrips = (lb.w + V1_SW - 1) / V1_SW, nsegs = (lb.h + seg - 1) / seg;
+    int work;
+    {
+        const unsigned b = blockIdx.x, nwg = gridDim.x, xcd = b & 7u, j = b >> 3;
+        const unsigned q = nwg >> 3, r = nwg & 7u;
+        work = (int)((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j);
+    }
+    const int strip = work % nstrips, rest = work / nstrips;
+    const int frame = frame0 + rest / nsegs;
     const int w = lb.w, h = lb.h, stride = lb.img_stride;
     const uint8_t* img = lb.img + (long long)frame * lb.img_pitch;
     int16_t* resp = lb.resp + (long long)frame * lb.resp_pitch;
-    const int strip_x = blockIdx.x * V1_SW;
-    const int ys = blockIdx.y * seg;
+    const int strip_x = strip * V1_SW;
+    const int ys = (rest % nsegs) * seg;
     const int ye = min(ys + seg, h);
 
     const int tid = threadIdx.x;
@@ -432,7 +445,7 @@ static int pick_segment(int w, int h, int nframes) {
 void launch_chess(const LevelBatch& lb, const CompTables& t, int frame0, int nframes, bool clamp, bool hot,
                   hipStream_t s) {
     const int seg = pick_segment(lb.w, lb.h, nframes);
-    dim3 grid((lb.w + V1_SW - 1) / V1_SW, (lb.h + seg - 1) / seg, nframes);
+    dim3 grid(((lb.w + V1_SW - 1) / V1_SW) * ((lb.h + seg - 1) / seg) * nframes);
     const size_t lds = 2 * V1_PLANE + (hot ? (V1_HOTBUF + 4) * sizeof(int) : 0);
     if (hot)
         hipLaunchKernelGGL((chess_v1_kernel<true, true>), grid, dim3(256), lds, s, lb, t, frame0, seg);
