@@ -82,6 +82,10 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="frames per GPU per step (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-points", type=int, default=256)
+    ap.add_argument("--distinct", type=int, default=0,
+                    help="render only this many distinct frames and repeat them to fill the batch (used for the "
+                         "rocprofv3 --pmc passes, where tracing the ~37k tiny kernels of the frame generator is "
+                         "the bottleneck); default: every frame distinct")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -104,7 +108,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     # every rank renders its own shard of the global batch (seed = global frame index)
     lo, _ = parallel.shard_range(world * batch, rank, world)
-    frames = synth.board_batch(batch, W, H, gridn=gridn, seed0=lo, device=dev)
+    if args.distinct and args.distinct < batch:
+        base = synth.board_batch(args.distinct, W, H, gridn=gridn, seed0=lo, device=dev)
+        frames = base.repeat((batch + args.distinct - 1) // args.distinct, 1, 1)[:batch].contiguous()
+        del base
+    else:
+        frames = synth.board_batch(batch, W, H, gridn=gridn, seed0=lo, device=dev)
     det = mrgingham_amd.Detector(local_rank)
     P = args.max_points
     out = (torch.empty((batch, P, 2), dtype=torch.float64, device=dev),
@@ -150,6 +159,17 @@ def main():
         frames_per_launch = batch / launches_per_step
         alg_bytes = frames_per_launch * W * H * 3.0
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        # HBM-side bytes per launch: PMC counters cannot be read from inside this process, so the
+        # figure is the per-pixel traffic measured by the committed rocprofv3 --pmc passes of this
+        # same command (profiles/chess_l0_traffic.json), scaled to this launch; null if absent.
+        traffic, traffic_src = None, None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "chess_l0_traffic.json")))
+            if (tj["width"], tj["height"]) == (W, H) and start_level >= 0:
+                traffic = tj["bytes_per_pixel"] * frames_per_launch * W * H
+                traffic_src = tj["source"]
+        except (OSError, KeyError, ValueError):
+            pass
         res = {
             "metric": "frames/sec, 4096x3072 10x10 board, corner-candidate path (ChESS + level decimation + "
                       "connected components), frames resident in HBM",
@@ -171,7 +191,7 @@ def main():
                        "start_level": start_level, "parallelism": f"frames sharded x{world}",
                        "frames_with_full_grid_last_step": found},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "level-0 ChESS response (+clamp +hot-pixel compaction)",
                          "bytes_model": "3 B/px (u8 read once + int16 written once)",
                          "bytes_per_launch": alg_bytes, "avg_launch_ms": kern_ms,

@@ -3,7 +3,7 @@
 
     python tools/pmc_summary.py gpurun_out/<run>/p*/p_counter_collection.csv
 
-Prints, per kernel name, the mean of every counter over its dispatches (the last
+Prints, per kernel name and grid size (= pyramid level), the mean of every counter over its dispatches (the last
 dispatch only with --last).  FETCH_SIZE / WRITE_SIZE are in KiB as rocprofv3
 reports them; see MI355X_MICROARCH.md (HBM section) for the gfx950 correction
 (FETCH_SIZE counts 64 B per 128-B request on wide streaming reads: double it).
@@ -20,7 +20,7 @@ def main(paths):
             name = row["Kernel_Name"]
             if "mrg::" not in name:
                 continue
-            short = name.split("(")[0].replace("void ", "")
+            short = name.split("(")[0].replace("void ", "") + f"  grid={row['Grid_Size']} wg={row['Workgroup_Size']}"
             acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k, ctrs in acc.items():
         print(k)
