@@ -196,6 +196,20 @@ __device__ __forceinline__ StageRegs stage_load(const uint8_t* img, int stride, 
     return s;
 }
 
+// Branch-free variant for frames whose width is a multiple of 16: every chunk is
+// either wholly inside or wholly outside the frame, and what an outside chunk (or
+// an outside row) holds never reaches an interior output, so addresses are simply
+// clamped into the frame.  No divergent control flow means hipcc does not park an
+// s_waitcnt vmcnt(0) behind the prefetch: the load stays in flight under the math.
+__device__ __forceinline__ StageRegs stage_load_fast(const uint8_t* img, int stride, int h, int r, int gx_c, int nx_c) {
+    StageRegs s;
+    const int rc = min(max(r, 0), h - 1);
+    const uint8_t* row = img + (long long)rc * stride;
+    __builtin_memcpy(&s.g, row + gx_c, 16);
+    s.next = row[nx_c];
+    return s;
+}
+
 // Registers -> both LDS planes (packed u16 pairs).
 __device__ __forceinline__ void stage_store(char* lds, int slot, int ch, const StageRegs& s) {
     const uint32_t g0 = s.g.x, g1 = s.g.y, g2 = s.g.z, g3 = s.g.w;
@@ -278,7 +292,7 @@ __device__ __forceinline__ void collect_hot(uint32_t bits, int p0, int* hotbuf, 
     }
 }
 
-template <bool CLAMP, bool HOT>
+template <bool CLAMP, bool HOT, bool W16>
 __global__ __launch_bounds__(256) void chess_v1_kernel(LevelBatch lb, CompTables t, int frame0, int seg) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     // XCD-aware work order: workgroup b is dispatched to XCD b % 8 (observed, used
@@ -311,13 +325,16 @@ __global__ __launch_bounds__(256) void chess_v1_kernel(LevelBatch lb, CompTables
     const bool stager = tid < V1_RB * V1_NCH;
     const int st_row = tid / V1_NCH, st_ch = tid - st_row * V1_NCH;
     const int st_gx = strip_x - V1_HL + 16 * st_ch;
+    const int st_gx_c = min(max(st_gx, 0), max(w - 16, 0));  // W16: clamped chunk start / following pixel
+    const int st_nx_c = min(max(st_gx + 16, 0), w - 1);
 
     // prologue: row groups G0..G2 = rows ys-5 .. ys+18
     if (stager) {
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
             const int r = ys - 5 + V1_RB * g + st_row;
-            const StageRegs s = stage_load(img, stride, w, h, r, st_gx);
+            const StageRegs s = W16 ? stage_load_fast(img, stride, h, r, st_gx_c, st_nx_c)
+                                    : stage_load(img, stride, w, h, r, st_gx);
             stage_store(lds, (r + 64) & (V1_NR - 1), st_ch, s);
         }
     }
@@ -325,36 +342,56 @@ __global__ __launch_bounds__(256) void chess_v1_kernel(LevelBatch lb, CompTables
 
     // per-lane constants
     const int x0 = strip_x + 8 * lx;
+    // CLAMP: results are carried with a +8192 bias per half (see below); the interior mask also
+    // strips that bias, so the frame mask, the un-bias and the clamp cost one AND
     uint32_t xmask[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int xa = x0 + 2 * k, xb = xa + 1;
-        xmask[k] = ((xa >= kMargin && xa < w - kMargin) ? 0x0000ffffu : 0u) |
-                   ((xb >= kMargin && xb < w - kMargin) ? 0xffff0000u : 0u);
+        const uint32_t keep = CLAMP ? 0x1fffu : 0xffffu;
+        xmask[k] = ((xa >= kMargin && xa < w - kMargin) ? keep : 0u) |
+                   ((xb >= kMargin && xb < w - kMargin) ? keep << 16 : 0u);
     }
-    const char* lane_base = lds + 16 + 16 * lx;  // address of D[-4] in a row of plane 0
+    // Row addressing: wave index and loop row are wave-uniform (SALU); the lane-dependent part is a
+    // constant.  A wave covers rows yy = y + 2*wv + half; for even dy the slot of half 1 is the
+    // slot of half 0 plus one (never wraps, the base slot is even), for odd dy (+-5) the two
+    // half-waves get separately wrapped uniform slots, selected with a mask.
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    const uint32_t lane_off = 16u + 16u * lx;                      // D[-4] of the lane within a row
+    const uint32_t lane_off_h = lane_off + (half ? V1_ROWB : 0u);  // + the half-wave's row
+    const uint32_t halfmask = half ? 0xffffffffu : 0u;
+    const bool seg_interior = ys >= kMargin && ye <= h - kMargin;  // workgroup-uniform
 
     int grp = 3;
     for (int y = ys; y < ye; y += V1_RB, ++grp) {
         // prefetch the group needed two iterations from now (rows y+19 .. y+26)
         StageRegs pre;
         const int pr = ys - 5 + V1_RB * grp + st_row;
-        if (stager) pre = stage_load(img, stride, w, h, pr, st_gx);
+        if (stager) pre = W16 ? stage_load_fast(img, stride, h, pr, st_gx_c, st_nx_c)
+                              : stage_load(img, stride, w, h, pr, st_gx);
 
-        const int yy = y + 2 * wv + half;
-        auto rowp = [&](int dy) { return lane_base + ((yy + dy + 64) & (V1_NR - 1)) * V1_ROWB; };
+        const int s0 = y + 2 * wvu + 64;  // uniform, even
+        const int yy = s0 - 64 + half;
+        auto row_even = [&](int dy) -> const char* {
+            return lds + (lane_off_h + (uint32_t)(((s0 + dy) & (V1_NR - 1)) * V1_ROWB));
+        };
+        auto row_odd = [&](int dy) -> const char* {
+            const uint32_t o0 = (uint32_t)(((s0 + dy) & (V1_NR - 1)) * V1_ROWB);
+            const uint32_t o1 = (uint32_t)(((s0 + dy + 1) & (V1_NR - 1)) * V1_ROWB);
+            return lds + (lane_off + o0 + (halfmask & (o1 - o0)));
+        };
         uint32_t m5[12], p5[12], m4[12], p4[12], m2[12], p2[12], z1[12];
-        load12(m5, rowp(-5));
-        load12(p5, rowp(+5));
-        load12(m4, rowp(-4));
-        load12(p4, rowp(+4));
-        load12(m2, rowp(-2) + V1_PLANE);
-        load12(p2, rowp(+2) + V1_PLANE);
-        load12(z1, rowp(0) + V1_PLANE);
-        const u32x4 z0v = lds_read_b128(rowp(0) + 16);
+        load12(m5, row_odd(-5));
+        load12(p5, row_odd(+5));
+        load12(m4, row_even(-4));
+        load12(p4, row_even(+4));
+        load12(m2, row_even(-2) + V1_PLANE);
+        load12(p2, row_even(+2) + V1_PLANE);
+        const char* r0 = row_even(0);
+        load12(z1, r0 + V1_PLANE);
+        const u32x4 z0v = lds_read_b128(r0 + 16);
         const uint32_t z0[4] = {z0v.x, z0v.y, z0v.z, z0v.w};
 
-        const bool row_interior = yy >= kMargin && yy < h - kMargin;
         uint32_t out[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -364,25 +401,32 @@ __global__ __launch_bounds__(256) void chess_v1_kernel(LevelBatch lb, CompTables
             const uint32_t a1 = m5[c], c1 = p5[c], b1 = z1[c - 3], d1 = z1[c + 2];
             const uint32_t a2 = m5[c - 1], c2 = p5[c + 1], b2 = p2[c - 3], d2 = m2[c + 2];
             const uint32_t a3 = m4[c - 2], c3 = p4[c + 2], b3 = p4[c - 2], d3 = m4[c + 2];
-            // halves never overflow 16 bits (sums <= 4080), so plain 32-bit adds act on both pixels
+            // Both pixels of a pair sit in one register and no half ever overflows or borrows, so
+            // every add / subtract below is a plain 32-bit op (2-cycle issue class on gfx950; the
+            // packed 16-bit forms are 4).  Only the twelve maxima need v_pk_max_u16.
             const uint32_t t10 = a0 + c0, t20 = b0 + d0, t11 = a1 + c1, t21 = b1 + d1;
             const uint32_t t12 = a2 + c2, t22 = b2 + d2, t13 = a3 + c3, t23 = b3 + d3;
-            const uint32_t M = (t10 + t20 + t11) + (t21 + t12 + t22) + (t13 + t23);
-            const uint32_t Y = (pk_max_u16(t10, t20) + pk_max_u16(t11, t21)) +
-                               (pk_max_u16(t12, t22) + pk_max_u16(t13, t23));
-            const uint32_t X = (pk_max_u16(a0, c0) + pk_max_u16(b0, d0) + pk_max_u16(a1, c1)) +
-                               (pk_max_u16(b1, d1) + pk_max_u16(a2, c2) + pk_max_u16(b2, d2)) +
-                               (pk_max_u16(a3, c3) + pk_max_u16(b3, d3));
+            const uint32_t M = ((t10 + t20) + (t11 + t21)) + ((t12 + t22) + (t13 + t23));
+            // Y carries a +4096 bias per half so that Y - X (>= -2040) stays positive
+            const uint32_t Yb = ((pk_max_u16(t10, t20) + pk_max_u16(t11, t21)) +
+                                 (pk_max_u16(t12, t22) + pk_max_u16(t13, t23))) + 0x10001000u;
+            const uint32_t X = ((pk_max_u16(a0, c0) + pk_max_u16(b0, d0)) + (pk_max_u16(a1, c1) + pk_max_u16(b1, d1))) +
+                               ((pk_max_u16(a2, c2) + pk_max_u16(b2, d2)) + (pk_max_u16(a3, c3) + pk_max_u16(b3, d3)));
             // local_mean = (I[x-1]+I[x]+I[x+1])*16/3, truncating (ChESS.c:86): floor(16n/3) = (n*349536)>>16, n <= 765
             const uint32_t n = z1[c - 1] + z0[k] + z1[c];
             const uint32_t lm_lo = __umul24(n & 0xffffu, 349536u);
             const uint32_t lm_hi = __umul24(n >> 16, 349536u);
             const uint32_t LM = __builtin_amdgcn_perm(lm_hi, lm_lo, 0x07060302u);
-            const uint32_t dev = pk_sub_i16(pk_max_u16(M, LM), pk_min_u16(M, LM));  // |M - LM|
-            const uint32_t yx = pk_sub_i16(Y, X);
-            uint32_t r = pk_sub_i16(pk_add_i16(yx, yx), dev);  // ChESS.c:104
-            if (CLAMP) r = pk_max_i16(r, 0u);
-            out[k] = row_interior ? (r & xmask[k]) : 0u;
+            const uint32_t dev = pk_max_u16(M, LM) - pk_min_u16(M, LM);  // |M - LM| per half
+            const uint32_t d1x = Yb - X;
+            const uint32_t P = (d1x + d1x) - dev;  // halves = response + 8192, in [2072, 10232]  (ChESS.c:104)
+            if (CLAMP) out[k] = pk_max_u16(P, 0x20002000u) & xmask[k];  // max(r,0): bit 13 is the bias, masked off
+            else out[k] = pk_sub_i16(P, 0x20002000u) & xmask[k];
+        }
+        if (!seg_interior) {
+            const uint32_t rm = (yy >= kMargin && yy < h - kMargin) ? 0xffffffffu : 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) out[k] &= rm;
         }
 
         if (HOT) {
@@ -447,12 +491,12 @@ void launch_chess(const LevelBatch& lb, const CompTables& t, int frame0, int nfr
     const int seg = pick_segment(lb.w, lb.h, nframes);
     dim3 grid(((lb.w + V1_SW - 1) / V1_SW) * ((lb.h + seg - 1) / seg) * nframes);
     const size_t lds = 2 * V1_PLANE + (hot ? (V1_HOTBUF + 4) * sizeof(int) : 0);
-    if (hot)
-        hipLaunchKernelGGL((chess_v1_kernel<true, true>), grid, dim3(256), lds, s, lb, t, frame0, seg);
-    else if (clamp)
-        hipLaunchKernelGGL((chess_v1_kernel<true, false>), grid, dim3(256), lds, s, lb, t, frame0, seg);
-    else
-        hipLaunchKernelGGL((chess_v1_kernel<false, false>), grid, dim3(256), lds, s, lb, t, frame0, seg);
+    const bool w16 = lb.w >= 16 && lb.w % 16 == 0;
+#define MRG_LAUNCH(C, H, A) hipLaunchKernelGGL((chess_v1_kernel<C, H, A>), grid, dim3(256), lds, s, lb, t, frame0, seg)
+    if (hot) { if (w16) MRG_LAUNCH(true, true, true); else MRG_LAUNCH(true, true, false); }
+    else if (clamp) { if (w16) MRG_LAUNCH(true, false, true); else MRG_LAUNCH(true, false, false); }
+    else { if (w16) MRG_LAUNCH(false, false, true); else MRG_LAUNCH(false, false, false); }
+#undef MRG_LAUNCH
 }
 
 }  // namespace mrg
