@@ -28,7 +28,7 @@ struct DevBuf {
 struct LevelScratch {
     int w = 0, h = 0, nframes = 0, cap = 0, cand_cap = 0, sort_cap = 0, pitch = 0, shift = -1;
     long long arena_cap = 0;
-    DevBuf img, resp, lidx, hot_cnt, status, hot_pix, parent, comp_cnt, roots, comp_box, arena, cand, sortkeys;
+    DevBuf img, resp, lidx, hot_cnt, status, hot_pix, parent, comp_cnt, roots, comp_first, comp_box, arena, cand, sortkeys;
 };
 
 }  // namespace mrg
@@ -150,6 +150,7 @@ static int ensure_level(mrgingham_amd_ctx* ctx, int level, int nframes, int W, i
     if ((rc = ensure(ctx, L.parent, nf * (size_t)cap * 4))) return rc;
     if ((rc = ensure(ctx, L.comp_cnt, nf * (size_t)cap * 4))) return rc;
     if ((rc = ensure(ctx, L.roots, nf * (size_t)cap * 4))) return rc;
+    if ((rc = ensure(ctx, L.comp_first, nf * (size_t)cap * 4))) return rc;
     if ((rc = ensure(ctx, L.comp_box, nf * (size_t)cap * 16))) return rc;
     if ((rc = ensure(ctx, L.arena, nf * (size_t)arena_cap * 4))) return rc;
     if ((rc = ensure(ctx, L.cand, nf * (size_t)cand_cap * sizeof(Cand)))) return rc;
@@ -188,6 +189,7 @@ static CompTables tables_of(const LevelScratch& L) {
     t.comp_cnt = (int32_t*)L.comp_cnt.p;
     t.comp_box = (int4*)L.comp_box.p;
     t.roots = (int32_t*)L.roots.p;
+    t.comp_first = (int32_t*)L.comp_first.p;
     t.lidx = (int32_t*)L.lidx.p;
     t.lidx_pitch = (long long)L.w * L.h;
     t.arena = (uint32_t*)L.arena.p;
@@ -307,8 +309,10 @@ mrgingham_amd_ctx* mrgingham_amd_create(int device_ordinal) {
     ctx->device = device_ordinal;
     const char* v0 = getenv("MRGINGHAM_AMD_CHESS_V0");
     ctx->use_v0 = v0 && atoi(v0) != 0;
-    bool ok = hipStreamCreateWithFlags(&ctx->pix, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&ctx->cc, hipStreamNonBlocking) == hipSuccess &&
+    int prio_lo = 0, prio_hi = 0;  // the component stream gets the highest dispatch priority
+    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    bool ok = hipStreamCreateWithPriority(&ctx->pix, hipStreamNonBlocking, prio_lo) == hipSuccess &&
+              hipStreamCreateWithPriority(&ctx->cc, hipStreamNonBlocking, prio_hi) == hipSuccess &&
               hipEventCreateWithFlags(&ctx->ev_cc_done, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i <= kMaxLevel; ++i)
         ok = hipEventCreateWithFlags(&ctx->ev_pix[i], hipEventDisableTiming) == hipSuccess;
@@ -326,7 +330,7 @@ void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx) {
     hipDeviceSynchronize();
     for (LevelScratch& L : ctx->lv) {
         DevBuf* bufs[] = {&L.img, &L.resp, &L.lidx, &L.hot_cnt, &L.status, &L.hot_pix, &L.parent,
-                          &L.comp_cnt, &L.roots, &L.comp_box, &L.arena, &L.cand, &L.sortkeys};
+                          &L.comp_cnt, &L.roots, &L.comp_first, &L.comp_box, &L.arena, &L.cand, &L.sortkeys};
         for (DevBuf* b : bufs)
             if (b->p) hipFree(b->p);
     }

@@ -15,8 +15,9 @@
 //      reference's sequence (raster order of seeds, push order +x,-x,+y,-y,
 //      first-maximum-wins) be replayed, and that is done by a single lane.
 //
-// One 1024-thread workgroup owns one frame, so every hand-off between the
-// phases below is a workgroup barrier (no cross-XCD traffic, no grid sync):
+// P1 and P2 are grid-wide kernels (kernel boundaries order them); from P3 on one
+// 1024-thread workgroup owns one frame, so every later hand-off is a workgroup
+// barrier (no cross-XCD traffic, no grid sync):
 //   P1 union-find over the hot list (left/up neighbours)        -> forest
 //   P2 flatten; per-root pixel count and bounding box
 //   P3 one lane per root: scan its box in raster order, replay the fills
@@ -33,7 +34,7 @@
 
 namespace mrg {
 
-constexpr int CC_THREADS = 1024;
+constexpr int CC_THREADS = 256;
 constexpr int CC_WAVES = CC_THREADS / 64;
 
 __device__ __forceinline__ int aload(const int32_t* p) {
@@ -69,7 +70,7 @@ struct FrameView {
     const uint8_t* img;
     int img_stride;
     int16_t* d;
-    int32_t *hot_pix, *parent, *comp_cnt, *roots, *lidx;
+    int32_t *hot_pix, *parent, *comp_cnt, *roots, *comp_first, *lidx;
     int4* comp_box;
     uint32_t* arena;
     long long arena_cap;
@@ -92,6 +93,7 @@ __device__ __forceinline__ FrameView make_view(const LevelBatch& lb, const CompT
     v.parent = t.parent + e;
     v.comp_cnt = t.comp_cnt + e;
     v.roots = t.roots + e;
+    v.comp_first = t.comp_first + e;
     v.comp_box = t.comp_box + e;
     v.lidx = t.lidx + (long long)frame * t.lidx_pitch;
     v.arena = t.arena + (long long)frame * t.arena_cap;
@@ -106,18 +108,36 @@ __device__ __forceinline__ FrameView make_view(const LevelBatch& lb, const CompT
     return v;
 }
 
-// P1 + P2.  Ends with a barrier; afterwards parent[i] is the root of i.
-__device__ void build_super_components(const FrameView& v) {
+// P1 and P2 run as their own grid-wide kernels (a few workgroups per frame): at
+// full resolution a noisy frame has tens of thousands of hot pixels, nearly all
+// of them isolated, and labelling them with the 1024 threads of the per-frame
+// workgroup was the longest phase of the component search.
+constexpr int CCL_THREADS = 256;
+constexpr int CCL_BLOCKS_PER_FRAME = 16;
+
+// P1: union-find over the hot list (left / up neighbours).
+__global__ __launch_bounds__(CCL_THREADS) void cc_union_kernel(LevelBatch lb, CompTables t, int frame0) {
+    const int frame = frame0 + blockIdx.y;
+    if (t.hot_cnt[frame] > t.cap) return;  // overflow is reported by the per-frame kernel
+    const FrameView v = make_view(lb, t, frame);
     const int w = v.w;
-    for (int i = threadIdx.x; i < v.n; i += CC_THREADS) {
+    for (int i = blockIdx.x * CCL_THREADS + threadIdx.x; i < v.n; i += CCL_BLOCKS_PER_FRAME * CCL_THREADS) {
         const int p = v.hot_pix[i];
         const int y = p / w, x = p - y * w;
         if (x > kMargin && v.d[p - 1] > kRespMin) uf_unite(v.parent, i, v.lidx[p - 1]);
         if (y > kMargin && v.d[p - w] > kRespMin) uf_unite(v.parent, i, v.lidx[p - w]);
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < v.n; i += CC_THREADS) {
+}
+
+// P2: flatten (parent[i] = root of i); per-root pixel count and bounding box.
+__global__ __launch_bounds__(CCL_THREADS) void cc_flatten_kernel(LevelBatch lb, CompTables t, int frame0) {
+    const int frame = frame0 + blockIdx.y;
+    if (t.hot_cnt[frame] > t.cap) return;
+    const FrameView v = make_view(lb, t, frame);
+    const int w = v.w;
+    for (int i = blockIdx.x * CCL_THREADS + threadIdx.x; i < v.n; i += CCL_BLOCKS_PER_FRAME * CCL_THREADS) {
         const int r = uf_root(v.parent, i);
+        // other threads may still walk through i: r is an ancestor, so their walks stay valid
         __hip_atomic_store(v.parent + i, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int p = v.hot_pix[i];
         const int y = p / w, x = p - y * w;
@@ -127,8 +147,15 @@ __device__ void build_super_components(const FrameView& v) {
         atomicMax(box + 2, x);
         atomicMax(box + 3, y);
         atomicAdd(v.comp_cnt + r, 1);
+        atomicMin(v.comp_first + r, p);
     }
-    __syncthreads();
+}
+
+void launch_cc_label(const LevelBatch& lb, const CompTables& t, int frame0, int nframes, hipStream_t s) {
+    if (nframes <= 0) return;
+    const dim3 grid(CCL_BLOCKS_PER_FRAME, nframes);
+    hipLaunchKernelGGL(cc_union_kernel, grid, dim3(CCL_THREADS), 0, s, lb, t, frame0);
+    hipLaunchKernelGGL(cc_flatten_kernel, grid, dim3(CCL_THREADS), 0, s, lb, t, frame0);
 }
 
 struct Blob {
@@ -137,19 +164,38 @@ struct Blob {
     bool touched;
 };
 
-// Drains the LIFO exactly like follow_connected_component (:236-256).
-__device__ __forceinline__ void drain_lifo(int16_t* d, int w, int h, uint32_t* stk, int sp, Blob& b) {
+// Drains the LIFO exactly like follow_connected_component (:236-256) and returns how many hot
+// pixels it consumed (zeroed).  Latency is what matters here (one lane, dependent global
+// accesses, usually underneath a bandwidth-saturating pixel kernel), so per pop there is ONE
+// round trip for the pixel and its four neighbours together (their addresses do not depend on
+// the pixel's value) and the top of the stack lives in a register (the entry pushed last is the
+// one popped next).
+__device__ __forceinline__ int drain_lifo(int16_t* d, int w, int h, uint32_t* stk, int sp, Blob& b) {
     b.srx = b.sry = b.sr = 0;
     b.npix = 0;
     b.rmax = 0;
     b.xpk = b.ypk = 0;
     b.touched = false;
-    while (sp > 0) {
-        const uint32_t e = stk[--sp];
+    int consumed = 0;
+    uint32_t top = 0;
+    bool has_top = false;
+    auto push = [&](uint32_t e) {
+        if (has_top) stk[sp++] = top;
+        top = e;
+        has_top = true;
+    };
+    while (true) {
+        uint32_t e;
+        if (has_top) { e = top; has_top = false; }
+        else if (sp > 0) e = stk[--sp];
+        else break;
         const int x = (int)(e & 0xffffu), y = (int)(e >> 16);
         const int q = y * w + x;
-        const int v = d[q];
+        // q is inside the fill region [7,w-7) x [7,h-7), so all four neighbours are inside the image
+        const int v = d[q], vxp = d[q + 1], vxm = d[q - 1], vyp = d[q + w], vym = d[q - w];
+        if (v <= 0) continue;                                  // visited already: d[q] = 0 is a no-op
         d[q] = 0;                                              // :245 / :250
+        consumed += v > kRespMin;
         if (!(v > kRespMin && v > (b.rmax >> 4))) continue;    // :159-171 with :27
         if (v > b.rmax) { b.rmax = v; b.xpk = x; b.ypk = y; }  // :176-181, first maximum wins
         b.srx += (unsigned long long)(v * x);
@@ -158,14 +204,15 @@ __device__ __forceinline__ void drain_lifo(int16_t* d, int w, int h, uint32_t* s
         b.npix++;
         // :252-255 then :216-226 (only hot pixels are worth pushing, see (1) above)
         if (x + 1 >= w - kMargin) b.touched = true;
-        else if (d[q + 1] > kRespMin) stk[sp++] = e + 1u;
+        else if (vxp > kRespMin) push(e + 1u);
         if (x - 1 < kMargin) b.touched = true;
-        else if (d[q - 1] > kRespMin) stk[sp++] = e - 1u;
+        else if (vxm > kRespMin) push(e - 1u);
         if (y + 1 >= h - kMargin) b.touched = true;
-        else if (d[q + w] > kRespMin) stk[sp++] = e + 0x10000u;
+        else if (vyp > kRespMin) push(e + 0x10000u);
         if (y - 1 < kMargin) b.touched = true;
-        else if (d[q - w] > kRespMin) stk[sp++] = e - 0x10000u;
+        else if (vym > kRespMin) push(e - 0x10000u);
     }
+    return consumed;
 }
 
 __device__ __forceinline__ bool blob_passes_cheap_tests(const Blob& b) {
@@ -237,6 +284,8 @@ __global__ __launch_bounds__(CC_THREADS) void cc_detect_kernel(LevelBatch lb, Co
                                                                DetectOut out, int frame0) {
     __shared__ int s_nroots, s_ncand, s_nvalid;
     __shared__ unsigned long long s_arena_top;
+    // latency-bound and tiny next to the pixel kernels it shares CUs with: take issue priority
+    __builtin_amdgcn_s_setprio(3);
     const int frame = frame0 + blockIdx.x;
     if (t.hot_cnt[frame] > t.cap) {  // table overflow: report, produce nothing
         if (threadIdx.x == 0) {
@@ -247,11 +296,12 @@ __global__ __launch_bounds__(CC_THREADS) void cc_detect_kernel(LevelBatch lb, Co
     }
     const FrameView v = make_view(lb, t, frame);
     if (threadIdx.x == 0) { s_nroots = 0; s_ncand = 0; s_nvalid = 0; s_arena_top = 0; }
-    build_super_components(v);
+    __syncthreads();
 
-    // P3a: compact the roots
+    // P3a: compact the roots.  A super-component of a single hot pixel can only ever give a
+    // one-pixel blob, which the size test rejects (:205), and nothing else can reach it: skipped.
     for (int i = threadIdx.x; i < v.n; i += CC_THREADS)
-        if (aload(v.parent + i) == i) v.roots[atomicAdd(&s_nroots, 1)] = i;
+        if (v.parent[i] == i && v.comp_cnt[i] >= kBlobMinPixels) v.roots[atomicAdd(&s_nroots, 1)] = i;
     __syncthreads();
     const int nroots = s_nroots;
 
@@ -266,24 +316,36 @@ __global__ __launch_bounds__(CC_THREADS) void cc_detect_kernel(LevelBatch lb, Co
         // seeds live in [8, w-8) x [8, h-8) (:332-333)
         const int ylo = max(box.y, kMargin + 1), yhi = min(box.w, h - kMargin - 2);
         const int xlo = max(box.x, kMargin + 1), xhi = min(box.z, w - kMargin - 2);
-        for (int y = ylo; y <= yhi; ++y)
-            for (int x = xlo; x <= xhi; ++x) {
+        int left = cnt;  // hot pixels of this super-component not consumed yet
+        auto fill_from = [&](int x, int y, int p) {
+            stk[0] = (uint32_t)x | ((uint32_t)y << 16);  // :338
+            Blob b;
+            left -= drain_lifo(v.d, w, h, stk, 1, b);
+            if (!blob_passes_cheap_tests(b)) return;
+            const int c = atomicAdd(&s_ncand, 1);
+            if (c < v.cand_cap) {
+                Cand cd;
+                cd.sum_rx = b.srx; cd.sum_ry = b.sry; cd.sum_r = b.sr;
+                cd.seed = p;
+                cd.x_peak = (uint16_t)b.xpk; cd.y_peak = (uint16_t)b.ypk;
+                cd.ok = 0; cd.pad = 0;
+                v.cand[c] = cd;
+            }
+        };
+        // The raster scan meets this super-component first at its smallest raster index.  If that
+        // pixel may seed, fill from it straight away; in the common case the fill consumes every
+        // hot pixel of the super-component and no scan of the bounding box is needed at all.
+        {
+            const int p = v.comp_first[r];
+            const int y = p / w, x = p - y * w;
+            if (x >= xlo && x <= xhi && y >= ylo && y <= yhi) fill_from(x, y, p);
+        }
+        for (int y = ylo; y <= yhi && left > 0; ++y)
+            for (int x = xlo; x <= xhi && left > 0; ++x) {
                 const int p = y * w + x;
-                if (!(v.d[p] > kRespMin)) continue;          // is_valid(.., NULL), :335
-                if (v.parent[v.lidx[p]] != r) continue;      // someone else's super-component
-                stk[0] = (uint32_t)x | ((uint32_t)y << 16);  // :338
-                Blob b;
-                drain_lifo(v.d, w, h, stk, 1, b);
-                if (!blob_passes_cheap_tests(b)) continue;
-                const int c = atomicAdd(&s_ncand, 1);
-                if (c < v.cand_cap) {
-                    Cand cd;
-                    cd.sum_rx = b.srx; cd.sum_ry = b.sry; cd.sum_r = b.sr;
-                    cd.seed = p;
-                    cd.x_peak = (uint16_t)b.xpk; cd.y_peak = (uint16_t)b.ypk;
-                    cd.ok = 0; cd.pad = 0;
-                    v.cand[c] = cd;
-                }
+                if (!(v.d[p] > kRespMin)) continue;      // is_valid(.., NULL), :335
+                if (v.parent[v.lidx[p]] != r) continue;  // someone else's super-component
+                fill_from(x, y, p);
             }
     }
     __syncthreads();
@@ -327,6 +389,7 @@ __global__ __launch_bounds__(CC_THREADS) void cc_detect_kernel(LevelBatch lb, Co
 void launch_cc_detect(const LevelBatch& lb, const CompTables& t, int level, const DetectOut& out, int frame0,
                       int nframes, hipStream_t s) {
     if (nframes <= 0) return;
+    launch_cc_label(lb, t, frame0, nframes, s);
     hipLaunchKernelGGL(cc_detect_kernel, dim3(nframes), dim3(CC_THREADS), 0, s, lb, t, level, out, frame0);
 }
 
@@ -337,6 +400,7 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, Co
                                                                RefineIO io, int frame0) {
     __shared__ int s_ncand, s_changed, s_nref;
     __shared__ unsigned long long s_arena_top;
+    __builtin_amdgcn_s_setprio(3);
     const int frame = frame0 + blockIdx.x;
     if (t.hot_cnt[frame] > t.cap) {
         if (threadIdx.x == 0) {
@@ -347,7 +411,7 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, Co
     }
     const FrameView v = make_view(lb, t, frame);
     if (threadIdx.x == 0) { s_ncand = 0; s_changed = 0; s_nref = 0; s_arena_top = 0; }
-    build_super_components(v);  // v.roots[] was preset to INT_MAX by the ChESS kernel: the claim table
+    __syncthreads();  // v.roots[] was preset to INT_MAX by the ChESS kernel: it is the claim table here
 
     const int w = v.w, h = v.h;
     const int npts = min(io.npoints[frame], io.pitch);
@@ -474,6 +538,7 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, Co
 void launch_cc_refine(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io, int frame0,
                       int nframes, hipStream_t s) {
     if (nframes <= 0) return;
+    launch_cc_label(lb, t, frame0, nframes, s);
     hipLaunchKernelGGL(cc_refine_kernel, dim3(nframes), dim3(CC_THREADS), 0, s, lb, t, level, io, frame0);
 }
 

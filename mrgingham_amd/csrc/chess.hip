@@ -42,6 +42,7 @@ __device__ __forceinline__ void append_hot(bool hot, int p, const CompTables& t,
             t.comp_cnt[e] = 0;
             t.comp_box[e] = make_int4(0x7fffffff, 0x7fffffff, -1, -1);
             t.roots[e] = 0x7fffffff;
+            t.comp_first[e] = 0x7fffffff;
             t.lidx[(long long)frame * t.lidx_pitch + p] = idx;
         }
     }
@@ -265,6 +266,7 @@ __device__ __forceinline__ void write_hot_entry(const CompTables& t, int frame, 
     t.comp_cnt[e] = 0;
     t.comp_box[e] = make_int4(0x7fffffff, 0x7fffffff, -1, -1);
     t.roots[e] = 0x7fffffff;
+    t.comp_first[e] = 0x7fffffff;
     t.lidx[(long long)frame * t.lidx_pitch + p] = idx;
 }
 

@@ -41,6 +41,7 @@ struct CompTables {
     int32_t* comp_cnt;        // [nframes*cap] hot pixels per super-component (at its root)
     int4* comp_box;           // [nframes*cap] (xmin, ymin, xmax, ymax) at the root
     int32_t* roots;           // [nframes*cap] compacted root list / claim table (refine)
+    int32_t* comp_first;      // [nframes*cap] smallest raster index of the super-component (at its root)
     int32_t* lidx;            // [nframes*w0*h0] pixel -> hot-list index (sparse writes)
     long long lidx_pitch;     // elements between frames
     uint32_t* arena;          // [nframes*arena_cap] DFS stacks
