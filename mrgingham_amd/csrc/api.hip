@@ -28,7 +28,7 @@ struct DevBuf {
 struct LevelScratch {
     int w = 0, h = 0, nframes = 0, cap = 0, cand_cap = 0, sort_cap = 0, pitch = 0, shift = -1;
     long long arena_cap = 0;
-    DevBuf img, resp, lidx, hot_cnt, status, hot_pix, parent, comp_cnt, roots, comp_first, comp_box, arena, cand, sortkeys;
+    DevBuf img, resp, lidx, hot_pix, parent, comp_cnt, roots, comp_first, comp_box, arena, cand, sortkeys;
 };
 
 }  // namespace mrg
@@ -48,7 +48,9 @@ struct mrgingham_amd_ctx {
     bool use_v0 = false;  // reference-shaped ChESS kernel instead of the tuned one
 
     mrg::LevelScratch lv[mrg::kMaxLevel + 1];
-    mrg::DevBuf leader, need, nseeds, seeds, cand_xy, cand_counts, aux_img, io_frame, io_out;
+    mrg::DevBuf counters;  // hot_cnt words [level][counters_nf], then status words [level][counters_nf]
+    int counters_nf = 0;
+    mrg::DevBuf leader, need, nseeds, seeds, sroot, cand_xy, cand_counts, aux_img, io_frame, io_out;
     int pts_nframes = 0, pts_pitch = 0;
     // levels (and frame counts) whose status words must be checked at the next sync
     int pending_frames[mrg::kMaxLevel + 1] = {};
@@ -140,11 +142,12 @@ static int ensure_level(mrgingham_amd_ctx* ctx, int level, int nframes, int W, i
     if (level > 0 && (rc = ensure(ctx, L.img, nf * (size_t)px + 16))) return rc;
     if ((rc = ensure(ctx, L.resp, nf * (size_t)px * 2 + 16))) return rc;
     if ((rc = ensure(ctx, L.lidx, nf * (size_t)px * 4 + 16))) return rc;
-    if (nf * 4 > L.status.bytes) {
-        if ((rc = ensure(ctx, L.hot_cnt, nf * 4))) return rc;
-        if ((rc = ensure(ctx, L.status, nf * 4))) return rc;
-        MRG_HIP_CHECK(hipMemset(L.hot_cnt.p, 0, L.hot_cnt.bytes));
-        MRG_HIP_CHECK(hipMemset(L.status.p, 0, L.status.bytes));
+    if (nframes > ctx->counters_nf) {
+        MRG_HIP_CHECK(hipDeviceSynchronize());
+        const int cnf = nframes + nframes / 8 + 8;
+        if ((rc = ensure(ctx, ctx->counters, (size_t)(kMaxLevel + 1) * 2 * cnf * 4))) return rc;
+        MRG_HIP_CHECK(hipMemset(ctx->counters.p, 0, ctx->counters.bytes));
+        ctx->counters_nf = cnf;
     }
     if ((rc = ensure(ctx, L.hot_pix, nf * (size_t)cap * 4))) return rc;
     if ((rc = ensure(ctx, L.parent, nf * (size_t)cap * 4))) return rc;
@@ -173,6 +176,7 @@ static int ensure_points(mrgingham_amd_ctx* ctx, int nframes, int pitch) {
     if ((rc = ensure(ctx, ctx->need, np * 4))) return rc;
     if ((rc = ensure(ctx, ctx->nseeds, np * 4))) return rc;
     if ((rc = ensure(ctx, ctx->seeds, np * 9 * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->sroot, np * 9 * 4))) return rc;
     if ((rc = ensure(ctx, ctx->cand_xy, np * 8))) return rc;
     if ((rc = ensure(ctx, ctx->cand_counts, (size_t)nframes * 4))) return rc;
     ctx->pts_nframes = nframes;
@@ -180,10 +184,18 @@ static int ensure_points(mrgingham_amd_ctx* ctx, int nframes, int pitch) {
     return 0;
 }
 
-static CompTables tables_of(const LevelScratch& L) {
+static int32_t* hot_cnt_of(mrgingham_amd_ctx* ctx, int level) {
+    return (int32_t*)ctx->counters.p + (size_t)level * ctx->counters_nf;
+}
+static int32_t* status_of(mrgingham_amd_ctx* ctx, int level) {
+    return (int32_t*)ctx->counters.p + (size_t)(kMaxLevel + 1 + level) * ctx->counters_nf;
+}
+
+static CompTables tables_of(mrgingham_amd_ctx* ctx, int level) {
+    const LevelScratch& L = ctx->lv[level];
     CompTables t;
     t.cap = L.cap;
-    t.hot_cnt = (int32_t*)L.hot_cnt.p;
+    t.hot_cnt = hot_cnt_of(ctx, level);
     t.hot_pix = (int32_t*)L.hot_pix.p;
     t.parent = (int32_t*)L.parent.p;
     t.comp_cnt = (int32_t*)L.comp_cnt.p;
@@ -198,7 +210,7 @@ static CompTables tables_of(const LevelScratch& L) {
     t.cand = (Cand*)L.cand.p;
     t.sortkeys = (unsigned long long*)L.sortkeys.p;
     t.sort_cap = L.sort_cap;
-    t.status = (int32_t*)L.status.p;
+    t.status = status_of(ctx, level);
     return t;
 }
 
@@ -228,8 +240,11 @@ static void launch_chess_any(mrgingham_amd_ctx* ctx, const LevelBatch& lb, const
 
 // Every detect / refine / chain call starts here: the pixel stream must not
 // overwrite level scratch the component stream of the previous call still reads.
-static void begin_op(mrgingham_amd_ctx* ctx) {
+static void begin_op(mrgingham_amd_ctx* ctx, int max_level) {
     if (ctx->cc_pending) hipStreamWaitEvent(ctx->pix, ctx->ev_cc_done, 0);
+    // hot-pixel counters of every level this call touches: one fill (status words only ever
+    // accumulate; mrgingham_amd_sync reads and clears them)
+    hipMemsetAsync(ctx->counters.p, 0, (size_t)(max_level + 1) * ctx->counters_nf * sizeof(int32_t), ctx->pix);
 }
 static void end_op(mrgingham_amd_ctx* ctx) {
     hipEventRecord(ctx->ev_cc_done, ctx->cc);
@@ -271,9 +286,7 @@ static LevelBatch queue_level_chess(mrgingham_amd_ctx* ctx, const mrgingham_amd_
     }
     lb.resp = (int16_t*)L.resp.p;
     lb.resp_pitch = (long long)L.w * L.h;
-    hipMemsetAsync(L.hot_cnt.p, 0, sizeof(int32_t) * fr->nframes, ctx->pix);
-    hipMemsetAsync(L.status.p, 0, sizeof(int32_t) * fr->nframes, ctx->pix);
-    launch_chess_any(ctx, lb, tables_of(L), fr->nframes, true, true, ctx->pix, level == 0);
+    launch_chess_any(ctx, lb, tables_of(ctx, level), fr->nframes, true, true, ctx->pix, level == 0);
     hipEventRecord(ctx->ev_pix[level], ctx->pix);
     if (fr->nframes > ctx->pending_frames[level]) ctx->pending_frames[level] = fr->nframes;
     return lb;
@@ -329,12 +342,12 @@ void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx) {
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
     for (LevelScratch& L : ctx->lv) {
-        DevBuf* bufs[] = {&L.img, &L.resp, &L.lidx, &L.hot_cnt, &L.status, &L.hot_pix, &L.parent,
+        DevBuf* bufs[] = {&L.img, &L.resp, &L.lidx, &L.hot_pix, &L.parent,
                           &L.comp_cnt, &L.roots, &L.comp_first, &L.comp_box, &L.arena, &L.cand, &L.sortkeys};
         for (DevBuf* b : bufs)
             if (b->p) hipFree(b->p);
     }
-    DevBuf* bufs[] = {&ctx->leader, &ctx->need, &ctx->nseeds, &ctx->seeds, &ctx->cand_xy, &ctx->cand_counts,
+    DevBuf* bufs[] = {&ctx->counters, &ctx->leader, &ctx->need, &ctx->nseeds, &ctx->seeds, &ctx->sroot, &ctx->cand_xy, &ctx->cand_counts,
                       &ctx->aux_img, &ctx->io_frame, &ctx->io_out};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
@@ -395,13 +408,13 @@ int mrgingham_amd_sync(mrgingham_amd_ctx* ctx) {
     for (int level = 0; level <= kMaxLevel; ++level) {
         const int nact = ctx->pending_frames[level];
         ctx->pending_frames[level] = 0;
-        if (nact <= 0 || !ctx->lv[level].status.p) continue;
+        if (nact <= 0 || !ctx->counters.p) continue;
         ctx->host_status.resize(nact);
-        MRG_HIP_CHECK(hipMemcpy(ctx->host_status.data(), ctx->lv[level].status.p, sizeof(int32_t) * nact,
+        MRG_HIP_CHECK(hipMemcpy(ctx->host_status.data(), status_of(ctx, level), sizeof(int32_t) * nact,
                                 hipMemcpyDeviceToHost));
         for (int f = 0; f < nact && rc == MRGINGHAM_AMD_OK; ++f)
             if (ctx->host_status[f]) {
-                MRG_HIP_CHECK(hipMemset(ctx->lv[level].status.p, 0, sizeof(int32_t) * nact));
+                MRG_HIP_CHECK(hipMemset(status_of(ctx, level), 0, sizeof(int32_t) * nact));
                 rc = fail(ctx, MRGINGHAM_AMD_ERR_CAPACITY,
                           "frame %d, level %d: component tables overflowed (status %d); lower "
                           "\"hot_capacity_shift\" (now %d) with mrgingham_amd_set_option and re-run",
@@ -501,7 +514,7 @@ int mrgingham_amd_detect_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frame
     if (fr->nframes == 0) return 0;
     MRG_HIP_CHECK(hipSetDevice(ctx->device));
     if ((rc = ensure_level(ctx, level, fr->nframes, fr->width, fr->height, 0))) return rc;
-    begin_op(ctx);
+    begin_op(ctx, level);
     if (level > 0) {
         const FrameBatch fb{fr->frames, fr->frame_pitch, fr->width, fr->height, fr->stride};
         launch_decimate(fb, level, (uint8_t*)ctx->lv[level].img.p, (long long)w * h, w, h, 0, fr->nframes,
@@ -509,7 +522,7 @@ int mrgingham_amd_detect_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frame
     }
     const LevelBatch lb = queue_level_chess(ctx, fr, level);
     MRG_HIP_CHECK(hipStreamWaitEvent(ctx->cc, ctx->ev_pix[level], 0));
-    launch_cc_detect(lb, tables_of(ctx->lv[level]), level, DetectOut{d_xy, capacity_per_frame, d_counts}, 0,
+    launch_cc_detect(lb, tables_of(ctx, level), level, DetectOut{d_xy, capacity_per_frame, d_counts}, 0,
                      fr->nframes, ctx->cc);
     end_op(ctx);
     MRG_HIP_CHECK(hipGetLastError());
@@ -530,7 +543,7 @@ int mrgingham_amd_refine_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frame
     MRG_HIP_CHECK(hipSetDevice(ctx->device));
     if ((rc = ensure_level(ctx, level, fr->nframes, fr->width, fr->height, points_pitch))) return rc;
     if ((rc = ensure_points(ctx, fr->nframes, points_pitch))) return rc;
-    begin_op(ctx);
+    begin_op(ctx, level);
     if (level > 0) {
         const FrameBatch fb{fr->frames, fr->frame_pitch, fr->width, fr->height, fr->stride};
         launch_decimate(fb, level, (uint8_t*)ctx->lv[level].img.p, (long long)w * h, w, h, 0, fr->nframes,
@@ -538,9 +551,9 @@ int mrgingham_amd_refine_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frame
     }
     const LevelBatch lb = queue_level_chess(ctx, fr, level);
     RefineIO io{d_points, d_levels, d_npoints, points_pitch, d_nrefined, (int32_t*)ctx->leader.p,
-                (int32_t*)ctx->need.p, (int32_t*)ctx->nseeds.p, (uint32_t*)ctx->seeds.p};
+                (int32_t*)ctx->need.p, (int32_t*)ctx->nseeds.p, (uint32_t*)ctx->seeds.p, (int32_t*)ctx->sroot.p};
     MRG_HIP_CHECK(hipStreamWaitEvent(ctx->cc, ctx->ev_pix[level], 0));
-    launch_cc_refine(lb, tables_of(ctx->lv[level]), level, io, 0, fr->nframes, ctx->cc);
+    launch_cc_refine(lb, tables_of(ctx, level), level, io, 0, fr->nframes, ctx->cc);
     end_op(ctx);
     MRG_HIP_CHECK(hipGetLastError());
     return 0;
@@ -560,10 +573,14 @@ int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames
     for (int L = 0; L <= start_level; ++L)
         if ((rc = ensure_level(ctx, L, fr->nframes, fr->width, fr->height, points_pitch))) return rc;
     if ((rc = ensure_points(ctx, fr->nframes, points_pitch))) return rc;
-    const DetectOut out{(int32_t*)ctx->cand_xy.p, points_pitch, (int32_t*)ctx->cand_counts.p};
+    DetectOut out{(int32_t*)ctx->cand_xy.p, points_pitch, (int32_t*)ctx->cand_counts.p};
+    out.points = d_points;
+    out.levels = d_levels;
+    out.npoints = d_npoints;
+    out.points_pitch = points_pitch;
     RefineIO io{d_points, d_levels, d_npoints, points_pitch, nullptr, (int32_t*)ctx->leader.p,
-                (int32_t*)ctx->need.p, (int32_t*)ctx->nseeds.p, (uint32_t*)ctx->seeds.p};
-    begin_op(ctx);
+                (int32_t*)ctx->need.p, (int32_t*)ctx->nseeds.p, (uint32_t*)ctx->seeds.p, (int32_t*)ctx->sroot.p};
+    begin_op(ctx, start_level);
     // pixel stream: every level image in one pass over the frames, then the responses top-down
     queue_level_images(ctx, fr, start_level);
     LevelBatch lbs[kMaxLevel + 1];
@@ -571,12 +588,10 @@ int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames
     // component stream: detect at the top (mrgingham.cc:50), candidates -> corners
     // (find_grid.cc:353-354), then refine level by level (mrgingham.cc:87-99)
     MRG_HIP_CHECK(hipStreamWaitEvent(ctx->cc, ctx->ev_pix[start_level], 0));
-    launch_cc_detect(lbs[start_level], tables_of(ctx->lv[start_level]), start_level, out, 0, fr->nframes, ctx->cc);
-    launch_points_from_candidates(out.xy, out.capacity, out.counts, d_points, d_levels, d_npoints, points_pitch,
-                                  start_level, 0, fr->nframes, ctx->cc);
+    launch_cc_detect(lbs[start_level], tables_of(ctx, start_level), start_level, out, 0, fr->nframes, ctx->cc);
     for (int L = start_level - 1; L >= 0; --L) {
         MRG_HIP_CHECK(hipStreamWaitEvent(ctx->cc, ctx->ev_pix[L], 0));
-        launch_cc_refine(lbs[L], tables_of(ctx->lv[L]), L, io, 0, fr->nframes, ctx->cc);
+        launch_cc_refine(lbs[L], tables_of(ctx, L), L, io, 0, fr->nframes, ctx->cc);
     }
     end_op(ctx);
     MRG_HIP_CHECK(hipGetLastError());

@@ -113,6 +113,7 @@ __device__ __forceinline__ FrameView make_view(const LevelBatch& lb, const CompT
 // of them isolated, and labelling them with the 1024 threads of the per-frame
 // workgroup was the longest phase of the component search.
 constexpr int CCL_THREADS = 256;
+constexpr int kSingletonFlag = 0x40000000;  // in hot_pix[]: the pixel has no hot 4-neighbour
 constexpr int CCL_BLOCKS_PER_FRAME = 16;
 
 // P1: union-find over the hot list (left / up neighbours).
@@ -123,9 +124,14 @@ __global__ __launch_bounds__(CCL_THREADS) void cc_union_kernel(LevelBatch lb, Co
     const int w = v.w;
     for (int i = blockIdx.x * CCL_THREADS + threadIdx.x; i < v.n; i += CCL_BLOCKS_PER_FRAME * CCL_THREADS) {
         const int p = v.hot_pix[i];
-        const int y = p / w, x = p - y * w;
-        if (x > kMargin && v.d[p - 1] > kRespMin) uf_unite(v.parent, i, v.lidx[p - 1]);
-        if (y > kMargin && v.d[p - w] > kRespMin) uf_unite(v.parent, i, v.lidx[p - w]);
+        // all four neighbours lie inside the image (p is in [7,w-7) x [7,h-7)); the frame is zero
+        const bool l = v.d[p - 1] > kRespMin, u = v.d[p - w] > kRespMin;
+        const bool r = v.d[p + 1] > kRespMin, dn = v.d[p + w] > kRespMin;
+        if (l) uf_unite(v.parent, i, v.lidx[p - 1]);
+        if (u) uf_unite(v.parent, i, v.lidx[p - w]);
+        // An isolated hot pixel is a finished super-component of size one: flag it so that P2 does
+        // not spend five atomics on it (at full resolution most hot pixels are isolated noise).
+        if (!(l || u || r || dn)) v.hot_pix[i] = p | kSingletonFlag;
     }
 }
 
@@ -136,10 +142,11 @@ __global__ __launch_bounds__(CCL_THREADS) void cc_flatten_kernel(LevelBatch lb, 
     const FrameView v = make_view(lb, t, frame);
     const int w = v.w;
     for (int i = blockIdx.x * CCL_THREADS + threadIdx.x; i < v.n; i += CCL_BLOCKS_PER_FRAME * CCL_THREADS) {
+        const int p = v.hot_pix[i];
+        if (p & kSingletonFlag) continue;  // its own root, count 0: never a blob, never shared
         const int r = uf_root(v.parent, i);
         // other threads may still walk through i: r is an ancestor, so their walks stay valid
         __hip_atomic_store(v.parent + i, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int p = v.hot_pix[i];
         const int y = p / w, x = p - y * w;
         int* box = reinterpret_cast<int*>(v.comp_box + r);
         atomicMin(box + 0, x);
@@ -219,43 +226,33 @@ __device__ __forceinline__ bool blob_passes_cheap_tests(const Blob& b) {
     return !b.touched && b.npix >= kBlobMinPixels && b.rmax > kPeakMin;  // :259, :205-206
 }
 
-// P4: the 21x21 window test of high_variance (:50-88), one wave per candidate.
-__device__ void variance_stage(const FrameView& v, int ncand) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// The 21x21 window test of high_variance (:50-88), by the lane that owns the blob, in one
+// pass: with S1 = sum(v), S2 = sum(v^2) and the reference's truncated mean m = S1/441,
+// sum((v-m)^2) = S2 - 2*m*S1 + 441*m^2 exactly (all integers), so var = that / 441 with the
+// same truncations.  The 84 loads of a window (8+8+4+1 bytes per row, never past the window)
+// are independent of each other: one round trip instead of a wave-wide phase and a barrier.
+__device__ __forceinline__ bool window_variance_high(const uint8_t* img, int stride, int w, int h, int x, int y) {
     constexpr int R = kVarWindowR, D = 2 * R + 1, NPIX = D * D;  // 441
-    for (int c = wave; c < ncand; c += CC_WAVES) {
-        const int x = v.cand[c].x_peak, y = v.cand[c].y_peak;
-        int ok = 0;
-        if (!(x - R < 0 || x + R >= v.w || y - R < 0 || y + R >= v.h)) {  // :52-57
-            int vals[7];
-            int sum = 0;
+    if (x - R < 0 || x + R >= w || y - R < 0 || y + R >= h) return false;  // :52-57
+    const uint8_t* p = img + (long long)(y - R) * stride + (x - R);
+    uint32_t s1 = 0, s2 = 0;
+#pragma unroll 3
+    for (int r = 0; r < D; ++r) {
+        uint32_t q[5];
+        __builtin_memcpy(q, p, 20);
+        const uint32_t last = p[20];
 #pragma unroll
-            for (int k = 0; k < 7; ++k) {
-                const int idx = lane + 64 * k;
-                int val = 0;
-                if (idx < NPIX) {
-                    const int dy = idx / D - R, dx = idx % D - R;
-                    val = v.img[(long long)(y + dy) * v.img_stride + x + dx];
-                }
-                vals[k] = val;
-                sum += val;
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-            const int mean = sum / NPIX;  // :69-70
-            int ssd = 0;
-#pragma unroll
-            for (int k = 0; k < 7; ++k)
-                if (lane + 64 * k < NPIX) {
-                    const int dev = vals[k] - mean;
-                    ssd += dev * dev;
-                }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) ssd += __shfl_xor(ssd, o);
-            ok = (ssd / NPIX) > kVarMin;  // :80-87
+        for (int k = 0; k < 5; ++k) {
+            s1 = __builtin_amdgcn_udot4(q[k], 0x01010101u, s1, false);
+            s2 = __builtin_amdgcn_udot4(q[k], q[k], s2, false);
         }
-        if (lane == 0) v.cand[c].ok = ok;
+        s1 += last;
+        s2 += last * last;
+        p += stride;
     }
+    const long long mean = s1 / NPIX;                                              // :69-70
+    const long long ssd = (long long)s2 - 2 * mean * (long long)s1 + NPIX * mean * mean;
+    return ssd / NPIX > kVarMin;                                                   // :80-87
 }
 
 // (p + 0.5) * scale - 0.5, find_chessboard_corners.cc:278-279
@@ -282,7 +279,7 @@ __device__ void bitonic_sort(unsigned long long* keys, int n_pad) {
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(CC_THREADS) void cc_detect_kernel(LevelBatch lb, CompTables t, int level,
                                                                DetectOut out, int frame0) {
-    __shared__ int s_nroots, s_ncand, s_nvalid;
+    __shared__ int s_nroots, s_ncand;
     __shared__ unsigned long long s_arena_top;
     // latency-bound and tiny next to the pixel kernels it shares CUs with: take issue priority
     __builtin_amdgcn_s_setprio(3);
@@ -295,7 +292,7 @@ __global__ __launch_bounds__(CC_THREADS) void cc_detect_kernel(LevelBatch lb, Co
         return;
     }
     const FrameView v = make_view(lb, t, frame);
-    if (threadIdx.x == 0) { s_nroots = 0; s_ncand = 0; s_nvalid = 0; s_arena_top = 0; }
+    if (threadIdx.x == 0) { s_nroots = 0; s_ncand = 0; s_arena_top = 0; }
     __syncthreads();
 
     // P3a: compact the roots.  A super-component of a single hot pixel can only ever give a
@@ -322,13 +319,14 @@ __global__ __launch_bounds__(CC_THREADS) void cc_detect_kernel(LevelBatch lb, Co
             Blob b;
             left -= drain_lifo(v.d, w, h, stk, 1, b);
             if (!blob_passes_cheap_tests(b)) return;
+            if (!window_variance_high(v.img, v.img_stride, w, h, b.xpk, b.ypk)) return;  // :207
             const int c = atomicAdd(&s_ncand, 1);
             if (c < v.cand_cap) {
                 Cand cd;
                 cd.sum_rx = b.srx; cd.sum_ry = b.sry; cd.sum_r = b.sr;
                 cd.seed = p;
                 cd.x_peak = (uint16_t)b.xpk; cd.y_peak = (uint16_t)b.ypk;
-                cd.ok = 0; cd.pad = 0;
+                cd.ok = 1; cd.pad = 0;
                 v.cand[c] = cd;
             }
         };
@@ -353,19 +351,11 @@ __global__ __launch_bounds__(CC_THREADS) void cc_detect_kernel(LevelBatch lb, Co
         if (threadIdx.x == 0) { atomicOr(v.status, kStatusCandOverflow); out.counts[frame] = -1; }
         return;
     }
-    const int ncand = s_ncand;
-
-    variance_stage(v, ncand);
-    __syncthreads();
+    const int nvalid = s_ncand;
 
     // P5: order by seed raster index = the reference's output order (:332-353)
-    for (int c = threadIdx.x; c < ncand; c += CC_THREADS)
-        if (v.cand[c].ok) {
-            const int k = atomicAdd(&s_nvalid, 1);
-            v.sortkeys[k] = ((unsigned long long)(uint32_t)v.cand[c].seed << 32) | (uint32_t)c;
-        }
-    __syncthreads();
-    const int nvalid = s_nvalid;
+    for (int c = threadIdx.x; c < nvalid; c += CC_THREADS)
+        v.sortkeys[c] = ((unsigned long long)(uint32_t)v.cand[c].seed << 32) | (uint32_t)c;
     int n_pad = 1;
     while (n_pad < nvalid) n_pad <<= 1;
     for (int i = nvalid + threadIdx.x; i < n_pad; i += CC_THREADS) v.sortkeys[i] = ~0ull;
@@ -375,15 +365,29 @@ __global__ __launch_bounds__(CC_THREADS) void cc_detect_kernel(LevelBatch lb, Co
     const double scale = (double)(uint16_t)(1u << level);  // :319
     int32_t* oxy = out.xy + (long long)frame * out.capacity * 2;
     const int nout = nvalid < out.capacity ? nvalid : out.capacity;
+    // the chain's hand-over to refinement, fused: every candidate becomes a corner at this level
+    // ((double)x / 1000, find_grid.cc:353-354; level tags, mrgingham.cc:81-85)
+    const int npt = out.points ? (nout < out.points_pitch ? nout : out.points_pitch) : 0;
+    double* opt = out.points ? out.points + (long long)frame * out.points_pitch * 2 : nullptr;
+    signed char* olv = out.points ? out.levels + (long long)frame * out.points_pitch : nullptr;
     for (int k = threadIdx.x; k < nout; k += CC_THREADS) {
         const Cand& cd = v.cand[(uint32_t)(v.sortkeys[k] & 0xffffffffu)];
         const double cx = (double)cd.sum_rx / (double)cd.sum_r;  // :262-263
         const double cy = (double)cd.sum_ry / (double)cd.sum_r;
         const double px = rescale_coord(cx, scale), py = rescale_coord(cy, scale);  // :346
-        oxy[2 * k + 0] = (int)(0.5 + px * kGridScale);  // :350-351
-        oxy[2 * k + 1] = (int)(0.5 + py * kGridScale);
+        const int ix = (int)(0.5 + px * kGridScale), iy = (int)(0.5 + py * kGridScale);  // :350-351
+        oxy[2 * k + 0] = ix;
+        oxy[2 * k + 1] = iy;
+        if (k < npt) {
+            opt[2 * k + 0] = (double)ix / kGridScale;
+            opt[2 * k + 1] = (double)iy / kGridScale;
+            olv[k] = (signed char)level;
+        }
     }
-    if (threadIdx.x == 0) out.counts[frame] = nvalid;
+    if (threadIdx.x == 0) {
+        out.counts[frame] = nvalid;
+        if (out.points) out.npoints[frame] = npt;
+    }
 }
 
 void launch_cc_detect(const LevelBatch& lb, const CompTables& t, int level, const DetectOut& out, int frame0,
@@ -398,7 +402,7 @@ void launch_cc_detect(const LevelBatch& lb, const CompTables& t, int level, cons
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, CompTables t, int level,
                                                                RefineIO io, int frame0) {
-    __shared__ int s_ncand, s_changed, s_nref;
+    __shared__ int s_changed, s_nref;
     __shared__ unsigned long long s_arena_top;
     __builtin_amdgcn_s_setprio(3);
     const int frame = frame0 + blockIdx.x;
@@ -410,7 +414,7 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, Co
         return;
     }
     const FrameView v = make_view(lb, t, frame);
-    if (threadIdx.x == 0) { s_ncand = 0; s_changed = 0; s_nref = 0; s_arena_top = 0; }
+    if (threadIdx.x == 0) { s_changed = 0; s_nref = 0; s_arena_top = 0; }
     __syncthreads();  // v.roots[] was preset to INT_MAX by the ChESS kernel: it is the claim table here
 
     const int w = v.w, h = v.h;
@@ -422,9 +426,11 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, Co
     int32_t* need = io.need + pb;
     int32_t* nseeds = io.nseeds + pb;
     uint32_t* seeds = io.seeds + 9 * pb;
+    int32_t* sroot = io.sroot + 9 * pb;
     const uint16_t coord_scale = (uint16_t)(1u << level);
 
-    // R1: seeds of every refinable point (:362-382), in the reference's push order
+    // R1: seeds of every refinable point (:362-382), in the reference's push order, and the
+    // super-component (root) each seed belongs to
     for (int i = threadIdx.x; i < npts; i += CC_THREADS) {
         int ns = -1;  // -1: not refinable at this level
         if (lv[i] == level + 1) {
@@ -436,8 +442,11 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, Co
                 for (int dy = -1; dy <= 1; ++dy) {
                     const int sx = (int16_t)(x + dx), sy = (int16_t)(y + dy);  // is_valid takes int16_t
                     if (sx < 0 || sx >= w || sy < 0 || sy >= h) continue;
-                    if (!(v.d[sy * w + sx] > kRespMin)) continue;
-                    seeds[9 * i + ns++] = (uint32_t)sx | ((uint32_t)sy << 16);
+                    const int p = sy * w + sx;
+                    if (!(v.d[p] > kRespMin)) continue;
+                    seeds[9 * i + ns] = (uint32_t)sx | ((uint32_t)sy << 16);
+                    sroot[9 * i + ns] = v.parent[v.lidx[p]];
+                    ++ns;
                 }
         }
         nseeds[i] = ns;
@@ -454,17 +463,10 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, Co
             const int ns = nseeds[i];
             if (ns <= 0) continue;
             int m = leader[i];
-            for (int k = 0; k < ns; ++k) {
-                const uint32_t e = seeds[9 * i + k];
-                const int r = v.parent[v.lidx[(int)(e >> 16) * w + (int)(e & 0xffffu)]];
-                m = min(m, aload(v.roots + r));
-            }
+            for (int k = 0; k < ns; ++k) m = min(m, aload(v.roots + sroot[9 * i + k]));
             bool changed = m < leader[i];
-            for (int k = 0; k < ns; ++k) {
-                const uint32_t e = seeds[9 * i + k];
-                const int r = v.parent[v.lidx[(int)(e >> 16) * w + (int)(e & 0xffffu)]];
-                if (atomicMin(v.roots + r, m) > m) changed = true;
-            }
+            for (int k = 0; k < ns; ++k)
+                if (atomicMin(v.roots + sroot[9 * i + k], m) > m) changed = true;
             leader[i] = m;
             if (changed) s_changed = 1;
         }
@@ -480,15 +482,13 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, Co
     for (int i = threadIdx.x; i < npts; i += CC_THREADS) {
         const int ns = nseeds[i];
         for (int k = 0; k < ns; ++k) {
-            const uint32_t e = seeds[9 * i + k];
-            const int r = v.parent[v.lidx[(int)(e >> 16) * w + (int)(e & 0xffffu)]];
-            const int old = atomicOr(v.comp_cnt + r, (int)0x80000000);
+            const int old = atomicOr(v.comp_cnt + sroot[9 * i + k], (int)0x80000000);
             if (old >= 0) atomicAdd(need + leader[i], 4 * old);
         }
     }
     __syncthreads();
 
-    // R4: one lane per group, members in index order (:358)
+    // R4: one lane per group, members in index order (:358); accepted points are written in place
     for (int i = threadIdx.x; i < npts; i += CC_THREADS) {
         if (nseeds[i] < 0 || leader[i] != i) continue;
         const unsigned long long off = atomicAdd(&s_arena_top, (unsigned long long)(need[i] + 10));
@@ -500,36 +500,14 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, Co
             Blob b;
             drain_lifo(v.d, w, h, stk, ns, b);
             if (!blob_passes_cheap_tests(b)) continue;
-            const int c = atomicAdd(&s_ncand, 1);
-            if (c < v.cand_cap) {
-                Cand cd;
-                cd.sum_rx = b.srx; cd.sum_ry = b.sry; cd.sum_r = b.sr;
-                cd.seed = j;  // point index
-                cd.x_peak = (uint16_t)b.xpk; cd.y_peak = (uint16_t)b.ypk;
-                cd.ok = 0; cd.pad = 0;
-                v.cand[c] = cd;
-            }
+            if (!window_variance_high(v.img, v.img_stride, w, h, b.xpk, b.ypk)) continue;  // :207
+            const double cx = (double)b.srx / (double)b.sr;  // :262-263
+            const double cy = (double)b.sry / (double)b.sr;
+            pts[2 * j + 0] = rescale_coord(cx, (double)coord_scale);  // :390
+            pts[2 * j + 1] = rescale_coord(cy, (double)coord_scale);
+            lv[j] = (signed char)level;  // :393
+            atomicAdd(&s_nref, 1);
         }
-    }
-    __syncthreads();
-    if (s_ncand > v.cand_cap) {
-        if (threadIdx.x == 0) { atomicOr(v.status, kStatusCandOverflow); if (io.nrefined) io.nrefined[frame] = -1; }
-        return;
-    }
-    const int ncand = s_ncand;
-    variance_stage(v, ncand);
-    __syncthreads();
-
-    for (int c = threadIdx.x; c < ncand; c += CC_THREADS) {
-        const Cand& cd = v.cand[c];
-        if (!cd.ok) continue;
-        const int j = cd.seed;
-        const double cx = (double)cd.sum_rx / (double)cd.sum_r;
-        const double cy = (double)cd.sum_ry / (double)cd.sum_r;
-        pts[2 * j + 0] = rescale_coord(cx, (double)coord_scale);  // :390
-        pts[2 * j + 1] = rescale_coord(cy, (double)coord_scale);
-        lv[j] = (signed char)level;  // :393
-        atomicAdd(&s_nref, 1);
     }
     __syncthreads();
     if (threadIdx.x == 0 && io.nrefined) io.nrefined[frame] = s_nref;
@@ -540,35 +518,6 @@ void launch_cc_refine(const LevelBatch& lb, const CompTables& t, int level, cons
     if (nframes <= 0) return;
     launch_cc_label(lb, t, frame0, nframes, s);
     hipLaunchKernelGGL(cc_refine_kernel, dim3(nframes), dim3(CC_THREADS), 0, s, lb, t, level, io, frame0);
-}
-
-// Candidate ints -> corner doubles, find_grid.cc:353-354 ((double)x / 1000.),
-// with every point tagged with the level it was detected at (mrgingham.cc:81-85).
-__global__ void points_from_candidates_kernel(const int32_t* xy, int capacity, const int32_t* counts,
-                                              double* points, signed char* levels, int32_t* npoints, int pitch,
-                                              int level, int frame0) {
-    const int frame = frame0 + blockIdx.y;
-    int n = counts[frame];
-    n = n < 0 ? 0 : (n < capacity ? n : capacity);
-    n = n < pitch ? n : pitch;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) npoints[frame] = n;
-    if (i >= n) return;
-    const int32_t* src = xy + ((long long)frame * capacity + i) * 2;
-    double* dst = points + ((long long)frame * pitch + i) * 2;
-    dst[0] = (double)src[0] / kGridScale;
-    dst[1] = (double)src[1] / kGridScale;
-    levels[(long long)frame * pitch + i] = (signed char)level;
-}
-
-void launch_points_from_candidates(const int32_t* xy, int capacity, const int32_t* counts, double* points,
-                                   signed char* levels, int32_t* npoints, int pitch, int level, int frame0,
-                                   int nframes, hipStream_t s) {
-    if (nframes <= 0) return;
-    const int m = capacity < pitch ? capacity : pitch;
-    dim3 grid((m + 255) / 256 > 0 ? (m + 255) / 256 : 1, nframes);
-    hipLaunchKernelGGL(points_from_candidates_kernel, grid, dim3(256), 0, s, xy, capacity, counts, points, levels,
-                       npoints, pitch, level, frame0);
 }
 
 }  // namespace mrg

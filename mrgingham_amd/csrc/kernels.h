@@ -30,6 +30,11 @@ struct DetectOut {
     int32_t* xy;      // [nframes*capacity*2]
     int capacity;
     int32_t* counts;  // [nframes]
+    // optional (chain): the candidates again as corners for the refinement below
+    double* points = nullptr;       // [nframes*points_pitch*2]
+    signed char* levels = nullptr;  // [nframes*points_pitch]
+    int32_t* npoints = nullptr;     // [nframes]
+    int points_pitch = 0;
 };
 struct RefineIO {
     double* points;          // [nframes*pitch*2]
@@ -42,13 +47,12 @@ struct RefineIO {
     int32_t* need;
     int32_t* nseeds;
     uint32_t* seeds;         // [nframes*pitch*9]
+    int32_t* sroot;          // [nframes*pitch*9] root of each seed's super-component
 };
 void launch_cc_detect(const LevelBatch& lb, const CompTables& t, int level, const DetectOut& out, int frame0,
                       int nframes, hipStream_t s);
 void launch_cc_refine(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io, int frame0,
                       int nframes, hipStream_t s);
-void launch_points_from_candidates(const int32_t* xy, int capacity, const int32_t* counts, double* points,
-                                   signed char* levels, int32_t* npoints, int pitch, int level, int frame0,
-                                   int nframes, hipStream_t s);
+
 
 }  // namespace mrg
