@@ -9,7 +9,10 @@ size BASELINE.json's metric is quoted on) the reference's found-frame schedule
 for image_pyramid_level < 0 -- detect at pyramid level 3, then refine through
 levels 2, 1, 0 (mrgingham.cc:50, :81-99; 1.328*W*H ChESS pixels per frame) --
 ending with the corner list on the device (and, for N > 1, ONE gather of the
-corner lists to rank 0 over RCCL).  Weak scaling: every rank owns its own B
+corner lists to rank 0 over RCCL).  Steps are queued back to back like a
+streaming pipeline would (no host sync between steps; the timed region is
+fenced by a full device sync + barrier on both sides), so the component search
+of step N overlaps the pixel kernels of step N+1.  Weak scaling: every rank owns its own B
 frames.  Rank 0 prints ONE JSON line.
 
   roofline      dominant kernel = the level-0 ChESS response kernel; achieved =
@@ -116,18 +119,25 @@ def main():
         frames = synth.board_batch(batch, W, H, gridn=gridn, seed0=lo, device=dev)
     det = mrgingham_amd.Detector(local_rank)
     P = args.max_points
-    out = (torch.empty((batch, P, 2), dtype=torch.float64, device=dev),
-           torch.empty((batch, P), dtype=torch.int8, device=dev),
-           torch.empty((batch,), dtype=torch.int32, device=dev))
+    # two output sets: consecutive steps overlap on the device (step N+1's pixel kernels run while
+    # step N's component kernels and gather finish), so a step must not overwrite its predecessor
+    outs = [(torch.empty((batch, P, 2), dtype=torch.float64, device=dev),
+             torch.empty((batch, P), dtype=torch.int8, device=dev),
+             torch.empty((batch,), dtype=torch.int32, device=dev)) for _ in range(2)]
     torch.cuda.synchronize()
+    nstep = [0]
 
     def step():
-        pts, lv, npts = det.chain(frames, start_level=start_level, max_points=P, out=out, sync=True)
+        out = outs[nstep[0] & 1]
+        nstep[0] += 1
+        pts, lv, npts = det.chain(frames, start_level=start_level, max_points=P, out=out, sync=False)
         if world > 1:
+            det.stream_wait()                                # torch's stream waits for this step on the device
             parallel.gather_corner_lists(pts, lv, npts, dst=0)
         return npts
 
     def fence():
+        det.sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

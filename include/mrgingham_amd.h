@@ -163,6 +163,13 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
  * section (1) do that retry themselves. */
 int mrgingham_amd_sync(mrgingham_amd_ctx* ctx);
 
+/* Device-side alternative to mrgingham_amd_sync for pipelines: makes `stream` (a hipStream_t,
+ * NULL = the default stream) wait for the most recently queued detect / refine / chain call,
+ * without blocking the host.  Consecutive calls overlap (the pixel kernels of call N+1 run while
+ * the component kernels of call N finish, on alternating scratch sets), so give each call in
+ * flight its own output buffers. */
+int mrgingham_amd_stream_wait(mrgingham_amd_ctx* ctx, void* stream);
+
 /* Average duration in milliseconds of the dominant kernel (the level-0 ChESS
  * response kernel) over the launches issued since the last call, measured with
  * hipEvents on the streams the kernel ran on; the number of launches is stored

@@ -156,6 +156,12 @@ class Detector:
     def sync(self):
         self._check(self.L.mrgingham_amd_sync(self.ctx))
 
+    def stream_wait(self, stream=None):
+        """Make a torch stream (default: the current one) wait for the last queued call, on the device."""
+        t = self.torch
+        st = t.cuda.current_stream(self.device) if stream is None else stream
+        self._check(self.L.mrgingham_amd_stream_wait(self.ctx, st.cuda_stream))
+
     def chess_response(self, frames, level=0, clamp=False, out=None):
         """Dense int16 response [B,h,w] (border zero).  Runs on torch's current stream."""
         t = self.torch

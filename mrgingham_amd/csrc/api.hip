@@ -41,19 +41,22 @@ struct mrgingham_amd_ctx {
     // underneath them.  Events order cc(L) after pix(L).
     hipStream_t pix = nullptr, cc = nullptr;
     hipEvent_t ev_pix[mrg::kMaxLevel + 1] = {};
-    hipEvent_t ev_cc_done = nullptr;
-    bool cc_pending = false;
+    // Level scratch exists twice: call N+1 fills set (N+1)%2 on the pixel stream while the
+    // component stream still works through call N in the other set.
+    hipEvent_t ev_cc_done[2] = {};
+    bool cc_pending[2] = {false, false};
+    int cur = 0;  // scratch set of the call being queued
     std::string err;
     int cap_shift = 3;    // hot-pixel table capacity = level pixels >> cap_shift per frame
     bool use_v0 = false;  // reference-shaped ChESS kernel instead of the tuned one
 
-    mrg::LevelScratch lv[mrg::kMaxLevel + 1];
-    mrg::DevBuf counters;  // hot_cnt words [level][counters_nf], then status words [level][counters_nf]
+    mrg::LevelScratch lvs[2][mrg::kMaxLevel + 1];
+    mrg::DevBuf counters2[2];  // per scratch set: hot_cnt words [level][counters_nf], then status words [level][counters_nf]
     int counters_nf = 0;
     mrg::DevBuf leader, need, nseeds, seeds, sroot, cand_xy, cand_counts, aux_img, io_frame, io_out;
     int pts_nframes = 0, pts_pitch = 0;
     // levels (and frame counts) whose status words must be checked at the next sync
-    int pending_frames[mrg::kMaxLevel + 1] = {};
+    int pending_frames[2][mrg::kMaxLevel + 1] = {};
 
     // dominant-kernel timing
     bool timing = false;
@@ -63,6 +66,8 @@ struct mrgingham_amd_ctx {
 };
 
 namespace mrg {
+
+static inline LevelScratch* cur_levels(mrgingham_amd_ctx* ctx) { return ctx->lvs[ctx->cur]; }
 
 static int fail(mrgingham_amd_ctx* ctx, int code, const char* fmt, ...) {
     char buf[512];
@@ -118,8 +123,8 @@ static int validate_frames(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* f
 }
 
 // Scratch of level `level` for a batch of nframes W x H frames and up to `pitch` points per frame.
-static int ensure_level(mrgingham_amd_ctx* ctx, int level, int nframes, int W, int H, int pitch) {
-    LevelScratch& L = ctx->lv[level];
+static int ensure_level_set(mrgingham_amd_ctx* ctx, int set, int level, int nframes, int W, int H, int pitch) {
+    LevelScratch& L = ctx->lvs[set][level];
     int w, h;
     level_dims(W, H, level, &w, &h);
     if (nframes <= L.nframes && w == L.w && h == L.h && pitch <= L.pitch && L.shift == ctx->cap_shift) return 0;
@@ -145,8 +150,10 @@ static int ensure_level(mrgingham_amd_ctx* ctx, int level, int nframes, int W, i
     if (nframes > ctx->counters_nf) {
         MRG_HIP_CHECK(hipDeviceSynchronize());
         const int cnf = nframes + nframes / 8 + 8;
-        if ((rc = ensure(ctx, ctx->counters, (size_t)(kMaxLevel + 1) * 2 * cnf * 4))) return rc;
-        MRG_HIP_CHECK(hipMemset(ctx->counters.p, 0, ctx->counters.bytes));
+        for (int k = 0; k < 2; ++k) {
+            if ((rc = ensure(ctx, ctx->counters2[k], (size_t)(kMaxLevel + 1) * 2 * cnf * 4))) return rc;
+            MRG_HIP_CHECK(hipMemset(ctx->counters2[k].p, 0, ctx->counters2[k].bytes));
+        }
         ctx->counters_nf = cnf;
     }
     if ((rc = ensure(ctx, L.hot_pix, nf * (size_t)cap * 4))) return rc;
@@ -162,6 +169,11 @@ static int ensure_level(mrgingham_amd_ctx* ctx, int level, int nframes, int W, i
     L.cap = (int)cap; L.cand_cap = (int)cand_cap; L.sort_cap = (int)sort_cap; L.arena_cap = arena_cap;
     L.shift = ctx->cap_shift;
     return 0;
+}
+
+static int ensure_level(mrgingham_amd_ctx* ctx, int level, int nframes, int W, int H, int pitch) {
+    int rc = ensure_level_set(ctx, 0, level, nframes, W, H, pitch);
+    return rc ? rc : ensure_level_set(ctx, 1, level, nframes, W, H, pitch);
 }
 
 // Per-batch point scratch shared by the levels (the component kernels of the
@@ -185,14 +197,14 @@ static int ensure_points(mrgingham_amd_ctx* ctx, int nframes, int pitch) {
 }
 
 static int32_t* hot_cnt_of(mrgingham_amd_ctx* ctx, int level) {
-    return (int32_t*)ctx->counters.p + (size_t)level * ctx->counters_nf;
+    return (int32_t*)ctx->counters2[ctx->cur].p + (size_t)level * ctx->counters_nf;
 }
 static int32_t* status_of(mrgingham_amd_ctx* ctx, int level) {
-    return (int32_t*)ctx->counters.p + (size_t)(kMaxLevel + 1 + level) * ctx->counters_nf;
+    return (int32_t*)ctx->counters2[ctx->cur].p + (size_t)(kMaxLevel + 1 + level) * ctx->counters_nf;
 }
 
 static CompTables tables_of(mrgingham_amd_ctx* ctx, int level) {
-    const LevelScratch& L = ctx->lv[level];
+    const LevelScratch& L = cur_levels(ctx)[level];
     CompTables t;
     t.cap = L.cap;
     t.hot_cnt = hot_cnt_of(ctx, level);
@@ -241,14 +253,16 @@ static void launch_chess_any(mrgingham_amd_ctx* ctx, const LevelBatch& lb, const
 // Every detect / refine / chain call starts here: the pixel stream must not
 // overwrite level scratch the component stream of the previous call still reads.
 static void begin_op(mrgingham_amd_ctx* ctx, int max_level) {
-    if (ctx->cc_pending) hipStreamWaitEvent(ctx->pix, ctx->ev_cc_done, 0);
+    ctx->cur ^= 1;  // this set was last used two calls ago
+    if (ctx->cc_pending[ctx->cur]) hipStreamWaitEvent(ctx->pix, ctx->ev_cc_done[ctx->cur], 0);
     // hot-pixel counters of every level this call touches: one fill (status words only ever
     // accumulate; mrgingham_amd_sync reads and clears them)
-    hipMemsetAsync(ctx->counters.p, 0, (size_t)(max_level + 1) * ctx->counters_nf * sizeof(int32_t), ctx->pix);
+    hipMemsetAsync(ctx->counters2[ctx->cur].p, 0, (size_t)(max_level + 1) * ctx->counters_nf * sizeof(int32_t),
+                   ctx->pix);
 }
 static void end_op(mrgingham_amd_ctx* ctx) {
-    hipEventRecord(ctx->ev_cc_done, ctx->cc);
-    ctx->cc_pending = true;
+    hipEventRecord(ctx->ev_cc_done[ctx->cur], ctx->cc);
+    ctx->cc_pending[ctx->cur] = true;
 }
 
 // Level images of levels [1, max_level] of the batch into the level scratch, on the pixel stream.
@@ -257,20 +271,20 @@ static void queue_level_images(mrgingham_amd_ctx* ctx, const mrgingham_amd_frame
     PyramidOut po{};
     int top = max_level < 3 ? max_level : 3;
     for (int L = 1; L <= top; ++L) {
-        po.out[L - 1] = (uint8_t*)ctx->lv[L].img.p;
-        po.w[L - 1] = ctx->lv[L].w;
-        po.h[L - 1] = ctx->lv[L].h;
+        po.out[L - 1] = (uint8_t*)cur_levels(ctx)[L].img.p;
+        po.w[L - 1] = cur_levels(ctx)[L].w;
+        po.h[L - 1] = cur_levels(ctx)[L].h;
     }
     if (top >= 1) launch_pyramid(fb, po, top, fr->nframes, ctx->pix);
     for (int L = 4; L <= max_level; ++L)
-        launch_decimate(fb, L, (uint8_t*)ctx->lv[L].img.p, (long long)ctx->lv[L].w * ctx->lv[L].h, ctx->lv[L].w,
-                        ctx->lv[L].h, 0, fr->nframes, ctx->pix);
+        launch_decimate(fb, L, (uint8_t*)cur_levels(ctx)[L].img.p, (long long)cur_levels(ctx)[L].w * cur_levels(ctx)[L].h,
+                        cur_levels(ctx)[L].w, cur_levels(ctx)[L].h, 0, fr->nframes, ctx->pix);
 }
 
 // ChESS response (+ hot list) of one level for the whole batch on the pixel
 // stream; records ev_pix[level].  Level images of levels > 0 must already be queued.
 static LevelBatch queue_level_chess(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int level) {
-    LevelScratch& L = ctx->lv[level];
+    LevelScratch& L = cur_levels(ctx)[level];
     LevelBatch lb;
     lb.nframes = fr->nframes;
     lb.w = L.w;
@@ -288,7 +302,7 @@ static LevelBatch queue_level_chess(mrgingham_amd_ctx* ctx, const mrgingham_amd_
     lb.resp_pitch = (long long)L.w * L.h;
     launch_chess_any(ctx, lb, tables_of(ctx, level), fr->nframes, true, true, ctx->pix, level == 0);
     hipEventRecord(ctx->ev_pix[level], ctx->pix);
-    if (fr->nframes > ctx->pending_frames[level]) ctx->pending_frames[level] = fr->nframes;
+    if (fr->nframes > ctx->pending_frames[ctx->cur][level]) ctx->pending_frames[ctx->cur][level] = fr->nframes;
     return lb;
 }
 
@@ -326,7 +340,8 @@ mrgingham_amd_ctx* mrgingham_amd_create(int device_ordinal) {
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     bool ok = hipStreamCreateWithPriority(&ctx->pix, hipStreamNonBlocking, prio_lo) == hipSuccess &&
               hipStreamCreateWithPriority(&ctx->cc, hipStreamNonBlocking, prio_hi) == hipSuccess &&
-              hipEventCreateWithFlags(&ctx->ev_cc_done, hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&ctx->ev_cc_done[0], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&ctx->ev_cc_done[1], hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i <= kMaxLevel; ++i)
         ok = hipEventCreateWithFlags(&ctx->ev_pix[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
@@ -341,13 +356,14 @@ void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
-    for (LevelScratch& L : ctx->lv) {
+    for (auto& set : ctx->lvs)
+    for (LevelScratch& L : set) {
         DevBuf* bufs[] = {&L.img, &L.resp, &L.lidx, &L.hot_pix, &L.parent,
                           &L.comp_cnt, &L.roots, &L.comp_first, &L.comp_box, &L.arena, &L.cand, &L.sortkeys};
         for (DevBuf* b : bufs)
             if (b->p) hipFree(b->p);
     }
-    DevBuf* bufs[] = {&ctx->counters, &ctx->leader, &ctx->need, &ctx->nseeds, &ctx->seeds, &ctx->sroot, &ctx->cand_xy, &ctx->cand_counts,
+    DevBuf* bufs[] = {&ctx->counters2[0], &ctx->counters2[1], &ctx->leader, &ctx->need, &ctx->nseeds, &ctx->seeds, &ctx->sroot, &ctx->cand_xy, &ctx->cand_counts,
                       &ctx->aux_img, &ctx->io_frame, &ctx->io_out};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
@@ -355,7 +371,8 @@ void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx) {
     for (auto e : ctx->event_pool) hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_pix)
         if (e) hipEventDestroy(e);
-    if (ctx->ev_cc_done) hipEventDestroy(ctx->ev_cc_done);
+    for (hipEvent_t e : ctx->ev_cc_done)
+        if (e) hipEventDestroy(e);
     if (ctx->pix) hipStreamDestroy(ctx->pix);
     if (ctx->cc) hipStreamDestroy(ctx->cc);
     delete ctx;
@@ -402,26 +419,38 @@ int mrgingham_amd_sync(mrgingham_amd_ctx* ctx) {
     MRG_HIP_CHECK(hipSetDevice(ctx->device));
     MRG_HIP_CHECK(hipStreamSynchronize(ctx->pix));
     MRG_HIP_CHECK(hipStreamSynchronize(ctx->cc));
-    ctx->cc_pending = false;
+    ctx->cc_pending[0] = ctx->cc_pending[1] = false;
     MRG_HIP_CHECK(hipGetLastError());
     int rc = MRGINGHAM_AMD_OK;
-    for (int level = 0; level <= kMaxLevel; ++level) {
-        const int nact = ctx->pending_frames[level];
-        ctx->pending_frames[level] = 0;
-        if (nact <= 0 || !ctx->counters.p) continue;
-        ctx->host_status.resize(nact);
-        MRG_HIP_CHECK(hipMemcpy(ctx->host_status.data(), status_of(ctx, level), sizeof(int32_t) * nact,
-                                hipMemcpyDeviceToHost));
-        for (int f = 0; f < nact && rc == MRGINGHAM_AMD_OK; ++f)
-            if (ctx->host_status[f]) {
-                MRG_HIP_CHECK(hipMemset(status_of(ctx, level), 0, sizeof(int32_t) * nact));
-                rc = fail(ctx, MRGINGHAM_AMD_ERR_CAPACITY,
-                          "frame %d, level %d: component tables overflowed (status %d); lower "
-                          "\"hot_capacity_shift\" (now %d) with mrgingham_amd_set_option and re-run",
-                          f, level, ctx->host_status[f], ctx->cap_shift);
-            }
-    }
+    const int saved = ctx->cur;
+    for (int set = 0; set < 2; ++set)
+        for (int level = 0; level <= kMaxLevel; ++level) {
+            const int nact = ctx->pending_frames[set][level];
+            ctx->pending_frames[set][level] = 0;
+            if (nact <= 0 || !ctx->counters2[set].p) continue;
+            ctx->cur = set;
+            ctx->host_status.resize(nact);
+            MRG_HIP_CHECK(hipMemcpy(ctx->host_status.data(), status_of(ctx, level), sizeof(int32_t) * nact,
+                                    hipMemcpyDeviceToHost));
+            for (int f = 0; f < nact && rc == MRGINGHAM_AMD_OK; ++f)
+                if (ctx->host_status[f]) {
+                    MRG_HIP_CHECK(hipMemset(status_of(ctx, level), 0, sizeof(int32_t) * nact));
+                    rc = fail(ctx, MRGINGHAM_AMD_ERR_CAPACITY,
+                              "frame %d, level %d: component tables overflowed (status %d); lower "
+                              "\"hot_capacity_shift\" (now %d) with mrgingham_amd_set_option and re-run",
+                              f, level, ctx->host_status[f], ctx->cap_shift);
+                }
+        }
+    ctx->cur = saved;
     return rc;
+}
+
+int mrgingham_amd_stream_wait(mrgingham_amd_ctx* ctx, void* stream) {
+    if (!ctx) return MRGINGHAM_AMD_ERR_ARG;
+    MRG_HIP_CHECK(hipSetDevice(ctx->device));
+    if (ctx->cc_pending[ctx->cur])
+        MRG_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, ctx->ev_cc_done[ctx->cur], 0));
+    return MRGINGHAM_AMD_OK;
 }
 
 int mrgingham_amd_chess_response_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int level,
@@ -517,7 +546,7 @@ int mrgingham_amd_detect_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frame
     begin_op(ctx, level);
     if (level > 0) {
         const FrameBatch fb{fr->frames, fr->frame_pitch, fr->width, fr->height, fr->stride};
-        launch_decimate(fb, level, (uint8_t*)ctx->lv[level].img.p, (long long)w * h, w, h, 0, fr->nframes,
+        launch_decimate(fb, level, (uint8_t*)cur_levels(ctx)[level].img.p, (long long)w * h, w, h, 0, fr->nframes,
                         ctx->pix);
     }
     const LevelBatch lb = queue_level_chess(ctx, fr, level);
@@ -546,7 +575,7 @@ int mrgingham_amd_refine_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frame
     begin_op(ctx, level);
     if (level > 0) {
         const FrameBatch fb{fr->frames, fr->frame_pitch, fr->width, fr->height, fr->stride};
-        launch_decimate(fb, level, (uint8_t*)ctx->lv[level].img.p, (long long)w * h, w, h, 0, fr->nframes,
+        launch_decimate(fb, level, (uint8_t*)cur_levels(ctx)[level].img.p, (long long)w * h, w, h, 0, fr->nframes,
                         ctx->pix);
     }
     const LevelBatch lb = queue_level_chess(ctx, fr, level);
@@ -693,7 +722,7 @@ bool find_chessboard_corners_from_image_array_C(int Nrows, int Ncols, int stride
         if (upload_frame(ctx, imagebuffer, Nrows, Ncols, stride, &fr)) break;
         if (ensure_level(ctx, image_pyramid_level, 1, Ncols, Nrows, 0)) break;
         if (ensure_points(ctx, 1, 1)) break;
-        const int cap = ctx->lv[image_pyramid_level].cand_cap;
+        const int cap = ctx->lvs[0][image_pyramid_level].cand_cap;
         if (ensure(ctx, ctx->io_out, (size_t)cap * 8 + 64)) break;
         if (mrgingham_amd_detect_batch(ctx, &fr, image_pyramid_level, (int32_t*)ctx->io_out.p, cap,
                                        (int32_t*)ctx->cand_counts.p))
