@@ -99,6 +99,8 @@ mrgingham_amd_ctx* mrgingham_amd_create(int device_ordinal);
 void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx);
 const char* mrgingham_amd_last_error(const mrgingham_amd_ctx* ctx);
 int mrgingham_amd_abi_version(void);
+/* Number of usable HIP devices (0 = none: every entry point will fail, there is no CPU path). */
+int mrgingham_amd_device_count(void);
 
 /* Size of pyramid level `level` of a width x height frame: what
  * cv::resize(.., 1/2^level, 1/2^level) produces (find_chessboard_corners.cc:449-450). */

@@ -24,7 +24,7 @@ class Frames(ctypes.Structure):
 EXPORTS = [
     "mrgingham_ChESS_response_5", "find_chessboard_corners_from_image_array_C",
     "refine_chessboard_corners_from_image_array_C", "mrgingham_amd_create", "mrgingham_amd_destroy",
-    "mrgingham_amd_last_error", "mrgingham_amd_abi_version", "mrgingham_amd_level_dims",
+    "mrgingham_amd_last_error", "mrgingham_amd_abi_version", "mrgingham_amd_device_count", "mrgingham_amd_level_dims",
     "mrgingham_amd_chess_response_batch", "mrgingham_amd_decimate_batch", "mrgingham_amd_box_blur_batch",
     "mrgingham_amd_detect_batch", "mrgingham_amd_refine_batch", "mrgingham_amd_chain_batch",
     "mrgingham_amd_set_option", "mrgingham_amd_sync", "mrgingham_amd_stream_wait", "mrgingham_amd_set_kernel_timing",
@@ -72,6 +72,7 @@ def lib():
     L.mrgingham_amd_last_error.argtypes = [c_vp]
     L.mrgingham_amd_last_error.restype = ctypes.c_char_p
     L.mrgingham_amd_abi_version.restype = c_int
+    L.mrgingham_amd_device_count.restype = c_int
     L.mrgingham_amd_level_dims.argtypes = [c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     L.mrgingham_amd_chess_response_batch.argtypes = [c_vp, FP, c_int, c_int, c_vp, c_vp]
     L.mrgingham_amd_decimate_batch.argtypes = [c_vp, FP, c_int, c_vp, c_vp]

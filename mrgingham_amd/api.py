@@ -19,6 +19,12 @@ def level_dims(width, height, level):
     return w.value, h.value
 
 
+def _require_device():
+    """The C symbols can only report a missing device as "nothing found"; the Python face fails loudly."""
+    if _lib.lib().mrgingham_amd_device_count() <= 0:
+        raise RuntimeError("mrgingham_amd: no usable HIP device, and there is no CPU fallback")
+
+
 def _check_image(image, exact_2d):
     image = np.asarray(image) if not isinstance(image, np.ndarray) else image
     # same checks, same messages as mrgingham_pywrap.c:53-68 / :163-178
@@ -42,6 +48,7 @@ def ChESS_response_5(image):
     computed; the reference leaves the 7-pixel frame uninitialised, here it is 0.
     """
     image = _check_image(image, exact_2d=False)
+    _require_device()
     L = _lib.lib()
     out = np.zeros(image.shape, dtype=np.int16)
     H, W = image.shape[-2:]
@@ -59,6 +66,7 @@ def find_points(image, image_pyramid_level=0, blobs=False, debug=False):
     if blobs and image_pyramid_level != 0:
         raise RuntimeError("blob detector requires that image_pyramid_level == 0")
     image = _check_image(image, exact_2d=True)
+    _require_device()
     result = []
 
     @_lib.ADD_POINTS_INT
@@ -86,6 +94,7 @@ def refine_points(points, levels, image, image_pyramid_level):
     """refine_chessboard_corners_from_image_array (find_chessboard_corners.hh:51-72):
     returns (points', levels', Nrefined); inputs are not modified."""
     image = _check_image(image, exact_2d=True)
+    _require_device()
     pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 2).copy()
     lv = np.ascontiguousarray(levels, dtype=np.int8).copy()
     assert len(lv) == len(pts)

@@ -314,6 +314,11 @@ extern "C" {
 
 int mrgingham_amd_abi_version(void) { return MRGINGHAM_AMD_ABI_VERSION; }
 
+int mrgingham_amd_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 int mrgingham_amd_level_dims(int width, int height, int level, int* w, int* h) {
     if (!w || !h || width < 0 || height < 0) return MRGINGHAM_AMD_ERR_ARG;
     return level_dims(width, height, level, w, h) == 0 ? MRGINGHAM_AMD_OK : MRGINGHAM_AMD_ERR_ARG;
@@ -539,8 +544,8 @@ int mrgingham_amd_detect_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frame
     int w, h;
     if (level_dims(fr->width, fr->height, level, &w, &h))
         return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "Got an unreasonable image_pyramid_level = %d", level);
-    if (!d_xy || !d_counts || capacity_per_frame < 0) return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "NULL outputs");
     if (fr->nframes == 0) return 0;
+    if (!d_xy || !d_counts || capacity_per_frame < 0) return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "NULL outputs");
     MRG_HIP_CHECK(hipSetDevice(ctx->device));
     if ((rc = ensure_level(ctx, level, fr->nframes, fr->width, fr->height, 0))) return rc;
     begin_op(ctx, level);
@@ -566,9 +571,9 @@ int mrgingham_amd_refine_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frame
     int w, h;
     if (level_dims(fr->width, fr->height, level, &w, &h))
         return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "Got an unreasonable image_pyramid_level = %d", level);
+    if (fr->nframes == 0) return 0;
     if (!d_points || !d_levels || !d_npoints || points_pitch <= 0)
         return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "NULL point buffers");
-    if (fr->nframes == 0) return 0;
     MRG_HIP_CHECK(hipSetDevice(ctx->device));
     if ((rc = ensure_level(ctx, level, fr->nframes, fr->width, fr->height, points_pitch))) return rc;
     if ((rc = ensure_points(ctx, fr->nframes, points_pitch))) return rc;
@@ -595,9 +600,9 @@ int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames
     int w, h;
     if (level_dims(fr->width, fr->height, start_level, &w, &h))
         return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "Got an unreasonable image_pyramid_level = %d", start_level);
+    if (fr->nframes == 0) return 0;
     if (!d_points || !d_levels || !d_npoints || points_pitch <= 0)
         return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "NULL point buffers");
-    if (fr->nframes == 0) return 0;
     MRG_HIP_CHECK(hipSetDevice(ctx->device));
     for (int L = 0; L <= start_level; ++L)
         if ((rc = ensure_level(ctx, L, fr->nframes, fr->width, fr->height, points_pitch))) return rc;

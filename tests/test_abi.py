@@ -56,9 +56,37 @@ def test_no_cpu_fallback_without_device():
         pytest.skip("a GPU is present")
     L = _lib.lib()
     assert L.mrgingham_amd_create(0) is None            # fails loudly, no host path
+    import numpy as np
     import mrgingham_amd
+    assert L.mrgingham_amd_device_count() == 0
     with pytest.raises(RuntimeError):
         mrgingham_amd.Detector()
+    img = np.zeros((64, 64), np.uint8)
+    for call in (lambda: mrgingham_amd.find_points(img), lambda: mrgingham_amd.ChESS_response_5(img),
+                 lambda: mrgingham_amd.refine_points(np.zeros((1, 2)), np.zeros(1, np.int8), img, 0)):
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            call()
+    # the raw C symbol can only say "nothing found" (and prints why); it must not write results
+    out = np.full((64, 64), -7, np.int16)
+    L.mrgingham_ChESS_response_5(out.ctypes.data, img.ctypes.data, 64, 64, 64)
+    assert (out == -7).all()
+
+
+def test_python_mirror_argument_checks_match_reference_messages():
+    import numpy as np
+    import mrgingham_amd
+    with pytest.raises(RuntimeError, match="exactly 2 dims"):            # mrgingham_pywrap.c:163-168
+        mrgingham_amd.find_points(np.zeros((2, 8, 8), np.uint8))
+    with pytest.raises(RuntimeError, match="8-bit unsigned"):            # :169-173
+        mrgingham_amd.find_points(np.zeros((8, 8), np.uint16))
+    with pytest.raises(RuntimeError, match="contiguous memory"):         # :174-178
+        mrgingham_amd.find_points(np.zeros((8, 16), np.uint8)[:, ::2])
+    with pytest.raises(RuntimeError, match="at least 2 dims"):           # :53-58
+        mrgingham_amd.ChESS_response_5(np.zeros(8, np.uint8))
+    with pytest.raises(RuntimeError, match="image_pyramid_level == 0"):  # :153-157
+        mrgingham_amd.find_points(np.zeros((8, 8), np.uint8), image_pyramid_level=1, blobs=True)
+    with pytest.raises(NotImplementedError):
+        mrgingham_amd.find_board(np.zeros((8, 8), np.uint8))
 
 
 def test_product_never_imports_the_oracle():

@@ -1,0 +1,161 @@
+"""GPU tests of the boundary's edge cases: ragged sizes, strided device frames, table
+overflow through the batch API, deep pyramid levels, tiny frames, concurrent host threads
+(the reference CLI calls the detector from --jobs worker threads,
+mrgingham-from-image.cc:374-379)."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import mrgingham_amd
+from mrgingham_amd import synth
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def det():
+    d = mrgingham_amd.Detector(0)
+    yield d
+    d.close()
+
+
+def _cuda(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("shape", [(333, 251), (1001, 999), (650, 490), (647, 483)])
+def test_ragged_sizes_every_level(det, shape):
+    """Sizes that are not multiples of 8/16: the generic staging, decimation and store paths."""
+    w, h = shape
+    frames = np.stack([synth.board_frame(w, h, 10, 3).numpy(), synth.noise_frame(w, h, 4, smooth=1).numpy()])
+    d = _cuda(frames)
+    for level in range(4):
+        xy, counts = det.detect(d, level, capacity=8192)
+        for f in range(2):
+            want = oracle.find_corners(frames[f], level)
+            assert int(counts[f]) == len(want), (shape, level, f)
+            assert np.array_equal(xy[f, :len(want)].cpu().numpy(), want), (shape, level, f)
+    pts, lv, npts = det.chain(d, 3, 4096)
+    for f in range(2):
+        wp, wl = oracle.chain(frames[f], 3)
+        n = int(npts[f])
+        assert n == len(wp) and np.array_equal(pts[f, :n].cpu().numpy(), wp) and np.array_equal(lv[f, :n].cpu().numpy(), wl)
+
+
+def test_strided_device_frames_detect_and_chain(det):
+    big = np.zeros((3, 500, 700), np.uint8)
+    inner = np.stack([synth.board_frame(640, 480, 10, s).numpy() for s in range(3)])
+    big[:, 10:490, 32:672] = inner
+    view = _cuda(big)[:, 10:490, 32:672]       # row stride 700, frame pitch 350000: nothing dense
+    assert not view.is_contiguous()
+    for level in (0, 2):
+        xy, counts = det.detect(view, level, capacity=1024)
+        for f in range(3):
+            want = oracle.find_corners(inner[f], level)
+            assert int(counts[f]) == len(want) and np.array_equal(xy[f, :len(want)].cpu().numpy(), want)
+    pts, lv, npts = det.chain(view, 3, 512)
+    for f in range(3):
+        wp, wl = oracle.chain(inner[f], 3)
+        n = int(npts[f])
+        assert n == len(wp) and np.array_equal(pts[f, :n].cpu().numpy(), wp)
+
+
+def test_table_overflow_is_reported_and_recoverable(det):
+    yy, xx = np.arange(240).reshape(-1, 1), np.arange(320).reshape(1, -1)
+    dense = (((yy // 3 + xx // 3) & 1) * 255).astype(np.uint8)          # 42 % hot pixels
+    frames = _cuda(np.stack([synth.board_frame(320, 240, 10, 0).numpy(), dense]))
+    with pytest.raises(RuntimeError, match="overflow"):
+        det.detect(frames, 0, capacity=65536)
+    det.set_option("hot_capacity_shift", 0)
+    try:
+        xy, counts = det.detect(frames, 0, capacity=65536)
+        for f, img in enumerate([synth.board_frame(320, 240, 10, 0).numpy(), dense]):
+            want = oracle.find_corners(img, 0)
+            assert int(counts[f]) == len(want) and np.array_equal(xy[f, :len(want)].cpu().numpy(), want)
+    finally:
+        det.set_option("hot_capacity_shift", 3)
+    # and the context keeps working at the default setting afterwards
+    xy, counts = det.detect(frames[:1], 0, capacity=1024)
+    assert int(counts[0]) == len(oracle.find_corners(synth.board_frame(320, 240, 10, 0).numpy(), 0))
+
+
+def test_deep_levels_and_tiny_frames(det):
+    img = synth.board_frame(1920, 1080, 10, 2).numpy()
+    d = _cuda(img[None])
+    for level in (4, 5, 7, 10):                  # beyond the one-pass pyramid: single-level decimation
+        assert np.array_equal(det.decimate(d, level)[0].cpu().numpy(), oracle.decimate(img, level))
+        xy, counts = det.detect(d, level, capacity=256)
+        want = oracle.find_corners(img, level)
+        assert int(counts[0]) == len(want) and np.array_equal(xy[0, :len(want)].cpu().numpy(), want)
+        got = mrgingham_amd.find_points(img, image_pyramid_level=level)
+        assert len(got) == len(want)
+    with pytest.raises(RuntimeError):
+        det.detect(d, 11)
+    for shape in [(1, 1), (1, 40), (14, 14), (15, 15), (16, 17), (22, 22), (23, 200)]:
+        tiny = np.random.RandomState(sum(shape)).randint(0, 256, size=shape).astype(np.uint8)
+        r = det.chess_response(_cuda(tiny[None]), 0)[0].cpu().numpy()
+        assert np.array_equal(r, oracle.chess_response_5(tiny, fill=0)), shape
+        for level in (0, 1):
+            want = oracle.find_corners(tiny, level)
+            got = mrgingham_amd.find_points(tiny, image_pyramid_level=level)
+            assert len(got) == (0 if want is None else len(want)), (shape, level)
+        pts, lv, npts = det.chain(_cuda(tiny[None]), 3, 16)
+        assert int(npts[0]) == len(oracle.chain(tiny, 3)[0])
+
+
+def test_zero_frames_and_zero_points(det):
+    empty = torch.empty((0, 480, 640), dtype=torch.uint8, device="cuda")
+    xy, counts = det.detect(empty, 0, capacity=8)
+    assert counts.numel() == 0
+    img = synth.board_frame(320, 240, 10, 0).numpy()
+    p, l, n = mrgingham_amd.refine_points(np.zeros((0, 2)), np.zeros(0, np.int8), img, 0)
+    assert n == 0 and p.shape == (0, 2)
+
+
+def test_concurrent_host_threads_use_private_contexts():
+    imgs = [synth.board_frame(640, 480, 10, s).numpy() for s in range(4)]
+    want = [oracle.find_corners(im, 1) for im in imgs]
+    errors = []
+
+    def worker(k):
+        try:
+            for _ in range(3):
+                got = mrgingham_amd.find_points(imgs[k], image_pyramid_level=1)
+                if not np.array_equal(np.round(got * 1000).astype(np.int64), want[k].astype(np.int64)):
+                    errors.append(k)
+                r = mrgingham_amd.ChESS_response_5(imgs[k])
+                if not np.array_equal(r, oracle.chess_response_5(imgs[k], fill=0)):
+                    errors.append(("chess", k))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
+def test_chain_start_levels_and_pitch_truncation(det):
+    frames = _cuda(np.stack([synth.board_frame(800, 600, 14, 1).numpy(), synth.noise_frame(800, 600, 2).numpy()]))
+    host = frames.cpu().numpy()
+    for start in (1, 4):
+        pts, lv, npts = det.chain(frames, start, 4096)
+        for f in range(2):
+            wp, wl = oracle.chain(host[f], start)
+            n = int(npts[f])
+            assert n == len(wp) and np.array_equal(pts[f, :n].cpu().numpy(), wp) and np.array_equal(lv[f, :n].cpu().numpy(), wl)
+    # fewer point slots than candidates: the first `pitch` candidates (reference order) are refined
+    pts, lv, npts = det.chain(frames, 2, 50)
+    for f in range(2):
+        cand = oracle.find_corners(host[f], 2)
+        m = min(50, len(cand))
+        p0 = cand[:m].astype(np.float64) / 1000.0
+        l0 = np.full(m, 2, np.int8)
+        for L in (1, 0):
+            p0, l0, _ = oracle.refine_corners(p0, l0, host[f], L)
+        assert int(npts[f]) == m and np.array_equal(pts[f, :m].cpu().numpy(), p0) and np.array_equal(lv[f, :m].cpu().numpy(), l0)
