@@ -37,3 +37,38 @@ def gather_corner_lists(points, levels, npoints, dst=0, group=None):
             cat = torch.cat(bufs, dim=0)
             outs.append(cat.view(torch.int8) if t.dtype == torch.int8 else cat)
     return tuple(outs) if rank == dst else None
+
+
+# ---------------------------------------------------------------------------
+# Mixed-resolution streams (BASELINE config 5)
+# ---------------------------------------------------------------------------
+
+def frame_cost(width, height, start_level=3):
+    """Relative cost of one frame through the chain: ChESS pixels summed over the levels
+    start_level .. 0 = W*H*(1 + 1/4 + ... ) (1.328*W*H for start_level 3)."""
+    return width * height * sum(0.25 ** L for L in range(start_level + 1))
+
+
+def lpt_assign(costs, world):
+    """Longest-processing-time-first assignment of items to `world` ranks: returns one list of
+    item indices per rank (greedy: heaviest remaining item to the currently lightest rank;
+    ties broken by rank index, so every rank computes the same plan without communicating)."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    loads = [0.0] * world
+    plan = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (loads[k], k))
+        plan[r].append(i)
+        loads[r] += costs[i]
+    return plan
+
+
+def plan_mixed_stream(sizes, world, rank, start_level=3):
+    """sizes: list of (width, height) per frame of the stream.  Returns this rank's work as
+    {(width, height): [frame indices]} -- the batch API takes equally-sized frames, so a rank
+    runs one batch per distinct resolution it was assigned."""
+    plan = lpt_assign([frame_cost(w, h, start_level) for (w, h) in sizes], world)[rank]
+    groups = {}
+    for i in sorted(plan):
+        groups.setdefault(tuple(sizes[i]), []).append(i)
+    return groups

@@ -159,3 +159,26 @@ def test_chain_start_levels_and_pitch_truncation(det):
         for L in (1, 0):
             p0, l0, _ = oracle.refine_corners(p0, l0, host[f], L)
         assert int(npts[f]) == m and np.array_equal(pts[f, :m].cpu().numpy(), p0) and np.array_equal(lv[f, :m].cpu().numpy(), l0)
+
+
+def test_mixed_resolution_stream_plan_runs_per_resolution_batches(det):
+    """BASELINE config 5 in miniature: an LPT plan over a mixed-resolution stream, one batch per
+    resolution on this rank, results keyed back to the stream order and equal to the oracle."""
+    from mrgingham_amd import parallel
+    res = [(640, 400), (960, 540), (1280, 720)]
+    sizes = [res[k % 3] for k in range(7)]
+    frames = [synth.board_frame(w, h, 10, k).numpy() for k, (w, h) in enumerate(sizes)]
+    results = {}
+    for world in (1, 2):
+        for rank in range(world):
+            for (w, h), idx in parallel.plan_mixed_stream(sizes, world, rank).items():
+                batch = _cuda(np.stack([frames[i] for i in idx]))
+                pts, lv, npts = det.chain(batch, 3, 512)
+                for j, i in enumerate(idx):
+                    n = int(npts[j])
+                    results[(world, i)] = (pts[j, :n].cpu().numpy(), lv[j, :n].cpu().numpy())
+    for i, img in enumerate(frames):
+        wp, wl = oracle.chain(img, 3)
+        for world in (1, 2):
+            gp, gl = results[(world, i)]
+            assert np.array_equal(gp, wp) and np.array_equal(gl, wl), (world, i)

@@ -59,3 +59,27 @@ def test_gather_corner_lists_world2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok
+
+
+def test_lpt_plan_for_mixed_resolution_stream():
+    sys.path.insert(0, ROOT)
+    from mrgingham_amd import parallel
+    import random
+    rnd = random.Random(5)
+    res = [(1280, 800), (1920, 1080), (2560, 1440), (4096, 2160), (4096, 3072)]
+    sizes = [res[rnd.randrange(5)] for _ in range(200)]
+    costs = [parallel.frame_cost(w, h) for (w, h) in sizes]
+    assert abs(parallel.frame_cost(4096, 3072) / (4096 * 3072) - 1.328125) < 1e-9
+    for world in (1, 2, 8):
+        plan = parallel.lpt_assign(costs, world)
+        assert sorted(i for p in plan for i in p) == list(range(200))          # a partition
+        loads = [sum(costs[i] for i in p) for p in plan]
+        assert max(loads) - min(loads) <= max(costs) + 1e-6                      # LPT bound
+        assert max(loads) <= (4 / 3) * sum(costs) / world + 1e-6                 # classic 4/3 guarantee
+        seen = []
+        for r in range(world):
+            groups = parallel.plan_mixed_stream(sizes, world, r)
+            for sz, idx in groups.items():
+                assert all(tuple(sizes[i]) == sz for i in idx) and idx == sorted(idx)
+                seen += idx
+        assert sorted(seen) == list(range(200))
