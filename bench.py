@@ -126,21 +126,29 @@ def main():
         frames = synth.board_batch(batch, W, H, gridn=gridn, seed0=lo, device=dev)
     det = mrgingham_amd.Detector(local_rank)
     P = args.max_points
-    # two output sets: consecutive steps overlap on the device (step N+1's pixel kernels run while
-    # step N's component kernels and gather finish), so a step must not overwrite its predecessor
+    # Output ring: consecutive steps overlap on the device (step N+1's pixel kernels run while step
+    # N's component kernels and gather finish), so a step must not overwrite a predecessor whose
+    # results may still be in use.  A buffer is reused three steps later, and only after the gather
+    # that read it has completed (event recorded behind the gather, host-waited before reuse).
+    NBUF = 3
     outs = [(torch.empty((batch, P, 2), dtype=torch.float64, device=dev),
              torch.empty((batch, P), dtype=torch.int8, device=dev),
-             torch.empty((batch,), dtype=torch.int32, device=dev)) for _ in range(2)]
+             torch.empty((batch,), dtype=torch.int32, device=dev)) for _ in range(NBUF)]
+    consumed = [None] * NBUF
     torch.cuda.synchronize()
     nstep = [0]
 
     def step():
-        out = outs[nstep[0] & 1]
+        k = nstep[0] % NBUF
         nstep[0] += 1
-        pts, lv, npts = det.chain(frames, start_level=start_level, max_points=P, out=out, sync=False)
+        if consumed[k] is not None:
+            consumed[k].synchronize()                        # gather of three steps ago: long done
+        pts, lv, npts = det.chain(frames, start_level=start_level, max_points=P, out=outs[k], sync=False)
         if world > 1:
             det.stream_wait()                                # torch's stream waits for this step on the device
             parallel.gather_corner_lists(pts, lv, npts, dst=0)
+            consumed[k] = torch.cuda.Event()
+            consumed[k].record()
         return npts
 
     def fence():
