@@ -67,6 +67,24 @@ int refine_chessboard_corners_from_image_array_C(int Nrows, int Ncols, int strid
                                                  double* points_xy, signed char* level, int Npoints,
                                                  int image_pyramid_level, bool debug);
 
+/* Replaces find_chessboard_from_image_array_C (mrgingham_pywrap_cplusplus_bridge.h:25-42,
+ * .cc:72-138) = mrgingham::find_chessboard_from_image_array with refinement on
+ * (mrgingham.hh:28-56, mrgingham.cc:38-140): image_pyramid_level >= 0 uses that level,
+ * < 0 tries levels 3, 2, 1, 0 until the grid finder succeeds; the gridn x gridn corners are then
+ * refined towards level 0 and handed to add_points(xy, gridn*gridn, cookie) in board order.
+ * The detector and the refinement run on the GPU, the grid finder (find_grid.cc) on the host.
+ * Returns false when no board is found or on an error; doblobs is not supported (false);
+ * debug / debug_sequence_* are accepted and ignored. */
+bool find_chessboard_from_image_array_C(int Nrows, int Ncols, int stride, char* imagebuffer, const int gridn,
+                                        int image_pyramid_level, bool doblobs, bool debug, int debug_sequence_x,
+                                        int debug_sequence_y,
+                                        bool (*add_points)(double* xy, int N, void* cookie), void* cookie);
+
+/* C face of mrgingham::find_grid_from_points (mrgingham.hh:83-87, find_grid.cc:1216-1445), host
+ * only: npoints interleaved (x,y)*1000 candidates in, gridn*gridn interleaved (x,y) corners out
+ * (rows top to bottom, each left to right).  false when no grid is found. */
+bool mrgingham_amd_find_grid_from_points(const int* xy_scaled, int npoints, int gridn, double* xy_out);
+
 /* ------------------------------------------------------------------------ */
 /* (2) Batch API over device-resident frames                                */
 /* ------------------------------------------------------------------------ */

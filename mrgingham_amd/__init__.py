@@ -9,9 +9,10 @@ memory and streams.
     import mrgingham_amd as mrgingham
     r   = mrgingham.ChESS_response_5(image)            # int16[..., H, W]
     pts = mrgingham.find_points(image, image_pyramid_level=0)   # float64[N, 2]
+    board = mrgingham.find_board(image, gridn=10)               # float64[100, 2] or None
 """
 from .api import (ChESS_response_5, find_points, find_chessboard_corners, refine_points, find_board, find_chessboard,
-                  Detector, level_dims)
+                  find_grid_from_points, Detector, level_dims)
 
 __all__ = ["ChESS_response_5", "find_points", "find_chessboard_corners", "refine_points", "find_board",
-           "find_chessboard", "Detector", "level_dims"]
+           "find_chessboard", "find_grid_from_points", "Detector", "level_dims"]

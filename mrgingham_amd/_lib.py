@@ -8,8 +8,9 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmrgingham_amd.so")
+LIB_PATH = os.environ.get("MRGINGHAM_AMD_LIB") or os.path.join(_HERE, "libmrgingham_amd.so")  # override: A/B builds
 
+ADD_POINTS_F64 = ctypes.CFUNCTYPE(ctypes.c_bool, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_void_p)
 ADD_POINTS_INT = ctypes.CFUNCTYPE(ctypes.c_bool, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_double,
                                   ctypes.c_void_p)
 
@@ -23,7 +24,8 @@ class Frames(ctypes.Structure):
 # every symbol include/mrgingham_amd.h declares
 EXPORTS = [
     "mrgingham_ChESS_response_5", "find_chessboard_corners_from_image_array_C",
-    "refine_chessboard_corners_from_image_array_C", "mrgingham_amd_create", "mrgingham_amd_destroy",
+    "refine_chessboard_corners_from_image_array_C", "find_chessboard_from_image_array_C",
+    "mrgingham_amd_find_grid_from_points", "mrgingham_amd_create", "mrgingham_amd_destroy",
     "mrgingham_amd_last_error", "mrgingham_amd_abi_version", "mrgingham_amd_device_count", "mrgingham_amd_level_dims",
     "mrgingham_amd_chess_response_batch", "mrgingham_amd_decimate_batch", "mrgingham_amd_box_blur_batch",
     "mrgingham_amd_detect_batch", "mrgingham_amd_refine_batch", "mrgingham_amd_chain_batch",
@@ -65,6 +67,11 @@ def lib():
     L.refine_chessboard_corners_from_image_array_C.argtypes = [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_int,
                                                                c_bool]
     L.refine_chessboard_corners_from_image_array_C.restype = c_int
+    L.find_chessboard_from_image_array_C.argtypes = [c_int, c_int, c_int, c_vp, c_int, c_int, c_bool, c_bool, c_int,
+                                                     c_int, ADD_POINTS_F64, c_vp]
+    L.find_chessboard_from_image_array_C.restype = c_bool
+    L.mrgingham_amd_find_grid_from_points.argtypes = [c_vp, c_int, c_int, c_vp]
+    L.mrgingham_amd_find_grid_from_points.restype = c_bool
     L.mrgingham_amd_create.argtypes = [c_int]
     L.mrgingham_amd_create.restype = c_vp
     L.mrgingham_amd_destroy.argtypes = [c_vp]

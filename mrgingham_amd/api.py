@@ -106,12 +106,45 @@ def refine_points(points, levels, image, image_pyramid_level):
     return pts, lv, n
 
 
+def find_grid_from_points(points_scaled, gridn=10):
+    """mrgingham::find_grid_from_points (find_grid.cc:1216-1445), host only: int (N,2) candidates
+    (pixel coordinates * 1000) -> float64 (gridn*gridn, 2) corners in board order, or None."""
+    pts = np.ascontiguousarray(points_scaled, dtype=np.int32).reshape(-1, 2)
+    out = np.empty((gridn * gridn, 2), dtype=np.float64)
+    ok = _lib.lib().mrgingham_amd_find_grid_from_points(pts.ctypes.data, len(pts), int(gridn), out.ctypes.data)
+    return out if ok else None
+
+
 def find_board(image, image_pyramid_level=-1, gridn=10, blobs=False, debug=False, debug_sequence=None):
-    """Needs the grid finder (find_grid.cc), which stays on the host in the
-    reference and is outside this library's hot path: not provided."""
-    raise NotImplementedError("find_board needs mrgingham's host-side grid finder (find_grid.cc); mrgingham_amd "
-                              "covers the corner-candidate path only.  Use mrgingham.find_grid_from_points on "
-                              "find_points()/Detector.chain() output.")
+    """The full detector: float64 (gridn*gridn, 2) board corners, or None (mrgingham_pywrap.c:227-337).
+
+    image_pyramid_level < 0 (default): try levels 3, 2, 1, 0 until a grid is found, then refine the
+    corners down to level 0 (mrgingham.cc:116-139, :81-99)."""
+    if blobs and image_pyramid_level != 0:
+        raise RuntimeError("blob detector requires that image_pyramid_level == 0")
+    dsx = dsy = -1
+    if debug_sequence is not None:
+        try:
+            dsx, dsy = (int(t) for t in str(debug_sequence).split(","))
+        except ValueError:
+            raise RuntimeError("Couldn't parse debug_sequence as an 'INTEGER,INTEGER' string") from None
+    image = _check_image(image, exact_2d=True)
+    if gridn < 2:
+        raise RuntimeError("gridn value must be >= 2")
+    _require_device()
+    result = []
+
+    @_lib.ADD_POINTS_F64
+    def add_points(xy, n, cookie):  # add_points__find_board, mrgingham_pywrap.c:214-226
+        result.append(np.ctypeslib.as_array(xy, shape=(2 * n,)).copy().reshape(n, 2))
+        return True
+
+    H, W = image.shape
+    stride = image.strides[0] if H > 1 else W
+    ok = _lib.lib().find_chessboard_from_image_array_C(H, W, stride, image.ctypes.data, int(gridn),
+                                                       int(image_pyramid_level), bool(blobs), bool(debug), dsx, dsy,
+                                                       add_points, None)
+    return result[0] if ok and result else None  # "possibly found no chessboard": None (:322-330)
 
 
 find_chessboard = find_board  # compatibility alias, mrgingham_pywrap.c:366

@@ -11,6 +11,7 @@
 
 #include "../../include/mrgingham_amd.h"
 #include "common.h"
+#include "grid.h"
 #include "kernels.h"
 
 namespace mrg {
@@ -792,6 +793,88 @@ int refine_chessboard_corners_from_image_array_C(int Nrows, int Ncols, int strid
     }
     ctx->cap_shift = saved_shift;
     return ok && nrefined > 0 ? nrefined : 0;
+}
+
+/* C face of mrgingham::find_grid_from_points (mrgingham.hh:83-87; find_grid.cc:1216-1445): host only. */
+bool mrgingham_amd_find_grid_from_points(const int* xy_scaled, int npoints, int gridn, double* xy_out) {
+    if (!xy_scaled || !xy_out || npoints < 0 || gridn < 2) return false;
+    std::vector<PointI> pts((size_t)npoints);
+    for (int i = 0; i < npoints; ++i) pts[i] = PointI{xy_scaled[2 * i], xy_scaled[2 * i + 1]};
+    std::vector<PointD> out;
+    if (!find_grid_from_points(out, pts, gridn) || (int)out.size() != gridn * gridn) return false;
+    memcpy(xy_out, out.data(), sizeof(double) * 2 * out.size());
+    return true;
+}
+
+/* Replaces find_chessboard_from_image_array_C (mrgingham_pywrap_cplusplus_bridge.h:25-42, .cc:72-138),
+ * i.e. mrgingham::find_chessboard_from_image_array with refinement on (mrgingham.cc:38-140): detector
+ * and refinement on the GPU, grid finder on the host. */
+bool find_chessboard_from_image_array_C(int Nrows, int Ncols, int stride, char* imagebuffer, const int gridn,
+                                        int image_pyramid_level, bool doblobs, bool debug, int debug_sequence_x,
+                                        int debug_sequence_y,
+                                        bool (*add_points)(double* xy, int N, void* cookie), void* cookie) {
+    (void)debug; (void)debug_sequence_x; (void)debug_sequence_y;
+    if (doblobs) {
+        fprintf(stderr, "mrgingham_amd: the blob detector (find_blobs.cc) is not part of this library\n");
+        return false;
+    }
+    if (Nrows < 0 || Ncols < 0 || stride < Ncols || !imagebuffer || !add_points || gridn < 2) return false;
+    if (image_pyramid_level > 10) {
+        fprintf(stderr, "mrgingham_amd: %s(): Got an unreasonable image_pyramid_level = %d. Sorry.\n", __func__,
+                image_pyramid_level);
+        return false;
+    }
+    mrgingham_amd_ctx* ctx = thread_ctx();
+    if (!ctx) return false;
+    hipSetDevice(ctx->device);
+    const int saved_shift = ctx->cap_shift;
+    mrgingham_amd_frames fr;
+    if (upload_frame(ctx, imagebuffer, Nrows, Ncols, stride, &fr)) return false;
+    const int N = gridn * gridn;
+    std::vector<PointD> board;
+    std::vector<int32_t> xy;
+    bool found = false;
+    // image_pyramid_level >= 0: that level only; < 0: 3, 2, 1, 0 until a grid is found (mrgingham.cc:116-139)
+    const int first = image_pyramid_level >= 0 ? image_pyramid_level : 3;
+    const int last = image_pyramid_level >= 0 ? image_pyramid_level : 0;
+    int level = first;
+    for (; level >= last && !found; --level) {
+        if (!check_level_and_layout(__func__, Nrows, Ncols, stride, level)) continue;
+        int32_t count = 0;
+        bool ok = false;
+        for (int attempt = 0; attempt < 2 && !ok; ++attempt) {
+            if (ensure_level(ctx, level, 1, Ncols, Nrows, N) || ensure_points(ctx, 1, N)) break;
+            const int cap = ctx->lvs[0][level].cand_cap;
+            if (ensure(ctx, ctx->io_out, (size_t)cap * 8 + (size_t)N * 17 + 256)) break;
+            if (mrgingham_amd_detect_batch(ctx, &fr, level, (int32_t*)ctx->io_out.p, cap, (int32_t*)ctx->cand_counts.p))
+                break;
+            const int rc = mrgingham_amd_sync(ctx);
+            if (rc == MRGINGHAM_AMD_ERR_CAPACITY && attempt == 0) { ctx->cap_shift = 0; continue; }
+            if (rc) break;
+            if (hipMemcpy(&count, ctx->cand_counts.p, sizeof(count), hipMemcpyDeviceToHost) != hipSuccess) break;
+            xy.resize((size_t)(count > 0 ? count : 0) * 2);
+            if (count > 0 && hipMemcpy(xy.data(), ctx->io_out.p, (size_t)count * 8, hipMemcpyDeviceToHost) != hipSuccess)
+                break;
+            ok = true;
+        }
+        ctx->cap_shift = saved_shift;
+        if (!ok || count < N) continue;
+        std::vector<PointI> cand((size_t)count);
+        for (int i = 0; i < count; ++i) cand[i] = PointI{xy[2 * i], xy[2 * i + 1]};
+        board.clear();
+        found = find_grid_from_points(board, cand, gridn) && (int)board.size() == N;  // mrgingham.cc:51
+        if (found) break;
+    }
+    if (!found) return false;
+    // refine towards level 0 while something still refines (mrgingham.cc:81-99)
+    std::vector<signed char> lv((size_t)N, (signed char)level);
+    for (int l = level - 1; l >= 0; --l) {
+        const int n = refine_chessboard_corners_from_image_array_C(Nrows, Ncols, stride, imagebuffer, &board[0].x,
+                                                                   lv.data(), N, l, false);
+        if (n <= 0) break;
+    }
+    static_assert(sizeof(PointD) == 2 * sizeof(double), "add_points() takes interleaved doubles");
+    return (*add_points)(&board[0].x, N, cookie);  // bridge.cc:133-137
 }
 
 }  // extern "C"

@@ -35,7 +35,6 @@
 namespace mrg {
 
 constexpr int CC_THREADS = 256;
-constexpr int CC_WAVES = CC_THREADS / 64;
 
 __device__ __forceinline__ int aload(const int32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -1,0 +1,572 @@
+// Host-side grid finder: orders the detector's corner candidates into a gridn x gridn board.
+//
+// This is the caller side of the hot path: the reference keeps it
+// on the host (find_grid.cc, ~100-300 points per frame, microseconds) and so does this library.
+// It restates mrgingham::find_grid_from_points (find_grid.cc:1216-1445) and the helpers it uses
+// (:88-140 neighbour iteration, :204-312 sequence growing, :314-346 sequence search,
+// :502-569 sequence candidates, :780-823 crossing test, :825-951 outer 4-cycles,
+// :953-1003 equal-and-opposite cycles, :1025-1190 clockwise cycle and top edge,
+// :1192-1214 sequence lookup), written from the algorithm, not copied.
+//
+// PARITY UNPINNED.  The reference reads its neighbour structure off boost::polygon's Voronoi
+// diagram (find_grid.cc:7, :1226-1227); boost is absent here and the reference has no test for this
+// file, so nothing executable pins this restatement.  The neighbour structure below is the Delaunay
+// triangulation of the same integer points (the dual of that Voronoi diagram) with exact integer
+// predicates; neighbours of a site are visited counter-clockwise (in the x,y plane as numbers) like
+// boost's edge->next(), sites in boost's cell order (sorted by x, then y).  Where the reference takes
+// "the first neighbour that matches" (find_grid.cc:216-222) the starting neighbour of the rotation is
+// an implementation detail of boost that is not reproduced; on clean boards exactly one neighbour
+// matches, and the final grid is fixed by geometry (unique 4-cycles, clockwise test, top edge), not by
+// visiting order.  Exactly cocircular quadruples (a degenerate Voronoi vertex) get one of their two
+// diagonals here and none in boost.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <set>
+#include <vector>
+
+#include "grid.h"
+
+namespace mrg {
+
+namespace {
+
+using i64 = long long;
+using i128 = __int128;
+
+// ---------------------------------------------------------------------------------------------
+// Delaunay triangulation (sweep insertion + Lawson flips, exact predicates)
+// ---------------------------------------------------------------------------------------------
+struct Tri {
+    int v[3];  // counter-clockwise
+    int n[3];  // n[k] = triangle across the edge opposite v[k], or -1
+};
+
+inline i64 orient(const PointI& a, const PointI& b, const PointI& c) {
+    return (i64)(b.x - a.x) * (i64)(c.y - a.y) - (i64)(b.y - a.y) * (i64)(c.x - a.x);
+}
+
+// > 0 when d lies strictly inside the circumcircle of the counter-clockwise triangle a,b,c
+inline int incircle(const PointI& a, const PointI& b, const PointI& c, const PointI& d) {
+    const i64 ax = (i64)a.x - d.x, ay = (i64)a.y - d.y;
+    const i64 bx = (i64)b.x - d.x, by = (i64)b.y - d.y;
+    const i64 cx = (i64)c.x - d.x, cy = (i64)c.y - d.y;
+    const i128 a2 = (i128)ax * ax + (i128)ay * ay;
+    const i128 b2 = (i128)bx * bx + (i128)by * by;
+    const i128 c2 = (i128)cx * cx + (i128)cy * cy;
+    const i128 det = a2 * ((i128)bx * cy - (i128)by * cx) - b2 * ((i128)ax * cy - (i128)ay * cx) +
+                     c2 * ((i128)ax * by - (i128)ay * bx);
+    return det > 0 ? 1 : (det < 0 ? -1 : 0);
+}
+
+class Delaunay {
+public:
+    explicit Delaunay(const std::vector<PointI>& pts) : p(pts) {}
+
+    // false when there is no triangle at all (fewer than 3 distinct points, or all collinear)
+    bool build() {
+        const int n = (int)p.size();
+        order.resize(n);
+        for (int i = 0; i < n; ++i) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](int a, int b) {
+            return p[a].x != p[b].x ? p[a].x < p[b].x : (p[a].y != p[b].y ? p[a].y < p[b].y : a < b);
+        });
+        // distinct points, in sweep order
+        std::vector<int> s;
+        for (int i : order)
+            if (s.empty() || p[s.back()].x != p[i].x || p[s.back()].y != p[i].y) s.push_back(i);
+        if (s.size() < 3) return false;
+        // the first point that is not collinear with the first two; the collinear prefix s[0..k-1]
+        size_t k = 2;
+        while (k < s.size() && orient(p[s[0]], p[s[1]], p[s[k]]) == 0) ++k;
+        if (k == s.size()) return false;
+        // fan from s[k] over the collinear prefix
+        const bool left = orient(p[s[0]], p[s[1]], p[s[k]]) > 0;
+        for (size_t i = 0; i + 1 < k; ++i) {
+            Tri t;
+            if (left) { t.v[0] = s[i]; t.v[1] = s[i + 1]; t.v[2] = s[k]; }
+            else { t.v[0] = s[i + 1]; t.v[1] = s[i]; t.v[2] = s[k]; }
+            t.n[0] = t.n[1] = t.n[2] = -1;
+            tris.push_back(t);
+        }
+        link_all();
+        // convex hull as a counter-clockwise cycle
+        hull_next.assign(n, -1);
+        hull_prev.assign(n, -1);
+        {
+            std::vector<int> h;
+            if (left) { for (size_t i = 0; i < k; ++i) h.push_back(s[i]); h.push_back(s[k]); }
+            else { for (size_t i = k; i-- > 0;) h.push_back(s[i]); h.push_back(s[k]); }
+            for (size_t i = 0; i < h.size(); ++i) {
+                hull_next[h[i]] = h[(i + 1) % h.size()];
+                hull_prev[h[(i + 1) % h.size()]] = h[i];
+            }
+        }
+        int last = s[k];
+        for (size_t i = k + 1; i < s.size(); ++i) {
+            insert_outside(s[i], last);
+            last = s[i];
+        }
+        return true;
+    }
+
+    const std::vector<PointI>& p;
+    std::vector<int> order;  // all point indices sorted by (x, y): boost's cell order
+    std::vector<Tri> tris;
+
+private:
+    std::vector<int> hull_next, hull_prev;
+    std::map<std::pair<int, int>, std::pair<int, int>> edge_owner;  // directed edge (a,b) -> (triangle, slot)
+
+    void link_all() {
+        edge_owner.clear();
+        for (int t = 0; t < (int)tris.size(); ++t)
+            for (int k = 0; k < 3; ++k) edge_owner[{tris[t].v[(k + 1) % 3], tris[t].v[(k + 2) % 3]}] = {t, k};
+        for (int t = 0; t < (int)tris.size(); ++t)
+            for (int k = 0; k < 3; ++k) {
+                auto it = edge_owner.find({tris[t].v[(k + 2) % 3], tris[t].v[(k + 1) % 3]});
+                tris[t].n[k] = it == edge_owner.end() ? -1 : it->second.first;
+            }
+    }
+
+    int add_tri(int a, int b, int c) {  // counter-clockwise a,b,c
+        Tri t;
+        t.v[0] = a; t.v[1] = b; t.v[2] = c;
+        t.n[0] = t.n[1] = t.n[2] = -1;
+        const int id = (int)tris.size();
+        tris.push_back(t);
+        for (int k = 0; k < 3; ++k) {
+            const int u = t.v[(k + 1) % 3], w = t.v[(k + 2) % 3];
+            edge_owner[{u, w}] = {id, k};
+            auto it = edge_owner.find({w, u});
+            if (it != edge_owner.end()) {
+                tris[id].n[k] = it->second.first;
+                tris[it->second.first].n[it->second.second] = id;
+            }
+        }
+        return id;
+    }
+
+    // q lies outside the current hull (sweep order guarantees it); `start` is a hull vertex it sees
+    void insert_outside(int q, int start) {
+        // visible hull edges (a -> hull_next[a]) are those with q strictly to their right
+        int lo = start, hi = start;
+        while (orient(p[hull_prev[lo]], p[lo], p[q]) < 0) lo = hull_prev[lo];
+        while (orient(p[hi], p[hull_next[hi]], p[q]) < 0) hi = hull_next[hi];
+        if (lo == hi) {
+            // q is collinear with the hull edges at `start` on both sides: cannot happen for a point
+            // strictly beyond the sweep line unless the hull is degenerate; nothing visible.
+            return;
+        }
+        std::vector<int> fresh;
+        for (int a = lo; a != hi;) {
+            const int b = hull_next[a];
+            fresh.push_back(add_tri(b, a, q));  // (a,b) is a ccw hull edge seen from outside: b,a,q is ccw
+            a = b;
+        }
+        hull_next[lo] = q; hull_prev[q] = lo;
+        hull_next[q] = hi; hull_prev[hi] = q;
+        // vertices strictly between lo and hi left the hull
+        for (int t : fresh) legalize(t, 2);
+    }
+
+    // Lawson: the edge of triangle t opposite its vertex slot k
+    void legalize(int t0, int k0) {
+        std::vector<std::pair<int, int>> stack{{t0, k0}};
+        while (!stack.empty()) {
+            auto [t, k] = stack.back();
+            stack.pop_back();
+            const int u = tris[t].n[k];
+            if (u < 0) continue;
+            const int a = tris[t].v[k], b = tris[t].v[(k + 1) % 3], c = tris[t].v[(k + 2) % 3];
+            int ku = -1;
+            for (int j = 0; j < 3; ++j)
+                if (tris[u].n[j] == t && tris[u].v[(j + 1) % 3] == c && tris[u].v[(j + 2) % 3] == b) ku = j;
+            if (ku < 0) continue;
+            const int d = tris[u].v[ku];
+            if (incircle(p[a], p[b], p[c], p[d]) <= 0) continue;
+            // flip edge (b,c) -> (a,d): triangles (a,b,d) and (a,d,c)
+            const int n_ab = tris[t].n[(k + 2) % 3], n_ca = tris[t].n[(k + 1) % 3];
+            const int n_bd = tris[u].n[(ku + 1) % 3], n_dc = tris[u].n[(ku + 2) % 3];
+            // note: in u, vertex order is d, c, b (ccw): edge opposite c is (b,d), opposite b is (d,c)
+            tris[t].v[0] = a; tris[t].v[1] = b; tris[t].v[2] = d;
+            tris[t].n[0] = n_bd; tris[t].n[1] = u; tris[t].n[2] = n_ab;
+            tris[u].v[0] = a; tris[u].v[1] = d; tris[u].v[2] = c;
+            tris[u].n[0] = n_dc; tris[u].n[1] = n_ca; tris[u].n[2] = t;
+            auto relink = [&](int nb, int from, int to) {
+                if (nb < 0) return;
+                for (int j = 0; j < 3; ++j)
+                    if (tris[nb].n[j] == from) { tris[nb].n[j] = to; return; }
+            };
+            relink(n_bd, u, t);
+            relink(n_ca, t, u);
+            edge_owner.erase({b, c});
+            edge_owner.erase({c, b});
+            for (int tt : {t, u})
+                for (int j = 0; j < 3; ++j) edge_owner[{tris[tt].v[(j + 1) % 3], tris[tt].v[(j + 2) % 3]}] = {tt, j};
+            stack.push_back({t, 0});
+            stack.push_back({u, 0});
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// What find_grid.cc reads off the Voronoi diagram, per site: the counter-clockwise ring of
+// neighbouring sites, whether consecutive neighbours close a triangle with the site, and the
+// site on the far side of that triangle's outer edge (find_grid.cc:41-87).
+// ---------------------------------------------------------------------------------------------
+struct Ring {
+    std::vector<int> nbr;   // neighbour sites, counter-clockwise
+    std::vector<char> tri;  // tri[k]: (site, nbr[k], nbr[k+1]) is a triangle
+    std::vector<int> far;   // far[k]: the site opposite `site` across edge (nbr[k], nbr[k+1]), or -1
+};
+
+struct SiteGraph {
+    std::vector<int> order;  // sites in cell order
+    std::vector<Ring> ring;
+};
+
+bool build_site_graph(const std::vector<PointI>& pts, SiteGraph& g) {
+    Delaunay dt(pts);
+    if (!dt.build()) return false;
+    const int n = (int)pts.size();
+    g.order = dt.order;
+    g.ring.assign(n, Ring());
+    // one incident triangle per vertex, preferring one whose clockwise side is open (hull start)
+    std::vector<int> inc(n, -1);
+    for (int t = 0; t < (int)dt.tris.size(); ++t)
+        for (int k = 0; k < 3; ++k) {
+            const int v = dt.tris[t].v[k];
+            // the edge (v, v_next) is opposite slot (k+2)%3; the edge (v_prev, v) opposite (k+1)%3.
+            // rotating clockwise around v crosses edge (v, v[k+1]) -> neighbour n[(k+2)%3]
+            if (inc[v] < 0 || dt.tris[t].n[(k + 2) % 3] < 0) inc[v] = t;
+        }
+    for (int v = 0; v < n; ++v) {
+        if (inc[v] < 0) continue;  // duplicate of another point: no cell of its own
+        Ring& r = g.ring[v];
+        // walk counter-clockwise around v starting at inc[v]
+        int t = inc[v];
+        const int t_first = t;
+        bool closed = false;
+        while (true) {
+            int k = 0;
+            while (dt.tris[t].v[k] != v) ++k;
+            const int b = dt.tris[t].v[(k + 1) % 3], c = dt.tris[t].v[(k + 2) % 3];
+            if (r.nbr.empty()) r.nbr.push_back(b);
+            r.tri.push_back(1);
+            // far vertex across (b,c): the triangle opposite v
+            const int u = dt.tris[t].n[k];
+            int d = -1;
+            if (u >= 0)
+                for (int j = 0; j < 3; ++j)
+                    if (dt.tris[u].v[j] != b && dt.tris[u].v[j] != c) d = dt.tris[u].v[j];
+            r.far.push_back(d);
+            // next triangle counter-clockwise: across edge (v, c), which is opposite slot (k+1)%3
+            const int nx = dt.tris[t].n[(k + 1) % 3];
+            if (nx == t_first) { closed = true; break; }
+            r.nbr.push_back(c);
+            if (nx < 0) break;
+            t = nx;
+        }
+        if (!closed) {
+            // hull site: the step from the last neighbour back to the first has no triangle
+            r.tri.push_back(0);
+            r.far.push_back(-1);
+        }
+    }
+    return true;
+}
+
+// The neighbours the reference considers from a site, in its order: for every ring position the
+// direct neighbour, then the "in-between" site across the triangle's far edge when it lies
+// angularly between the two (find_grid.cc:88-140).
+template <typename F>
+bool for_each_adjacent(const SiteGraph& g, const std::vector<PointI>& pts, int c, F&& visit) {
+    const Ring& r = g.ring[c];
+    const int deg = (int)r.nbr.size();
+    const PointI& pt = pts[c];
+    for (int k = 0; k < deg; ++k) {
+        const int b = r.nbr[k];
+        if (visit(b, PointI{pts[b].x - pt.x, pts[b].y - pt.y})) return true;
+        if (deg < 2) continue;
+        const int cn = r.nbr[(k + 1) % deg];
+        const i64 v0x = pts[b].x - pt.x, v0y = pts[b].y - pt.y;
+        const i64 v1x = pts[cn].x - pt.x, v1y = pts[cn].y - pt.y;
+        if (v1x * v0y > v0x * v1y) continue;  // not an acute turn: graph boundary (:116-117)
+        if (!r.tri[k]) continue;              // the two edges do not close a triangle (:121-122)
+        const int d = r.far[k];
+        if (d < 0) continue;
+        const i64 vmx = pts[d].x - pt.x, vmy = pts[d].y - pt.y;
+        if (v1x * vmy > vmx * v1y) continue;  // must lie angularly between its neighbours (:128-131)
+        if (vmx * v0y > v0x * vmy) continue;
+        if (visit(d, PointI{(int)vmx, (int)vmy})) return true;
+    }
+    return false;
+}
+
+// thresholds, find_grid.cc:204-207
+constexpr double kSpacingCos = 0.984;
+constexpr double kLenRatioMin = 0.7, kLenRatioMax = 1.4, kLenRatioDev = 0.35;
+
+struct SeqStats {  // HypothesisStatistics, :166-172
+    PointI delta_last;
+    double ratio_sum;
+    int ratio_n;
+};
+
+// get_adjacent_cell_along_sequence, :209-312: the first neighbour continuing the sequence, or -1
+int next_along_sequence(const SiteGraph& g, const std::vector<PointI>& pts, int c, SeqStats& st) {
+    const double last_len = std::hypot((double)st.delta_last.x, (double)st.delta_last.y);
+    int found = -1;
+    for_each_adjacent(g, pts, c, [&](int cand, PointI delta) {
+        const double len = std::hypot((double)delta.x, (double)delta.y);
+        const double cos_err = ((double)st.delta_last.x * (double)delta.x + (double)st.delta_last.y * (double)delta.y) /
+                               (last_len * len);
+        if (cos_err < kSpacingCos) return false;
+        const double ratio = len / last_len;
+        if (ratio < kLenRatioMin || ratio > kLenRatioMax) return false;
+        if (st.ratio_n > 2) {
+            const double dev = ratio - st.ratio_sum / (double)st.ratio_n;
+            if (dev < -kLenRatioDev || dev > kLenRatioDev) return false;
+        }
+        st.ratio_sum += ratio;
+        st.ratio_n++;
+        st.delta_last = delta;
+        found = cand;
+        return true;
+    });
+    return found;
+}
+
+struct Sequence {  // CandidateSequence, :148-162
+    int c0, c1, clast;
+    PointD delta_mean;
+};
+
+// walks n_remaining steps from c along delta; fills `path` (if given) with the sites visited
+int walk_sequence(const SiteGraph& g, const std::vector<PointI>& pts, PointI delta, int c, int n_remaining,
+                  PointD* delta_mean, std::vector<int>* path) {
+    SeqStats st{delta, 0.0, 0};
+    double sx = delta.x, sy = delta.y;
+    int last = -1;
+    for (int i = 0; i < n_remaining; ++i) {
+        const int nx = next_along_sequence(g, pts, c, st);
+        if (nx < 0) return -1;
+        sx += st.delta_last.x;
+        sy += st.delta_last.y;
+        if (path) path->push_back(nx);
+        last = nx;
+        c = nx;
+    }
+    if (delta_mean) { delta_mean->x = sx / (double)(n_remaining + 1); delta_mean->y = sy / (double)(n_remaining + 1); }
+    return last;
+}
+
+std::vector<int> sequence_points(const SiteGraph& g, const std::vector<PointI>& pts, const Sequence& s, int gridn) {
+    std::vector<int> out{s.c0, s.c1};
+    walk_sequence(g, pts, PointI{pts[s.c1].x - pts[s.c0].x, pts[s.c1].y - pts[s.c0].y}, s.c1, gridn - 2, nullptr, &out);
+    return out;
+}
+
+// is_crossing, :780-823 (single precision, like the reference)
+bool segments_cross(int a0, int a1, int b0, int b1, const std::vector<PointI>& p) {
+    const float l0[2] = {(float)(p[a1].x - p[a0].x), (float)(p[a1].y - p[a0].y)};
+    const float q0[2] = {(float)(p[b0].x - p[a0].x), (float)(p[b0].y - p[a0].y)};
+    const float q1[2] = {(float)(p[b1].x - p[a0].x), (float)(p[b1].y - p[a0].y)};
+    const float d2 = l0[0] * l0[0] + l0[1] * l0[1];
+    const float r0[2] = {q0[0] * l0[0] + q0[1] * l0[1], -q0[0] * l0[1] + q0[1] * l0[0]};
+    const float r1[2] = {q1[0] * l0[0] + q1[1] * l0[1], -q1[0] * l0[1] + q1[1] * l0[0]};
+    if (r0[1] * r1[1] > 0) return false;
+    if ((r0[0] < 0 && r1[0] < 0) || (r0[0] > d2 && r1[0] > d2)) return false;
+    const float k = r0[1] / (r0[1] - r1[1]);
+    const float x = r0[0] + k * (r1[0] - r0[0]);
+    return x >= 0.0f && x <= d2;
+}
+
+struct Cycle { int e[4]; };
+
+struct CycleSearch {
+    const std::vector<Sequence>& seq;
+    const std::vector<int>& outer;  // indices into seq
+    const std::map<int, std::vector<int>>& outer_from;  // start site -> positions in `outer`
+    const std::vector<PointI>& pts;
+
+    // next_outer_edge, :825-951
+    bool extend(Cycle& cyc, int count, int start_site) const {
+        bool found = false;
+        Cycle best{};
+        const Sequence& cur = seq[outer[cyc.e[count - 1]]];
+        auto it = outer_from.find(cur.clast);
+        if (it == outer_from.end()) return false;
+        for (int pos : it->second) {
+            const Sequence& nx = seq[outer[pos]];
+            if (nx.clast == cur.c0) continue;  // straight back
+            if (count != 3) {
+                if (nx.clast == start_site) continue;
+                if (count == 2 && segments_cross(seq[outer[cyc.e[0]]].c0, seq[outer[cyc.e[0]]].clast, nx.c0, nx.clast, pts))
+                    continue;
+                cyc.e[count] = pos;
+                if (!extend(cyc, count + 1, start_site)) continue;
+                if (found) return false;  // must be unique
+                found = true;
+                best = cyc;
+            } else {
+                if (nx.clast != start_site) continue;
+                if (segments_cross(seq[outer[cyc.e[1]]].c0, seq[outer[cyc.e[1]]].clast, nx.c0, nx.clast, pts)) return false;
+                cyc.e[3] = pos;
+                return true;
+            }
+        }
+        if (!found) return false;
+        cyc = best;
+        return true;
+    }
+};
+
+}  // namespace
+
+bool find_grid_from_points(std::vector<PointD>& out, const std::vector<PointI>& pts, int gridn) {
+    if (gridn < 2 || (int)pts.size() < gridn * gridn) return false;
+    SiteGraph g;
+    if (!build_site_graph(pts, g)) return false;
+
+    // get_sequence_candidates, :502-569
+    std::vector<Sequence> seq;
+    for (int c : g.order) {
+        if (g.ring[c].nbr.empty()) continue;
+        for_each_adjacent(g, pts, c, [&](int c1, PointI delta) {
+            PointD mean;
+            const int clast = walk_sequence(g, pts, delta, c1, gridn - 2, &mean, nullptr);
+            if (clast >= 0) seq.push_back(Sequence{c, c1, clast, mean});
+            return false;
+        });
+    }
+
+    // outer-edge candidates: sequences whose start site starts at least two sequences (:1246-1262)
+    std::map<int, int> started;
+    for (const Sequence& s : seq) started[s.c0]++;
+    std::vector<int> outer;
+    for (int i = 0; i < (int)seq.size(); ++i)
+        if (started[seq[i].c0] >= 2) outer.push_back(i);
+    if (outer.size() < 8) return false;
+    std::map<int, std::vector<int>> outer_from;
+    for (int i = 0; i < (int)outer.size(); ++i) outer_from[seq[outer[i]].c0].push_back(i);
+
+    // 4-cycles of outer edges (:1287-1322)
+    std::vector<Cycle> cycles;
+    std::set<int> used;
+    const CycleSearch search{seq, outer, outer_from, pts};
+    for (int i = 0; i < (int)outer.size(); ++i) {
+        if (used.count(i)) continue;
+        Cycle cyc{};
+        cyc.e[0] = i;
+        if (!search.extend(cyc, 1, seq[outer[i]].c0)) continue;
+        cycles.push_back(cyc);
+        for (int k = 0; k < 4; ++k) used.insert(cyc.e[k]);
+    }
+    if (cycles.size() < 2) return false;
+
+    // exactly one equal-and-opposite pair (:953-1003, :1324-1352)
+    auto opposite = [&](const Cycle& a, const Cycle& b) {
+        int ia = 0, ib = -1;
+        const int p0 = seq[outer[a.e[0]]].c0;
+        for (int k = 0; k < 4; ++k)
+            if (seq[outer[b.e[k]]].clast == p0) { ib = k; break; }
+        if (ib < 0) return false;
+        for (int i = 0; i < 4; ++i) {
+            const Sequence& sa = seq[outer[a.e[ia]]];
+            const Sequence& sb = seq[outer[b.e[ib]]];
+            if (sa.c0 != sb.clast || sa.clast != sb.c0) return false;
+            ia = (ia + 1) % 4;
+            ib = (ib + 3) % 4;
+        }
+        return true;
+    };
+    int pair[2] = {-1, -1};
+    for (int i0 = 0; i0 < (int)cycles.size(); ++i0)
+        for (int i1 = i0 + 1; i1 < (int)cycles.size(); ++i1)
+            if (opposite(cycles[i0], cycles[i1])) {
+                if (pair[0] >= 0) return false;
+                pair[0] = i0;
+                pair[1] = i1;
+            }
+    if (pair[0] < 0) return false;
+
+    // clockwise cycle and its top edge (:1025-1190)
+    const Cycle* cyc2[2] = {&cycles[pair[0]], &cycles[pair[1]]};
+    int v[4][2];
+    for (int i = 0; i < 4; ++i) {
+        const Sequence& s = seq[outer[cyc2[0]->e[i]]];
+        v[i][0] = (pts[s.clast].x - pts[s.c0].x) / 1024;  // FIND_GRID_SCALE_APPROX_POWER2
+        v[i][1] = (pts[s.clast].y - pts[s.c0].y) / 1024;
+    }
+    bool sign[4];
+    for (int i0 = 0; i0 < 4; ++i0) {
+        const int i1 = (i0 + 1) % 4;
+        sign[i0] = v[i1][0] * v[i0][1] < v[i0][0] * v[i1][1];
+    }
+    int iclockwise;
+    if (sign[0] && sign[1] && sign[2] && sign[3]) iclockwise = 0;
+    else if (!sign[0] && !sign[1] && !sign[2] && !sign[3]) iclockwise = 1;
+    else return false;  // not convex
+
+    int itop[2];
+    for (int ic = 0; ic < 2; ++ic) {
+        int ymin[2] = {INT32_MAX, INT32_MAX}, emin[2] = {-1, -1}, plo[2] = {0, 0}, phi[2] = {0, 0};
+        for (int i = 0; i < 4; ++i) {
+            const Sequence& s = seq[outer[cyc2[ic]->e[i]]];
+            int y_here, lo, hi;
+            if (pts[s.c0].y < pts[s.clast].y) { y_here = pts[s.c0].y; lo = s.c0; hi = s.clast; }
+            else { y_here = pts[s.clast].y; lo = s.clast; hi = s.c0; }
+            if (y_here < ymin[0]) {
+                ymin[1] = ymin[0]; emin[1] = emin[0]; plo[1] = plo[0]; phi[1] = phi[0];
+                ymin[0] = y_here; emin[0] = i; plo[0] = lo; phi[0] = hi;
+            } else if (y_here < ymin[1]) {
+                ymin[1] = y_here; emin[1] = i; plo[1] = lo; phi[1] = hi;
+            }
+        }
+        i64 v0y = (pts[phi[0]].y - pts[plo[0]].y) / 1024, v0x = (pts[phi[0]].x - pts[plo[0]].x) / 1024;
+        i64 v1y = (pts[phi[1]].y - pts[plo[1]].y) / 1024, v1x = (pts[phi[1]].x - pts[plo[1]].x) / 1024;
+        v0x = v0x > 0 ? v0x : -v0x;
+        v1x = v1x > 0 ? v1x : -v1x;
+        const i64 cr = (v0x * v1y - v0y * v1x) * (v0x * v1y - v0y * v1x);
+        const i64 den = (v0x * v0x + v0y * v0y) * (v1x * v1x + v1y * v1y);
+        if ((cr > 0 ? cr : -cr) * 8 < den * 1) return false;  // the two highest edges are too parallel (:1153-1156)
+        const i64 l = v0y * v1x, rr = v1y * v0x;
+        itop[ic] = ((l > 0 ? l : -l) < (rr > 0 ? rr : -rr)) ? emin[0] : emin[1];
+    }
+
+    // rows between the two vertical outer edges (:1378-1440)
+    std::map<int, std::vector<int>> seq_from;
+    for (int i = 0; i < (int)seq.size(); ++i) seq_from[seq[i].c0].push_back(i);
+    auto seq_from_to = [&](int from, int to) {
+        auto it = seq_from.find(from);
+        if (it == seq_from.end()) return -1;
+        for (int i : it->second)
+            if (seq[i].clast == to) return i;
+        return -1;
+    };
+    std::vector<int> rows(gridn);
+    rows[0] = outer[cyc2[iclockwise]->e[itop[iclockwise]]];
+    const int vleft = outer[cyc2[1 - iclockwise]->e[(itop[1 - iclockwise] + 1) % 4]];
+    const int vright = outer[cyc2[iclockwise]->e[(itop[iclockwise] + 1) % 4]];
+    const std::vector<int> lp = sequence_points(g, pts, seq[vleft], gridn);
+    const std::vector<int> rp = sequence_points(g, pts, seq[vright], gridn);
+    if ((int)lp.size() != gridn || (int)rp.size() != gridn) return false;
+    for (int i = 1; i < gridn; ++i) {
+        const int s = seq_from_to(lp[i], rp[i]);
+        if (s < 0) return false;
+        rows[i] = s;
+        if (seq_from_to(rp[i], lp[i]) < 0) return false;
+    }
+    for (int i = 0; i < gridn; ++i) {
+        const std::vector<int> row = sequence_points(g, pts, seq[rows[i]], gridn);
+        if ((int)row.size() != gridn) return false;
+        for (int s : row) out.push_back(PointD{(double)pts[s].x / 1000.0, (double)pts[s].y / 1000.0});  // :353-354
+    }
+    return true;
+}
+
+}  // namespace mrg

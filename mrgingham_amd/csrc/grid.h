@@ -1,0 +1,14 @@
+// Host-side grid finder (see grid.cpp).
+#pragma once
+#include <vector>
+
+namespace mrg {
+
+struct PointI { int x, y; };        // candidate, pixel coordinates * 1000 (point.hh:5-9)
+struct PointD { double x, y; };     // corner, pixel coordinates (point.hh:11-15)
+
+// mrgingham::find_grid_from_points (mrgingham.hh:83-87, find_grid.cc:1216-1445): appends the
+// gridn*gridn corners in board order (rows top to bottom, each left to right) to `out`.
+bool find_grid_from_points(std::vector<PointD>& out, const std::vector<PointI>& pts, int gridn);
+
+}  // namespace mrg

@@ -1,0 +1,69 @@
+"""GPU tests of the full detector, find_chessboard_from_image_array_C / find_board: level loop
+(mrgingham.cc:116-139), host grid finder, refinement to level 0 (mrgingham.cc:81-99).  Expected
+values: the CPU oracle for the detector and the refinement, composed with the same grid finder."""
+import numpy as np
+import pytest
+
+import mrgingham_amd
+from mrgingham_amd import synth
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _expected_board(img, gridn, level):
+    levels = [level] if level >= 0 else [3, 2, 1, 0]
+    for L in levels:
+        cand = oracle.find_corners(img, L)
+        if cand is None or len(cand) < gridn * gridn:
+            continue
+        grid = mrgingham_amd.find_grid_from_points(cand, gridn)
+        if grid is None:
+            continue
+        pts, lv = grid.copy(), np.full(gridn * gridn, L, np.int8)
+        for l in range(L - 1, -1, -1):
+            pts, lv, n = oracle.refine_corners(pts, lv, img, l)
+            if n <= 0:
+                break
+        return pts, L
+    return None, None
+
+
+@pytest.mark.parametrize("case", [(640, 480, 10, 0), (640, 480, 10, 5), (800, 600, 14, 1), (1920, 1080, 10, 3),
+                                  (4096, 3072, 10, 11)])
+def test_find_board_matches_composed_oracle(case):
+    w, h, gridn, seed = case
+    img = synth.board_frame(w, h, gridn, seed).numpy()
+    for level in (-1, 0, 1, 2):
+        want, found_at = _expected_board(img, gridn, level)
+        got = mrgingham_amd.find_board(img, image_pyramid_level=level, gridn=gridn)
+        if want is None:
+            assert got is None, (case, level)
+            continue
+        assert got is not None and got.shape == (gridn * gridn, 2), (case, level)
+        assert np.abs(got - want).max() <= 1e-4 and np.array_equal(got, want), (case, level, found_at)
+    # the default level search starts at level 3 (mrgingham.cc:127) and the refined corners sit on the
+    # level-0 lattice of the board: rows top to bottom, columns left to right
+    got = mrgingham_amd.find_chessboard(img, gridn=gridn)            # alias, mrgingham_pywrap.c:366
+    assert got is not None
+    c, s = np.cos(0.1), np.sin(0.1)
+    U = (got[:, 0] * c + got[:, 1] * s).reshape(gridn, gridn)
+    V = (-got[:, 0] * s + got[:, 1] * c).reshape(gridn, gridn)
+    assert (np.diff(U, axis=1) > 0).all() and (np.diff(V, axis=0) > 0).all()
+
+
+def test_find_board_negative_and_argument_paths():
+    noise = synth.noise_frame(640, 480, 1, smooth=1).numpy()
+    assert mrgingham_amd.find_board(noise) is None                        # no board: None (:326-330)
+    assert mrgingham_amd.find_board(np.zeros((64, 64), np.uint8)) is None
+    img = synth.board_frame(640, 480, 10, 0).numpy()
+    assert mrgingham_amd.find_board(img, gridn=12) is None                # wrong board size
+    assert mrgingham_amd.find_board(img, blobs=True, image_pyramid_level=0) is None
+    assert mrgingham_amd.find_board(img, image_pyramid_level=11) is None
+    with pytest.raises(RuntimeError, match="gridn"):
+        mrgingham_amd.find_board(img, gridn=1)
+    with pytest.raises(RuntimeError, match="image_pyramid_level == 0"):
+        mrgingham_amd.find_board(img, blobs=True)
+    with pytest.raises(RuntimeError, match="INTEGER,INTEGER"):
+        mrgingham_amd.find_board(img, debug_sequence="1;2")
+    assert mrgingham_amd.find_board(img, debug_sequence="3,4") is not None
