@@ -63,6 +63,7 @@ def test_no_cpu_fallback_without_device():
         mrgingham_amd.Detector()
     img = np.zeros((64, 64), np.uint8)
     for call in (lambda: mrgingham_amd.find_points(img), lambda: mrgingham_amd.ChESS_response_5(img),
+                 lambda: mrgingham_amd.find_board(img),
                  lambda: mrgingham_amd.refine_points(np.zeros((1, 2)), np.zeros(1, np.int8), img, 0)):
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             call()
@@ -85,8 +86,10 @@ def test_python_mirror_argument_checks_match_reference_messages():
         mrgingham_amd.ChESS_response_5(np.zeros(8, np.uint8))
     with pytest.raises(RuntimeError, match="image_pyramid_level == 0"):  # :153-157
         mrgingham_amd.find_points(np.zeros((8, 8), np.uint8), image_pyramid_level=1, blobs=True)
-    with pytest.raises(NotImplementedError):
-        mrgingham_amd.find_board(np.zeros((8, 8), np.uint8))
+    with pytest.raises(RuntimeError, match="gridn value must be >= 2"):    # :312-316
+        mrgingham_amd.find_board(np.zeros((8, 8), np.uint8), gridn=1)
+    with pytest.raises(RuntimeError, match="INTEGER,INTEGER"):            # :275-282
+        mrgingham_amd.find_board(np.zeros((8, 8), np.uint8), debug_sequence="x")
 
 
 def test_product_never_imports_the_oracle():
