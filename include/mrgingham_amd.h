@@ -170,6 +170,17 @@ int mrgingham_amd_refine_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frame
 int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* frames, int start_level,
                               double* d_points, signed char* d_levels, int32_t* d_npoints, int points_pitch);
 
+/* Batch form of the full detector (what find_chessboard_from_image_array_C does per frame, for
+ * image_pyramid_level < 0 the reference's default "first level of 3,2,1,0 at which the grid finder
+ * succeeds", mrgingham.cc:116-139): per level the GPU detects candidates for the whole batch, up to
+ * `nthreads` host threads (<= 0: all cores) run the grid finder on the frames that have no board
+ * yet, and the boards found at that level are refined to level 0 on the GPU.  Synchronous.
+ * h_boards (HOST): nframes x gridn*gridn x 2 doubles, board order; h_found_level[f] (HOST): the
+ * level frame f's grid was found at, or -1 (then its h_boards block is left untouched). */
+int mrgingham_amd_find_boards_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* frames, int gridn,
+                                    int image_pyramid_level, double* h_boards, signed char* h_found_level,
+                                    int nthreads);
+
 /* Tunables outside the reference's surface.  Known names:
  *   "hot_capacity_shift"  per-frame capacity of the hot-pixel / component tables is
  *                         (width*height) >> shift entries (default 3; 0 = one per pixel)

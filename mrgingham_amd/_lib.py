@@ -29,6 +29,7 @@ EXPORTS = [
     "mrgingham_amd_last_error", "mrgingham_amd_abi_version", "mrgingham_amd_device_count", "mrgingham_amd_level_dims",
     "mrgingham_amd_chess_response_batch", "mrgingham_amd_decimate_batch", "mrgingham_amd_box_blur_batch",
     "mrgingham_amd_detect_batch", "mrgingham_amd_refine_batch", "mrgingham_amd_chain_batch",
+    "mrgingham_amd_find_boards_batch",
     "mrgingham_amd_set_option", "mrgingham_amd_sync", "mrgingham_amd_stream_wait", "mrgingham_amd_set_kernel_timing",
     "mrgingham_amd_chess_kernel_ms",
 ]
@@ -87,6 +88,7 @@ def lib():
     L.mrgingham_amd_detect_batch.argtypes = [c_vp, FP, c_int, c_vp, c_int, c_vp]
     L.mrgingham_amd_refine_batch.argtypes = [c_vp, FP, c_int, c_vp, c_vp, c_vp, c_int, c_vp]
     L.mrgingham_amd_chain_batch.argtypes = [c_vp, FP, c_int, c_vp, c_vp, c_vp, c_int]
+    L.mrgingham_amd_find_boards_batch.argtypes = [c_vp, FP, c_int, c_int, c_vp, c_vp, c_int]
     L.mrgingham_amd_set_option.argtypes = [c_vp, ctypes.c_char_p, c_int]
     L.mrgingham_amd_sync.argtypes = [c_vp]
     L.mrgingham_amd_stream_wait.argtypes = [c_vp, c_vp]

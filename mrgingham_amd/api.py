@@ -276,6 +276,19 @@ class Detector:
             self.sync()
         return pts, lv, npts
 
+    def find_boards(self, frames, gridn=10, image_pyramid_level=-1, nthreads=0):
+        """Full detector over a batch: -> (boards float64 [B, gridn*gridn, 2] (numpy, host),
+        found_level int8 [B], -1 where no board was found).  Synchronous."""
+        t = self.torch
+        fr, B, H, W = self._frames(frames)
+        boards = np.full((B, gridn * gridn, 2), np.nan, dtype=np.float64)
+        found = np.full((B,), -1, dtype=np.int8)
+        t.cuda.current_stream(frames.device).synchronize()
+        self._check(self.L.mrgingham_amd_find_boards_batch(self.ctx, ctypes.byref(fr), int(gridn),
+                                                           int(image_pyramid_level), boards.ctypes.data,
+                                                           found.ctypes.data, int(nthreads)))
+        return boards, found
+
     def set_kernel_timing(self, enable):
         self.L.mrgingham_amd_set_kernel_timing(self.ctx, int(enable))
 

@@ -6,7 +6,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mrgingham_amd.h"
@@ -875,6 +877,107 @@ bool find_chessboard_from_image_array_C(int Nrows, int Ncols, int stride, char* 
     }
     static_assert(sizeof(PointD) == 2 * sizeof(double), "add_points() takes interleaved doubles");
     return (*add_points)(&board[0].x, N, cookie);  // bridge.cc:133-137
+}
+
+/* Batch form of the full detector (the reference's default schedule, image_pyramid_level < 0, per
+ * frame: mrgingham.cc:116-139 and :81-99): the GPU runs the candidate detector of a level for the
+ * whole batch, host threads run the grid finder on the frames that have no board yet, and the
+ * corners of the frames whose board was found at that level are refined level by level on the
+ * GPU.  Synchronous.  h_boards: nframes x gridn*gridn x 2 doubles (host); h_found_level[f] is the
+ * level at which frame f's grid was found, -1 if none. */
+int mrgingham_amd_find_boards_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int gridn,
+                                    int image_pyramid_level, double* h_boards, signed char* h_found_level,
+                                    int nthreads) {
+    int rc = validate_frames(ctx, fr);
+    if (rc) return rc;
+    if (gridn < 2 || image_pyramid_level > kMaxLevel || !h_boards || !h_found_level)
+        return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "bad gridn / level / NULL outputs");
+    const int B = fr->nframes, N = gridn * gridn;
+    if (B == 0) return 0;
+    MRG_HIP_CHECK(hipSetDevice(ctx->device));
+    const int first = image_pyramid_level >= 0 ? image_pyramid_level : 3;
+    const int last = image_pyramid_level >= 0 ? image_pyramid_level : 0;
+    const int cap = 4 * N + 64;  // candidates kept per frame for the grid finder
+    if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
+    if (nthreads <= 0) nthreads = 1;
+    if (nthreads > B) nthreads = B;
+
+    DevBuf d_xy, d_cnt, d_pts, d_lv, d_np;
+    auto cleanup = [&]() {
+        for (DevBuf* b : {&d_xy, &d_cnt, &d_pts, &d_lv, &d_np})
+            if (b->p) hipFree(b->p);
+    };
+    if ((rc = ensure(ctx, d_xy, (size_t)B * cap * 8)) || (rc = ensure(ctx, d_cnt, (size_t)B * 4)) ||
+        (rc = ensure(ctx, d_pts, (size_t)B * N * 16)) || (rc = ensure(ctx, d_lv, (size_t)B * N)) ||
+        (rc = ensure(ctx, d_np, (size_t)B * 4))) {
+        cleanup();
+        return rc;
+    }
+    std::vector<int32_t> h_xy((size_t)B * cap * 2), h_cnt(B), h_np(B, 0);
+    std::vector<signed char> h_lv((size_t)B * N, 0);
+    for (int f = 0; f < B; ++f) h_found_level[f] = -1;
+    int nfound_total = 0;
+
+    for (int L = first; L >= last && nfound_total < B; --L) {
+        // (a) candidates of every frame at level L
+        if ((rc = mrgingham_amd_detect_batch(ctx, fr, L, (int32_t*)d_xy.p, cap, (int32_t*)d_cnt.p)) ||
+            (rc = mrgingham_amd_sync(ctx))) break;
+        if (hipMemcpy(h_cnt.data(), d_cnt.p, (size_t)B * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(h_xy.data(), d_xy.p, (size_t)B * cap * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = fail(ctx, MRGINGHAM_AMD_ERR_DEVICE, "candidate download failed");
+            break;
+        }
+        // (b) grid finder on host threads, for the frames still without a board
+        std::vector<char> found_now(B, 0);
+        std::atomic<int> next{0};
+        auto worker = [&]() {
+            for (int f; (f = next.fetch_add(1)) < B;) {
+                if (h_found_level[f] >= 0) continue;
+                const int n = h_cnt[f] < cap ? h_cnt[f] : cap;  // more candidates than `cap`: clutter, no board
+                if (n < N || h_cnt[f] > cap) continue;
+                std::vector<PointI> cand((size_t)n);
+                for (int i = 0; i < n; ++i) cand[i] = PointI{h_xy[((size_t)f * cap + i) * 2], h_xy[((size_t)f * cap + i) * 2 + 1]};
+                std::vector<PointD> board;
+                if (find_grid_from_points(board, cand, gridn) && (int)board.size() == N) {
+                    memcpy(h_boards + (size_t)f * N * 2, board.data(), sizeof(double) * 2 * N);
+                    found_now[f] = 1;
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker);
+        worker();
+        for (auto& th : pool) th.join();
+        int nnow = 0;
+        for (int f = 0; f < B; ++f)
+            if (found_now[f]) { h_found_level[f] = (signed char)L; ++nnow; }
+        nfound_total += nnow;
+        if (nnow == 0 || L == 0) continue;
+        // (c) refine the boards found at this level down to level 0 (the others have npoints = 0)
+        for (int f = 0; f < B; ++f) {
+            h_np[f] = found_now[f] ? N : 0;
+            if (found_now[f]) memset(h_lv.data() + (size_t)f * N, L, (size_t)N);
+        }
+        if (hipMemcpy(d_pts.p, h_boards, (size_t)B * N * 16, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_lv.p, h_lv.data(), (size_t)B * N, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_np.p, h_np.data(), (size_t)B * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            rc = fail(ctx, MRGINGHAM_AMD_ERR_DEVICE, "board upload failed");
+            break;
+        }
+        for (int l = L - 1; l >= 0 && !rc; --l)  // (refining past "nothing refined" is a no-op, mrgingham.cc:97-98)
+            rc = mrgingham_amd_refine_batch(ctx, fr, l, (double*)d_pts.p, (signed char*)d_lv.p, (const int32_t*)d_np.p,
+                                            N, nullptr);
+        if (rc || (rc = mrgingham_amd_sync(ctx))) break;
+        std::vector<double> refined((size_t)B * N * 2);
+        if (hipMemcpy(refined.data(), d_pts.p, (size_t)B * N * 16, hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = fail(ctx, MRGINGHAM_AMD_ERR_DEVICE, "board download failed");
+            break;
+        }
+        for (int f = 0; f < B; ++f)
+            if (found_now[f]) memcpy(h_boards + (size_t)f * N * 2, refined.data() + (size_t)f * N * 2, sizeof(double) * 2 * N);
+    }
+    cleanup();
+    return rc;
 }
 
 }  // extern "C"

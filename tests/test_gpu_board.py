@@ -67,3 +67,31 @@ def test_find_board_negative_and_argument_paths():
     with pytest.raises(RuntimeError, match="INTEGER,INTEGER"):
         mrgingham_amd.find_board(img, debug_sequence="1;2")
     assert mrgingham_amd.find_board(img, debug_sequence="3,4") is not None
+
+
+def test_find_boards_batch_adaptive_levels():
+    """Per-frame adaptive pyramid depth: frames whose grid is found at level 3 stop there, the others
+    go on to levels 2, 1, 0; every board equals the single-frame detector's."""
+    det = mrgingham_amd.Detector(0)
+    import torch
+    imgs = [synth.board_frame(1280, 960, 10, s).numpy() for s in (0, 1, 2)]       # found at level 3
+    small = np.full((960, 1280), 200, np.uint8)                                     # a small board in a big frame:
+    small[:480, :640] = synth.board_frame(640, 480, 10, 4).numpy()                  # level 3 is too coarse for it
+    imgs.append(small)
+    imgs.append(synth.noise_frame(1280, 960, 3, smooth=1).numpy())                  # no board at all
+    frames = torch.from_numpy(np.stack(imgs)).cuda()
+    boards, found = det.find_boards(frames, gridn=10, nthreads=3)
+    single = [mrgingham_amd.find_board(im, gridn=10) for im in imgs]
+    assert found[4] == -1 and single[4] is None
+    levels = [_expected_board(im, 10, -1)[1] for im in imgs[:4]]
+    assert found[:4].tolist() == levels and 3 in levels and min(levels) < 3
+    for f in range(4):
+        assert single[f] is not None and np.array_equal(boards[f], single[f]), f
+    assert np.isnan(boards[4]).all()
+    b1, f1 = det.find_boards(frames, gridn=10, image_pyramid_level=1, nthreads=1)
+    for f in range(5):
+        s = mrgingham_amd.find_board(imgs[f], image_pyramid_level=1, gridn=10)
+        assert (f1[f] == 1) == (s is not None)
+        if s is not None:
+            assert np.array_equal(b1[f], s)
+    det.close()
