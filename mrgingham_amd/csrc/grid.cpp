@@ -118,34 +118,45 @@ public:
 
 private:
     std::vector<int> hull_next, hull_prev;
-    std::map<std::pair<int, int>, std::pair<int, int>> edge_owner;  // directed edge (a,b) -> (triangle, slot)
+    // hull edge a -> hull_next[a] belongs to triangle hull_tri[a], opposite its vertex slot hull_slot[a]
+    std::vector<int> hull_tri, hull_slot;
 
-    void link_all() {
-        edge_owner.clear();
-        for (int t = 0; t < (int)tris.size(); ++t)
-            for (int k = 0; k < 3; ++k) edge_owner[{tris[t].v[(k + 1) % 3], tris[t].v[(k + 2) % 3]}] = {t, k};
-        for (int t = 0; t < (int)tris.size(); ++t)
-            for (int k = 0; k < 3; ++k) {
-                auto it = edge_owner.find({tris[t].v[(k + 2) % 3], tris[t].v[(k + 1) % 3]});
-                tris[t].n[k] = it == edge_owner.end() ? -1 : it->second.first;
+    void note_hull_edges(int t) {
+        for (int k = 0; k < 3; ++k)
+            if (tris[t].n[k] < 0) {
+                const int a = tris[t].v[(k + 1) % 3];
+                hull_tri[a] = t;
+                hull_slot[a] = k;
             }
     }
 
-    int add_tri(int a, int b, int c) {  // counter-clockwise a,b,c
+    // the initial fan: consecutive triangles share the edge from the apex to a prefix point
+    void link_all() {
+        hull_tri.assign(p.size(), -1);
+        hull_slot.assign(p.size(), -1);
+        for (int t = 0; t + 1 < (int)tris.size(); ++t)
+            for (int k = 0; k < 3; ++k)
+                for (int j = 0; j < 3; ++j)
+                    if (tris[t].v[(k + 1) % 3] == tris[t + 1].v[(j + 2) % 3] &&
+                        tris[t].v[(k + 2) % 3] == tris[t + 1].v[(j + 1) % 3]) {
+                        tris[t].n[k] = t + 1;
+                        tris[t + 1].n[j] = t;
+                    }
+        for (int t = 0; t < (int)tris.size(); ++t) note_hull_edges(t);
+    }
+
+    // new triangle (b, a, q) on the visible hull edge a -> b; `prev` = the triangle added just before
+    // on the neighbouring hull edge (it shares the edge a-q), or -1
+    int add_tri_on_hull(int a, int b, int q, int prev) {
         Tri t;
-        t.v[0] = a; t.v[1] = b; t.v[2] = c;
-        t.n[0] = t.n[1] = t.n[2] = -1;
+        t.v[0] = b; t.v[1] = a; t.v[2] = q;
+        t.n[0] = prev;          // edge (a, q)
+        t.n[1] = -1;            // edge (q, b): shared with the next new triangle, or hull
+        t.n[2] = hull_tri[a];   // edge (b, a): the old hull edge
         const int id = (int)tris.size();
         tris.push_back(t);
-        for (int k = 0; k < 3; ++k) {
-            const int u = t.v[(k + 1) % 3], w = t.v[(k + 2) % 3];
-            edge_owner[{u, w}] = {id, k};
-            auto it = edge_owner.find({w, u});
-            if (it != edge_owner.end()) {
-                tris[id].n[k] = it->second.first;
-                tris[it->second.first].n[it->second.second] = id;
-            }
-        }
+        tris[hull_tri[a]].n[hull_slot[a]] = id;
+        if (prev >= 0) tris[prev].n[1] = id;  // prev = (a, a_prev, q): its edge (q, a) is opposite slot 1
         return id;
     }
 
@@ -161,14 +172,17 @@ private:
             return;
         }
         std::vector<int> fresh;
+        int prev = -1;
         for (int a = lo; a != hi;) {
             const int b = hull_next[a];
-            fresh.push_back(add_tri(b, a, q));  // (a,b) is a ccw hull edge seen from outside: b,a,q is ccw
+            prev = add_tri_on_hull(a, b, q, prev);  // (a,b) is a ccw hull edge seen from outside: b,a,q is ccw
+            fresh.push_back(prev);
             a = b;
         }
         hull_next[lo] = q; hull_prev[q] = lo;
         hull_next[q] = hi; hull_prev[hi] = q;
-        // vertices strictly between lo and hi left the hull
+        // vertices strictly between lo and hi left the hull; the two new hull edges are lo -> q, q -> hi
+        for (int t : fresh) note_hull_edges(t);
         for (int t : fresh) legalize(t, 2);
     }
 
@@ -202,10 +216,8 @@ private:
             };
             relink(n_bd, u, t);
             relink(n_ca, t, u);
-            edge_owner.erase({b, c});
-            edge_owner.erase({c, b});
-            for (int tt : {t, u})
-                for (int j = 0; j < 3; ++j) edge_owner[{tris[tt].v[(j + 1) % 3], tris[tt].v[(j + 2) % 3]}] = {tt, j};
+            note_hull_edges(t);
+            note_hull_edges(u);
             stack.push_back({t, 0});
             stack.push_back({u, 0});
         }
@@ -310,34 +322,51 @@ bool for_each_adjacent(const SiteGraph& g, const std::vector<PointI>& pts, int c
 constexpr double kSpacingCos = 0.984;
 constexpr double kLenRatioMin = 0.7, kLenRatioMax = 1.4, kLenRatioDev = 0.35;
 
+// The adjacency of every site in the reference's visiting order, built once: the sequence search
+// walks it tens of thousands of times per frame.
+struct Adj {
+    int site;
+    PointI delta;
+    double len;
+};
+using AdjLists = std::vector<std::vector<Adj>>;
+
+AdjLists build_adjacency(const SiteGraph& g, const std::vector<PointI>& pts) {
+    AdjLists adj(pts.size());
+    for (int c = 0; c < (int)pts.size(); ++c)
+        for_each_adjacent(g, pts, c, [&](int cand, PointI delta) {
+            adj[c].push_back(Adj{cand, delta, std::hypot((double)delta.x, (double)delta.y)});
+            return false;
+        });
+    return adj;
+}
+
 struct SeqStats {  // HypothesisStatistics, :166-172
     PointI delta_last;
+    double last_len;
     double ratio_sum;
     int ratio_n;
 };
 
 // get_adjacent_cell_along_sequence, :209-312: the first neighbour continuing the sequence, or -1
-int next_along_sequence(const SiteGraph& g, const std::vector<PointI>& pts, int c, SeqStats& st) {
-    const double last_len = std::hypot((double)st.delta_last.x, (double)st.delta_last.y);
-    int found = -1;
-    for_each_adjacent(g, pts, c, [&](int cand, PointI delta) {
-        const double len = std::hypot((double)delta.x, (double)delta.y);
-        const double cos_err = ((double)st.delta_last.x * (double)delta.x + (double)st.delta_last.y * (double)delta.y) /
-                               (last_len * len);
-        if (cos_err < kSpacingCos) return false;
-        const double ratio = len / last_len;
-        if (ratio < kLenRatioMin || ratio > kLenRatioMax) return false;
+int next_along_sequence(const AdjLists& adj, int c, SeqStats& st) {
+    for (const Adj& a : adj[c]) {
+        const double cos_err = ((double)st.delta_last.x * (double)a.delta.x + (double)st.delta_last.y * (double)a.delta.y) /
+                               (st.last_len * a.len);
+        if (cos_err < kSpacingCos) continue;
+        const double ratio = a.len / st.last_len;
+        if (ratio < kLenRatioMin || ratio > kLenRatioMax) continue;
         if (st.ratio_n > 2) {
             const double dev = ratio - st.ratio_sum / (double)st.ratio_n;
-            if (dev < -kLenRatioDev || dev > kLenRatioDev) return false;
+            if (dev < -kLenRatioDev || dev > kLenRatioDev) continue;
         }
         st.ratio_sum += ratio;
         st.ratio_n++;
-        st.delta_last = delta;
-        found = cand;
-        return true;
-    });
-    return found;
+        st.delta_last = a.delta;
+        st.last_len = a.len;
+        return a.site;
+    }
+    return -1;
 }
 
 struct Sequence {  // CandidateSequence, :148-162
@@ -346,13 +375,12 @@ struct Sequence {  // CandidateSequence, :148-162
 };
 
 // walks n_remaining steps from c along delta; fills `path` (if given) with the sites visited
-int walk_sequence(const SiteGraph& g, const std::vector<PointI>& pts, PointI delta, int c, int n_remaining,
-                  PointD* delta_mean, std::vector<int>* path) {
-    SeqStats st{delta, 0.0, 0};
+int walk_sequence(const AdjLists& adj, PointI delta, int c, int n_remaining, PointD* delta_mean, std::vector<int>* path) {
+    SeqStats st{delta, std::hypot((double)delta.x, (double)delta.y), 0.0, 0};
     double sx = delta.x, sy = delta.y;
     int last = -1;
     for (int i = 0; i < n_remaining; ++i) {
-        const int nx = next_along_sequence(g, pts, c, st);
+        const int nx = next_along_sequence(adj, c, st);
         if (nx < 0) return -1;
         sx += st.delta_last.x;
         sy += st.delta_last.y;
@@ -364,9 +392,9 @@ int walk_sequence(const SiteGraph& g, const std::vector<PointI>& pts, PointI del
     return last;
 }
 
-std::vector<int> sequence_points(const SiteGraph& g, const std::vector<PointI>& pts, const Sequence& s, int gridn) {
+std::vector<int> sequence_points(const AdjLists& adj, const std::vector<PointI>& pts, const Sequence& s, int gridn) {
     std::vector<int> out{s.c0, s.c1};
-    walk_sequence(g, pts, PointI{pts[s.c1].x - pts[s.c0].x, pts[s.c1].y - pts[s.c0].y}, s.c1, gridn - 2, nullptr, &out);
+    walk_sequence(adj, PointI{pts[s.c1].x - pts[s.c0].x, pts[s.c1].y - pts[s.c0].y}, s.c1, gridn - 2, nullptr, &out);
     return out;
 }
 
@@ -433,16 +461,14 @@ bool find_grid_from_points(std::vector<PointD>& out, const std::vector<PointI>& 
     if (!build_site_graph(pts, g)) return false;
 
     // get_sequence_candidates, :502-569
+    const AdjLists adj = build_adjacency(g, pts);
     std::vector<Sequence> seq;
-    for (int c : g.order) {
-        if (g.ring[c].nbr.empty()) continue;
-        for_each_adjacent(g, pts, c, [&](int c1, PointI delta) {
+    for (int c : g.order)
+        for (const Adj& a : adj[c]) {
             PointD mean;
-            const int clast = walk_sequence(g, pts, delta, c1, gridn - 2, &mean, nullptr);
-            if (clast >= 0) seq.push_back(Sequence{c, c1, clast, mean});
-            return false;
-        });
-    }
+            const int clast = walk_sequence(adj, a.delta, a.site, gridn - 2, &mean, nullptr);
+            if (clast >= 0) seq.push_back(Sequence{c, a.site, clast, mean});
+        }
 
     // outer-edge candidates: sequences whose start site starts at least two sequences (:1246-1262)
     std::map<int, int> started;
@@ -552,8 +578,8 @@ bool find_grid_from_points(std::vector<PointD>& out, const std::vector<PointI>& 
     rows[0] = outer[cyc2[iclockwise]->e[itop[iclockwise]]];
     const int vleft = outer[cyc2[1 - iclockwise]->e[(itop[1 - iclockwise] + 1) % 4]];
     const int vright = outer[cyc2[iclockwise]->e[(itop[iclockwise] + 1) % 4]];
-    const std::vector<int> lp = sequence_points(g, pts, seq[vleft], gridn);
-    const std::vector<int> rp = sequence_points(g, pts, seq[vright], gridn);
+    const std::vector<int> lp = sequence_points(adj, pts, seq[vleft], gridn);
+    const std::vector<int> rp = sequence_points(adj, pts, seq[vright], gridn);
     if ((int)lp.size() != gridn || (int)rp.size() != gridn) return false;
     for (int i = 1; i < gridn; ++i) {
         const int s = seq_from_to(lp[i], rp[i]);
@@ -562,7 +588,7 @@ bool find_grid_from_points(std::vector<PointD>& out, const std::vector<PointI>& 
         if (seq_from_to(rp[i], lp[i]) < 0) return false;
     }
     for (int i = 0; i < gridn; ++i) {
-        const std::vector<int> row = sequence_points(g, pts, seq[rows[i]], gridn);
+        const std::vector<int> row = sequence_points(adj, pts, seq[rows[i]], gridn);
         if ((int)row.size() != gridn) return false;
         for (int s : row) out.push_back(PointD{(double)pts[s].x / 1000.0, (double)pts[s].y / 1000.0});  // :353-354
     }
