@@ -26,7 +26,7 @@ class Op:
         self.dst, self.kind, self.asm, self.srcs, self.pair = dst, kind, asm, srcs, pair
 
 
-def build_dag(clamp=True):
+def build_dag(clamp=True, add3=False):
     """Ops of the 4 pixel pairs; inputs are the C arrays m5,p5,m4,p4,m2,p2,z1 (12 dwords) and z0 (4)."""
     ops = []
 
@@ -53,6 +53,15 @@ def build_dag(clamp=True):
 
         def tree(prefix, leaves):
             lvl, n = list(leaves), 0
+            while add3 and len(lvl) > 2:
+                nxt = []
+                j = 0
+                while j + 2 < len(lvl):
+                    nxt.append(add(f"{prefix}{n}_{k}", SLOW, "v_add3_u32 %0, %1, %2, %3", [lvl[j], lvl[j + 1], lvl[j + 2]], k))
+                    n += 1
+                    j += 3
+                nxt.extend(lvl[j:])
+                lvl = nxt
             while len(lvl) > 1:
                 nxt = []
                 for j in range(0, len(lvl) - 1, 2):
@@ -175,11 +184,11 @@ POLICIES = {
 }
 
 
-def bench_source(policies=None):
+def bench_source(policies=None, add3=False):
     global POLICIES
     if policies:
         POLICIES = policies
-    ops = build_dag()
+    ops = build_dag(add3=add3)
     out = ['#include <hip/hip_runtime.h>', '#include <stdio.h>', '#include <stdint.h>']
     for name, pol in POLICIES.items():
         order = schedule(ops, **pol)
@@ -234,6 +243,9 @@ int main() {
 if __name__ == "__main__":
     if sys.argv[1] == "bench":
         open(sys.argv[2], "w").write(bench_source())
+    elif sys.argv[1] == "bench3":
+        pols = {k: POLICIES[k] for k in ("seq_d1", "seq_d3_r42", "seq_d3_r63", "w2_d4_r21", "seq_d2", "seq_d4", "w2_d4", "seq_d1_nocrit")}
+        open(sys.argv[2], "w").write(bench_source(pols, add3=True))
     elif sys.argv[1] == "bench2":
         pols = {}
         for w, D, ra, rp in itertools.product([1, 2], [3, 4, 5], [2, 3, 4, 5, 6], [1, 2, 3]):
