@@ -144,6 +144,14 @@ int mrgingham_amd_decimate_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_fra
 int mrgingham_amd_box_blur_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* frames, int radius,
                                  uint8_t* d_out, void* stream);
 
+/* The contrast preprocessing the reference CLI applies to an 8-bit frame before
+ * detection (mrgingham-from-image.cc:38-45, :71-79, :106-111): when do_clahe,
+ * cv::normalize(0, 255, NORM_MINMAX) then CLAHE (clip limit 8, 8x8 tiles); then a
+ * (2*blur_radius+1)^2 box blur (0 = none).  d_out receives nframes dense byte
+ * images and must not alias the input.  OpenCV arithmetic: parity unpinned. */
+int mrgingham_amd_preprocess_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* frames, int do_clahe,
+                                   int blur_radius, uint8_t* d_out, void* stream);
+
 /* find_chessboard_corners_from_image_array for every frame of the batch at one
  * pyramid level.  Device outputs: d_xy holds nframes blocks of
  * capacity_per_frame interleaved (x,y)*1000 int pairs in the reference's

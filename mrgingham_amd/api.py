@@ -233,6 +233,17 @@ class Detector:
         self._check(self.L.mrgingham_amd_box_blur_batch(self.ctx, ctypes.byref(fr), radius, out.data_ptr(), stream))
         return out
 
+    def preprocess(self, frames, clahe=True, blur_radius=1):
+        """The reference CLI's preprocessing (mrgingham-from-image.cc:71-111): normalize + CLAHE(8),
+        then a box blur; on torch's current stream."""
+        t = self.torch
+        fr, B, H, W = self._frames(frames)
+        out = t.empty((B, H, W), dtype=t.uint8, device=frames.device)
+        stream = t.cuda.current_stream(frames.device).cuda_stream
+        self._check(self.L.mrgingham_amd_preprocess_batch(self.ctx, ctypes.byref(fr), int(bool(clahe)),
+                                                          int(blur_radius), out.data_ptr(), stream))
+        return out
+
     def detect(self, frames, level, capacity=4096, sync=True):
         """-> (xy int32 [B,capacity,2], counts int32 [B]) on the device."""
         t = self.torch

@@ -57,6 +57,7 @@ struct mrgingham_amd_ctx {
     mrg::DevBuf counters2[2];  // per scratch set: hot_cnt words [level][counters_nf], then status words [level][counters_nf]
     int counters_nf = 0;
     mrg::DevBuf leader, need, nseeds, seeds, sroot, cand_xy, cand_counts, aux_img, io_frame, io_out;
+    mrg::DevBuf pre_scratch, pre_tmp;  // preprocessing: extrema + tile histograms + LUTs, CLAHE output before the blur
     int pts_nframes = 0, pts_pitch = 0;
     // levels (and frame counts) whose status words must be checked at the next sync
     int pending_frames[2][mrg::kMaxLevel + 1] = {};
@@ -372,7 +373,7 @@ void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx) {
             if (b->p) hipFree(b->p);
     }
     DevBuf* bufs[] = {&ctx->counters2[0], &ctx->counters2[1], &ctx->leader, &ctx->need, &ctx->nseeds, &ctx->seeds, &ctx->sroot, &ctx->cand_xy, &ctx->cand_counts,
-                      &ctx->aux_img, &ctx->io_frame, &ctx->io_out};
+                      &ctx->aux_img, &ctx->io_frame, &ctx->io_out, &ctx->pre_scratch, &ctx->pre_tmp};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     for (auto& pr : ctx->events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
@@ -536,6 +537,39 @@ int mrgingham_amd_box_blur_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_fra
     hipStream_t s = (hipStream_t)stream;  // used as given: NULL is HIP's default stream
     FrameBatch fb{fr->frames, fr->frame_pitch, fr->width, fr->height, fr->stride};
     launch_box_blur(fb, radius, d_out, 0, fr->nframes, s);
+    MRG_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int mrgingham_amd_preprocess_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int do_clahe,
+                                   int blur_radius, uint8_t* d_out, void* stream) {
+    int rc = validate_frames(ctx, fr);
+    if (rc) return rc;
+    if (blur_radius < 0 || blur_radius > 64 || !d_out)
+        return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "bad blur radius or output");
+    if (fr->nframes == 0) return 0;
+    MRG_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;  // used as given: NULL is HIP's default stream
+    FrameBatch fb{fr->frames, fr->frame_pitch, fr->width, fr->height, fr->stride};
+    if (do_clahe) {
+        if (fr->width < 8 || fr->height < 8)
+            return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "CLAHE needs a frame of at least 8x8 pixels");
+        const size_t frame_bytes = (size_t)fr->width * fr->height;
+        if ((rc = ensure(ctx, ctx->pre_scratch, clahe_scratch_bytes(fr->nframes)))) return rc;
+        uint8_t* clahe_out = d_out;
+        if (blur_radius > 0) {
+            if ((rc = ensure(ctx, ctx->pre_tmp, frame_bytes * fr->nframes))) return rc;
+            clahe_out = (uint8_t*)ctx->pre_tmp.p;
+        }
+        // clip limit 8, default 8x8 tiles: mrgingham-from-image.cc:41-45
+        launch_clahe(fb, fr->nframes, 8.0, true, clahe_out, ctx->pre_scratch.p, s);
+        if (blur_radius > 0) {
+            const FrameBatch tb{clahe_out, (long long)frame_bytes, fr->width, fr->height, fr->width};
+            launch_box_blur(tb, blur_radius, d_out, 0, fr->nframes, s);
+        }
+    } else {
+        launch_box_blur(fb, blur_radius, d_out, 0, fr->nframes, s);  // radius 0 = dense copy
+    }
     MRG_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -25,6 +25,11 @@ struct PyramidOut {
 void launch_pyramid(const FrameBatch& in, const PyramidOut& po, int top, int nframes, hipStream_t s);
 void launch_box_blur(const FrameBatch& in, int radius, uint8_t* out, int frame0, int nframes, hipStream_t s);
 
+// preprocess.hip: cv::normalize(0..255, NORM_MINMAX) + CLAHE (8x8 tiles), mrgingham-from-image.cc:71-79
+size_t clahe_scratch_bytes(int nframes);
+bool launch_clahe(const FrameBatch& in, int nframes, double clip_limit, bool do_normalize, uint8_t* out,
+                  void* scratch, hipStream_t s);
+
 // cc.hip
 struct DetectOut {
     int32_t* xy;      // [nframes*capacity*2]

@@ -208,6 +208,153 @@ void oracle_box_blur(uint8_t* out, const uint8_t* in, int w, int h, int stride, 
 }
 
 /* ------------------------------------------------------------------------- */
+/* The CLI's contrast preprocessing (mrgingham-from-image.cc:38-45, :71-79):   */
+/*   cv::normalize(image, image, 0, 255, NORM_MINMAX); clahe->apply(image)     */
+/* with cv::createCLAHE() defaults (8x8 tiles) and setClipLimit(8).            */
+/* PARITY UNPINNED: the arithmetic is OpenCV's (un-vendored, version unpinned  */
+/* upstream, and its convertTo has FMA-dispatching SIMD paths).  Restated from  */
+/* OpenCV's published algorithm (modules/core norm.cpp / convert_scale,         */
+/* modules/imgproc clahe.cpp), single-precision, unfused multiply-add,          */
+/* round-half-even.                                                             */
+/* ------------------------------------------------------------------------- */
+#define CLAHE_TILES 8
+#define CLAHE_BINS 256
+
+static uint8_t sat_u8_rint(float v)
+{
+    const long r = lrintf(v); /* cvRound: round half to even (default rounding mode) */
+    return (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+}
+
+/* cv::normalize(src, dst, 0, 255, NORM_MINMAX) for CV_8U: scale/shift in double, then
+ * convertTo's float multiply-add per pixel.  lut[v] = normalised value of v. */
+void oracle_normalize_lut(uint8_t lut[256], int vmin, int vmax)
+{
+    const double smin = vmin, smax = vmax, dmin = 0., dmax = 255.;
+    const double scale = (dmax - dmin) * (smax - smin > 2.220446049250313e-16 ? 1. / (smax - smin) : 0.);
+    const double shift = dmin - smin * scale;
+    const float a = (float)scale, b = (float)shift;
+    for (int v = 0; v < 256; v++) {
+        const float prod = (float)v * a; /* kept as its own rounding step: no fused multiply-add */
+        lut[v] = sat_u8_rint(prod + b);
+    }
+}
+
+void oracle_normalize_minmax(uint8_t* out, const uint8_t* in, int w, int h, int stride)
+{
+    int vmin = 255, vmax = 0;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const int v = in[(size_t)y * stride + x];
+            if (v < vmin) vmin = v;
+            if (v > vmax) vmax = v;
+        }
+    uint8_t lut[256];
+    oracle_normalize_lut(lut, vmin, vmax);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) out[(size_t)y * w + x] = lut[in[(size_t)y * stride + x]];
+}
+
+/* CLAHE, 8-bit, tiles 8x8.  clip_limit is the user-facing value (8 in the CLI). */
+int oracle_clahe(uint8_t* out, const uint8_t* in, int w, int h, int stride, double clip_limit)
+{
+    /* frames that do not divide into the tile grid are extended to the right and below with
+     * BORDER_REFLECT_101 by (tiles - size % tiles) -- on BOTH axes as soon as either needs it */
+    int ew = w, eh = h;
+    if (w % CLAHE_TILES != 0 || h % CLAHE_TILES != 0) {
+        ew = w + (CLAHE_TILES - w % CLAHE_TILES);
+        eh = h + (CLAHE_TILES - h % CLAHE_TILES);
+    }
+    const int tw = ew / CLAHE_TILES, th = eh / CLAHE_TILES, area = tw * th;
+    if (tw <= 0 || th <= 0) return -1;
+    const float lut_scale = (float)(CLAHE_BINS - 1) / (float)area;
+    int clip = 0;
+    if (clip_limit > 0.0) {
+        clip = (int)(clip_limit * area / CLAHE_BINS);
+        if (clip < 1) clip = 1;
+    }
+    uint8_t* lut = (uint8_t*)malloc((size_t)CLAHE_TILES * CLAHE_TILES * CLAHE_BINS);
+    if (!lut) return -1;
+    for (int ty = 0; ty < CLAHE_TILES; ty++)
+        for (int tx = 0; tx < CLAHE_TILES; tx++) {
+            int hist[CLAHE_BINS] = {0};
+            for (int y = ty * th; y < (ty + 1) * th; y++) {
+                const uint8_t* row = in + (size_t)reflect101(y, h) * stride;
+                for (int x = tx * tw; x < (tx + 1) * tw; x++) hist[row[reflect101(x, w)]]++;
+            }
+            if (clip > 0) {
+                int clipped = 0;
+                for (int i = 0; i < CLAHE_BINS; i++)
+                    if (hist[i] > clip) {
+                        clipped += hist[i] - clip;
+                        hist[i] = clip;
+                    }
+                const int batch = clipped / CLAHE_BINS;
+                int residual = clipped - batch * CLAHE_BINS;
+                for (int i = 0; i < CLAHE_BINS; i++) hist[i] += batch;
+                if (residual != 0) {
+                    const int step = CLAHE_BINS / residual > 1 ? CLAHE_BINS / residual : 1;
+                    for (int i = 0; i < CLAHE_BINS && residual > 0; i += step, residual--) hist[i]++;
+                }
+            }
+            uint8_t* tl = lut + (size_t)(ty * CLAHE_TILES + tx) * CLAHE_BINS;
+            int sum = 0;
+            for (int i = 0; i < CLAHE_BINS; i++) {
+                sum += hist[i];
+                tl[i] = sat_u8_rint((float)sum * lut_scale);
+            }
+        }
+    /* bilinear interpolation between the four surrounding tile LUTs (tile centres) */
+    const float inv_tw = 1.0f / (float)tw, inv_th = 1.0f / (float)th;
+    for (int y = 0; y < h; y++) {
+        const float tyf = (float)y * inv_th - 0.5f;
+        int ty1 = (int)floorf(tyf), ty2 = ty1 + 1;
+        const float ya = tyf - (float)ty1, ya1 = 1.0f - ya;
+        if (ty1 < 0) ty1 = 0;
+        if (ty2 > CLAHE_TILES - 1) ty2 = CLAHE_TILES - 1;
+        for (int x = 0; x < w; x++) {
+            const float txf = (float)x * inv_tw - 0.5f;
+            int tx1 = (int)floorf(txf), tx2 = tx1 + 1;
+            const float xa = txf - (float)tx1, xa1 = 1.0f - xa;
+            if (tx1 < 0) tx1 = 0;
+            if (tx2 > CLAHE_TILES - 1) tx2 = CLAHE_TILES - 1;
+            const int v = in[(size_t)y * stride + x];
+            const float l11 = lut[(size_t)(ty1 * CLAHE_TILES + tx1) * CLAHE_BINS + v];
+            const float l12 = lut[(size_t)(ty1 * CLAHE_TILES + tx2) * CLAHE_BINS + v];
+            const float l21 = lut[(size_t)(ty2 * CLAHE_TILES + tx1) * CLAHE_BINS + v];
+            const float l22 = lut[(size_t)(ty2 * CLAHE_TILES + tx2) * CLAHE_BINS + v];
+            const float p11 = l11 * xa1, p12 = l12 * xa, p21 = l21 * xa1, p22 = l22 * xa;
+            const float top = (p11 + p12) * ya1, bot = (p21 + p22) * ya;
+            out[(size_t)y * w + x] = sat_u8_rint(top + bot);
+        }
+    }
+    free(lut);
+    return 0;
+}
+
+/* mrgingham-from-image.cc:71-111 for an 8-bit frame: [normalize + CLAHE(8)] then box blur. */
+int oracle_preprocess(uint8_t* out, const uint8_t* in, int w, int h, int stride, int do_clahe, int blur_radius)
+{
+    uint8_t* a = (uint8_t*)malloc((size_t)w * h);
+    uint8_t* b = (uint8_t*)malloc((size_t)w * h);
+    if (!a || !b) { free(a); free(b); return -1; }
+    const uint8_t* cur = in;
+    int cur_stride = stride;
+    if (do_clahe) {
+        oracle_normalize_minmax(a, in, w, h, stride);
+        if (oracle_clahe(b, a, w, h, w, 8.0) != 0) { free(a); free(b); return -1; }
+        cur = b;
+        cur_stride = w;
+    }
+    if (blur_radius > 0) oracle_box_blur(out, cur, w, h, cur_stride, blur_radius);
+    else
+        for (int y = 0; y < h; y++) memcpy(out + (size_t)y * w, cur + (size_t)y * cur_stride, (size_t)w);
+    free(a);
+    free(b);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
 /* Connected components over the clamped response.                            */
 /* Restates find_chessboard_corners.cc:18-44 (thresholds), :50-88             */
 /* (high_variance), :91-141 (LIFO), :143-267 (fill), :269-280 (scaling),      */

@@ -20,6 +20,13 @@ int oracle_decimate(uint8_t* out, const uint8_t* in, int W, int H, int stride, i
 /* cv::blur with a (2r+1)^2 box, BORDER_REFLECT_101 (mrgingham-from-image.cc:106-111). */
 void oracle_box_blur(uint8_t* out, const uint8_t* in, int w, int h, int stride, int radius);
 
+/* The CLI's contrast preprocessing (mrgingham-from-image.cc:38-45, :71-111); OpenCV arithmetic,
+ * parity unpinned (see the .c file). */
+void oracle_normalize_lut(uint8_t lut[256], int vmin, int vmax);
+void oracle_normalize_minmax(uint8_t* out, const uint8_t* in, int w, int h, int stride);
+int oracle_clahe(uint8_t* out, const uint8_t* in, int w, int h, int stride, double clip_limit);
+int oracle_preprocess(uint8_t* out, const uint8_t* in, int w, int h, int stride, int do_clahe, int blur_radius);
+
 /* Clamped (negatives -> 0, border zero) response and the level image the
  * connected-component stage sees (find_chessboard_corners.cc:495-529). */
 int oracle_clamped_response(int16_t* resp_out, uint8_t* level_image_out, const uint8_t* image, int H, int W,

@@ -117,6 +117,32 @@ def box_blur(image, radius=1):
     return out
 
 
+def normalize_minmax(image):
+    image, H, W, stride = _img2d(image)
+    out = np.empty((H, W), dtype=np.uint8)
+    lib().oracle_normalize_minmax(out.ctypes.data_as(_u8p), image.ctypes.data_as(_u8p), W, H, stride)
+    return out
+
+
+def clahe(image, clip_limit=8.0):
+    image, H, W, stride = _img2d(image)
+    out = np.empty((H, W), dtype=np.uint8)
+    lib().oracle_clahe.argtypes = [_u8p, _u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double]
+    if lib().oracle_clahe(out.ctypes.data_as(_u8p), image.ctypes.data_as(_u8p), W, H, stride, float(clip_limit)) != 0:
+        raise RuntimeError("oracle_clahe failed")
+    return out
+
+
+def preprocess(image, clahe=True, blur_radius=1):
+    """mrgingham-from-image.cc:71-111 for an 8-bit frame."""
+    image, H, W, stride = _img2d(image)
+    out = np.empty((H, W), dtype=np.uint8)
+    if lib().oracle_preprocess(out.ctypes.data_as(_u8p), image.ctypes.data_as(_u8p), W, H, stride,
+                               int(bool(clahe)), int(blur_radius)) != 0:
+        raise RuntimeError("oracle_preprocess failed")
+    return out
+
+
 def clamped_response(image, level):
     image, H, W, stride = _img2d(image)
     w, h = level_dims(W, H, level)

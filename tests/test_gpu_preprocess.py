@@ -1,0 +1,79 @@
+"""Row (f)-2: the CLI's contrast preprocessing on the device against the oracle's restatement of
+OpenCV's published normalize / CLAHE / blur arithmetic (parity unpinned: OpenCV itself is absent).
+Bit-exact, through the C-ABI (mrgingham_amd_preprocess_batch)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames(kind, H, W, n, seed):
+    from mrgingham_amd import synth
+    rng = np.random.RandomState(seed)
+    out = []
+    for i in range(n):
+        if kind == "board":
+            f = synth.board_frame(W, H, gridn=10, seed=seed + i).numpy().astype(np.float64)
+            f = f * rng.uniform(0.3, 0.8) + rng.uniform(0, 50)          # reduced dynamic range
+        elif kind == "noise":
+            f = rng.rand(H, W) * rng.uniform(60, 255)
+        elif kind == "ramp":
+            f = np.add.outer(np.arange(H) * 0.05, np.arange(W) * 0.1) + 20
+        else:
+            f = np.full((H, W), 77.0)
+        out.append(np.clip(f, 0, 255).astype(np.uint8))
+    return np.stack(out)
+
+
+@pytest.mark.parametrize("kind,H,W", [
+    ("board", 480, 640), ("noise", 96, 128), ("ramp", 200, 320), ("flat", 64, 64),
+    ("board", 487, 643),     # neither side divides into the 8x8 tile grid: both sides get padded
+    ("noise", 96, 131),      # only the width is ragged (OpenCV still pads the height by 8)
+    ("noise", 101, 128),
+    ("board", 1080, 1920),
+])
+@pytest.mark.parametrize("clahe,blur", [(True, 1), (True, 0), (False, 1), (False, 2), (True, 3)])
+def test_preprocess_matches_oracle(kind, H, W, clahe, blur):
+    import torch
+    import mrgingham_amd
+    from oracle import oracle
+    frames = _frames(kind, H, W, 3, seed=H + W)
+    det = mrgingham_amd.Detector(0)
+    got = det.preprocess(torch.from_numpy(frames).cuda(), clahe=clahe, blur_radius=blur)
+    torch.cuda.synchronize()
+    got = got.cpu().numpy()
+    for i in range(len(frames)):
+        want = oracle.preprocess(frames[i], clahe=clahe, blur_radius=blur)
+        assert np.array_equal(got[i], want), (kind, H, W, clahe, blur, i, int(np.abs(got[i].astype(int) - want).max()))
+
+
+def test_preprocess_strided_input_and_no_ops():
+    import torch
+    import mrgingham_amd
+    from oracle import oracle
+    base = _frames("board", 240, 352, 2, seed=5)
+    wide = np.zeros((2, 240, 400), dtype=np.uint8)
+    wide[:, :, :352] = base
+    det = mrgingham_amd.Detector(0)
+    t = torch.from_numpy(wide).cuda()[:, :, :352]                        # row stride 400
+    got = det.preprocess(t, clahe=True, blur_radius=1).cpu().numpy()
+    for i in range(2):
+        assert np.array_equal(got[i], oracle.preprocess(base[i], clahe=True, blur_radius=1))
+    same = det.preprocess(t, clahe=False, blur_radius=0).cpu().numpy()   # dense copy
+    assert np.array_equal(same, base)
+
+
+def test_preprocessed_frames_give_the_same_board():
+    """End to end like the CLI: preprocess on the device, then the level driver."""
+    import torch
+    import mrgingham_amd
+    from mrgingham_amd import synth
+    from oracle import oracle
+    frame = (synth.board_frame(1280, 960, gridn=10, seed=3).numpy().astype(np.float64) * 0.5 + 40).astype(np.uint8)
+    det = mrgingham_amd.Detector(0)
+    pre = det.preprocess(torch.from_numpy(frame[None]).cuda(), clahe=True, blur_radius=1)
+    pts, lv = det.find_boards(pre, gridn=10)
+    want_img = oracle.preprocess(frame, clahe=True, blur_radius=1)
+    ref = mrgingham_amd.find_board(want_img, gridn=10)
+    assert lv[0] >= 0 and ref is not None
+    assert np.array_equal(np.asarray(pts[0]), ref)
