@@ -178,6 +178,17 @@ int mrgingham_amd_refine_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frame
 int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* frames, int start_level,
                               double* d_points, signed char* d_levels, int32_t* d_npoints, int points_pitch);
 
+/* What one worker of the reference CLI does with one decoded 8-bit image
+ * (mrgingham-from-image.cc:71-111, :160-171): [normalize + CLAHE(8)] -> box blur of
+ * blur_radius -> find_chessboard_from_image_array(gridn, image_pyramid_level), with the
+ * per-corner refinement when do_refine.  Host image in, gridn*gridn corners (xy_out,
+ * interleaved doubles) and their refinement levels (levels_out, may be NULL) out.  Uses the
+ * calling thread's context.  Returns the level the board was found at, -1 if there is
+ * none, -2 on an argument or device error. */
+int mrgingham_amd_process_image(const uint8_t* image, int width, int height, int stride, int do_clahe,
+                                int blur_radius, int gridn, int image_pyramid_level, int do_refine,
+                                double* xy_out, signed char* levels_out);
+
 /* Batch form of the full detector (what find_chessboard_from_image_array_C does per frame, for
  * image_pyramid_level < 0 the reference's default "first level of 3,2,1,0 at which the grid finder
  * succeeds", mrgingham.cc:116-139): per level the GPU detects candidates for the whole batch, up to

@@ -57,7 +57,7 @@ struct mrgingham_amd_ctx {
     mrg::DevBuf counters2[2];  // per scratch set: hot_cnt words [level][counters_nf], then status words [level][counters_nf]
     int counters_nf = 0;
     mrg::DevBuf leader, need, nseeds, seeds, sroot, cand_xy, cand_counts, aux_img, io_frame, io_out;
-    mrg::DevBuf pre_scratch, pre_tmp;  // preprocessing: extrema + tile histograms + LUTs, CLAHE output before the blur
+    mrg::DevBuf pre_scratch, pre_tmp, pre_out;  // preprocessing: extrema + tile histograms + LUTs, CLAHE output before the blur
     int pts_nframes = 0, pts_pitch = 0;
     // levels (and frame counts) whose status words must be checked at the next sync
     int pending_frames[2][mrg::kMaxLevel + 1] = {};
@@ -373,7 +373,7 @@ void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx) {
             if (b->p) hipFree(b->p);
     }
     DevBuf* bufs[] = {&ctx->counters2[0], &ctx->counters2[1], &ctx->leader, &ctx->need, &ctx->nseeds, &ctx->seeds, &ctx->sroot, &ctx->cand_xy, &ctx->cand_counts,
-                      &ctx->aux_img, &ctx->io_frame, &ctx->io_out, &ctx->pre_scratch, &ctx->pre_tmp};
+                      &ctx->aux_img, &ctx->io_frame, &ctx->io_out, &ctx->pre_scratch, &ctx->pre_tmp, &ctx->pre_out};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     for (auto& pr : ctx->events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
@@ -788,23 +788,13 @@ bool find_chessboard_corners_from_image_array_C(int Nrows, int Ncols, int stride
     return (*add_points)(xy.data(), (int)count, 1. / kGridScale, cookie);  // bridge.cc:66-69
 }
 
-int refine_chessboard_corners_from_image_array_C(int Nrows, int Ncols, int stride, char* imagebuffer,
-                                                 double* points_xy, signed char* level, int Npoints,
-                                                 int image_pyramid_level, bool debug) {
-    (void)debug;
-    if (Nrows < 0 || Ncols < 0 || stride < Ncols || !imagebuffer || Npoints < 0) return 0;
-    if (Npoints > 0 && (!points_xy || !level)) return 0;
-    if (!check_level_and_layout(__func__, Nrows, Ncols, stride, image_pyramid_level)) return 0;
-    if (Npoints == 0) return 0;
-    mrgingham_amd_ctx* ctx = thread_ctx();
-    if (!ctx) return 0;
-    hipSetDevice(ctx->device);
+// Refinement of host-side points against a frame that already lives on the device (one frame).
+static int refine_on_device(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, double* points_xy,
+                            signed char* level, int Npoints, int image_pyramid_level) {
     const int saved_shift = ctx->cap_shift;
     int32_t nrefined = 0;
     bool ok = false;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        mrgingham_amd_frames fr;
-        if (upload_frame(ctx, imagebuffer, Nrows, Ncols, stride, &fr)) break;
         // layout of io_out: points | levels | npoints | nrefined
         const size_t o_lv = (size_t)Npoints * 16, o_np = o_lv + (((size_t)Npoints + 7) & ~(size_t)7), o_nr = o_np + 8;
         if (ensure(ctx, ctx->io_out, o_nr + 8)) break;
@@ -815,7 +805,7 @@ int refine_chessboard_corners_from_image_array_C(int Nrows, int Ncols, int strid
         if (hipMemcpyAsync(base + o_lv, level, (size_t)Npoints, hipMemcpyHostToDevice, s0) != hipSuccess) break;
         if (hipMemcpyAsync(base + o_np, &np, 4, hipMemcpyHostToDevice, s0) != hipSuccess) break;
         if (hipStreamSynchronize(s0) != hipSuccess) break;  // `np` lives on this stack frame
-        if (mrgingham_amd_refine_batch(ctx, &fr, image_pyramid_level, (double*)base, (signed char*)(base + o_lv),
+        if (mrgingham_amd_refine_batch(ctx, fr, image_pyramid_level, (double*)base, (signed char*)(base + o_lv),
                                        (const int32_t*)(base + o_np), Npoints, (int32_t*)(base + o_nr)))
             break;
         const int rc = mrgingham_amd_sync(ctx);
@@ -831,6 +821,22 @@ int refine_chessboard_corners_from_image_array_C(int Nrows, int Ncols, int strid
     return ok && nrefined > 0 ? nrefined : 0;
 }
 
+int refine_chessboard_corners_from_image_array_C(int Nrows, int Ncols, int stride, char* imagebuffer,
+                                                 double* points_xy, signed char* level, int Npoints,
+                                                 int image_pyramid_level, bool debug) {
+    (void)debug;
+    if (Nrows < 0 || Ncols < 0 || stride < Ncols || !imagebuffer || Npoints < 0) return 0;
+    if (Npoints > 0 && (!points_xy || !level)) return 0;
+    if (!check_level_and_layout(__func__, Nrows, Ncols, stride, image_pyramid_level)) return 0;
+    if (Npoints == 0) return 0;
+    mrgingham_amd_ctx* ctx = thread_ctx();
+    if (!ctx) return 0;
+    hipSetDevice(ctx->device);
+    mrgingham_amd_frames fr;
+    if (upload_frame(ctx, imagebuffer, Nrows, Ncols, stride, &fr)) return 0;
+    return refine_on_device(ctx, &fr, points_xy, level, Npoints, image_pyramid_level);
+}
+
 /* C face of mrgingham::find_grid_from_points (mrgingham.hh:83-87; find_grid.cc:1216-1445): host only. */
 bool mrgingham_amd_find_grid_from_points(const int* xy_scaled, int npoints, int gridn, double* xy_out) {
     if (!xy_scaled || !xy_out || npoints < 0 || gridn < 2) return false;
@@ -840,6 +846,58 @@ bool mrgingham_amd_find_grid_from_points(const int* xy_scaled, int npoints, int 
     if (!find_grid_from_points(out, pts, gridn) || (int)out.size() != gridn * gridn) return false;
     memcpy(xy_out, out.data(), sizeof(double) * 2 * out.size());
     return true;
+}
+
+// mrgingham::find_chessboard_from_image_array (mrgingham.cc:38-140) on ONE frame that already lives
+// on the device (dense, stride == width): detector and refinement on the GPU, grid finder on the
+// host.  Returns the level the grid was found at, or -1.  `lv` receives the per-corner refinement
+// level; without do_refine nothing is refined and every entry is the found level.
+static int find_board_on_device(mrgingham_amd_ctx* ctx, const char* who, const mrgingham_amd_frames* fr, int gridn,
+                                int image_pyramid_level, bool do_refine, std::vector<PointD>& board,
+                                std::vector<signed char>& lv) {
+    const int Nrows = fr->height, Ncols = fr->width;
+    const int saved_shift = ctx->cap_shift;
+    const int N = gridn * gridn;
+    std::vector<int32_t> xy;
+    bool found = false;
+    // image_pyramid_level >= 0: that level only; < 0: 3, 2, 1, 0 until a grid is found (mrgingham.cc:116-139)
+    const int first = image_pyramid_level >= 0 ? image_pyramid_level : 3;
+    const int last = image_pyramid_level >= 0 ? image_pyramid_level : 0;
+    int level = first;
+    for (; level >= last && !found; --level) {
+        if (!check_level_and_layout(who, Nrows, Ncols, fr->stride, level)) continue;
+        int32_t count = 0;
+        bool ok = false;
+        for (int attempt = 0; attempt < 2 && !ok; ++attempt) {
+            if (ensure_level(ctx, level, 1, Ncols, Nrows, N) || ensure_points(ctx, 1, N)) break;
+            const int cap = ctx->lvs[0][level].cand_cap;
+            if (ensure(ctx, ctx->io_out, (size_t)cap * 8 + (size_t)N * 17 + 256)) break;
+            if (mrgingham_amd_detect_batch(ctx, fr, level, (int32_t*)ctx->io_out.p, cap, (int32_t*)ctx->cand_counts.p))
+                break;
+            const int rc = mrgingham_amd_sync(ctx);
+            if (rc == MRGINGHAM_AMD_ERR_CAPACITY && attempt == 0) { ctx->cap_shift = 0; continue; }
+            if (rc) break;
+            if (hipMemcpy(&count, ctx->cand_counts.p, sizeof(count), hipMemcpyDeviceToHost) != hipSuccess) break;
+            xy.resize((size_t)(count > 0 ? count : 0) * 2);
+            if (count > 0 && hipMemcpy(xy.data(), ctx->io_out.p, (size_t)count * 8, hipMemcpyDeviceToHost) != hipSuccess)
+                break;
+            ok = true;
+        }
+        ctx->cap_shift = saved_shift;
+        if (!ok || count < N) continue;
+        std::vector<PointI> cand((size_t)count);
+        for (int i = 0; i < count; ++i) cand[i] = PointI{xy[2 * i], xy[2 * i + 1]};
+        board.clear();
+        found = find_grid_from_points(board, cand, gridn) && (int)board.size() == N;  // mrgingham.cc:51
+        if (found) break;
+    }
+    if (!found) return -1;
+    lv.assign((size_t)N, (signed char)level);
+    // refine towards level 0 while something still refines (mrgingham.cc:81-99)
+    if (do_refine)
+        for (int l = level - 1; l >= 0; --l)
+            if (refine_on_device(ctx, fr, &board[0].x, lv.data(), N, l) <= 0) break;
+    return level;
 }
 
 /* Replaces find_chessboard_from_image_array_C (mrgingham_pywrap_cplusplus_bridge.h:25-42, .cc:72-138),
@@ -863,54 +921,47 @@ bool find_chessboard_from_image_array_C(int Nrows, int Ncols, int stride, char* 
     mrgingham_amd_ctx* ctx = thread_ctx();
     if (!ctx) return false;
     hipSetDevice(ctx->device);
-    const int saved_shift = ctx->cap_shift;
     mrgingham_amd_frames fr;
     if (upload_frame(ctx, imagebuffer, Nrows, Ncols, stride, &fr)) return false;
-    const int N = gridn * gridn;
     std::vector<PointD> board;
-    std::vector<int32_t> xy;
-    bool found = false;
-    // image_pyramid_level >= 0: that level only; < 0: 3, 2, 1, 0 until a grid is found (mrgingham.cc:116-139)
-    const int first = image_pyramid_level >= 0 ? image_pyramid_level : 3;
-    const int last = image_pyramid_level >= 0 ? image_pyramid_level : 0;
-    int level = first;
-    for (; level >= last && !found; --level) {
-        if (!check_level_and_layout(__func__, Nrows, Ncols, stride, level)) continue;
-        int32_t count = 0;
-        bool ok = false;
-        for (int attempt = 0; attempt < 2 && !ok; ++attempt) {
-            if (ensure_level(ctx, level, 1, Ncols, Nrows, N) || ensure_points(ctx, 1, N)) break;
-            const int cap = ctx->lvs[0][level].cand_cap;
-            if (ensure(ctx, ctx->io_out, (size_t)cap * 8 + (size_t)N * 17 + 256)) break;
-            if (mrgingham_amd_detect_batch(ctx, &fr, level, (int32_t*)ctx->io_out.p, cap, (int32_t*)ctx->cand_counts.p))
-                break;
-            const int rc = mrgingham_amd_sync(ctx);
-            if (rc == MRGINGHAM_AMD_ERR_CAPACITY && attempt == 0) { ctx->cap_shift = 0; continue; }
-            if (rc) break;
-            if (hipMemcpy(&count, ctx->cand_counts.p, sizeof(count), hipMemcpyDeviceToHost) != hipSuccess) break;
-            xy.resize((size_t)(count > 0 ? count : 0) * 2);
-            if (count > 0 && hipMemcpy(xy.data(), ctx->io_out.p, (size_t)count * 8, hipMemcpyDeviceToHost) != hipSuccess)
-                break;
-            ok = true;
-        }
-        ctx->cap_shift = saved_shift;
-        if (!ok || count < N) continue;
-        std::vector<PointI> cand((size_t)count);
-        for (int i = 0; i < count; ++i) cand[i] = PointI{xy[2 * i], xy[2 * i + 1]};
-        board.clear();
-        found = find_grid_from_points(board, cand, gridn) && (int)board.size() == N;  // mrgingham.cc:51
-        if (found) break;
-    }
-    if (!found) return false;
-    // refine towards level 0 while something still refines (mrgingham.cc:81-99)
-    std::vector<signed char> lv((size_t)N, (signed char)level);
-    for (int l = level - 1; l >= 0; --l) {
-        const int n = refine_chessboard_corners_from_image_array_C(Nrows, Ncols, stride, imagebuffer, &board[0].x,
-                                                                   lv.data(), N, l, false);
-        if (n <= 0) break;
-    }
+    std::vector<signed char> lv;
+    if (find_board_on_device(ctx, __func__, &fr, gridn, image_pyramid_level, true, board, lv) < 0) return false;
     static_assert(sizeof(PointD) == 2 * sizeof(double), "add_points() takes interleaved doubles");
-    return (*add_points)(&board[0].x, N, cookie);  // bridge.cc:133-137
+    return (*add_points)(&board[0].x, gridn * gridn, cookie);  // bridge.cc:133-137
+}
+
+/* What one worker of the reference CLI does with one decoded 8-bit image
+ * (mrgingham-from-image.cc:71-111 and :160-171): [normalize + CLAHE] -> box blur ->
+ * find_chessboard_from_image_array.  The frame is uploaded once; preprocessing, detector and
+ * refinement run on the device, the grid finder on the host.  Returns the level the board was found
+ * at (>= 0), -1 when no board was found, -2 on an argument / device error. */
+int mrgingham_amd_process_image(const uint8_t* image, int width, int height, int stride, int do_clahe,
+                                int blur_radius, int gridn, int image_pyramid_level, int do_refine, double* xy_out,
+                                signed char* levels_out) {
+    if (!image || width <= 0 || height <= 0 || stride < width || gridn < 2 || !xy_out || blur_radius < 0) return -2;
+    if (image_pyramid_level > 10) {
+        fprintf(stderr, "mrgingham_amd: %s(): Got an unreasonable image_pyramid_level = %d. Sorry.\n", __func__,
+                image_pyramid_level);
+        return -2;
+    }
+    mrgingham_amd_ctx* ctx = thread_ctx();
+    if (!ctx) return -2;
+    hipSetDevice(ctx->device);
+    mrgingham_amd_frames fr;
+    if (upload_frame(ctx, image, height, width, stride, &fr)) return -2;
+    if (do_clahe || blur_radius > 0) {
+        if (ensure(ctx, ctx->pre_out, (size_t)width * height + 64)) return -2;
+        if (mrgingham_amd_preprocess_batch(ctx, &fr, do_clahe, blur_radius, (uint8_t*)ctx->pre_out.p, ctx->pix))
+            return -2;
+        fr.frames = (const uint8_t*)ctx->pre_out.p;  // same stream as the detector's pixel kernels
+    }
+    std::vector<PointD> board;
+    std::vector<signed char> lv;
+    const int level = find_board_on_device(ctx, __func__, &fr, gridn, image_pyramid_level, do_refine != 0, board, lv);
+    if (level < 0) return -1;
+    memcpy(xy_out, &board[0].x, sizeof(double) * 2 * (size_t)gridn * gridn);
+    if (levels_out) memcpy(levels_out, lv.data(), (size_t)gridn * gridn);
+    return level;
 }
 
 /* Batch form of the full detector (the reference's default schedule, image_pyramid_level < 0, per

@@ -1,0 +1,185 @@
+"""Row (f)-3: the command-line tool (mrgingham_amd/bin/mrgingham-amd-from-image), the reference's
+mrgingham-from-image.cc over the library.  CPU tests: option / argument behaviour (exit codes and
+messages of mrgingham-from-image.cc:222-330).  GPU tests: vnlog output for PGM / PNG files against the
+oracle's preprocessing + detector + refinement composed with the grid finder."""
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "mrgingham_amd", "bin", "mrgingham-amd-from-image")
+
+
+def _run(*args):
+    return subprocess.run([CLI, *args], capture_output=True, text=True, timeout=600)
+
+
+def _write_pgm(path, img, maxval=255):
+    with open(path, "wb") as f:
+        f.write(b"P5\n# a comment line\n%d %d\n%d\n" % (img.shape[1], img.shape[0], maxval))
+        f.write(img.astype(">u2").tobytes() if maxval > 255 else img.astype(np.uint8).tobytes())
+
+
+def _write_png(path, img, rgb=False):
+    """Minimal PNG writer (8-bit grey or RGB), every row with a different filter type."""
+    h, w = img.shape[:2]
+    ch = 3 if rgb else 1
+    rows = img.reshape(h, w * ch).astype(np.int32)
+    raw = bytearray()
+    prev = np.zeros(w * ch, np.int32)
+    for y in range(h):
+        ft = y % 5
+        cur = rows[y]
+        left = np.concatenate([np.zeros(ch, np.int32), cur[:-ch]])
+        upleft = np.concatenate([np.zeros(ch, np.int32), prev[:-ch]])
+        if ft == 0:
+            pred = np.zeros_like(cur)
+        elif ft == 1:
+            pred = left
+        elif ft == 2:
+            pred = prev
+        elif ft == 3:
+            pred = (left + prev) >> 1
+        else:
+            p = left + prev - upleft
+            pa, pb, pc = np.abs(p - left), np.abs(p - prev), np.abs(p - upleft)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+        raw.append(ft)
+        raw += ((cur - pred) & 0xff).astype(np.uint8).tobytes()
+        prev = cur
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    comp = zlib.compress(bytes(raw), 6)
+    half = len(comp) // 2                                   # two IDAT chunks
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2 if rgb else 0, 0, 0, 0)) +
+                chunk(b"IDAT", comp[:half]) + chunk(b"IDAT", comp[half:]) + chunk(b"IEND", b""))
+
+
+def test_cli_is_built_and_prints_usage():
+    assert os.path.exists(CLI), "run python __graft_entry__.py (make -C mrgingham_amd/csrc)"
+    r = _run("--help")
+    assert r.returncode == 0 and "imageglobs" in r.stdout and "--gridn" in r.stdout
+
+
+def test_cli_argument_errors(tmp_path):
+    r = _run()
+    assert r.returncode == 1 and "Not enough arguments: need image globs" in r.stderr
+    r = _run("--jobs", "0", "x*.pgm")
+    assert r.returncode == 1 and "The job count must be a positive integer" in r.stderr
+    r = _run("--gridn", "1", "x*.pgm")
+    assert r.returncode == 1 and "--gridn value must be >= 2" in r.stderr
+    r = _run("--blobs", "x*.pgm")
+    assert r.returncode == 1 and "blobs" in r.stderr
+    r = _run("--debug-sequence", "nonsense", "x*.pgm")
+    assert r.returncode != 0 and "could not parse 'x,y'" in r.stderr
+    r = _run("--frobnicate", "x*.pgm")
+    assert r.returncode == 1 and "Unknown option" in r.stderr
+    r = _run(str(tmp_path / "nothing-here-*.pgm"))
+    assert r.returncode == 1 and "matched no files!" in r.stderr
+    a, b = tmp_path / "a.pgm", tmp_path / "b.pgm"
+    for p in (a, b):
+        _write_pgm(p, np.zeros((32, 32), np.uint8))
+    r = _run("--debug", str(tmp_path / "*.pgm"))
+    assert r.returncode == 1 and "When debugging, pass one image at a time. Got 2 instead" in r.stderr
+
+
+def test_cli_without_a_gpu_fails_loudly(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    p = tmp_path / "a.pgm"
+    _write_pgm(p, np.zeros((64, 64), np.uint8))
+    r = _run(str(p))
+    assert r.returncode == 2 and "no HIP device" in r.stderr and "# filename" not in r.stdout
+
+
+def _expected(img, gridn, level, clahe, blur, refine=True):
+    import mrgingham_amd
+    from oracle import oracle
+    pre = oracle.preprocess(img, clahe=clahe, blur_radius=blur)
+    for L in ([level] if level >= 0 else [3, 2, 1, 0]):
+        cand = oracle.find_corners(pre, L)
+        if cand is None or len(cand) < gridn * gridn:
+            continue
+        grid = mrgingham_amd.find_grid_from_points(cand, gridn)
+        if grid is None:
+            continue
+        pts, lv = grid.copy(), np.full(gridn * gridn, L, np.int8)
+        if refine:
+            for l in range(L - 1, -1, -1):
+                pts, lv, n = oracle.refine_corners(pts, lv, pre, l)
+                if n <= 0:
+                    break
+        return pts, lv
+    return None, None
+
+
+def _parse(stdout):
+    out = {}
+    lines = stdout.splitlines()
+    assert lines[0].startswith("## generated with") and lines[1] == "# filename x y level"
+    for ln in lines[2:]:
+        if ln.startswith("#"):
+            continue
+        name, x, y, lv = ln.split()
+        out.setdefault(name, []).append(None if x == "-" else (float(x), float(y), int(lv)))
+    return out
+
+
+@pytest.mark.gpu
+def test_cli_vnlog_matches_composed_oracle(tmp_path):
+    from mrgingham_amd import synth
+    files = {}
+    for i, (w, h, seed) in enumerate([(640, 480, 0), (1280, 960, 1), (800, 600, 2)]):
+        img = (synth.board_frame(w, h, 10, seed).numpy().astype(np.float64) * 0.6 + 30).astype(np.uint8)
+        p = str(tmp_path / f"board{i}.{'png' if i == 1 else 'pgm'}")
+        (_write_png if i == 1 else _write_pgm)(p, img)
+        files[p] = img
+    noise = str(tmp_path / "board_none.pgm")
+    files[noise] = synth.noise_frame(640, 480, 3, smooth=1).numpy()
+    _write_pgm(noise, files[noise])
+    for args, clahe, blur, level, refine in [((), True, 1, -1, True), (("--noclahe", "--blur", "0", "--level", "1"), False, 0, 1, True),
+                                             (("--no-refine", "-j", "3"), True, 1, -1, False)]:
+        r = _run(*args, str(tmp_path / "board*.p[gn][mg]"))
+        assert r.returncode == 0, r.stderr
+        got = _parse(r.stdout)
+        assert set(got) == set(files)
+        for name, img in files.items():
+            want, lv = _expected(img, 10, level, clahe, blur, refine)
+            if want is None:
+                assert got[name] == [None], name
+                continue
+            assert len(got[name]) == 100, (name, args)
+            g = np.array([(x, y) for x, y, _ in got[name]])
+            assert np.abs(g - want).max() < 1e-6, (name, args)               # "%f": 6 decimals
+            assert [l for _, _, l in got[name]] == list(lv), (name, args)
+
+
+@pytest.mark.gpu
+def test_cli_rgb_png_16bit_pgm_and_unreadable_file(tmp_path):
+    from mrgingham_amd import synth
+    img = synth.board_frame(640, 480, 10, 7).numpy()
+    rgb = np.stack([img, img, img], axis=-1)                                 # grey stored as RGB: weights sum to 2^14
+    p_rgb, p_16, p_bad = str(tmp_path / "a_rgb.png"), str(tmp_path / "b_16.pgm"), str(tmp_path / "c_bad.pgm")
+    _write_png(p_rgb, rgb, rgb=True)
+    _write_pgm(p_16, img.astype(np.uint16) * 257, maxval=65535)              # 8-bit values on the 16-bit scale
+    open(p_bad, "wb").write(b"P5\nnot an image")
+    want, lv = _expected(img, 10, -1, False, 1)
+    r = _run("--noclahe", p_rgb, p_16)
+    assert r.returncode == 0, r.stderr
+    got = _parse(r.stdout)
+    for name in (p_rgb, p_16):
+        g = np.array([(x, y) for x, y, _ in got[name]])
+        assert g.shape == (100, 2) and np.abs(g - want).max() < 1e-6, name
+    r = _run(p_16)                                                           # 16 bit needs --noclahe in this build
+    assert r.returncode == 0 and _parse(r.stdout)[p_16] == [None] and "16-bit" in r.stderr
+    r = _run(p_bad, p_rgb)                                                   # one worker: the bad file ends it (:58-68)
+    assert r.returncode == 0 and "Couldn't open image" in r.stderr
+    got = _parse(r.stdout)
+    assert got[p_bad] == [None] and p_rgb not in got
