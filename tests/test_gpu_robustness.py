@@ -182,3 +182,30 @@ def test_mixed_resolution_stream_plan_runs_per_resolution_batches(det):
         for world in (1, 2):
             gp, gl = results[(world, i)]
             assert np.array_equal(gp, wp) and np.array_equal(gl, wl), (world, i)
+
+
+@pytest.mark.parametrize("shape", [(32752, 48), (48, 32752), (32767, 33), (31, 32767)])
+def test_extreme_aspect_frames_near_the_int16_coordinate_limit(det, shape):
+    """The reference keeps pixel coordinates in int16 (find_chessboard_corners.cc:50, :91, :332-333), so a
+    side can be at most 32767: 128 strips of one segment, or one strip of 256 segments."""
+    w, h = shape
+    base = synth.noise_frame(w, h, 9, smooth=1).numpy()
+    # paste corner-like 2x2 checker junctions so that there are candidates along the long side
+    frame = base.copy()
+    n = max(w, h) // 97
+    for i in range(n):
+        cx = (31 + 97 * i) if w > h else w // 2
+        cy = h // 2 if w > h else (31 + 97 * i)
+        x0, x1, y0, y1 = max(cx - 12, 0), min(cx + 12, w), max(cy - 12, 0), min(cy + 12, h)
+        yy, xx = np.mgrid[y0:y1, x0:x1]
+        frame[y0:y1, x0:x1] = np.where((xx < cx) ^ (yy < cy), 30, 220).astype(np.uint8)
+    frame = synth.box_blur3(torch.from_numpy(frame).to(torch.int64)).numpy().astype(np.uint8)
+    d = _cuda(frame[None])
+    resp = det.chess_response(d, 0, clamp=True).cpu().numpy()[0]
+    want_resp, _ = oracle.clamped_response(frame, 0)
+    assert np.array_equal(resp, want_resp)
+    for level in (0, 1):
+        xy, counts = det.detect(d, level, capacity=16384)
+        want = oracle.find_corners(frame, level)
+        assert int(counts[0]) == len(want) and (level > 0 or len(want) > 0), (shape, level, len(want))
+        assert np.array_equal(xy[0, :len(want)].cpu().numpy(), want), (shape, level)
