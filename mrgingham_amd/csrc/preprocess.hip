@@ -20,11 +20,9 @@
 
 namespace mrg {
 
-namespace {
-
 constexpr int kTiles = 8, kBins = 256;
 
-__device__ __forceinline__ int reflect101_pp(int i, int n) {
+static __device__ __forceinline__ int reflect101_pp(int i, int n) {
     if (n == 1) return 0;
     while (i < 0 || i >= n) {
         if (i < 0) i = -i;
@@ -33,14 +31,14 @@ __device__ __forceinline__ int reflect101_pp(int i, int n) {
     return i;
 }
 
-__device__ __forceinline__ uint8_t sat_u8_rint(float v) {
+static __device__ __forceinline__ uint8_t sat_u8_rint(float v) {
     const float r = __builtin_rintf(v);  // cvRound: half to even
     return (uint8_t)(r < 0.f ? 0.f : r > 255.f ? 255.f : r);
 }
 
 // normalised value of v for a frame whose extrema are (vmin, vmax): cv::normalize's double
 // scale / shift, then convertTo's float multiply and add (two roundings, no fma)
-__device__ __forceinline__ uint8_t normalize_value(int v, int vmin, int vmax) {
+static __device__ __forceinline__ uint8_t normalize_value(int v, int vmin, int vmax) {
     const double smin = vmin, smax = vmax;
     const double scale = 255. * (smax - smin > 2.220446049250313e-16 ? 1. / (smax - smin) : 0.);
     const double shift = 0. - smin * scale;
@@ -280,8 +278,6 @@ __global__ __launch_bounds__(256) void clahe_apply_fast_kernel(FrameBatch in, Cl
         *reinterpret_cast<uint4*>(dst + (long long)y * in.width + x0) = make_uint4(o[0], o[1], o[2], o[3]);
     }
 }
-
-}  // namespace
 
 size_t clahe_scratch_bytes(int nframes) {
     // extrema (2 ints) + 64 histograms + 64 LUTs per frame

@@ -1,0 +1,35 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence behind bench.py's roofline numbers.  Runs ON the GPU box:
+#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r01'
+# Writes under gpurun_out/<tag>/ (scratch, merged back by gpurun); tools/make_profiles.py turns that
+# into the committed summaries under profiles/.  PMC passes are their own runs (no trace domains).
+set -u
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $R/bench.py --steps 10 --warmup 3"
+PMCB="python $R/bench.py --distinct 4 --steps 3 --warmup 1 --no-cpu-baseline"
+# 1. the bench line itself
+timeout 600 $BENCH > $OUT/bench.json 2> $OUT/bench.err
+# 2. kernel trace of the same command (no CPU baseline: it only adds host time)
+timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- $BENCH --no-cpu-baseline > $OUT/trace_bench.json 2> $OUT/trace.err
+# 3. EA (fabric) traffic: read requests by size, write requests, and the derived KiB counters
+timeout 900 rocprofv3 --pmc TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_128B --kernel-trace --output-format csv -d $OUT/pmc_rd -o p -- $PMCB > $OUT/pmc_rd.json 2> $OUT/pmc_rd.err
+timeout 900 rocprofv3 --pmc TCC_EA0_WRREQ TCC_EA0_WRREQ_64B --kernel-trace --output-format csv -d $OUT/pmc_wr -o p -- $PMCB > $OUT/pmc_wr.json 2> $OUT/pmc_wr.err
+timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o p -- $PMCB > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
+timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o p -- $PMCB > $OUT/pmc_write.json 2> $OUT/pmc_write.err
+# 4. issue / wait / LDS counters of the level-0 response kernel alone
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_sq1 -o p -- python $R/tools/chess_l0_alone.py > /dev/null 2> $OUT/pmc_sq1.err
+timeout 600 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2 -o p -- python $R/tools/chess_l0_alone.py > /dev/null 2> $OUT/pmc_sq2.err
+# 5. preprocessing kernels (row (f)-2)
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/pre -o t -- python $R/tools/preprocess_bench.py > $OUT/prebench.txt 2> $OUT/pre.err
+# summaries on the box (the raw rocprofv3 output is too big to travel back), then drop the raw files
+python $R/tools/rocprof_summary.py $OUT/trace/t_results.db > $OUT/bench_kernel_trace.txt 2>> $OUT/trace.err
+python $R/tools/rocprof_summary.py $OUT/pre/t_results.db > $OUT/preprocess_kernel_trace.txt 2>> $OUT/pre.err
+for d in pmc_rd pmc_wr pmc_fetch pmc_write pmc_sq1 pmc_sq2; do
+    python $R/tools/pmc_summary.py $OUT/$d/p_counter_collection.csv > $OUT/$d.txt 2>> $OUT/$d.err
+done
+rm -rf $OUT/trace $OUT/pre $OUT/pmc_rd $OUT/pmc_wr $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq1 $OUT/pmc_sq2
+ls -la $OUT

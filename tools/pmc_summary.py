@@ -20,7 +20,7 @@ def main(paths):
             name = row["Kernel_Name"]
             if "mrg::" not in name:
                 continue
-            short = name.split("(")[0].replace("void ", "") + f"  grid={row['Grid_Size']} wg={row['Workgroup_Size']}"
+            short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "") + f"  grid={row['Grid_Size']} wg={row['Workgroup_Size']}"
             acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k, ctrs in acc.items():
         print(k)

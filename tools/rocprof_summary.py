@@ -21,7 +21,7 @@ def main(path):
             other[0] += 1
             other[1] += dur
             continue
-        short = name.split("(")[0].replace("void ", "")
+        short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         groups.setdefault((short, gx, gy, gz, wx, vg, sg, lds), []).append(dur)
     print(f"# {path}")
     print(f"# {'kernel':58s} {'grid(threads)':>22s} {'wg':>5s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} "
