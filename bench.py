@@ -131,9 +131,10 @@ def main():
     # results may still be in use.  A buffer is reused three steps later, and only after the gather
     # that read it has completed (event recorded behind the gather, host-waited before reuse).
     NBUF = 3
-    outs = [(torch.empty((batch, P, 2), dtype=torch.float64, device=dev),
-             torch.empty((batch, P), dtype=torch.int8, device=dev),
-             torch.empty((batch,), dtype=torch.int32, device=dev)) for _ in range(NBUF)]
+    packs = [parallel.packed_outputs(batch, P, dev) for _ in range(NBUF)]   # (pack, points, levels, npoints)
+    outs = [p[1:] for p in packs]
+    gathered = [torch.empty((world, packs[0][0].numel()), dtype=torch.uint8, device=dev) if (world > 1 and rank == 0)
+                else None for _ in range(NBUF)]
     consumed = [None] * NBUF
     torch.cuda.synchronize()
     nstep = [0]
@@ -146,7 +147,7 @@ def main():
         pts, lv, npts = det.chain(frames, start_level=start_level, max_points=P, out=outs[k], sync=False)
         if world > 1:
             det.stream_wait()                                # torch's stream waits for this step on the device
-            parallel.gather_corner_lists(pts, lv, npts, dst=0)
+            parallel.gather_packed(packs[k][0], dst=0, out=gathered[k])    # the ONE collective of the path
             consumed[k] = torch.cuda.Event()
             consumed[k].record()
         return npts

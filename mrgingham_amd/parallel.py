@@ -39,6 +39,48 @@ def gather_corner_lists(points, levels, npoints, dst=0, group=None):
     return tuple(outs) if rank == dst else None
 
 
+def packed_outputs(nframes, max_points, device):
+    """One byte buffer per step that holds all three outputs of `Detector.chain`, so that the
+    gather below is a single collective: -> (pack uint8 [nbytes], points f64 [B,P,2] view,
+    levels int8 [B,P] view, npoints int32 [B] view)."""
+    B, P = int(nframes), int(max_points)
+    o_lv = B * P * 16
+    o_np = (o_lv + B * P + 7) // 8 * 8
+    pack = torch.zeros(o_np + 4 * B, dtype=torch.uint8, device=device)
+    points = pack[:o_lv].view(torch.float64).view(B, P, 2)
+    levels = pack[o_lv:o_lv + B * P].view(torch.int8).view(B, P)
+    npoints = pack[o_np:o_np + 4 * B].view(torch.int32)
+    return pack, points, levels, npoints
+
+
+def unpack_outputs(pack, nframes, max_points):
+    """Views into a buffer (or a [world, nbytes] stack of buffers) laid out by packed_outputs."""
+    B, P = int(nframes), int(max_points)
+    o_lv = B * P * 16
+    o_np = (o_lv + B * P + 7) // 8 * 8
+    lead = pack.shape[:-1]
+    points = pack[..., :o_lv].contiguous().view(torch.float64).view(*lead, B, P, 2)
+    levels = pack[..., o_lv:o_lv + B * P].contiguous().view(torch.int8).view(*lead, B, P)
+    npoints = pack[..., o_np:o_np + 4 * B].contiguous().view(torch.int32).view(*lead, B)
+    return points, levels, npoints
+
+
+def gather_packed(pack, dst=0, group=None, out=None):
+    """THE collective of the path: one gather of every rank's packed corner lists to `dst`
+    (-> uint8 [world, nbytes] there, None elsewhere).  `out` may be a preallocated [world, nbytes]
+    buffer on `dst`."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return pack.unsqueeze(0)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    bufs = None
+    if rank == dst:
+        if out is None:
+            out = torch.empty((world, pack.numel()), dtype=torch.uint8, device=pack.device)
+        bufs = list(out.unbind(0))
+    dist.gather(pack, bufs, dst=dst, group=group)
+    return out if rank == dst else None
+
+
 # ---------------------------------------------------------------------------
 # Mixed-resolution streams (BASELINE config 5)
 # ---------------------------------------------------------------------------

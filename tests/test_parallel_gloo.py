@@ -32,6 +32,24 @@ def _worker(rank, world, port, ret):
         ret.put(ok)
     else:
         assert out is None
+    # the packed form bench.py uses: every output of a step lives in one byte buffer, one gather
+    pack, ppts, plv, pnp = parallel.packed_outputs(B, P, "cpu")
+    ppts.copy_(pts)
+    plv.copy_(lv)
+    pnp.copy_(npts)
+    pre = torch.empty((world, pack.numel()), dtype=torch.uint8) if rank == 0 else None
+    got = parallel.gather_packed(pack, dst=0, out=pre)
+    if rank == 0:
+        assert got is pre
+        gp, gl, gn = parallel.unpack_outputs(got, B, P)
+        ok2 = gp.shape == (world, B, P, 2) and gl.shape == (world, B, P) and gn.shape == (world, B)
+        for r in range(world):
+            ok2 &= bool(torch.equal(gp[r], torch.arange(B * P * 2, dtype=torch.float64).reshape(B, P, 2) + 1000 * r))
+            ok2 &= bool(torch.equal(gl[r], (torch.arange(B * P, dtype=torch.int64).reshape(B, P) % 4).to(torch.int8) - r))
+            ok2 &= gn[r].tolist() == [r + 1, r + 2, r + 3]
+        ret.put(ok2)
+    else:
+        assert got is None
     dist.barrier()
     dist.destroy_process_group()
 
@@ -54,7 +72,7 @@ def test_gather_corner_lists_world2_gloo():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
     for p in procs:
         p.start()
-    ok = ret.get(timeout=120)
+    ok = ret.get(timeout=120) and ret.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
