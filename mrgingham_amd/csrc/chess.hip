@@ -452,8 +452,9 @@ __global__ __launch_bounds__(256) void chess_v1_kernel(LevelBatch lb, CompTables
         if (yy < ye && x0 < w) {
             int16_t* dst = resp + (long long)yy * w + x0;
             if (x0 + 8 <= w) {
-                const uint4 v = make_uint4(out[0], out[1], out[2], out[3]);
-                __builtin_memcpy(dst, &v, 16);
+                // streamed out: the dense response is only ever re-read around the few hot pixels
+                const u32x4 v = {out[0], out[1], out[2], out[3]};
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst));
             } else {
                 for (int i = 0; i < w - x0; ++i) dst[i] = (int16_t)(out[i >> 1] >> (16 * (i & 1)));
             }
