@@ -21,6 +21,7 @@
 namespace mrg {
 
 constexpr int kTiles = 8, kBins = 256;
+using u32x4n = uint32_t __attribute__((ext_vector_type(4)));  // for non-temporal 16-byte accesses
 
 static __device__ __forceinline__ int reflect101_pp(int i, int n) {
     if (n == 1) return 0;
@@ -99,7 +100,8 @@ __global__ __launch_bounds__(256) void clahe_hist_kernel(FrameBatch in, ClaheGeo
         for (int y = y0 + wv; y < y1; y += 4) {
             const uint4* row = reinterpret_cast<const uint4*>(src + (long long)y * in.stride + x0);
             for (int c = lane; c < chunks; c += 64) {
-                const uint4 v = row[c];
+                const u32x4n vv = __builtin_nontemporal_load(reinterpret_cast<const u32x4n*>(row + c));
+                const uint4 v = make_uint4(vv.x, vv.y, vv.z, vv.w);
                 const uint32_t q[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -261,7 +263,8 @@ __global__ __launch_bounds__(256) void clahe_apply_fast_kernel(FrameBatch in, Cl
         const int ty1 = (int)__builtin_floorf(tyf);
         const float ya = __fsub_rn(tyf, (float)ty1), ya1 = __fsub_rn(1.0f, ya);
         const uint32_t* qrow = &quad[(ty1 - cy0) * 2][0];
-        const uint4 gv = *reinterpret_cast<const uint4*>(src + (long long)y * in.stride + x0);
+        const u32x4n gvv = __builtin_nontemporal_load(reinterpret_cast<const u32x4n*>(src + (long long)y * in.stride + x0));
+        const uint4 gv = make_uint4(gvv.x, gvv.y, gvv.z, gvv.w);
         const uint32_t gq[4] = {gv.x, gv.y, gv.z, gv.w};
         uint32_t o[4] = {0, 0, 0, 0};
 #pragma unroll
