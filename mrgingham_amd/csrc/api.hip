@@ -38,11 +38,17 @@ struct LevelScratch {
 
 struct mrgingham_amd_ctx {
     int device = 0;
-    // Two HIP streams per context: `pix` runs the HBM-bound pixel kernels
-    // (pyramid, ChESS) back to back, each over the whole batch; `cc` runs the
-    // latency-bound component kernels, which only occupy one workgroup per frame,
-    // underneath them.  Events order cc(L) after pix(L).
-    hipStream_t pix = nullptr, cc = nullptr;
+    // HIP streams of a context: `pix` runs the pixel kernels (pyramid, ChESS) back to back, each
+    // over the whole batch; `ccs[set]` run the latency-bound component kernels (a serial chain
+    // detect -> refine -> refine ... per call) underneath them, one stream per scratch set so that
+    // the chains of consecutive calls overlap each other as well.  Events order cc(L) after pix(L).
+    hipStream_t pix = nullptr;
+    hipStream_t ccs[2] = {nullptr, nullptr};
+    // Device buffers the last call of each set wrote / read (caller-owned outputs and inputs):
+    // consecutive calls run on different component streams, so a call that touches a buffer the
+    // previous call wrote (or writes one it read) must wait for it explicitly.
+    struct Span { const char* p; size_t n; };
+    std::vector<Span> last_w[2], last_r[2];
     hipEvent_t ev_pix[mrg::kMaxLevel + 1] = {};
     // Level scratch exists twice: call N+1 fills set (N+1)%2 on the pixel stream while the
     // component stream still works through call N in the other set.
@@ -56,7 +62,8 @@ struct mrgingham_amd_ctx {
     mrg::LevelScratch lvs[2][mrg::kMaxLevel + 1];
     mrg::DevBuf counters2[2];  // per scratch set: hot_cnt words [level][counters_nf], then status words [level][counters_nf]
     int counters_nf = 0;
-    mrg::DevBuf leader, need, nseeds, seeds, sroot, cand_xy, cand_counts, aux_img, io_frame, io_out;
+    struct PointScratch { mrg::DevBuf leader, need, nseeds, seeds, sroot, cand_xy, cand_counts; } pts[2];  // per scratch set
+    mrg::DevBuf aux_img, io_frame, io_out, io_counts;
     mrg::DevBuf pre_scratch, pre_tmp, pre_out;  // preprocessing: extrema + tile histograms + LUTs, CLAHE output before the blur
     int pts_nframes = 0, pts_pitch = 0;
     // levels (and frame counts) whose status words must be checked at the next sync
@@ -180,21 +187,23 @@ static int ensure_level(mrgingham_amd_ctx* ctx, int level, int nframes, int W, i
     return rc ? rc : ensure_level_set(ctx, 1, level, nframes, W, H, pitch);
 }
 
-// Per-batch point scratch shared by the levels (the component kernels of the
-// levels of one batch run one after the other on the cc stream).
+// Per-call point scratch shared by the levels (the component kernels of the levels of one call
+// run one after the other on that call's component stream); one copy per scratch set.
 static int ensure_points(mrgingham_amd_ctx* ctx, int nframes, int pitch) {
     if (nframes <= ctx->pts_nframes && pitch <= ctx->pts_pitch) return 0;
     nframes = nframes > ctx->pts_nframes ? nframes : ctx->pts_nframes;
     pitch = pitch > ctx->pts_pitch ? pitch : ctx->pts_pitch;
     const size_t np = (size_t)nframes * (size_t)(pitch > 0 ? pitch : 1);
     int rc = 0;
-    if ((rc = ensure(ctx, ctx->leader, np * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->need, np * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->nseeds, np * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->seeds, np * 9 * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->sroot, np * 9 * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->cand_xy, np * 8))) return rc;
-    if ((rc = ensure(ctx, ctx->cand_counts, (size_t)nframes * 4))) return rc;
+    for (auto& ps : ctx->pts) {
+        if ((rc = ensure(ctx, ps.leader, np * 4))) return rc;
+        if ((rc = ensure(ctx, ps.need, np * 4))) return rc;
+        if ((rc = ensure(ctx, ps.nseeds, np * 4))) return rc;
+        if ((rc = ensure(ctx, ps.seeds, np * 9 * 4))) return rc;
+        if ((rc = ensure(ctx, ps.sroot, np * 9 * 4))) return rc;
+        if ((rc = ensure(ctx, ps.cand_xy, np * 8))) return rc;
+        if ((rc = ensure(ctx, ps.cand_counts, (size_t)nframes * 4))) return rc;
+    }
     ctx->pts_nframes = nframes;
     ctx->pts_pitch = pitch;
     return 0;
@@ -264,8 +273,31 @@ static void begin_op(mrgingham_amd_ctx* ctx, int max_level) {
     hipMemsetAsync(ctx->counters2[ctx->cur].p, 0, (size_t)(max_level + 1) * ctx->counters_nf * sizeof(int32_t),
                    ctx->pix);
 }
+static hipStream_t cur_cc(mrgingham_amd_ctx* ctx) { return ctx->ccs[ctx->cur]; }
+// Registers the caller-owned device buffers this call writes (w) and reads (r) and makes its
+// component stream wait for the previous call (which runs on the OTHER component stream) when
+// they overlap anything that call wrote or read-then-we-write.  Call after begin_op.
+static void order_after_previous(mrgingham_amd_ctx* ctx, std::initializer_list<mrgingham_amd_ctx::Span> w,
+                                 std::initializer_list<mrgingham_amd_ctx::Span> r) {
+    const int cur = ctx->cur, prev = cur ^ 1;
+    auto overlaps = [](const mrgingham_amd_ctx::Span& a, const mrgingham_amd_ctx::Span& b) {
+        return a.p && b.p && a.n && b.n && a.p < b.p + b.n && b.p < a.p + a.n;
+    };
+    bool dep = false;
+    if (ctx->cc_pending[prev]) {
+        for (const auto& pw : ctx->last_w[prev]) {
+            for (const auto& x : w) dep |= overlaps(x, pw);
+            for (const auto& x : r) dep |= overlaps(x, pw);
+        }
+        for (const auto& pr : ctx->last_r[prev])
+            for (const auto& x : w) dep |= overlaps(x, pr);
+    }
+    if (dep) hipStreamWaitEvent(ctx->ccs[cur], ctx->ev_cc_done[prev], 0);
+    ctx->last_w[cur].assign(w.begin(), w.end());
+    ctx->last_r[cur].assign(r.begin(), r.end());
+}
 static void end_op(mrgingham_amd_ctx* ctx) {
-    hipEventRecord(ctx->ev_cc_done[ctx->cur], ctx->cc);
+    hipEventRecord(ctx->ev_cc_done[ctx->cur], cur_cc(ctx));
     ctx->cc_pending[ctx->cur] = true;
 }
 
@@ -348,7 +380,8 @@ mrgingham_amd_ctx* mrgingham_amd_create(int device_ordinal) {
     int prio_lo = 0, prio_hi = 0;  // the component stream gets the highest dispatch priority
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     bool ok = hipStreamCreateWithPriority(&ctx->pix, hipStreamNonBlocking, prio_lo) == hipSuccess &&
-              hipStreamCreateWithPriority(&ctx->cc, hipStreamNonBlocking, prio_hi) == hipSuccess &&
+              hipStreamCreateWithPriority(&ctx->ccs[0], hipStreamNonBlocking, prio_hi) == hipSuccess &&
+              hipStreamCreateWithPriority(&ctx->ccs[1], hipStreamNonBlocking, prio_hi) == hipSuccess &&
               hipEventCreateWithFlags(&ctx->ev_cc_done[0], hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&ctx->ev_cc_done[1], hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i <= kMaxLevel; ++i)
@@ -372,8 +405,10 @@ void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx) {
         for (DevBuf* b : bufs)
             if (b->p) hipFree(b->p);
     }
-    DevBuf* bufs[] = {&ctx->counters2[0], &ctx->counters2[1], &ctx->leader, &ctx->need, &ctx->nseeds, &ctx->seeds, &ctx->sroot, &ctx->cand_xy, &ctx->cand_counts,
-                      &ctx->aux_img, &ctx->io_frame, &ctx->io_out, &ctx->pre_scratch, &ctx->pre_tmp, &ctx->pre_out};
+    for (auto& ps : ctx->pts)
+        for (DevBuf* b : {&ps.leader, &ps.need, &ps.nseeds, &ps.seeds, &ps.sroot, &ps.cand_xy, &ps.cand_counts})
+            if (b->p) hipFree(b->p);
+    DevBuf* bufs[] = {&ctx->counters2[0], &ctx->counters2[1], &ctx->io_counts, &ctx->aux_img, &ctx->io_frame, &ctx->io_out, &ctx->pre_scratch, &ctx->pre_tmp, &ctx->pre_out};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     for (auto& pr : ctx->events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
@@ -383,7 +418,8 @@ void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx) {
     for (hipEvent_t e : ctx->ev_cc_done)
         if (e) hipEventDestroy(e);
     if (ctx->pix) hipStreamDestroy(ctx->pix);
-    if (ctx->cc) hipStreamDestroy(ctx->cc);
+    for (hipStream_t c : ctx->ccs)
+        if (c) hipStreamDestroy(c);
     delete ctx;
 }
 
@@ -427,7 +463,8 @@ int mrgingham_amd_sync(mrgingham_amd_ctx* ctx) {
     if (!ctx) return MRGINGHAM_AMD_ERR_ARG;
     MRG_HIP_CHECK(hipSetDevice(ctx->device));
     MRG_HIP_CHECK(hipStreamSynchronize(ctx->pix));
-    MRG_HIP_CHECK(hipStreamSynchronize(ctx->cc));
+    MRG_HIP_CHECK(hipStreamSynchronize(ctx->ccs[0]));
+    MRG_HIP_CHECK(hipStreamSynchronize(ctx->ccs[1]));
     ctx->cc_pending[0] = ctx->cc_pending[1] = false;
     MRG_HIP_CHECK(hipGetLastError());
     int rc = MRGINGHAM_AMD_OK;
@@ -457,8 +494,8 @@ int mrgingham_amd_sync(mrgingham_amd_ctx* ctx) {
 int mrgingham_amd_stream_wait(mrgingham_amd_ctx* ctx, void* stream) {
     if (!ctx) return MRGINGHAM_AMD_ERR_ARG;
     MRG_HIP_CHECK(hipSetDevice(ctx->device));
-    if (ctx->cc_pending[ctx->cur])
-        MRG_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, ctx->ev_cc_done[ctx->cur], 0));
+    for (int set = 0; set < 2; ++set)  // consecutive calls finish on different component streams
+        if (ctx->cc_pending[set]) MRG_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, ctx->ev_cc_done[set], 0));
     return MRGINGHAM_AMD_OK;
 }
 
@@ -592,9 +629,11 @@ int mrgingham_amd_detect_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frame
                         ctx->pix);
     }
     const LevelBatch lb = queue_level_chess(ctx, fr, level);
-    MRG_HIP_CHECK(hipStreamWaitEvent(ctx->cc, ctx->ev_pix[level], 0));
+    order_after_previous(ctx, {{(const char*)d_xy, (size_t)fr->nframes * capacity_per_frame * 8},
+                               {(const char*)d_counts, (size_t)fr->nframes * 4}}, {});
+    MRG_HIP_CHECK(hipStreamWaitEvent(cur_cc(ctx), ctx->ev_pix[level], 0));
     launch_cc_detect(lb, tables_of(ctx, level), level, DetectOut{d_xy, capacity_per_frame, d_counts}, 0,
-                     fr->nframes, ctx->cc);
+                     fr->nframes, cur_cc(ctx));
     end_op(ctx);
     MRG_HIP_CHECK(hipGetLastError());
     return 0;
@@ -621,10 +660,15 @@ int mrgingham_amd_refine_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frame
                         ctx->pix);
     }
     const LevelBatch lb = queue_level_chess(ctx, fr, level);
-    RefineIO io{d_points, d_levels, d_npoints, points_pitch, d_nrefined, (int32_t*)ctx->leader.p,
-                (int32_t*)ctx->need.p, (int32_t*)ctx->nseeds.p, (uint32_t*)ctx->seeds.p, (int32_t*)ctx->sroot.p};
-    MRG_HIP_CHECK(hipStreamWaitEvent(ctx->cc, ctx->ev_pix[level], 0));
-    launch_cc_refine(lb, tables_of(ctx, level), level, io, 0, fr->nframes, ctx->cc);
+    auto& ps = ctx->pts[ctx->cur];
+    RefineIO io{d_points, d_levels, d_npoints, points_pitch, d_nrefined, (int32_t*)ps.leader.p,
+                (int32_t*)ps.need.p, (int32_t*)ps.nseeds.p, (uint32_t*)ps.seeds.p, (int32_t*)ps.sroot.p};
+    const size_t np = (size_t)fr->nframes * points_pitch;
+    order_after_previous(ctx, {{(const char*)d_points, np * 16}, {(const char*)d_levels, np},
+                               {(const char*)d_nrefined, d_nrefined ? (size_t)fr->nframes * 4 : 0}},
+                         {{(const char*)d_npoints, (size_t)fr->nframes * 4}});
+    MRG_HIP_CHECK(hipStreamWaitEvent(cur_cc(ctx), ctx->ev_pix[level], 0));
+    launch_cc_refine(lb, tables_of(ctx, level), level, io, 0, fr->nframes, cur_cc(ctx));
     end_op(ctx);
     MRG_HIP_CHECK(hipGetLastError());
     return 0;
@@ -644,25 +688,31 @@ int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames
     for (int L = 0; L <= start_level; ++L)
         if ((rc = ensure_level(ctx, L, fr->nframes, fr->width, fr->height, points_pitch))) return rc;
     if ((rc = ensure_points(ctx, fr->nframes, points_pitch))) return rc;
-    DetectOut out{(int32_t*)ctx->cand_xy.p, points_pitch, (int32_t*)ctx->cand_counts.p};
+    begin_op(ctx, start_level);
+    auto& ps = ctx->pts[ctx->cur];
+    DetectOut out{(int32_t*)ps.cand_xy.p, points_pitch, (int32_t*)ps.cand_counts.p};
     out.points = d_points;
     out.levels = d_levels;
     out.npoints = d_npoints;
     out.points_pitch = points_pitch;
-    RefineIO io{d_points, d_levels, d_npoints, points_pitch, nullptr, (int32_t*)ctx->leader.p,
-                (int32_t*)ctx->need.p, (int32_t*)ctx->nseeds.p, (uint32_t*)ctx->seeds.p, (int32_t*)ctx->sroot.p};
-    begin_op(ctx, start_level);
+    RefineIO io{d_points, d_levels, d_npoints, points_pitch, nullptr, (int32_t*)ps.leader.p,
+                (int32_t*)ps.need.p, (int32_t*)ps.nseeds.p, (uint32_t*)ps.seeds.p, (int32_t*)ps.sroot.p};
+    {
+        const size_t np = (size_t)fr->nframes * points_pitch;
+        order_after_previous(ctx, {{(const char*)d_points, np * 16}, {(const char*)d_levels, np},
+                                   {(const char*)d_npoints, (size_t)fr->nframes * 4}}, {});
+    }
     // pixel stream: every level image in one pass over the frames, then the responses top-down
     queue_level_images(ctx, fr, start_level);
     LevelBatch lbs[kMaxLevel + 1];
     for (int L = start_level; L >= 0; --L) lbs[L] = queue_level_chess(ctx, fr, L);
     // component stream: detect at the top (mrgingham.cc:50), candidates -> corners
     // (find_grid.cc:353-354), then refine level by level (mrgingham.cc:87-99)
-    MRG_HIP_CHECK(hipStreamWaitEvent(ctx->cc, ctx->ev_pix[start_level], 0));
-    launch_cc_detect(lbs[start_level], tables_of(ctx, start_level), start_level, out, 0, fr->nframes, ctx->cc);
+    MRG_HIP_CHECK(hipStreamWaitEvent(cur_cc(ctx), ctx->ev_pix[start_level], 0));
+    launch_cc_detect(lbs[start_level], tables_of(ctx, start_level), start_level, out, 0, fr->nframes, cur_cc(ctx));
     for (int L = start_level - 1; L >= 0; --L) {
-        MRG_HIP_CHECK(hipStreamWaitEvent(ctx->cc, ctx->ev_pix[L], 0));
-        launch_cc_refine(lbs[L], tables_of(ctx, L), L, io, 0, fr->nframes, ctx->cc);
+        MRG_HIP_CHECK(hipStreamWaitEvent(cur_cc(ctx), ctx->ev_pix[L], 0));
+        launch_cc_refine(lbs[L], tables_of(ctx, L), L, io, 0, fr->nframes, cur_cc(ctx));
     }
     end_op(ctx);
     MRG_HIP_CHECK(hipGetLastError());
@@ -765,9 +815,9 @@ bool find_chessboard_corners_from_image_array_C(int Nrows, int Ncols, int stride
         if (ensure_level(ctx, image_pyramid_level, 1, Ncols, Nrows, 0)) break;
         if (ensure_points(ctx, 1, 1)) break;
         const int cap = ctx->lvs[0][image_pyramid_level].cand_cap;
-        if (ensure(ctx, ctx->io_out, (size_t)cap * 8 + 64)) break;
+        if (ensure(ctx, ctx->io_out, (size_t)cap * 8 + 64) || ensure(ctx, ctx->io_counts, 64)) break;
         if (mrgingham_amd_detect_batch(ctx, &fr, image_pyramid_level, (int32_t*)ctx->io_out.p, cap,
-                                       (int32_t*)ctx->cand_counts.p))
+                                       (int32_t*)ctx->io_counts.p))
             break;
         const int rc = mrgingham_amd_sync(ctx);
         if (rc == MRGINGHAM_AMD_ERR_CAPACITY && attempt == 0) {
@@ -775,7 +825,7 @@ bool find_chessboard_corners_from_image_array_C(int Nrows, int Ncols, int stride
             continue;
         }
         if (rc) break;
-        if (hipMemcpy(&count, ctx->cand_counts.p, sizeof(count), hipMemcpyDeviceToHost) != hipSuccess) break;
+        if (hipMemcpy(&count, ctx->io_counts.p, sizeof(count), hipMemcpyDeviceToHost) != hipSuccess) break;
         if (count > 0) {
             xy.resize((size_t)count * 2);
             if (hipMemcpy(xy.data(), ctx->io_out.p, (size_t)count * 8, hipMemcpyDeviceToHost) != hipSuccess) break;
@@ -871,13 +921,13 @@ static int find_board_on_device(mrgingham_amd_ctx* ctx, const char* who, const m
         for (int attempt = 0; attempt < 2 && !ok; ++attempt) {
             if (ensure_level(ctx, level, 1, Ncols, Nrows, N) || ensure_points(ctx, 1, N)) break;
             const int cap = ctx->lvs[0][level].cand_cap;
-            if (ensure(ctx, ctx->io_out, (size_t)cap * 8 + (size_t)N * 17 + 256)) break;
-            if (mrgingham_amd_detect_batch(ctx, fr, level, (int32_t*)ctx->io_out.p, cap, (int32_t*)ctx->cand_counts.p))
+            if (ensure(ctx, ctx->io_out, (size_t)cap * 8 + (size_t)N * 17 + 256) || ensure(ctx, ctx->io_counts, 64)) break;
+            if (mrgingham_amd_detect_batch(ctx, fr, level, (int32_t*)ctx->io_out.p, cap, (int32_t*)ctx->io_counts.p))
                 break;
             const int rc = mrgingham_amd_sync(ctx);
             if (rc == MRGINGHAM_AMD_ERR_CAPACITY && attempt == 0) { ctx->cap_shift = 0; continue; }
             if (rc) break;
-            if (hipMemcpy(&count, ctx->cand_counts.p, sizeof(count), hipMemcpyDeviceToHost) != hipSuccess) break;
+            if (hipMemcpy(&count, ctx->io_counts.p, sizeof(count), hipMemcpyDeviceToHost) != hipSuccess) break;
             xy.resize((size_t)(count > 0 ? count : 0) * 2);
             if (count > 0 && hipMemcpy(xy.data(), ctx->io_out.p, (size_t)count * 8, hipMemcpyDeviceToHost) != hipSuccess)
                 break;

@@ -313,3 +313,29 @@ def test_full_size_frames_bit_exact_and_properties(det):
         assert n == len(wp) and np.array_equal(pts[f, :n].cpu().numpy(), wp) and np.array_equal(lv[f, :n].cpu().numpy(), wl)
         assert torch.equal(again[0][f, :n], pts[f, :n])                  # deterministic re-run
         assert int((lv[f, :n] == 0).sum()) >= 100                        # the 10x10 grid reaches level 0
+
+
+def test_dependent_calls_without_sync_are_ordered(det):
+    """Consecutive calls finish on different component streams; a call that reads or overwrites a
+    device buffer the previous call wrote must still run after it (no host sync in between)."""
+    imgs = [synth.board_frame(1280, 960, 10, s).numpy() for s in range(4)]
+    frames = _cuda(np.stack(imgs))
+    # reference: the library's own chain (detect at level 2, refine 1, 0)
+    rp, rl, rn = [t.clone() for t in det.chain(frames, 2, 256)]
+    # the same thing as three dependent calls on shared buffers, queued back to back
+    xy, counts = det.detect(frames, 2, capacity=256, sync=True)
+    pts = (xy.to(torch.float64) / 1000.0).contiguous()
+    lv = torch.full((4, 256), 2, dtype=torch.int8, device="cuda")
+    npts = counts.clone()
+    for rep in range(3):                                    # repeated: a race would not show every time
+        p, l = pts.clone(), lv.clone()
+        torch.cuda.synchronize()
+        det.refine(frames, 1, p, l, npts, sync=False)
+        det.refine(frames, 0, p, l, npts, sync=False)       # reads what the call before wrote
+        out2 = det.chain(frames, 2, 256, out=(p.clone(), l.clone(), npts.clone()), sync=False)  # unrelated buffers
+        det.sync()
+        for f in range(4):
+            k = int(rn[f])
+            assert int(npts[f]) == k
+            assert torch.equal(p[f, :k], rp[f, :k]) and torch.equal(l[f, :k], rl[f, :k]), (rep, f)
+            assert torch.equal(out2[0][f, :k], rp[f, :k])
