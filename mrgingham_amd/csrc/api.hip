@@ -438,6 +438,7 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
         return 0;
     }
     if (!strcmp(name, "chess_v0")) { ctx->use_v0 = value != 0; return 0; }
+    if (!strcmp(name, "chess_seg")) { mrg::chess_seg_override = value > 0 ? value : 0; return 0; }
     return MRGINGHAM_AMD_ERR_ARG;
 }
 

@@ -113,15 +113,18 @@ __device__ __forceinline__ FrameView make_view(const LevelBatch& lb, const CompT
 // workgroup was the longest phase of the component search.
 constexpr int CCL_THREADS = 256;
 constexpr int kSingletonFlag = 0x40000000;  // in hot_pix[]: the pixel has no hot 4-neighbour
-constexpr int CCL_BLOCKS_PER_FRAME = 16;
+// Workgroups per frame of the two labelling kernels.  They run underneath the pixel kernels of the
+// next call, and every resident labelling workgroup slows those down: 4 per frame instead of 16
+// costs nothing on the component chain (it is not the critical path) and gives 3 % on the chain rate.
+constexpr int CCL_BLOCKS_PER_FRAME = 4;
 
 // P1: union-find over the hot list (left / up neighbours).
-__global__ __launch_bounds__(CCL_THREADS) void cc_union_kernel(LevelBatch lb, CompTables t, int frame0) {
+__global__ __launch_bounds__(CCL_THREADS) void cc_union_kernel(LevelBatch lb, CompTables t, int frame0, int bpf) {
     const int frame = frame0 + blockIdx.y;
     if (t.hot_cnt[frame] > t.cap) return;  // overflow is reported by the per-frame kernel
     const FrameView v = make_view(lb, t, frame);
     const int w = v.w;
-    for (int i = blockIdx.x * CCL_THREADS + threadIdx.x; i < v.n; i += CCL_BLOCKS_PER_FRAME * CCL_THREADS) {
+    for (int i = blockIdx.x * CCL_THREADS + threadIdx.x; i < v.n; i += bpf * CCL_THREADS) {
         const int p = v.hot_pix[i];
         // all four neighbours lie inside the image (p is in [7,w-7) x [7,h-7)); the frame is zero
         const bool l = v.d[p - 1] > kRespMin, u = v.d[p - w] > kRespMin;
@@ -135,12 +138,12 @@ __global__ __launch_bounds__(CCL_THREADS) void cc_union_kernel(LevelBatch lb, Co
 }
 
 // P2: flatten (parent[i] = root of i); per-root pixel count and bounding box.
-__global__ __launch_bounds__(CCL_THREADS) void cc_flatten_kernel(LevelBatch lb, CompTables t, int frame0) {
+__global__ __launch_bounds__(CCL_THREADS) void cc_flatten_kernel(LevelBatch lb, CompTables t, int frame0, int bpf) {
     const int frame = frame0 + blockIdx.y;
     if (t.hot_cnt[frame] > t.cap) return;
     const FrameView v = make_view(lb, t, frame);
     const int w = v.w;
-    for (int i = blockIdx.x * CCL_THREADS + threadIdx.x; i < v.n; i += CCL_BLOCKS_PER_FRAME * CCL_THREADS) {
+    for (int i = blockIdx.x * CCL_THREADS + threadIdx.x; i < v.n; i += bpf * CCL_THREADS) {
         const int p = v.hot_pix[i];
         if (p & kSingletonFlag) continue;  // its own root, count 0: never a blob, never shared
         const int r = uf_root(v.parent, i);
@@ -159,9 +162,10 @@ __global__ __launch_bounds__(CCL_THREADS) void cc_flatten_kernel(LevelBatch lb, 
 
 void launch_cc_label(const LevelBatch& lb, const CompTables& t, int frame0, int nframes, hipStream_t s) {
     if (nframes <= 0) return;
-    const dim3 grid(CCL_BLOCKS_PER_FRAME, nframes);
-    hipLaunchKernelGGL(cc_union_kernel, grid, dim3(CCL_THREADS), 0, s, lb, t, frame0);
-    hipLaunchKernelGGL(cc_flatten_kernel, grid, dim3(CCL_THREADS), 0, s, lb, t, frame0);
+    const int bpf = CCL_BLOCKS_PER_FRAME;
+    const dim3 grid(bpf, nframes);
+    hipLaunchKernelGGL(cc_union_kernel, grid, dim3(CCL_THREADS), 0, s, lb, t, frame0, bpf);
+    hipLaunchKernelGGL(cc_flatten_kernel, grid, dim3(CCL_THREADS), 0, s, lb, t, frame0, bpf);
 }
 
 struct Blob {

@@ -478,7 +478,10 @@ __global__ __launch_bounds__(256) void chess_v1_kernel(LevelBatch lb, CompTables
     }
 }
 
+int chess_seg_override = 0;  // tuning hook (mrgingham_amd_set_option "chess_seg"): 0 = automatic
+
 static int pick_segment(int w, int h, int nframes) {
+    if (chess_seg_override > 0) return (chess_seg_override + 7) / 8 * 8;
     // tall segments amortise the 10-row halo; short ones fill the 256 CUs when the batch is small
     const long long strips = (w + V1_SW - 1) / V1_SW;
     for (int seg : {256, 128, 64, 32}) {
