@@ -31,6 +31,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# A context uses three HIP streams (pixel kernels + two component chains) that must overlap; HIP maps
+# streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share one serialise.
+# With torch's and RCCL's own streams in the process, leave room (must be set before HIP initialises).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
