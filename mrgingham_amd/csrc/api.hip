@@ -266,12 +266,13 @@ static void launch_chess_any(mrgingham_amd_ctx* ctx, const LevelBatch& lb, const
 // Every detect / refine / chain call starts here: the pixel stream must not
 // overwrite level scratch the component stream of the previous call still reads.
 static void begin_op(mrgingham_amd_ctx* ctx, int max_level) {
+    (void)max_level;
     ctx->cur ^= 1;  // this set was last used two calls ago
     if (ctx->cc_pending[ctx->cur]) hipStreamWaitEvent(ctx->pix, ctx->ev_cc_done[ctx->cur], 0);
-    // hot-pixel counters of every level this call touches: one fill (status words only ever
-    // accumulate; mrgingham_amd_sync reads and clears them)
-    hipMemsetAsync(ctx->counters2[ctx->cur].p, 0, (size_t)(max_level + 1) * ctx->counters_nf * sizeof(int32_t),
-                   ctx->pix);
+    // The hot-pixel counters of this set are zero here: they are zeroed at allocation and again by
+    // end_op behind the component kernels that consumed them -- on the component stream, off the
+    // pixel stream's critical path.  (Status words only ever accumulate; mrgingham_amd_sync reads
+    // and clears them.)
 }
 static hipStream_t cur_cc(mrgingham_amd_ctx* ctx) { return ctx->ccs[ctx->cur]; }
 // Registers the caller-owned device buffers this call writes (w) and reads (r) and makes its
@@ -297,6 +298,8 @@ static void order_after_previous(mrgingham_amd_ctx* ctx, std::initializer_list<m
     ctx->last_r[cur].assign(r.begin(), r.end());
 }
 static void end_op(mrgingham_amd_ctx* ctx) {
+    hipMemsetAsync(ctx->counters2[ctx->cur].p, 0, (size_t)(kMaxLevel + 1) * ctx->counters_nf * sizeof(int32_t),
+                   cur_cc(ctx));
     hipEventRecord(ctx->ev_cc_done[ctx->cur], cur_cc(ctx));
     ctx->cc_pending[ctx->cur] = true;
 }
