@@ -36,9 +36,18 @@ namespace mrg {
 
 constexpr int CC_THREADS = 256;
 
-__device__ __forceinline__ int aload(const int32_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+// Every table of a frame is only ever touched by ONE workgroup per kernel (the labelling kernels
+// and the detect / refine kernels all run one workgroup per frame), so the atomics on them are
+// WORKGROUP scope: they execute in the XCD's L2.  Agent-scope atomics on this multi-XCD part go to
+// the memory side instead; a few hundred thousand of them per level were slowing the HBM-streaming
+// pixel kernels they run underneath by ~6 % (measured by replacing the labelling kernels with empty
+// ones).  Kernel boundaries make the results visible to the next kernel.
+#define MRG_WG __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP
+__device__ __forceinline__ int aload(const int32_t* p) { return __hip_atomic_load(p, MRG_WG); }
+__device__ __forceinline__ int wg_min(int32_t* p, int v) { return __hip_atomic_fetch_min(p, v, MRG_WG); }
+__device__ __forceinline__ int wg_max(int32_t* p, int v) { return __hip_atomic_fetch_max(p, v, MRG_WG); }
+__device__ __forceinline__ int wg_add(int32_t* p, int v) { return __hip_atomic_fetch_add(p, v, MRG_WG); }
+__device__ __forceinline__ int wg_or(int32_t* p, int v) { return __hip_atomic_fetch_or(p, v, MRG_WG); }
 
 __device__ __forceinline__ int uf_root(const int32_t* parent, int i) {
     int p = aload(parent + i);
@@ -58,7 +67,7 @@ __device__ __forceinline__ void uf_unite(int32_t* parent, int a, int b) {
         b = uf_root(parent, b);
         if (a == b) return;
         if (a < b) { const int t = a; a = b; b = t; }
-        const int old = atomicMin(parent + a, b);
+        const int old = wg_min(parent + a, b);
         if (old == a) return;
         a = old;
     }
@@ -107,24 +116,18 @@ __device__ __forceinline__ FrameView make_view(const LevelBatch& lb, const CompT
     return v;
 }
 
-// P1 and P2 run as their own grid-wide kernels (a few workgroups per frame): at
-// full resolution a noisy frame has tens of thousands of hot pixels, nearly all
-// of them isolated, and labelling them with the 1024 threads of the per-frame
-// workgroup was the longest phase of the component search.
-constexpr int CCL_THREADS = 256;
+// P1 and P2 are their own kernels, one 1024-thread workgroup per frame (so that workgroup-scope
+// atomics suffice, see above): at full resolution a noisy frame has tens of thousands of hot
+// pixels, nearly all of them isolated, which P1 flags so that P2 skips them.
+constexpr int CCL_THREADS = 1024;
 constexpr int kSingletonFlag = 0x40000000;  // in hot_pix[]: the pixel has no hot 4-neighbour
-// Workgroups per frame of the two labelling kernels.  They run underneath the pixel kernels of the
-// next call, and every resident labelling workgroup slows those down: 4 per frame instead of 16
-// costs nothing on the component chain (it is not the critical path) and gives 3 % on the chain rate.
-constexpr int CCL_BLOCKS_PER_FRAME = 4;
-
 // P1: union-find over the hot list (left / up neighbours).
-__global__ __launch_bounds__(CCL_THREADS) void cc_union_kernel(LevelBatch lb, CompTables t, int frame0, int bpf) {
+__global__ __launch_bounds__(CCL_THREADS) void cc_union_kernel(LevelBatch lb, CompTables t, int frame0) {
     const int frame = frame0 + blockIdx.y;
     if (t.hot_cnt[frame] > t.cap) return;  // overflow is reported by the per-frame kernel
     const FrameView v = make_view(lb, t, frame);
     const int w = v.w;
-    for (int i = blockIdx.x * CCL_THREADS + threadIdx.x; i < v.n; i += bpf * CCL_THREADS) {
+    for (int i = threadIdx.x; i < v.n; i += CCL_THREADS) {
         const int p = v.hot_pix[i];
         // all four neighbours lie inside the image (p is in [7,w-7) x [7,h-7)); the frame is zero
         const bool l = v.d[p - 1] > kRespMin, u = v.d[p - w] > kRespMin;
@@ -138,34 +141,33 @@ __global__ __launch_bounds__(CCL_THREADS) void cc_union_kernel(LevelBatch lb, Co
 }
 
 // P2: flatten (parent[i] = root of i); per-root pixel count and bounding box.
-__global__ __launch_bounds__(CCL_THREADS) void cc_flatten_kernel(LevelBatch lb, CompTables t, int frame0, int bpf) {
+__global__ __launch_bounds__(CCL_THREADS) void cc_flatten_kernel(LevelBatch lb, CompTables t, int frame0) {
     const int frame = frame0 + blockIdx.y;
     if (t.hot_cnt[frame] > t.cap) return;
     const FrameView v = make_view(lb, t, frame);
     const int w = v.w;
-    for (int i = blockIdx.x * CCL_THREADS + threadIdx.x; i < v.n; i += bpf * CCL_THREADS) {
+    for (int i = threadIdx.x; i < v.n; i += CCL_THREADS) {
         const int p = v.hot_pix[i];
         if (p & kSingletonFlag) continue;  // its own root, count 0: never a blob, never shared
         const int r = uf_root(v.parent, i);
         // other threads may still walk through i: r is an ancestor, so their walks stay valid
-        __hip_atomic_store(v.parent + i, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(v.parent + i, r, MRG_WG);
         const int y = p / w, x = p - y * w;
         int* box = reinterpret_cast<int*>(v.comp_box + r);
-        atomicMin(box + 0, x);
-        atomicMin(box + 1, y);
-        atomicMax(box + 2, x);
-        atomicMax(box + 3, y);
-        atomicAdd(v.comp_cnt + r, 1);
-        atomicMin(v.comp_first + r, p);
+        wg_min(box + 0, x);
+        wg_min(box + 1, y);
+        wg_max(box + 2, x);
+        wg_max(box + 3, y);
+        wg_add(v.comp_cnt + r, 1);
+        wg_min(v.comp_first + r, p);
     }
 }
 
 void launch_cc_label(const LevelBatch& lb, const CompTables& t, int frame0, int nframes, hipStream_t s) {
     if (nframes <= 0) return;
-    const int bpf = CCL_BLOCKS_PER_FRAME;
-    const dim3 grid(bpf, nframes);
-    hipLaunchKernelGGL(cc_union_kernel, grid, dim3(CCL_THREADS), 0, s, lb, t, frame0, bpf);
-    hipLaunchKernelGGL(cc_flatten_kernel, grid, dim3(CCL_THREADS), 0, s, lb, t, frame0, bpf);
+    const dim3 grid(1, nframes);
+    hipLaunchKernelGGL(cc_union_kernel, grid, dim3(CCL_THREADS), 0, s, lb, t, frame0);
+    hipLaunchKernelGGL(cc_flatten_kernel, grid, dim3(CCL_THREADS), 0, s, lb, t, frame0);
 }
 
 struct Blob {
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(CC_THREADS) void cc_detect_kernel(LevelBatch lb, Co
     const int frame = frame0 + blockIdx.x;
     if (t.hot_cnt[frame] > t.cap) {  // table overflow: report, produce nothing
         if (threadIdx.x == 0) {
-            atomicOr(t.status + frame, kStatusHotOverflow);
+            wg_or(t.status + frame, kStatusHotOverflow);
             out.counts[frame] = -1;
         }
         return;
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(CC_THREADS) void cc_detect_kernel(LevelBatch lb, Co
     }
     __syncthreads();
     if (s_ncand > v.cand_cap) {
-        if (threadIdx.x == 0) { atomicOr(v.status, kStatusCandOverflow); out.counts[frame] = -1; }
+        if (threadIdx.x == 0) { wg_or(v.status, kStatusCandOverflow); out.counts[frame] = -1; }
         return;
     }
     const int nvalid = s_ncand;
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, Co
     const int frame = frame0 + blockIdx.x;
     if (t.hot_cnt[frame] > t.cap) {
         if (threadIdx.x == 0) {
-            atomicOr(t.status + frame, kStatusHotOverflow);
+            wg_or(t.status + frame, kStatusHotOverflow);
             if (io.nrefined) io.nrefined[frame] = -1;
         }
         return;
@@ -469,7 +471,7 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, Co
             for (int k = 0; k < ns; ++k) m = min(m, aload(v.roots + sroot[9 * i + k]));
             bool changed = m < leader[i];
             for (int k = 0; k < ns; ++k)
-                if (atomicMin(v.roots + sroot[9 * i + k], m) > m) changed = true;
+                if (wg_min(v.roots + sroot[9 * i + k], m) > m) changed = true;
             leader[i] = m;
             if (changed) s_changed = 1;
         }
@@ -485,8 +487,8 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, Co
     for (int i = threadIdx.x; i < npts; i += CC_THREADS) {
         const int ns = nseeds[i];
         for (int k = 0; k < ns; ++k) {
-            const int old = atomicOr(v.comp_cnt + sroot[9 * i + k], (int)0x80000000);
-            if (old >= 0) atomicAdd(need + leader[i], 4 * old);
+            const int old = wg_or(v.comp_cnt + sroot[9 * i + k], (int)0x80000000);
+            if (old >= 0) wg_add(need + leader[i], 4 * old);
         }
     }
     __syncthreads();
