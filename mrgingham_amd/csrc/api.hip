@@ -7,6 +7,10 @@
 #include <string.h>
 
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -36,6 +40,61 @@ struct LevelScratch {
 
 }  // namespace mrg
 
+// Host worker threads of a context (the grid finder of mrgingham_amd_find_boards_batch): started
+// once and parked on a condition variable, because spawning threads per call cost more than the
+// grid finder itself.
+struct HostPool {
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable cv_start, cv_done;
+    std::function<void()> job;
+    long generation = 0;
+    int wanted = 0, running = 0;
+    bool stop = false;
+
+    void loop(int id) {
+        long seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(m);
+            cv_start.wait(lk, [&] { return stop || (generation != seen && id < wanted); });
+            if (stop) return;
+            seen = generation;
+            lk.unlock();
+            job();
+            lk.lock();
+            if (--running == 0) cv_done.notify_all();
+        }
+    }
+    // runs f on n threads (the caller is one of them) and returns when all of them are done
+    void run(int n, const std::function<void()>& f) {
+        if (n <= 1) { f(); return; }
+        {
+            std::unique_lock<std::mutex> lk(m);
+            while ((int)threads.size() < n - 1) {
+                const int id = (int)threads.size();
+                threads.emplace_back([this, id] { loop(id); });
+            }
+            job = f;
+            wanted = n - 1;
+            running = n - 1;
+            ++generation;
+        }
+        cv_start.notify_all();
+        f();
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return running == 0; });
+        wanted = 0;
+    }
+    ~HostPool() {
+        {
+            std::unique_lock<std::mutex> lk(m);
+            stop = true;
+        }
+        cv_start.notify_all();
+        for (auto& t : threads) t.join();
+    }
+};
+
 struct mrgingham_amd_ctx {
     int device = 0;
     // HIP streams of a context: `pix` runs the pixel kernels (pyramid, ChESS) back to back, each
@@ -64,7 +123,9 @@ struct mrgingham_amd_ctx {
     int counters_nf = 0;
     struct PointScratch { mrg::DevBuf leader, need, nseeds, seeds, sroot, cand_xy, cand_counts; } pts[2];  // per scratch set
     mrg::DevBuf aux_img, io_frame, io_out, io_counts;
-    mrg::DevBuf pre_scratch, pre_tmp, pre_out;  // preprocessing: extrema + tile histograms + LUTs, CLAHE output before the blur
+    mrg::DevBuf pre_scratch, pre_tmp, pre_out;
+    mrg::DevBuf fb_xy, fb_cnt, fb_pts, fb_lv, fb_np, fb_frames, fb_frames2;  // find_boards_batch: candidates, counts, boards, levels, point counts
+    HostPool pool;  // preprocessing: extrema + tile histograms + LUTs, CLAHE output before the blur
     int pts_nframes = 0, pts_pitch = 0;
     // levels (and frame counts) whose status words must be checked at the next sync
     int pending_frames[2][mrg::kMaxLevel + 1] = {};
@@ -411,7 +472,8 @@ void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx) {
     for (auto& ps : ctx->pts)
         for (DevBuf* b : {&ps.leader, &ps.need, &ps.nseeds, &ps.seeds, &ps.sroot, &ps.cand_xy, &ps.cand_counts})
             if (b->p) hipFree(b->p);
-    DevBuf* bufs[] = {&ctx->counters2[0], &ctx->counters2[1], &ctx->io_counts, &ctx->aux_img, &ctx->io_frame, &ctx->io_out, &ctx->pre_scratch, &ctx->pre_tmp, &ctx->pre_out};
+    DevBuf* bufs[] = {&ctx->counters2[0], &ctx->counters2[1], &ctx->io_counts, &ctx->aux_img, &ctx->io_frame, &ctx->io_out, &ctx->pre_scratch, &ctx->pre_tmp, &ctx->pre_out,
+                      &ctx->fb_xy, &ctx->fb_cnt, &ctx->fb_pts, &ctx->fb_lv, &ctx->fb_np, &ctx->fb_frames, &ctx->fb_frames2};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     for (auto& pr : ctx->events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
@@ -1037,85 +1099,132 @@ int mrgingham_amd_find_boards_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_
     const int first = image_pyramid_level >= 0 ? image_pyramid_level : 3;
     const int last = image_pyramid_level >= 0 ? image_pyramid_level : 0;
     const int cap = 4 * N + 64;  // candidates kept per frame for the grid finder
-    if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
+    if (nthreads <= 0) {  // the grid finder takes ~0.3 ms per frame: a few dozen threads cover a batch
+        nthreads = (int)std::thread::hardware_concurrency();
+        if (nthreads > 32) nthreads = 32;
+    }
     if (nthreads <= 0) nthreads = 1;
-    if (nthreads > B) nthreads = B;
 
-    DevBuf d_xy, d_cnt, d_pts, d_lv, d_np;
-    auto cleanup = [&]() {
-        for (DevBuf* b : {&d_xy, &d_cnt, &d_pts, &d_lv, &d_np})
-            if (b->p) hipFree(b->p);
-    };
+    DevBuf &d_xy = ctx->fb_xy, &d_cnt = ctx->fb_cnt, &d_pts = ctx->fb_pts, &d_lv = ctx->fb_lv, &d_np = ctx->fb_np;
     if ((rc = ensure(ctx, d_xy, (size_t)B * cap * 8)) || (rc = ensure(ctx, d_cnt, (size_t)B * 4)) ||
         (rc = ensure(ctx, d_pts, (size_t)B * N * 16)) || (rc = ensure(ctx, d_lv, (size_t)B * N)) ||
-        (rc = ensure(ctx, d_np, (size_t)B * 4))) {
-        cleanup();
+        (rc = ensure(ctx, d_np, (size_t)B * 4)))
         return rc;
-    }
     std::vector<int32_t> h_xy((size_t)B * cap * 2), h_cnt(B), h_np(B, 0);
     std::vector<signed char> h_lv((size_t)B * N, 0);
+    std::vector<double> h_pts((size_t)B * N * 2);
     for (int f = 0; f < B; ++f) h_found_level[f] = -1;
-    int nfound_total = 0;
 
-    for (int L = first; L >= last && nfound_total < B; --L) {
-        // (a) candidates of every frame at level L
-        if ((rc = mrgingham_amd_detect_batch(ctx, fr, L, (int32_t*)d_xy.p, cap, (int32_t*)d_cnt.p)) ||
+    // A dense copy of a few frames of the batch, so that a late level only runs on the frames that
+    // still need it (one straggler must not cost the whole batch another two ChESS passes).
+    const size_t frame_bytes = (size_t)fr->width * fr->height;
+    auto gather = [&](DevBuf& buf, const std::vector<int>& idx, mrgingham_amd_frames* sub) -> int {
+        int r = ensure(ctx, buf, frame_bytes * idx.size() + 64);
+        if (r) return r;
+        for (size_t k = 0; k < idx.size(); ++k)
+            MRG_HIP_CHECK(hipMemcpy2DAsync((char*)buf.p + k * frame_bytes, fr->width,
+                                           fr->frames + (size_t)idx[k] * fr->frame_pitch, fr->stride, fr->width,
+                                           fr->height, hipMemcpyDeviceToDevice, ctx->pix));
+        *sub = mrgingham_amd_frames{(const uint8_t*)buf.p, (int64_t)frame_bytes, (int)idx.size(), fr->width, fr->height,
+                                    fr->width};
+        return 0;
+    };
+
+    static const bool dbg_t = getenv("MRG_DBG_FB") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto lap = [&](const char* what, int L, int n) { if (dbg_t) { const double t = now(); fprintf(stderr, "  [fb] L%d %-14s %3d frames %7.3f ms\n", L, what, n, t - t_prev); t_prev = t; } };
+
+    std::vector<int> open(B);  // frames without a board yet, ascending
+    for (int f = 0; f < B; ++f) open[f] = f;
+    std::vector<int> cur_idx = open;         // original index of every frame of the batch the detector runs on
+    mrgingham_amd_frames cur = *fr, rsub;
+
+    for (int L = first; L >= last && !open.empty(); --L) {
+        // (a) candidates at level L of the frames still open (compacted once at most half are left)
+        if (open.size() * 2 <= cur_idx.size()) {
+            if ((rc = gather(ctx->fb_frames, open, &cur))) break;
+            cur_idx = open;
+        }
+        const int nb = (int)cur_idx.size();
+        if ((rc = mrgingham_amd_detect_batch(ctx, &cur, L, (int32_t*)d_xy.p, cap, (int32_t*)d_cnt.p)) ||
             (rc = mrgingham_amd_sync(ctx))) break;
-        if (hipMemcpy(h_cnt.data(), d_cnt.p, (size_t)B * 4, hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(h_xy.data(), d_xy.p, (size_t)B * cap * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+        if (hipMemcpy(h_cnt.data(), d_cnt.p, (size_t)nb * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(h_xy.data(), d_xy.p, (size_t)nb * cap * 8, hipMemcpyDeviceToHost) != hipSuccess) {
             rc = fail(ctx, MRGINGHAM_AMD_ERR_DEVICE, "candidate download failed");
             break;
         }
-        // (b) grid finder on host threads, for the frames still without a board
-        std::vector<char> found_now(B, 0);
+        lap("detect+D2H", L, nb);
+        // (b) grid finder on host threads (mrgingham.cc:51), for the frames still without a board
+        std::vector<char> found_now(nb, 0);
         std::atomic<int> next{0};
         auto worker = [&]() {
-            for (int f; (f = next.fetch_add(1)) < B;) {
+            for (int k; (k = next.fetch_add(1)) < nb;) {
+                const int f = cur_idx[k];
                 if (h_found_level[f] >= 0) continue;
-                const int n = h_cnt[f] < cap ? h_cnt[f] : cap;  // more candidates than `cap`: clutter, no board
-                if (n < N || h_cnt[f] > cap) continue;
+                const int n = h_cnt[k] < cap ? h_cnt[k] : cap;  // more candidates than `cap`: clutter, no board
+                if (n < N || h_cnt[k] > cap) continue;
                 std::vector<PointI> cand((size_t)n);
-                for (int i = 0; i < n; ++i) cand[i] = PointI{h_xy[((size_t)f * cap + i) * 2], h_xy[((size_t)f * cap + i) * 2 + 1]};
+                for (int i = 0; i < n; ++i) cand[i] = PointI{h_xy[((size_t)k * cap + i) * 2], h_xy[((size_t)k * cap + i) * 2 + 1]};
                 std::vector<PointD> board;
                 if (find_grid_from_points(board, cand, gridn) && (int)board.size() == N) {
                     memcpy(h_boards + (size_t)f * N * 2, board.data(), sizeof(double) * 2 * N);
-                    found_now[f] = 1;
+                    found_now[k] = 1;
                 }
             }
         };
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker);
-        worker();
-        for (auto& th : pool) th.join();
-        int nnow = 0;
-        for (int f = 0; f < B; ++f)
-            if (found_now[f]) { h_found_level[f] = (signed char)L; ++nnow; }
-        nfound_total += nnow;
-        if (nnow == 0 || L == 0) continue;
-        // (c) refine the boards found at this level down to level 0 (the others have npoints = 0)
-        for (int f = 0; f < B; ++f) {
-            h_np[f] = found_now[f] ? N : 0;
-            if (found_now[f]) memset(h_lv.data() + (size_t)f * N, L, (size_t)N);
+        ctx->pool.run(nthreads < nb ? nthreads : nb, worker);
+        std::vector<int> found_pos;  // positions within the current batch
+        for (int k = 0; k < nb; ++k)
+            if (found_now[k]) { h_found_level[cur_idx[k]] = (signed char)L; found_pos.push_back(k); }
+        lap("grid finder", L, (int)found_pos.size());
+        if (found_pos.empty()) continue;
+        {
+            std::vector<int> still;
+            for (int f : open)
+                if (h_found_level[f] < 0) still.push_back(f);
+            open.swap(still);
         }
-        if (hipMemcpy(d_pts.p, h_boards, (size_t)B * N * 16, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(d_lv.p, h_lv.data(), (size_t)B * N, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(d_np.p, h_np.data(), (size_t)B * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        if (L == 0) continue;
+        // (c) refine the boards found at this level down to level 0 (mrgingham.cc:81-99): on the current
+        // batch with zero points for the other frames, or on a dense copy of just those frames
+        const mrgingham_amd_frames* rb = &cur;
+        std::vector<int> ridx;  // position in the refine batch -> original frame
+        if (found_pos.size() * 2 <= (size_t)nb) {
+            for (int k : found_pos) ridx.push_back(cur_idx[k]);
+            if ((rc = gather(ctx->fb_frames2, ridx, &rsub))) break;
+            rb = &rsub;
+        } else {
+            ridx = cur_idx;
+        }
+        const int nr = (int)ridx.size();
+        for (int k = 0; k < nr; ++k) {
+            const int f = ridx[k];
+            const bool is_new = h_found_level[f] == L;
+            h_np[k] = is_new ? N : 0;
+            if (is_new) {
+                memset(h_lv.data() + (size_t)k * N, L, (size_t)N);
+                memcpy(h_pts.data() + (size_t)k * N * 2, h_boards + (size_t)f * N * 2, sizeof(double) * 2 * N);
+            }
+        }
+        if (hipMemcpy(d_pts.p, h_pts.data(), (size_t)nr * N * 16, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_lv.p, h_lv.data(), (size_t)nr * N, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_np.p, h_np.data(), (size_t)nr * 4, hipMemcpyHostToDevice) != hipSuccess) {
             rc = fail(ctx, MRGINGHAM_AMD_ERR_DEVICE, "board upload failed");
             break;
         }
         for (int l = L - 1; l >= 0 && !rc; --l)  // (refining past "nothing refined" is a no-op, mrgingham.cc:97-98)
-            rc = mrgingham_amd_refine_batch(ctx, fr, l, (double*)d_pts.p, (signed char*)d_lv.p, (const int32_t*)d_np.p,
+            rc = mrgingham_amd_refine_batch(ctx, rb, l, (double*)d_pts.p, (signed char*)d_lv.p, (const int32_t*)d_np.p,
                                             N, nullptr);
         if (rc || (rc = mrgingham_amd_sync(ctx))) break;
-        std::vector<double> refined((size_t)B * N * 2);
-        if (hipMemcpy(refined.data(), d_pts.p, (size_t)B * N * 16, hipMemcpyDeviceToHost) != hipSuccess) {
+        if (hipMemcpy(h_pts.data(), d_pts.p, (size_t)nr * N * 16, hipMemcpyDeviceToHost) != hipSuccess) {
             rc = fail(ctx, MRGINGHAM_AMD_ERR_DEVICE, "board download failed");
             break;
         }
-        for (int f = 0; f < B; ++f)
-            if (found_now[f]) memcpy(h_boards + (size_t)f * N * 2, refined.data() + (size_t)f * N * 2, sizeof(double) * 2 * N);
+        for (int k = 0; k < nr; ++k)
+            if (h_np[k]) memcpy(h_boards + (size_t)ridx[k] * N * 2, h_pts.data() + (size_t)k * N * 2, sizeof(double) * 2 * N);
+        lap("refine+D2H", L, nr);
     }
-    cleanup();
     return rc;
 }
 
