@@ -294,9 +294,11 @@ __device__ __forceinline__ void collect_hot(uint32_t bits, int p0, int* hotbuf, 
     }
 }
 
+// The body of the kernel for workgroup `bid` of `nwg` of one level (the multi-level launch below runs
+// several levels in one grid).
 template <bool CLAMP, bool HOT, bool W16>
-__global__ __launch_bounds__(256) void chess_v1_kernel(LevelBatch lb, CompTables t, int frame0, int seg) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
+__device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTables& t, int frame0, int seg, unsigned bid,
+                                              unsigned nwg_level, char* lds) {
     // XCD-aware work order: workgroup b is dispatched to XCD b % 8 (observed, used
     // for speed only).  Give each XCD a contiguous run of work items, strips
     // fastest, so the 32-pixel column halo and the 10-row segment halo a
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(256) void chess_v1_kernel(LevelBatch lb, CompTables
     const int nstrips = (lb.w + V1_SW - 1) / V1_SW, nsegs = (lb.h + seg - 1) / seg;
     int work;
     {
-        const unsigned b = blockIdx.x, nwg = gridDim.x, xcd = b & 7u, j = b >> 3;
+        const unsigned b = bid, nwg = nwg_level, xcd = b & 7u, j = b >> 3;
         const unsigned q = nwg >> 3, r = nwg & 7u;
         work = (int)((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j);
     }
@@ -478,6 +480,32 @@ __global__ __launch_bounds__(256) void chess_v1_kernel(LevelBatch lb, CompTables
     }
 }
 
+template <bool CLAMP, bool HOT, bool W16>
+__global__ __launch_bounds__(256) void chess_v1_kernel(LevelBatch lb, CompTables t, int frame0, int seg) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    chess_v1_body<CLAMP, HOT, W16>(lb, t, frame0, seg, blockIdx.x, gridDim.x, lds);
+}
+
+// Several pyramid levels of the same batch in ONE grid (clamp + hot list, widths that are multiples
+// of 16): the small levels have too few workgroups to fill the chip on their own, and every kernel
+// boundary on the pixel stream costs 7-12 us (end-of-kernel cache write-back + dispatch).  The
+// levels are laid out largest first, so the small ones fill the tail of the large one.
+struct ChessMulti {
+    LevelBatch lb[3];
+    CompTables t[3];
+    int first_wg[4];  // workgroup range of level slot k is [first_wg[k], first_wg[k+1])
+    int seg[3];
+    int n;
+};
+__global__ __launch_bounds__(256, 4) void chess_v1_multi_kernel(ChessMulti a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int b = blockIdx.x;
+    const int k = (a.n > 2 && b >= a.first_wg[2]) ? 2 : (a.n > 1 && b >= a.first_wg[1]) ? 1 : 0;  // uniform
+    chess_v1_body<true, true, true>(a.lb[k], a.t[k], 0, a.seg[k], (unsigned)(b - a.first_wg[k]),
+                                    (unsigned)(a.first_wg[k + 1] - a.first_wg[k]), lds);
+}
+
+
 int chess_seg_override = 0;  // tuning hook (mrgingham_amd_set_option "chess_seg"): 0 = automatic
 
 static int pick_segment(int w, int h, int nframes) {
@@ -503,6 +531,28 @@ void launch_chess(const LevelBatch& lb, const CompTables& t, int frame0, int nfr
     else if (clamp) { if (w16) MRG_LAUNCH(true, false, true); else MRG_LAUNCH(true, false, false); }
     else { if (w16) MRG_LAUNCH(false, false, true); else MRG_LAUNCH(false, false, false); }
 #undef MRG_LAUNCH
+}
+
+// Levels lbs[0..n) (n <= 3, largest first) of one batch in one launch; returns false when the shapes do
+// not qualify (then the caller launches them one by one).
+bool launch_chess_multi(const LevelBatch* lbs, const CompTables* ts, int n, int nframes, hipStream_t s) {
+    if (n < 2 || n > 3 || nframes <= 0) return false;
+    ChessMulti a;
+    a.n = n;
+    int total = 0;
+    for (int k = 0; k < n; ++k) {
+        if (lbs[k].w < 16 || lbs[k].w % 16 != 0 || lbs[k].h <= 0) return false;
+        a.lb[k] = lbs[k];
+        a.t[k] = ts[k];
+        a.seg[k] = pick_segment(lbs[k].w, lbs[k].h, nframes);
+        a.first_wg[k] = total;
+        total += ((lbs[k].w + V1_SW - 1) / V1_SW) * ((lbs[k].h + a.seg[k] - 1) / a.seg[k]) * nframes;
+    }
+    for (int k = n; k <= 3; ++k) a.first_wg[k] = total;
+    for (int k = n; k < 3; ++k) { a.lb[k] = lbs[0]; a.t[k] = ts[0]; a.seg[k] = a.seg[0]; }
+    const size_t lds = 2 * V1_PLANE + (V1_HOTBUF + 4) * sizeof(int);
+    hipLaunchKernelGGL(chess_v1_multi_kernel, dim3(total), dim3(256), lds, s, a);
+    return true;
 }
 
 }  // namespace mrg

@@ -10,6 +10,7 @@ void launch_chess_v0(const LevelBatch& lb, const CompTables& t, int frame0, int 
 void launch_chess(const LevelBatch& lb, const CompTables& t, int frame0, int nframes, bool clamp, bool hot,
                   hipStream_t s);
 
+bool launch_chess_multi(const LevelBatch* lbs, const CompTables* ts, int n, int nframes, hipStream_t s);
 extern int chess_seg_override;
 
 // decimate.hip

@@ -339,3 +339,27 @@ def test_dependent_calls_without_sync_are_ordered(det):
             assert int(npts[f]) == k
             assert torch.equal(p[f, :k], rp[f, :k]) and torch.equal(l[f, :k], rl[f, :k]), (rep, f)
             assert torch.equal(out2[0][f, :k], rp[f, :k])
+
+
+def test_multi_level_launch_option_gives_the_same_chain():
+    """set_option("multi_level_launch", 1): levels 3, 2, 1 of a chain share one grid."""
+    d2 = mrgingham_amd.Detector(0)
+    try:
+        d2.set_option("multi_level_launch", 1)
+        frames = np.stack([synth.board_frame(1280, 960, 10, s).numpy() for s in (0, 3)] +
+                          [synth.noise_frame(1280, 960, 2, smooth=1).numpy()])
+        d = _cuda(frames)
+        for start in (3, 2):
+            pts, lv, npts = d2.chain(d, start_level=start, max_points=4096)
+            for f in range(len(frames)):
+                wp, wl = oracle.chain(frames[f], start)
+                n = int(npts[f])
+                assert n == len(wp), (start, f)
+                assert np.array_equal(pts[f, :n].cpu().numpy(), wp) and np.array_equal(lv[f, :n].cpu().numpy(), wl)
+        # a width that is not a multiple of 16 falls back to one launch per level
+        odd = np.stack([synth.board_frame(1000, 760, 10, 1).numpy()])
+        pts, lv, npts = d2.chain(_cuda(odd), start_level=3, max_points=2048)
+        wp, wl = oracle.chain(odd[0], 3)
+        assert int(npts[0]) == len(wp) and np.array_equal(pts[0, :len(wp)].cpu().numpy(), wp)
+    finally:
+        d2.close()
