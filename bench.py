@@ -90,8 +90,10 @@ def cpu_baseline(frames_host, start_level, cpu_seconds=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    # a step is ~1.2 ms: the first few dozen run below the steady-state rate (clocks / TLBs warming up),
+    # so the defaults are long enough to measure the steady state and still finish in well under a minute
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c3_4096x3072_chain", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="frames per GPU per step (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -9,12 +9,13 @@ R=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 10 --warmup 3"
+BENCH="python $R/bench.py"                              # defaults: 200 steps, 20 warmup
+TRACEB="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline"   # short run under the tracer
 PMCB="python $R/bench.py --distinct 4 --steps 3 --warmup 1 --no-cpu-baseline"
 # 1. the bench line itself
 timeout 600 $BENCH > $OUT/bench.json 2> $OUT/bench.err
 # 2. kernel trace of the same command (no CPU baseline: it only adds host time)
-timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- $BENCH --no-cpu-baseline > $OUT/trace_bench.json 2> $OUT/trace.err
+timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- $TRACEB > $OUT/trace_bench.json 2> $OUT/trace.err
 # 3. EA (fabric) traffic: read requests by size, write requests, and the derived KiB counters
 timeout 900 rocprofv3 --pmc TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_128B --kernel-trace --output-format csv -d $OUT/pmc_rd -o p -- $PMCB > $OUT/pmc_rd.json 2> $OUT/pmc_rd.err
 timeout 900 rocprofv3 --pmc TCC_EA0_WRREQ TCC_EA0_WRREQ_64B --kernel-trace --output-format csv -d $OUT/pmc_wr -o p -- $PMCB > $OUT/pmc_wr.json 2> $OUT/pmc_wr.err

@@ -15,9 +15,9 @@ strip = lambda t: re.sub(r"/tmp/[^ ]*?/gpurun_out/", "gpurun_out/", t)
 
 # 1. kernel trace of the bench command
 tb, b = json.loads(rd("trace_bench.json")), json.loads(rd("bench.json"))
-hdr = (f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline   (round 1, final kernels; tools/collect_profiles.sh {tag})\n"
-       f"# bench.py under the tracer: {tb['value']:.0f} frames/s, {tb['ms_per_step']:.3f} ms/step, level-0 ChESS launch {tb['roofline']['avg_launch_ms']*1e3:.1f} us by hipEvents (trace below: avg over 13 launches incl. warmup)\n"
-       f"# bench.py without the tracer, same box, same build: {b['value']:.0f} frames/s, {b['ms_per_step']:.3f} ms/step, level-0 ChESS launch {b['roofline']['avg_launch_ms']*1e3:.1f} us -> {b['roofline']['achieved']:.0f} GB/s = {b['roofline']['frac']*100:.1f} % of 8 TB/s\n")
+hdr = (f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline   (round 1, final kernels; tools/collect_profiles.sh {tag})\n"
+       f"# bench.py under the tracer: {tb['value']:.0f} frames/s, {tb['ms_per_step']:.3f} ms/step, level-0 ChESS launch {tb['roofline']['avg_launch_ms']*1e3:.1f} us by hipEvents (trace below: avg over 25 launches incl. warmup)\n"
+       f"# bench.py with its defaults (200 steps) without the tracer, same box, same build: {b['value']:.0f} frames/s, {b['ms_per_step']:.3f} ms/step, level-0 ChESS launch {b['roofline']['avg_launch_ms']*1e3:.1f} us -> {b['roofline']['achieved']:.0f} GB/s = {b['roofline']['frac']*100:.1f} % of 8 TB/s\n")
 open(os.path.join(P, "r01_bench_kernel_trace.txt"), "w").write(hdr + strip(rd("bench_kernel_trace.txt")))
 open(os.path.join(P, "r01_bench.json"), "w").write(rd("bench.json"))
 
