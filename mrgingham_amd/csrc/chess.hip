@@ -450,7 +450,14 @@ __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTa
 
         // ring first, results second: the wait for the prefetched rows must not also
         // wait for this iteration's output stores (loads and stores share vmcnt)
-        if (stager) stage_store(lds, (pr + 64) & (V1_NR - 1), st_ch, pre);
+        // The waves that stage are the last to reach the barrier (16 v_perm + four 13-cycle LDS stores
+        // more than the others), and the rest of the workgroup waits for them: issue priority for
+        // exactly that stretch (-1.2 ... -2.6 % on the launch, A/B on three boxes).
+        if (stager) {
+            __builtin_amdgcn_s_setprio(2);
+            stage_store(lds, (pr + 64) & (V1_NR - 1), st_ch, pre);
+            __builtin_amdgcn_s_setprio(0);
+        }
         if (yy < ye && x0 < w) {
             int16_t* dst = resp + (long long)yy * w + x0;
             if (x0 + 8 <= w) {
