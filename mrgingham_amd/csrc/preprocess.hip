@@ -267,16 +267,25 @@ __global__ __launch_bounds__(256) void clahe_apply_fast_kernel(FrameBatch in, Cl
         const uint4 gv = make_uint4(gvv.x, gvv.y, gvv.z, gvv.w);
         const uint32_t gq[4] = {gv.x, gv.y, gv.z, gv.w};
         uint32_t o[4] = {0, 0, 0, 0};
+        // two pixels per packed-f32 instruction (v_pk_mul_f32 / v_pk_add_f32: the same IEEE single
+        // operations as the scalar expression, nothing fused), and v_cvt_pk_u8_f32 for the
+        // round-half-even + saturate + byte insert of saturate_cast<uchar>
+        using f32x2 = float __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const uint32_t v = (gq[j >> 2] >> (8 * (j & 3))) & 0xffu;
-            const uint32_t q = qrow[((cxbit >> j) & 1u) * kBins + v];
-            const float l11 = (float)(q & 0xffu), l12 = (float)((q >> 8) & 0xffu);
-            const float l21 = (float)((q >> 16) & 0xffu), l22 = (float)(q >> 24);
-            const float xa1 = __fsub_rn(1.0f, xa[j]);
-            const float top = __fmul_rn(__fadd_rn(__fmul_rn(l11, xa1), __fmul_rn(l12, xa[j])), ya1);
-            const float bot = __fmul_rn(__fadd_rn(__fmul_rn(l21, xa1), __fmul_rn(l22, xa[j])), ya);
-            o[j >> 2] |= (uint32_t)sat_u8_rint(__fadd_rn(top, bot)) << (8 * (j & 3));
+        for (int j = 0; j < 16; j += 2) {
+            const uint32_t v0 = (gq[j >> 2] >> (8 * (j & 3))) & 0xffu, v1 = (gq[j >> 2] >> (8 * ((j + 1) & 3))) & 0xffu;
+            const uint32_t q0 = qrow[((cxbit >> j) & 1u) * kBins + v0], q1 = qrow[((cxbit >> (j + 1)) & 1u) * kBins + v1];
+            const f32x2 l11 = {(float)(q0 & 0xffu), (float)(q1 & 0xffu)};
+            const f32x2 l12 = {(float)((q0 >> 8) & 0xffu), (float)((q1 >> 8) & 0xffu)};
+            const f32x2 l21 = {(float)((q0 >> 16) & 0xffu), (float)((q1 >> 16) & 0xffu)};
+            const f32x2 l22 = {(float)(q0 >> 24), (float)(q1 >> 24)};
+            const f32x2 a = {xa[j], xa[j + 1]};
+            const f32x2 a1 = (f32x2){1.0f, 1.0f} - a;
+            const f32x2 top = (l11 * a1 + l12 * a) * (f32x2){ya1, ya1};
+            const f32x2 bot = (l21 * a1 + l22 * a) * (f32x2){ya, ya};
+            const f32x2 r = top + bot;
+            o[j >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(r.x, j & 3, o[j >> 2]);
+            o[j >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(r.y, (j + 1) & 3, o[j >> 2]);
         }
         *reinterpret_cast<uint4*>(dst + (long long)y * in.width + x0) = make_uint4(o[0], o[1], o[2], o[3]);
     }
