@@ -209,3 +209,41 @@ def test_extreme_aspect_frames_near_the_int16_coordinate_limit(det, shape):
         want = oracle.find_corners(frame, level)
         assert int(counts[0]) == len(want) and (level > 0 or len(want) > 0), (shape, level, len(want))
         assert np.array_equal(xy[0, :len(want)].cpu().numpy(), want), (shape, level)
+
+
+def test_randomised_size_sweep(det):
+    """Seeded sweep over awkward frame sizes, strides and content mixes: response (raw and clamped),
+    detection at levels 0..2 and the chain must equal the oracle for every case."""
+    rng = np.random.RandomState(20240917)
+    sizes = [(15, 15), (16, 16), (17, 31), (31, 17), (32, 47), (48, 48), (63, 65), (64, 64), (80, 33), (96, 100),
+             (127, 129), (128, 128), (130, 70), (160, 120), (255, 257), (256, 256), (272, 64), (288, 31), (300, 300),
+             (320, 240), (511, 40), (512, 64), (528, 48), (640, 39)]
+    for (w, h) in sizes:
+        kind = rng.randint(3)
+        if kind == 0 or min(w, h) < 64:
+            img = rng.randint(0, 256, size=(h, w)).astype(np.uint8)
+        elif kind == 1:
+            img = synth.noise_frame(w, h, int(rng.randint(1000)), smooth=1).numpy()
+        else:
+            img = synth.board_frame(w, h, 6, int(rng.randint(1000))).numpy()
+        pad = int(rng.choice([0, 1, 13, 16]))
+        buf = np.zeros((h, w + pad), dtype=np.uint8)
+        buf[:, :w] = img
+        d = torch.from_numpy(buf).cuda()[None, :, :w]                     # row stride w + pad
+        for clamp in (False, True):
+            got = det.chess_response(d, 0, clamp=clamp).cpu().numpy()[0]
+            want = oracle.chess_response_5(img, fill=0)
+            if clamp:
+                want = np.maximum(want, 0)
+            assert np.array_equal(got, want), (w, h, pad, clamp)
+        for level in (0, 1, 2):
+            xy, counts = det.detect(d, level, capacity=8192)
+            want = oracle.find_corners(img, level)
+            n = 0 if want is None else len(want)
+            assert int(counts[0]) == n, (w, h, pad, level)
+            if n:
+                assert np.array_equal(xy[0, :n].cpu().numpy(), want), (w, h, pad, level)
+        pts, lv, npts = det.chain(d, 2, 4096)
+        wp, wl = oracle.chain(img, 2)
+        n = int(npts[0])
+        assert n == len(wp) and np.array_equal(pts[0, :n].cpu().numpy(), wp) and np.array_equal(lv[0, :n].cpu().numpy(), wl), (w, h, pad)
