@@ -1,4 +1,4 @@
-"""Steady-state interleaved A/B of ChESS kernel variants: python tools/chess_ab.py a.so b.so[:seg] ...  (libraries built e.g. with scratch/build_variant2.sh)"""
+"""Steady-state interleaved A/B of ChESS kernel variants: python tools/chess_ab.py a.so b.so[:seg] ...  (libraries built e.g. with tools/build_variant.sh)"""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
