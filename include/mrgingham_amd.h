@@ -178,6 +178,12 @@ int mrgingham_amd_refine_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frame
 int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* frames, int start_level,
                               double* d_points, signed char* d_levels, int32_t* d_npoints, int points_pitch);
 
+/* The same preprocessing for one HOST image (out: dense width x height bytes, host): what the Python
+ * recipe of find_board.docstring:8-10 does with cv2 before find_board.  Uses the calling thread's
+ * context.  Returns 0, or -2 on an argument or device error. */
+int mrgingham_amd_preprocess_image(const uint8_t* image, int width, int height, int stride, int do_clahe,
+                                   int blur_radius, uint8_t* out);
+
 /* What one worker of the reference CLI does with one decoded 8-bit image
  * (mrgingham-from-image.cc:71-111, :160-171): [normalize + CLAHE(8)] -> box blur of
  * blur_radius -> find_chessboard_from_image_array(gridn, image_pyramid_level), with the

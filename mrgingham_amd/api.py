@@ -115,6 +115,24 @@ def find_grid_from_points(points_scaled, gridn=10):
     return out if ok else None
 
 
+def preprocess(image, clahe=True, blur_radius=1):
+    """The CLI's preprocessing of an 8-bit image on the GPU (mrgingham-from-image.cc:71-111; the cv2
+    recipe of find_board.docstring:8-10): normalize + CLAHE(8) when `clahe`, then a box blur of
+    `blur_radius` (0 = none).  -> uint8 [H, W]."""
+    _require_device()
+    image = _check_image(image, exact_2d=True)
+    H, W = image.shape
+    out = np.empty((H, W), dtype=np.uint8)
+    L = _lib.lib()
+    L.mrgingham_amd_preprocess_image.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_int, ctypes.c_void_p]
+    rc = L.mrgingham_amd_preprocess_image(image.ctypes.data, W, H, image.strides[0], int(bool(clahe)), int(blur_radius),
+                                          out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("mrgingham_amd: preprocessing failed (bad arguments or no device)")
+    return out
+
+
 def find_board(image, image_pyramid_level=-1, gridn=10, blobs=False, debug=False, debug_sequence=None):
     """The full detector: float64 (gridn*gridn, 2) board corners, or None (mrgingham_pywrap.c:227-337).
 

@@ -1075,6 +1075,25 @@ bool find_chessboard_from_image_array_C(int Nrows, int Ncols, int stride, char* 
     return (*add_points)(&board[0].x, gridn * gridn, cookie);  // bridge.cc:133-137
 }
 
+/* The preprocessing alone, host image in, host image out (dense width x height bytes): what the
+ * Python recipe in find_board.docstring:8-10 does with cv2 before calling find_board.  Returns 0, or
+ * -2 on an argument / device error. */
+int mrgingham_amd_preprocess_image(const uint8_t* image, int width, int height, int stride, int do_clahe,
+                                   int blur_radius, uint8_t* out) {
+    if (!image || !out || width <= 0 || height <= 0 || stride < width || blur_radius < 0) return -2;
+    mrgingham_amd_ctx* ctx = thread_ctx();
+    if (!ctx) return -2;
+    hipSetDevice(ctx->device);
+    mrgingham_amd_frames fr;
+    if (upload_frame(ctx, image, height, width, stride, &fr)) return -2;
+    if (ensure(ctx, ctx->pre_out, (size_t)width * height + 64)) return -2;
+    if (mrgingham_amd_preprocess_batch(ctx, &fr, do_clahe, blur_radius, (uint8_t*)ctx->pre_out.p, ctx->pix)) return -2;
+    if (hipMemcpyAsync(out, ctx->pre_out.p, (size_t)width * height, hipMemcpyDeviceToHost, ctx->pix) != hipSuccess ||
+        hipStreamSynchronize(ctx->pix) != hipSuccess)
+        return -2;
+    return 0;
+}
+
 /* What one worker of the reference CLI does with one decoded 8-bit image
  * (mrgingham-from-image.cc:71-111 and :160-171): [normalize + CLAHE] -> box blur ->
  * find_chessboard_from_image_array.  The frame is uploaded once; preprocessing, detector and

@@ -77,3 +77,23 @@ def test_preprocessed_frames_give_the_same_board():
     ref = mrgingham_amd.find_board(want_img, gridn=10)
     assert lv[0] >= 0 and ref is not None
     assert np.array_equal(np.asarray(pts[0]), ref)
+
+
+def test_host_image_preprocess_and_the_find_board_recipe():
+    """mrgingham_amd.preprocess (host image in / out) + find_board = the cv2 recipe of
+    find_board.docstring:8-10, and equals what the command-line tool does per image."""
+    import mrgingham_amd
+    from mrgingham_amd import synth
+    from oracle import oracle
+    frame = (synth.board_frame(800, 600, gridn=10, seed=9).numpy().astype(np.float64) * 0.55 + 35).astype(np.uint8)
+    wide = np.zeros((600, 832), np.uint8)
+    wide[:, :800] = frame
+    for clahe, blur in [(True, 1), (False, 2), (True, 0)]:
+        want = oracle.preprocess(frame, clahe=clahe, blur_radius=blur)
+        assert np.array_equal(mrgingham_amd.preprocess(frame, clahe=clahe, blur_radius=blur), want)
+        assert np.array_equal(mrgingham_amd.preprocess(wide[:, :800], clahe=clahe, blur_radius=blur), want)   # strided rows
+    pre = mrgingham_amd.preprocess(frame)
+    board = mrgingham_amd.find_board(pre, gridn=10)
+    assert board is not None and board.shape == (100, 2)
+    with pytest.raises(RuntimeError, match="8-bit"):
+        mrgingham_amd.preprocess(frame.astype(np.uint16))
