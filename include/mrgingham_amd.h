@@ -178,6 +178,16 @@ int mrgingham_amd_refine_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frame
 int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* frames, int start_level,
                               double* d_points, signed char* d_levels, int32_t* d_npoints, int points_pitch);
 
+/* C faces of find_chessboard_corners_from_image_file (find_chessboard_corners.hh:32-44, .cc:623-648)
+ * and find_chessboard_from_image_file (mrgingham.hh:77-83, mrgingham.cc:145-170): the image file is
+ * decoded (binary PGM or non-interlaced PNG; the reference uses cv::imread) and handed to the array
+ * functions above.  false when the file cannot be read or nothing is found. */
+bool find_chessboard_corners_from_image_file_C(const char* filename, int image_pyramid_level, bool debug,
+                                               bool (*add_points)(int* xy, int N, double scale, void* cookie),
+                                               void* cookie);
+bool find_chessboard_from_image_file_C(const char* filename, const int gridn, int image_pyramid_level, bool debug,
+                                       bool (*add_points)(double* xy, int N, void* cookie), void* cookie);
+
 /* The same preprocessing for one HOST image (out: dense width x height bytes, host): what the Python
  * recipe of find_board.docstring:8-10 does with cv2 before find_board.  Uses the calling thread's
  * context.  Returns 0, or -2 on an argument or device error. */

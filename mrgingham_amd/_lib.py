@@ -29,6 +29,7 @@ EXPORTS = [
     "mrgingham_amd_last_error", "mrgingham_amd_abi_version", "mrgingham_amd_device_count", "mrgingham_amd_level_dims",
     "mrgingham_amd_chess_response_batch", "mrgingham_amd_decimate_batch", "mrgingham_amd_box_blur_batch",
     "mrgingham_amd_preprocess_batch", "mrgingham_amd_process_image", "mrgingham_amd_preprocess_image",
+    "find_chessboard_corners_from_image_file_C", "find_chessboard_from_image_file_C",
     "mrgingham_amd_detect_batch", "mrgingham_amd_refine_batch", "mrgingham_amd_chain_batch",
     "mrgingham_amd_find_boards_batch",
     "mrgingham_amd_set_option", "mrgingham_amd_sync", "mrgingham_amd_stream_wait", "mrgingham_amd_set_kernel_timing",

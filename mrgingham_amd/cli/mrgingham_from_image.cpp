@@ -20,158 +20,18 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <zlib.h>
 
 #include <cmath>
 #include <string>
 #include <vector>
 
 #include "mrgingham_amd.h"
+#include "../csrc/image_io.h"
 
 namespace {
 
-struct Image {
-    int w = 0, h = 0, depth = 0;  // depth 8 or 16
-    std::vector<uint8_t> px8;
-    std::vector<uint16_t> px16;
-};
-
-bool read_file(const char* path, std::vector<uint8_t>& buf) {
-    FILE* f = fopen(path, "rb");
-    if (!f) return false;
-    fseek(f, 0, SEEK_END);
-    const long n = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    if (n <= 0) { fclose(f); return false; }
-    buf.resize((size_t)n);
-    const bool ok = fread(buf.data(), 1, (size_t)n, f) == (size_t)n;
-    fclose(f);
-    return ok;
-}
-
-bool decode_pgm(const std::vector<uint8_t>& b, Image& im) {
-    size_t p = 2;
-    auto next_int = [&](int& v) {
-        for (;;) {
-            while (p < b.size() && (b[p] == ' ' || b[p] == '\t' || b[p] == '\n' || b[p] == '\r')) ++p;
-            if (p < b.size() && b[p] == '#') { while (p < b.size() && b[p] != '\n') ++p; continue; }
-            break;
-        }
-        if (p >= b.size() || b[p] < '0' || b[p] > '9') return false;
-        long x = 0;
-        while (p < b.size() && b[p] >= '0' && b[p] <= '9') { x = x * 10 + (b[p] - '0'); if (x > 1 << 30) return false; ++p; }
-        v = (int)x;
-        return true;
-    };
-    int w, h, maxval;
-    if (!next_int(w) || !next_int(h) || !next_int(maxval)) return false;
-    if (p >= b.size()) return false;
-    ++p;  // the single whitespace after maxval
-    if (w <= 0 || h <= 0 || maxval <= 0 || maxval > 65535) return false;
-    const size_t n = (size_t)w * h;
-    im.w = w; im.h = h;
-    if (maxval < 256) {
-        if (b.size() - p < n) return false;
-        im.depth = 8;
-        im.px8.assign(b.begin() + p, b.begin() + p + n);
-    } else {
-        if (b.size() - p < 2 * n) return false;
-        im.depth = 16;
-        im.px16.resize(n);
-        for (size_t i = 0; i < n; ++i) im.px16[i] = (uint16_t)((b[p + 2 * i] << 8) | b[p + 2 * i + 1]);
-    }
-    return true;
-}
-
-inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | (p[1] << 16) | (p[2] << 8) | p[3]; }
-
-bool decode_png(const std::vector<uint8_t>& b, Image& im) {
-    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
-    if (b.size() < 8 + 25 || memcmp(b.data(), sig, 8)) return false;
-    size_t p = 8;
-    int w = 0, h = 0, bits = 0, ctype = -1, interlace = 0;
-    std::vector<uint8_t> idat, plte;
-    while (p + 12 <= b.size()) {
-        const uint32_t len = be32(&b[p]);
-        const char* type = (const char*)&b[p + 4];
-        if (p + 12 + (size_t)len > b.size()) return false;
-        const uint8_t* d = &b[p + 8];
-        if (!memcmp(type, "IHDR", 4) && len >= 13) {
-            w = (int)be32(d); h = (int)be32(d + 4); bits = d[8]; ctype = d[9]; interlace = d[12];
-        } else if (!memcmp(type, "PLTE", 4)) plte.assign(d, d + len);
-        else if (!memcmp(type, "IDAT", 4)) idat.insert(idat.end(), d, d + len);
-        else if (!memcmp(type, "IEND", 4)) break;
-        p += 12 + (size_t)len;
-    }
-    if (w <= 0 || h <= 0 || interlace != 0 || (bits != 8 && bits != 16)) return false;
-    int ch;
-    switch (ctype) {
-        case 0: ch = 1; break;
-        case 2: ch = 3; break;
-        case 3: ch = 1; if (bits != 8) return false; break;
-        case 4: ch = 2; break;
-        case 6: ch = 4; break;
-        default: return false;
-    }
-    const size_t bpp = (size_t)ch * bits / 8, rowb = (size_t)w * bpp;
-    std::vector<uint8_t> raw((rowb + 1) * (size_t)h);
-    uLongf rawlen = (uLongf)raw.size();
-    if (uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size()) return false;
-    std::vector<uint8_t> img(rowb * (size_t)h);
-    for (int y = 0; y < h; ++y) {
-        const uint8_t ft = raw[(rowb + 1) * y];
-        const uint8_t* s = &raw[(rowb + 1) * y + 1];
-        uint8_t* o = &img[rowb * y];
-        const uint8_t* up = y ? o - rowb : nullptr;
-        for (size_t i = 0; i < rowb; ++i) {
-            const int a = i >= bpp ? o[i - bpp] : 0, bb = up ? up[i] : 0, c = (up && i >= bpp) ? up[i - bpp] : 0;
-            int pred = 0;
-            switch (ft) {
-                case 0: pred = 0; break;
-                case 1: pred = a; break;
-                case 2: pred = bb; break;
-                case 3: pred = (a + bb) >> 1; break;
-                case 4: {
-                    const int pa = abs(bb - c), pb = abs(a - c), pc = abs(a + bb - 2 * c);
-                    pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? bb : c);
-                    break;
-                }
-                default: return false;
-            }
-            o[i] = (uint8_t)(s[i] + pred);
-        }
-    }
-    const size_t n = (size_t)w * h;
-    im.w = w; im.h = h; im.depth = bits;
-    auto grey = [](uint32_t r, uint32_t g, uint32_t bl) { return (r * 4899u + g * 9617u + bl * 1868u + 8192u) >> 14; };
-    if (bits == 8) {
-        im.px8.resize(n);
-        for (size_t i = 0; i < n; ++i) {
-            const uint8_t* q = &img[i * bpp];
-            if (ctype == 0 || ctype == 4) im.px8[i] = q[0];
-            else if (ctype == 3) {
-                if ((size_t)q[0] * 3 + 2 >= plte.size()) return false;
-                im.px8[i] = (uint8_t)grey(plte[q[0] * 3], plte[q[0] * 3 + 1], plte[q[0] * 3 + 2]);
-            } else im.px8[i] = (uint8_t)grey(q[0], q[1], q[2]);
-        }
-    } else {
-        im.px16.resize(n);
-        for (size_t i = 0; i < n; ++i) {
-            const uint8_t* q = &img[i * bpp];
-            auto s16 = [&](int k) { return (uint32_t)((q[2 * k] << 8) | q[2 * k + 1]); };
-            im.px16[i] = (uint16_t)((ctype == 0 || ctype == 4) ? s16(0) : grey(s16(0), s16(1), s16(2)));
-        }
-    }
-    return true;
-}
-
-bool read_image(const char* path, Image& im) {
-    std::vector<uint8_t> b;
-    if (!read_file(path, b) || b.size() < 8) return false;
-    if (b[0] == 'P' && b[1] == '5') return decode_pgm(b, im);
-    if (b[0] == 0x89 && b[1] == 'P') return decode_png(b, im);
-    return false;
-}
+using mrg::Image;
+using mrg::read_image;
 
 struct Options {
     glob_t globbed;
@@ -228,11 +88,7 @@ void* worker(void* arg) {
                 break;
             }
             // image0.convertTo(image1, CV_8U, 255./65535.), mrgingham-from-image.cc:91
-            tmp8.resize(im.px16.size());
-            for (size_t k = 0; k < tmp8.size(); ++k) {
-                const long r = lrint((double)im.px16[k] * (255. / 65535.));
-                tmp8[k] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
-            }
+            mrg::to_8bit(im, tmp8);
             px = tmp8.data();
         }
         const int level = mrgingham_amd_process_image(px, im.w, im.h, im.w, opt.doclahe, opt.blur_radius, opt.gridn,

@@ -18,6 +18,7 @@
 #include "../../include/mrgingham_amd.h"
 #include "common.h"
 #include "grid.h"
+#include "image_io.h"
 #include "kernels.h"
 
 namespace mrg {
@@ -1073,6 +1074,47 @@ bool find_chessboard_from_image_array_C(int Nrows, int Ncols, int stride, char* 
     if (find_board_on_device(ctx, __func__, &fr, gridn, image_pyramid_level, true, board, lv) < 0) return false;
     static_assert(sizeof(PointD) == 2 * sizeof(double), "add_points() takes interleaved doubles");
     return (*add_points)(&board[0].x, gridn * gridn, cookie);  // bridge.cc:133-137
+}
+
+/* The reference's file entry points: find_chessboard_corners_from_image_file
+ * (find_chessboard_corners.cc:623-648) and find_chessboard_from_image_file (mrgingham.cc:145-170) are
+ * cv::imread(GRAYSCALE) followed by the array functions.  Here the file is decoded by csrc/image_io
+ * (binary PGM, non-interlaced PNG; 16-bit samples are reduced to 8 bit) -- same results as the array
+ * functions on the decoded pixels, same "Couldn't open image" failure. */
+static bool load_gray8(const char* who, const char* filename, mrg::Image& im, std::vector<uint8_t>& tmp,
+                       const uint8_t** px) {
+    if (!filename || !mrg::read_image(filename, im)) {
+        fprintf(stderr, "mrgingham_amd: %s(): Couldn't open image '%s'. Sorry.\n", who, filename ? filename : "(null)");
+        return false;
+    }
+    if (im.depth == 16) {
+        mrg::to_8bit(im, tmp);
+        *px = tmp.data();
+    } else {
+        *px = im.px8.data();
+    }
+    return true;
+}
+
+bool find_chessboard_corners_from_image_file_C(const char* filename, int image_pyramid_level, bool debug,
+                                               bool (*add_points)(int* xy, int N, double scale, void* cookie),
+                                               void* cookie) {
+    mrg::Image im;
+    std::vector<uint8_t> tmp;
+    const uint8_t* px = nullptr;
+    if (!load_gray8(__func__, filename, im, tmp, &px)) return false;
+    return find_chessboard_corners_from_image_array_C(im.h, im.w, im.w, (char*)px, image_pyramid_level, false, debug,
+                                                      add_points, cookie);
+}
+
+bool find_chessboard_from_image_file_C(const char* filename, const int gridn, int image_pyramid_level, bool debug,
+                                       bool (*add_points)(double* xy, int N, void* cookie), void* cookie) {
+    mrg::Image im;
+    std::vector<uint8_t> tmp;
+    const uint8_t* px = nullptr;
+    if (!load_gray8(__func__, filename, im, tmp, &px)) return false;
+    return find_chessboard_from_image_array_C(im.h, im.w, im.w, (char*)px, gridn, image_pyramid_level, false, debug, -1,
+                                              -1, add_points, cookie);
 }
 
 /* The preprocessing alone, host image in, host image out (dense width x height bytes): what the

@@ -1,0 +1,24 @@
+// Image decoding for the file-based entry points and the command-line tool (the reference uses
+// cv::imread; OpenCV is not available to this build): binary PGM (P5, 8 or 16 bit) and
+// non-interlaced PNG (8 or 16 bit; grey, grey+alpha, RGB, RGBA, 8-bit palette) via zlib.  Colour is
+// reduced to grey with the fixed-point BT.601 weights (4899 R + 9617 G + 1868 B + 8192) >> 14;
+// byte-identity with cv::imread on colour files is not claimed (its conversion depends on the codec
+// build).
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+namespace mrg {
+
+struct Image {
+    int w = 0, h = 0, depth = 0;  // depth 8 or 16
+    std::vector<uint8_t> px8;
+    std::vector<uint16_t> px16;
+};
+
+bool read_image(const char* path, Image& im);
+// 16 -> 8 bit the way the reference CLI does it: convertTo(CV_8U, 255./65535.) (mrgingham-from-image.cc:91)
+void to_8bit(const Image& im, std::vector<uint8_t>& out);
+
+}  // namespace mrg

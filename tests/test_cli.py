@@ -183,3 +183,34 @@ def test_cli_rgb_png_16bit_pgm_and_unreadable_file(tmp_path):
     assert r.returncode == 0 and "Couldn't open image" in r.stderr
     got = _parse(r.stdout)
     assert got[p_bad] == [None] and p_rgb not in got
+
+
+@pytest.mark.gpu
+def test_file_entry_points_match_the_array_functions(tmp_path):
+    """find_chessboard_corners_from_image_file / find_chessboard_from_image_file (find_chessboard_corners.cc:623-648,
+    mrgingham.cc:145-170) = decode the file + the array function."""
+    import ctypes
+    import mrgingham_amd
+    from mrgingham_amd import synth, _lib
+    L = _lib.lib()
+    img = synth.board_frame(800, 600, 10, 4).numpy()
+    p_pgm, p_png = str(tmp_path / "f.pgm"), str(tmp_path / "f.png")
+    _write_pgm(p_pgm, img)
+    _write_png(p_png, img)
+    ADD_I = ctypes.CFUNCTYPE(ctypes.c_bool, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_double, ctypes.c_void_p)
+    ADD_D = ctypes.CFUNCTYPE(ctypes.c_bool, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_void_p)
+    L.find_chessboard_corners_from_image_file_C.restype = ctypes.c_bool
+    L.find_chessboard_corners_from_image_file_C.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_bool, ADD_I, ctypes.c_void_p]
+    L.find_chessboard_from_image_file_C.restype = ctypes.c_bool
+    L.find_chessboard_from_image_file_C.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_bool, ADD_D, ctypes.c_void_p]
+    for path in (p_pgm, p_png):
+        got = []
+        cb = ADD_I(lambda xy, n, scale, _: got.append(np.ctypeslib.as_array(xy, (2 * n,)).reshape(n, 2).copy() * scale) or True)
+        assert L.find_chessboard_corners_from_image_file_C(path.encode(), 1, False, cb, None)
+        assert np.array_equal(got[0], mrgingham_amd.find_points(img, image_pyramid_level=1))
+        board = []
+        cbd = ADD_D(lambda xy, n, _: board.append(np.ctypeslib.as_array(xy, (2 * n,)).reshape(n, 2).copy()) or True)
+        assert L.find_chessboard_from_image_file_C(path.encode(), 10, -1, False, cbd, None)
+        assert np.array_equal(board[0], mrgingham_amd.find_board(img, gridn=10))
+    nothing = ADD_I(lambda *a: True)
+    assert not L.find_chessboard_corners_from_image_file_C(str(tmp_path / "missing.pgm").encode(), 0, False, nothing, None)
