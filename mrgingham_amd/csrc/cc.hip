@@ -116,13 +116,15 @@ __device__ __forceinline__ FrameView make_view(const LevelBatch& lb, const CompT
     return v;
 }
 
-// P1 and P2 are their own kernels, one 1024-thread workgroup per frame (so that workgroup-scope
+// P1 and P2 are one kernel of their own, one 1024-thread workgroup per frame (so that workgroup-scope
 // atomics suffice, see above): at full resolution a noisy frame has tens of thousands of hot
 // pixels, nearly all of them isolated, which P1 flags so that P2 skips them.
 constexpr int CCL_THREADS = 1024;
 constexpr int kSingletonFlag = 0x40000000;  // in hot_pix[]: the pixel has no hot 4-neighbour
-// P1: union-find over the hot list (left / up neighbours).
-__global__ __launch_bounds__(CCL_THREADS) void cc_union_kernel(LevelBatch lb, CompTables t, int frame0) {
+// P1: union-find over the hot list (left / up neighbours); P2: flatten (parent[i] = root of i),
+// per-root pixel count, bounding box and smallest raster index.  One kernel, one workgroup per
+// frame, a workgroup barrier between the phases.
+__global__ __launch_bounds__(CCL_THREADS) void cc_label_kernel(LevelBatch lb, CompTables t, int frame0) {
     const int frame = frame0 + blockIdx.y;
     if (t.hot_cnt[frame] > t.cap) return;  // overflow is reported by the per-frame kernel
     const FrameView v = make_view(lb, t, frame);
@@ -138,14 +140,7 @@ __global__ __launch_bounds__(CCL_THREADS) void cc_union_kernel(LevelBatch lb, Co
         // not spend five atomics on it (at full resolution most hot pixels are isolated noise).
         if (!(l || u || r || dn)) v.hot_pix[i] = p | kSingletonFlag;
     }
-}
-
-// P2: flatten (parent[i] = root of i); per-root pixel count and bounding box.
-__global__ __launch_bounds__(CCL_THREADS) void cc_flatten_kernel(LevelBatch lb, CompTables t, int frame0) {
-    const int frame = frame0 + blockIdx.y;
-    if (t.hot_cnt[frame] > t.cap) return;
-    const FrameView v = make_view(lb, t, frame);
-    const int w = v.w;
+    __syncthreads();  // every union of the frame is done (the tables are only touched by this workgroup)
     for (int i = threadIdx.x; i < v.n; i += CCL_THREADS) {
         const int p = v.hot_pix[i];
         if (p & kSingletonFlag) continue;  // its own root, count 0: never a blob, never shared
@@ -166,8 +161,7 @@ __global__ __launch_bounds__(CCL_THREADS) void cc_flatten_kernel(LevelBatch lb, 
 void launch_cc_label(const LevelBatch& lb, const CompTables& t, int frame0, int nframes, hipStream_t s) {
     if (nframes <= 0) return;
     const dim3 grid(1, nframes);
-    hipLaunchKernelGGL(cc_union_kernel, grid, dim3(CCL_THREADS), 0, s, lb, t, frame0);
-    hipLaunchKernelGGL(cc_flatten_kernel, grid, dim3(CCL_THREADS), 0, s, lb, t, frame0);
+    hipLaunchKernelGGL(cc_label_kernel, grid, dim3(CCL_THREADS), 0, s, lb, t, frame0);
 }
 
 struct Blob {
