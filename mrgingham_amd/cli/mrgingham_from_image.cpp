@@ -175,6 +175,9 @@ int main(int argc, char* argv[]) {
         fprintf(stderr, "When debugging, pass one image at a time. Got %d instead\n", (int)opt.globbed.gl_pathc);
         return 1;
     }
+    // every worker's context overlaps three HIP streams; HIP maps streams onto GPU_MAX_HW_QUEUES
+    // hardware queues (default 4) and streams that share one serialise (must be set before HIP starts)
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     if (mrgingham_amd_device_count() <= 0) {
         fprintf(stderr, "mrgingham-amd-from-image: no HIP device: this tool has no CPU path\n");
         return 2;
