@@ -66,9 +66,9 @@ void* worker(void* arg) {
     std::vector<double> xy((size_t)N * 2);
     std::vector<signed char> lv((size_t)N);
     std::vector<uint8_t> tmp8;
+    Image im;  // reused: its buffers keep their pages from image to image
     for (int i = ijob; i < (int)opt.globbed.gl_pathc; i += opt.jobs) {
         const char* filename = opt.globbed.gl_pathv[i];
-        Image im;
         if (!read_image(filename, im)) {  // mrgingham-from-image.cc:58-68
             fprintf(stderr, "Couldn't open image '%s'\n", filename);
             flockfile(stdout);

@@ -140,7 +140,7 @@ static bool decode_png(const std::vector<uint8_t>& b, Image& im) {
 }
 
 bool read_image(const char* path, Image& im) {
-    std::vector<uint8_t> b;
+    std::vector<uint8_t>& b = im.file;
     if (!read_file(path, b) || b.size() < 8) return false;
     if (b[0] == 'P' && b[1] == '5') return decode_pgm(b, im);
     if (b[0] == 0x89 && b[1] == 'P') return decode_png(b, im);

@@ -15,6 +15,7 @@ struct Image {
     int w = 0, h = 0, depth = 0;  // depth 8 or 16
     std::vector<uint8_t> px8;
     std::vector<uint16_t> px16;
+    std::vector<uint8_t> file;  // the undecoded file; an Image that is reused keeps its buffers (and their warm pages)
 };
 
 bool read_image(const char* path, Image& im);
