@@ -222,3 +222,42 @@ def test_refine_rules():
     p4, lv4, n4 = oracle.cc_refine_on_response(np.array([[20.0, 20.0], [20.0, 20.0]]), np.array([1, 1], np.int8),
                                                d, img, 0)
     assert n4 == 1 and lv4.tolist() == [0, 1]
+
+
+# ----------------------------------------------------------------------------- preprocessing (row (f)-2)
+
+def test_oracle_normalize_and_clahe_properties():
+    """Hand-derived properties of the restated cv::normalize / CLAHE arithmetic (parity unpinned:
+    OpenCV is absent, see the oracle's header)."""
+    from oracle import oracle
+    rng = np.random.RandomState(3)
+    img = (rng.rand(96, 128) * 100 + 50).astype(np.uint8)
+    n = oracle.normalize_minmax(img)
+    assert n.min() == 0 and n.max() == 255                       # NORM_MINMAX to [0, 255]
+    lo, hi = int(img.min()), int(img.max())
+    scale = 255.0 / (hi - lo)
+    want = np.clip(np.rint(np.float32(img.astype(np.float32) * np.float32(scale)) + np.float32(-lo * scale)), 0, 255)
+    assert np.array_equal(n, want.astype(np.uint8))              # float multiply, float add, round half even
+    order = np.argsort(img.ravel(), kind="stable")
+    assert (np.diff(n.ravel()[order].astype(int)) >= 0).all()      # a per-frame value map: monotone
+    flat = np.full((64, 64), 91, np.uint8)
+    assert (oracle.normalize_minmax(flat) == 0).all()            # max == min: scale 0, everything maps to dmin
+    # CLAHE of a constant 64x64 frame (tiles of 8x8 = 64 pixels, clip = int(8*64/256) = 2): bin 91 is
+    # clipped to 2, the 62 clipped pixels go one each to bins 0, 4, ..., 244 (step 256/62 = 4), so the
+    # cumulative count at 91 is 23 + 2 = 25 and the LUT value round(25 * 255/64) = 100
+    c = oracle.clahe(flat)
+    assert (c == 100).all()
+    # every tile with the same content (a 32-column ramp per 32-column tile): all 64 LUTs are equal, the
+    # blend returns LUT[v], and a LUT is a cumulative histogram -- monotone in v, identical in every tile
+    ramp = np.tile((np.arange(32) * 8).astype(np.uint8), (64, 8))
+    out = oracle.clahe(ramp)
+    assert (np.diff(out[0, :32].astype(int)) >= 0).all() and out[0, 31] == 255
+    assert all(np.array_equal(out[:, :32], out[:, 32 * k:32 * k + 32]) for k in range(8))
+    # ragged size: both axes are padded as soon as one of them does not divide into 8 tiles
+    odd = (rng.rand(61, 64) * 255).astype(np.uint8)
+    assert oracle.clahe(odd).shape == (61, 64)
+    # blur of a constant frame is the constant; preprocess composes the three steps
+    assert (oracle.box_blur(flat, 2) == 91).all()
+    p = oracle.preprocess(img, clahe=True, blur_radius=1)
+    assert np.array_equal(p, oracle.box_blur(oracle.clahe(oracle.normalize_minmax(img)), 1))
+    assert np.array_equal(oracle.preprocess(img, clahe=False, blur_radius=0), img)
