@@ -11,5 +11,5 @@ EXTRA=""; [ "$NAME" = chess ] && EXTRA="-mllvm -amdgpu-sched-strategy=max-ilp"
 rm -f $R/mrgingham_amd/csrc/_variant_$NAME.hip
 OBJS=""
 for n in chess decimate preprocess cc api; do if [ $n = $NAME ]; then OBJS="$OBJS /tmp/_variant_$NAME.o"; else OBJS="$OBJS $B/$n.o"; fi; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJS $B/grid.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJS $B/grid.o $B/image_io.o -lz
 echo built $OUT
