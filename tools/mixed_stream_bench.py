@@ -1,0 +1,97 @@
+"""BASELINE config 5 end to end: a mixed-resolution stream (1 MP .. 12 MP) with per-frame adaptive pyramid
+depth, balanced over the ranks with the LPT plan, boards gathered to rank 0.
+
+  python tools/mixed_stream_bench.py [--frames 200]                      # one GPU
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+         --master-port P tools/mixed_stream_bench.py --frames 1600       # N GPUs, one process each
+
+Every rank computes the same plan without communicating (parallel.plan_mixed_stream), renders its own
+frames, runs mrgingham_amd_find_boards_batch once per resolution it was assigned, and sends
+(frame index, found level, board) records to rank 0 in one gather.  Prints ONE JSON line on rank 0."""
+import argparse, json, os, random, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import torch.distributed as dist
+
+RES = [(1280, 800), (1920, 1080), (2560, 1440), (4096, 2160), (4096, 3072)]   # SURVEY.md 8d, all divisible by 8
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=200)
+    ap.add_argument("--gridn", type=int, default=10)
+    ap.add_argument("--repeat", type=int, default=3)
+    args = ap.parse_args()
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    import mrgingham_amd
+    from mrgingham_amd import parallel, synth
+    rnd = random.Random(5)
+    sizes = [RES[rnd.randrange(len(RES))] for _ in range(args.frames)]
+    mine = parallel.plan_mixed_stream(sizes, world, rank)                  # {(w, h): [frame indices]}
+    det = mrgingham_amd.Detector(local)
+    N = args.gridn * args.gridn
+    batches = {}
+    for (w, h), idx in mine.items():
+        batches[(w, h)] = (idx, torch.stack([synth.board_frame(w, h, args.gridn, seed=i, device=dev) for i in idx]))
+    torch.cuda.synchronize()
+
+    def run_once():
+        recs = []
+        for (w, h), (idx, frames) in batches.items():
+            for lo in range(0, len(idx), 64):                              # sub-batches of at most 64 frames
+                boards, found = det.find_boards(frames[lo:lo + 64], gridn=args.gridn)
+                for k, f in enumerate(idx[lo:lo + 64]):
+                    recs.append((f, int(found[k]), boards[k]))
+        return recs
+
+    run_once()                                                             # warm-up (allocations)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.repeat):
+        recs = run_once()
+        # one gather of fixed-size records: [frame, level, 2N coordinates]
+        mine_n = len(recs)
+        pack = torch.full((args.frames, 2 + 2 * N), -1.0, dtype=torch.float64, device=dev)
+        if mine_n:
+            arr = np.array([[f, lv] + list(np.nan_to_num(b, nan=-1.0).ravel()) for f, lv, b in recs])
+            pack[:mine_n] = torch.from_numpy(arr).to(dev)
+        if world > 1:
+            bufs = [torch.empty_like(pack) for _ in range(world)] if rank == 0 else None
+            dist.gather(pack, bufs, dst=0)
+        else:
+            bufs = [pack]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = (time.perf_counter() - t0) / args.repeat
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        allrec = torch.cat(bufs).cpu().numpy()
+        allrec = allrec[allrec[:, 0] >= 0]
+        levels = allrec[:, 1].astype(int)
+        mpx = sum(w * h for w, h in sizes) / 1e6
+        loads = [sum(parallel.frame_cost(*sizes[i]) for i in p) for p in parallel.lpt_assign([parallel.frame_cost(w, h) for w, h in sizes], world)]
+        print(json.dumps({"metric": "frames/sec, mixed-resolution stream, full detector with adaptive pyramid depth", "value": args.frames / dt,
+                          "unit": "frames/s", "n_gpus": world, "frames": args.frames, "megapixels": mpx, "seconds_per_pass": dt,
+                          "records_on_rank0": int(len(allrec)), "found_at_level": np.bincount(levels[levels >= 0], minlength=4).tolist(),
+                          "not_found": int((levels < 0).sum()), "lpt_imbalance": max(loads) / (sum(loads) / world)}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
