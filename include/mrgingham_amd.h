@@ -178,6 +178,25 @@ int mrgingham_amd_refine_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frame
 int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* frames, int start_level,
                               double* d_points, signed char* d_levels, int32_t* d_npoints, int points_pitch);
 
+/* The connected-component stage ALONE, on caller-supplied responses: what
+ * process_connected_components (find_chessboard_corners.cc:284-397) does with the buffer the
+ * reference hands it, for the rule tests (running-maximum order dependence, thresholds 15 / 120,
+ * N >= 2, margin columns, variance window, response mutation between refined points) that a natural
+ * image only meets by chance.  d_response: nframes dense w x h int16 images (device), used the way
+ * the reference's buffer arrives there: negatives count as 0 (:527-529) and everything outside
+ * [7,w-7) x [7,h-7) as 0 (:506; the ChESS pass never writes there) -- the input is not modified.
+ * d_level_image: nframes dense w x h byte images, the image the variance test reads (:50-88).
+ * `level` only scales the output coordinates (:319, :346, :369, :390).  Exactly one mode:
+ *   detect  d_xy / capacity_per_frame / d_counts as mrgingham_amd_detect_batch, d_points NULL;
+ *   refine  d_points / d_levels / d_npoints / points_pitch / d_nrefined as
+ *           mrgingham_amd_refine_batch, d_xy NULL.
+ * Asynchronous like the other batch calls. */
+int mrgingham_amd_cc_on_response_batch(mrgingham_amd_ctx* ctx, const int16_t* d_response,
+                                       const uint8_t* d_level_image, int nframes, int w, int h, int level,
+                                       int32_t* d_xy, int capacity_per_frame, int32_t* d_counts,
+                                       double* d_points, signed char* d_levels, const int32_t* d_npoints,
+                                       int points_pitch, int32_t* d_nrefined);
+
 /* C faces of find_chessboard_corners_from_image_file (find_chessboard_corners.hh:32-44, .cc:623-648)
  * and find_chessboard_from_image_file (mrgingham.hh:77-83, mrgingham.cc:145-170): the image file is
  * decoded (binary PGM or non-interlaced PNG; the reference uses cv::imread) and handed to the array
@@ -215,6 +234,9 @@ int mrgingham_amd_process_image(const uint8_t* image, int width, int height, int
 int mrgingham_amd_find_boards_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* frames, int gridn,
                                     int image_pyramid_level, double* h_boards, signed char* h_found_level,
                                     int nthreads);
+
+/* Device memory the context currently holds (level scratch of both sets, point scratch, staging). */
+long long mrgingham_amd_scratch_bytes(const mrgingham_amd_ctx* ctx);
 
 /* Tunables outside the reference's surface.  Known names:
  *   "hot_capacity_shift"  per-frame capacity of the hot-pixel / component tables is

@@ -305,6 +305,41 @@ class Detector:
             self.sync()
         return pts, lv, npts
 
+    def cc_detect_on_response(self, resp, level_images, level=0, capacity=4096, sync=True):
+        """The component search alone on caller-built responses (int16 [B,h,w], device) and level
+        images (uint8 [B,h,w]): -> (xy int32 [B,capacity,2], counts int32 [B]).  For the rule tests."""
+        t = self.torch
+        assert resp.dtype == t.int16 and resp.is_cuda and resp.is_contiguous() and resp.dim() == 3
+        assert level_images.dtype == t.uint8 and level_images.is_contiguous() and level_images.shape == resp.shape
+        B, h, w = resp.shape
+        xy = t.empty((B, capacity, 2), dtype=t.int32, device=resp.device)
+        counts = t.empty((B,), dtype=t.int32, device=resp.device)
+        t.cuda.current_stream(resp.device).synchronize()
+        self._check(self.L.mrgingham_amd_cc_on_response_batch(self.ctx, resp.data_ptr(), level_images.data_ptr(), B, w,
+                                                              h, level, xy.data_ptr(), capacity, counts.data_ptr(),
+                                                              None, None, None, 0, None))
+        if sync:
+            self.sync()
+        return xy, counts
+
+    def cc_refine_on_response(self, resp, level_images, level, points, levels, npoints, sync=True):
+        """In-place refinement of points f64 [B,P,2] / levels int8 [B,P] / npoints int32 [B] against
+        caller-built responses; -> nrefined int32 [B]."""
+        t = self.torch
+        assert resp.dtype == t.int16 and resp.is_cuda and resp.is_contiguous() and resp.dim() == 3
+        assert level_images.dtype == t.uint8 and level_images.is_contiguous() and level_images.shape == resp.shape
+        assert points.dtype == t.float64 and points.is_contiguous() and levels.dtype == t.int8
+        B, h, w = resp.shape
+        nref = t.empty((B,), dtype=t.int32, device=resp.device)
+        t.cuda.current_stream(resp.device).synchronize()
+        self._check(self.L.mrgingham_amd_cc_on_response_batch(self.ctx, resp.data_ptr(), level_images.data_ptr(), B, w,
+                                                              h, level, None, 0, None, points.data_ptr(),
+                                                              levels.data_ptr(), npoints.data_ptr(), points.shape[1],
+                                                              nref.data_ptr()))
+        if sync:
+            self.sync()
+        return nref
+
     def find_boards(self, frames, gridn=10, image_pyramid_level=-1, nthreads=0):
         """Full detector over a batch: -> (boards float64 [B, gridn*gridn, 2] (numpy, host),
         found_level int8 [B], -1 where no board was found).  Synchronous."""
@@ -317,6 +352,10 @@ class Detector:
                                                            int(image_pyramid_level), boards.ctypes.data,
                                                            found.ctypes.data, int(nthreads)))
         return boards, found
+
+    def scratch_bytes(self):
+        """Device memory the context holds right now."""
+        return int(self.L.mrgingham_amd_scratch_bytes(self.ctx))
 
     def set_kernel_timing(self, enable):
         self.L.mrgingham_amd_set_kernel_timing(self.ctx, int(enable))

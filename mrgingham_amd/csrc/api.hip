@@ -36,7 +36,7 @@ struct DevBuf {
 struct LevelScratch {
     int w = 0, h = 0, nframes = 0, cap = 0, cand_cap = 0, sort_cap = 0, pitch = 0, shift = -1;
     long long arena_cap = 0;
-    DevBuf img, resp, lidx, hot_pix, parent, comp_cnt, roots, comp_first, comp_box, arena, cand, sortkeys;
+    DevBuf img, resp, gidx, hot_xy, parent, comp_cnt, roots, comp_first, comp_box, arena, cand, sortkeys;
 };
 
 }  // namespace mrg
@@ -121,6 +121,10 @@ struct mrgingham_amd_ctx {
     // levels 3..1 of a chain in one launch (set_option "multi_level_launch"): +1.5 % chain rate, but the
     // component chains then start later and overlap the level-0 launch more (+5 % on that launch): off
     bool multi_level = false;
+    // component-chain schedule of chain_batch: 0 = every level's component kernels start as soon as
+    // that level's response is done; 1 = levels 1 and 0 wait for the level-0 response (they then run
+    // underneath the NEXT call's pyramid and small levels instead of underneath this call's level 0)
+    int cc_schedule = 0;
 
     mrg::LevelScratch lvs[2][mrg::kMaxLevel + 1];
     mrg::DevBuf counters2[2];  // per scratch set: hot_cnt words [level][counters_nf], then status words [level][counters_nf]
@@ -213,16 +217,21 @@ static int ensure_level_set(mrgingham_amd_ctx* ctx, int set, int level, int nfra
     if (cap < 4096) cap = 4096;
     if (cap > px) cap = px > 0 ? px : 1;
     if (cap > 0x3fffffff) return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "frame too large");
-    long long cand_cap = cap / 2 + 1;
+    // Components that pass the size / peak / margin tests: at most cap / 2 (two pixels each).  Tables of
+    // that size are only allocated at shift 0 (the "one entry per pixel" retry of the reference-symbol
+    // wrappers); otherwise a fraction, with overflow reported like a hot-list overflow.
+    long long cand_cap = ctx->cap_shift == 0 ? cap / 2 + 1 : cap / 16 + 1024;
     if (cand_cap < pitch) cand_cap = pitch;
     long long sort_cap = 1;
     while (sort_cap < cand_cap) sort_cap <<= 1;
-    const long long arena_cap = 5 * cap + 16LL * (pitch > 1024 ? pitch : 1024);
+    // LIFO arena: a super-component of n hot pixels gets 4n + 1 words (every pixel is pushed at most
+    // once per neighbour), so 5 * cap bounds a frame.  Same policy as the candidate table.
+    const long long arena_cap = (ctx->cap_shift == 0 ? 5 * cap : cap + cap / 4) + 16LL * (pitch > 1024 ? pitch : 1024);
     const size_t nf = (size_t)nframes;
     int rc = 0;
     if (level > 0 && (rc = ensure(ctx, L.img, nf * (size_t)px + 16))) return rc;
     if ((rc = ensure(ctx, L.resp, nf * (size_t)px * 2 + 16))) return rc;
-    if ((rc = ensure(ctx, L.lidx, nf * (size_t)px * 4 + 16))) return rc;
+    if ((rc = ensure(ctx, L.gidx, nf * (size_t)((w + 7) / 8) * h * 8 + 16))) return rc;
     if (nframes > ctx->counters_nf) {
         MRG_HIP_CHECK(hipDeviceSynchronize());
         const int cnf = nframes + nframes / 8 + 8;
@@ -232,7 +241,7 @@ static int ensure_level_set(mrgingham_amd_ctx* ctx, int set, int level, int nfra
         }
         ctx->counters_nf = cnf;
     }
-    if ((rc = ensure(ctx, L.hot_pix, nf * (size_t)cap * 4))) return rc;
+    if ((rc = ensure(ctx, L.hot_xy, nf * (size_t)cap * 4))) return rc;
     if ((rc = ensure(ctx, L.parent, nf * (size_t)cap * 4))) return rc;
     if ((rc = ensure(ctx, L.comp_cnt, nf * (size_t)cap * 4))) return rc;
     if ((rc = ensure(ctx, L.roots, nf * (size_t)cap * 4))) return rc;
@@ -286,14 +295,15 @@ static CompTables tables_of(mrgingham_amd_ctx* ctx, int level) {
     CompTables t;
     t.cap = L.cap;
     t.hot_cnt = hot_cnt_of(ctx, level);
-    t.hot_pix = (int32_t*)L.hot_pix.p;
+    t.hot_xy = (uint32_t*)L.hot_xy.p;
     t.parent = (int32_t*)L.parent.p;
     t.comp_cnt = (int32_t*)L.comp_cnt.p;
     t.comp_box = (int4*)L.comp_box.p;
     t.roots = (int32_t*)L.roots.p;
     t.comp_first = (int32_t*)L.comp_first.p;
-    t.lidx = (int32_t*)L.lidx.p;
-    t.lidx_pitch = (long long)L.w * L.h;
+    t.gidx = (uint2*)L.gidx.p;
+    t.gw = (L.w + 7) / 8;
+    t.gidx_pitch = (long long)t.gw * L.h;
     t.arena = (uint32_t*)L.arena.p;
     t.arena_cap = L.arena_cap;
     t.cand_cap = L.cand_cap;
@@ -451,11 +461,29 @@ mrgingham_amd_ctx* mrgingham_amd_create(int device_ordinal) {
     ctx->use_v0 = v0 && atoi(v0) != 0;
     int prio_lo = 0, prio_hi = 0;  // the component stream gets the highest dispatch priority
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    bool ok = hipStreamCreateWithPriority(&ctx->pix, hipStreamNonBlocking, prio_lo) == hipSuccess &&
-              hipStreamCreateWithPriority(&ctx->ccs[0], hipStreamNonBlocking, prio_hi) == hipSuccess &&
-              hipStreamCreateWithPriority(&ctx->ccs[1], hipStreamNonBlocking, prio_hi) == hipSuccess &&
-              hipEventCreateWithFlags(&ctx->ev_cc_done[0], hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&ctx->ev_cc_done[1], hipEventDisableTiming) == hipSuccess;
+    // Experiment hooks (tools/interference_ab.py): MRGINGHAM_AMD_CC_CUS = k confines the component
+    // streams to k CUs per XCD (CU-mask bit i is XCD i % 8, CU i / 8: probed with
+    // tools/ubench/cu_mask.hip); MRGINGHAM_AMD_PIX_COMPLEMENT = 1 keeps the pixel stream off them.
+    const char* ecc = getenv("MRGINGHAM_AMD_CC_CUS");
+    const int cc_cus = ecc ? atoi(ecc) : 0;
+    const char* epx = getenv("MRGINGHAM_AMD_PIX_COMPLEMENT");
+    const bool pix_compl = epx && atoi(epx) != 0;
+    bool ok = true;
+    if (cc_cus > 0 && cc_cus < 32) {
+        uint32_t mask[8] = {}, inv[8];
+        for (int b = 0; b < 8 * cc_cus; ++b) mask[b >> 5] |= 1u << (b & 31);
+        for (int i = 0; i < 8; ++i) inv[i] = ~mask[i];
+        ok = hipExtStreamCreateWithCUMask(&ctx->ccs[0], 8, mask) == hipSuccess &&
+             hipExtStreamCreateWithCUMask(&ctx->ccs[1], 8, mask) == hipSuccess &&
+             (pix_compl ? hipExtStreamCreateWithCUMask(&ctx->pix, 8, inv)
+                        : hipStreamCreateWithPriority(&ctx->pix, hipStreamNonBlocking, prio_lo)) == hipSuccess;
+    } else {
+        ok = hipStreamCreateWithPriority(&ctx->pix, hipStreamNonBlocking, prio_lo) == hipSuccess &&
+             hipStreamCreateWithPriority(&ctx->ccs[0], hipStreamNonBlocking, prio_hi) == hipSuccess &&
+             hipStreamCreateWithPriority(&ctx->ccs[1], hipStreamNonBlocking, prio_hi) == hipSuccess;
+    }
+    ok = ok && hipEventCreateWithFlags(&ctx->ev_cc_done[0], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&ctx->ev_cc_done[1], hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i <= kMaxLevel; ++i)
         ok = hipEventCreateWithFlags(&ctx->ev_pix[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
@@ -472,7 +500,7 @@ void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx) {
     hipDeviceSynchronize();
     for (auto& set : ctx->lvs)
     for (LevelScratch& L : set) {
-        DevBuf* bufs[] = {&L.img, &L.resp, &L.lidx, &L.hot_pix, &L.parent,
+        DevBuf* bufs[] = {&L.img, &L.resp, &L.gidx, &L.hot_xy, &L.parent,
                           &L.comp_cnt, &L.roots, &L.comp_first, &L.comp_box, &L.arena, &L.cand, &L.sortkeys};
         for (DevBuf* b : bufs)
             if (b->p) hipFree(b->p);
@@ -496,6 +524,24 @@ void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx) {
     delete ctx;
 }
 
+long long mrgingham_amd_scratch_bytes(const mrgingham_amd_ctx* ctx) {
+    if (!ctx) return 0;
+    long long total = 0;
+    for (const auto& set : ctx->lvs)
+        for (const LevelScratch& L : set)
+            for (const DevBuf* b : {&L.img, &L.resp, &L.gidx, &L.hot_xy, &L.parent, &L.comp_cnt, &L.roots, &L.comp_first,
+                                    &L.comp_box, &L.arena, &L.cand, &L.sortkeys})
+                total += (long long)b->bytes;
+    for (const auto& ps : ctx->pts)
+        for (const DevBuf* b : {&ps.leader, &ps.need, &ps.nseeds, &ps.seeds, &ps.sroot, &ps.cand_xy, &ps.cand_counts})
+            total += (long long)b->bytes;
+    for (const DevBuf* b : {&ctx->counters2[0], &ctx->counters2[1], &ctx->io_counts, &ctx->aux_img, &ctx->io_frame,
+                            &ctx->io_out, &ctx->pre_scratch, &ctx->pre_tmp, &ctx->pre_out, &ctx->fb_xy, &ctx->fb_cnt,
+                            &ctx->fb_pts, &ctx->fb_lv, &ctx->fb_np, &ctx->fb_frames, &ctx->fb_frames2})
+        total += (long long)b->bytes;
+    return total;
+}
+
 const char* mrgingham_amd_last_error(const mrgingham_amd_ctx* ctx) { return ctx ? ctx->err.c_str() : "no context"; }
 
 void mrgingham_amd_set_kernel_timing(mrgingham_amd_ctx* ctx, int enable) {
@@ -512,6 +558,7 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
     }
     if (!strcmp(name, "chess_v0")) { ctx->use_v0 = value != 0; return 0; }
     if (!strcmp(name, "multi_level_launch")) { ctx->multi_level = value != 0; return 0; }
+    if (!strcmp(name, "cc_schedule")) { ctx->cc_schedule = value; return 0; }
     if (!strcmp(name, "chess_seg")) { mrg::chess_seg_override = value > 0 ? value : 0; return 0; }
     return MRGINGHAM_AMD_ERR_ARG;
 }
@@ -553,14 +600,18 @@ int mrgingham_amd_sync(mrgingham_amd_ctx* ctx) {
             ctx->host_status.resize(nact);
             MRG_HIP_CHECK(hipMemcpy(ctx->host_status.data(), status_of(ctx, level), sizeof(int32_t) * nact,
                                     hipMemcpyDeviceToHost));
-            for (int f = 0; f < nact && rc == MRGINGHAM_AMD_OK; ++f)
-                if (ctx->host_status[f]) {
-                    MRG_HIP_CHECK(hipMemset(status_of(ctx, level), 0, sizeof(int32_t) * nact));
+            // every pending status block is inspected and cleared; only the first error is reported
+            bool dirty = false;
+            for (int f = 0; f < nact; ++f) {
+                if (!ctx->host_status[f]) continue;
+                dirty = true;
+                if (rc == MRGINGHAM_AMD_OK)
                     rc = fail(ctx, MRGINGHAM_AMD_ERR_CAPACITY,
                               "frame %d, level %d: component tables overflowed (status %d); lower "
                               "\"hot_capacity_shift\" (now %d) with mrgingham_amd_set_option and re-run",
                               f, level, ctx->host_status[f], ctx->cap_shift);
-                }
+            }
+            if (dirty) MRG_HIP_CHECK(hipMemset(status_of(ctx, level), 0, sizeof(int32_t) * nact));
         }
     ctx->cur = saved;
     return rc;
@@ -804,11 +855,70 @@ int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames
         if (!merged || L == 0) lbs[L] = queue_level_chess(ctx, fr, L);
     // component stream: detect at the top (mrgingham.cc:50), candidates -> corners
     // (find_grid.cc:353-354), then refine level by level (mrgingham.cc:87-99)
-    MRG_HIP_CHECK(hipStreamWaitEvent(cur_cc(ctx), ctx->ev_pix[start_level], 0));
+    MRG_HIP_CHECK(hipStreamWaitEvent(cur_cc(ctx), ctx->ev_pix[ctx->cc_schedule == 2 ? 0 : start_level], 0));
     launch_cc_detect(lbs[start_level], tables_of(ctx, start_level), start_level, out, 0, fr->nframes, cur_cc(ctx));
     for (int L = start_level - 1; L >= 0; --L) {
-        MRG_HIP_CHECK(hipStreamWaitEvent(cur_cc(ctx), ctx->ev_pix[L], 0));
+        const int gate = (ctx->cc_schedule == 1 && L <= 1) ? 0 : (ctx->cc_schedule == 2 ? 0 : L);
+        MRG_HIP_CHECK(hipStreamWaitEvent(cur_cc(ctx), ctx->ev_pix[gate], 0));
         launch_cc_refine(lbs[L], tables_of(ctx, L), L, io, 0, fr->nframes, cur_cc(ctx));
+    }
+    end_op(ctx);
+    MRG_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int mrgingham_amd_cc_on_response_batch(mrgingham_amd_ctx* ctx, const int16_t* d_response,
+                                       const uint8_t* d_level_image, int nframes, int w, int h, int level,
+                                       int32_t* d_xy, int capacity_per_frame, int32_t* d_counts,
+                                       double* d_points, signed char* d_levels, const int32_t* d_npoints,
+                                       int points_pitch, int32_t* d_nrefined) {
+    if (!ctx) return MRGINGHAM_AMD_ERR_ARG;
+    const bool detect = d_xy != nullptr, refine = d_points != nullptr;
+    if (detect == refine) return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "exactly one of d_xy (detect) and d_points (refine)");
+    if (nframes < 0 || w < 0 || h < 0 || w > 32767 || h > 32767 || level < 0 || level > kMaxLevel ||
+        (nframes > 0 && (!d_response || !d_level_image)))
+        return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "bad response batch descriptor");
+    if (detect && (!d_counts || capacity_per_frame < 0)) return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "NULL outputs");
+    if (refine && (!d_levels || !d_npoints || points_pitch <= 0))
+        return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "NULL point buffers");
+    if (nframes == 0) return 0;
+    MRG_HIP_CHECK(hipSetDevice(ctx->device));
+    // the level-0 scratch of a w x h "frame": the response is the level image's as far as the
+    // component search is concerned; `level` only enters through the coordinate scale
+    int rc;
+    const int pitch = refine ? points_pitch : 0;
+    if ((rc = ensure_level(ctx, 0, nframes, w, h, pitch))) return rc;
+    if (refine && (rc = ensure_points(ctx, nframes, points_pitch))) return rc;
+    begin_op(ctx, 0);
+    const LevelScratch& L = cur_levels(ctx)[0];
+    LevelBatch lb;
+    lb.nframes = nframes;
+    lb.w = w;
+    lb.h = h;
+    lb.img = d_level_image;
+    lb.img_pitch = (long long)w * h;
+    lb.img_stride = w;
+    lb.resp = (int16_t*)L.resp.p;
+    lb.resp_pitch = (long long)w * h;
+    const CompTables t = tables_of(ctx, 0);
+    launch_hot_from_response(d_response, lb, t, 0, nframes, ctx->pix);
+    hipEventRecord(ctx->ev_pix[0], ctx->pix);
+    if (nframes > ctx->pending_frames[ctx->cur][0]) ctx->pending_frames[ctx->cur][0] = nframes;
+    if (detect) {
+        order_after_previous(ctx, {{(const char*)d_xy, (size_t)nframes * capacity_per_frame * 8},
+                                   {(const char*)d_counts, (size_t)nframes * 4}}, {});
+        MRG_HIP_CHECK(hipStreamWaitEvent(cur_cc(ctx), ctx->ev_pix[0], 0));
+        launch_cc_detect(lb, t, level, DetectOut{d_xy, capacity_per_frame, d_counts}, 0, nframes, cur_cc(ctx));
+    } else {
+        auto& ps = ctx->pts[ctx->cur];
+        RefineIO io{d_points, d_levels, d_npoints, points_pitch, d_nrefined, (int32_t*)ps.leader.p,
+                    (int32_t*)ps.need.p, (int32_t*)ps.nseeds.p, (uint32_t*)ps.seeds.p, (int32_t*)ps.sroot.p};
+        const size_t np = (size_t)nframes * points_pitch;
+        order_after_previous(ctx, {{(const char*)d_points, np * 16}, {(const char*)d_levels, np},
+                                   {(const char*)d_nrefined, d_nrefined ? (size_t)nframes * 4 : 0}},
+                             {{(const char*)d_npoints, (size_t)nframes * 4}});
+        MRG_HIP_CHECK(hipStreamWaitEvent(cur_cc(ctx), ctx->ev_pix[0], 0));
+        launch_cc_refine(lb, t, level, io, 0, nframes, cur_cc(ctx));
     }
     end_op(ctx);
     MRG_HIP_CHECK(hipGetLastError());

@@ -30,6 +30,7 @@
 // reference's exact double expressions (:262-263, :278-279, :350-351); the file
 // is compiled with -ffp-contract=off so no FMA changes a truncation.
 #include "common.h"
+#include "hotlist.h"
 #include "kernels.h"
 
 namespace mrg {
@@ -78,7 +79,10 @@ struct FrameView {
     const uint8_t* img;
     int img_stride;
     int16_t* d;
-    int32_t *hot_pix, *parent, *comp_cnt, *roots, *comp_first, *lidx;
+    uint32_t* hot_xy;
+    int32_t *parent, *comp_cnt, *roots, *comp_first;
+    const uint2* gidx;
+    int gw;
     int4* comp_box;
     uint32_t* arena;
     long long arena_cap;
@@ -97,13 +101,14 @@ __device__ __forceinline__ FrameView make_view(const LevelBatch& lb, const CompT
     v.img_stride = lb.img_stride;
     v.d = lb.resp + (long long)frame * lb.resp_pitch;
     const long long e = (long long)frame * t.cap;
-    v.hot_pix = t.hot_pix + e;
+    v.hot_xy = t.hot_xy + e;
     v.parent = t.parent + e;
     v.comp_cnt = t.comp_cnt + e;
     v.roots = t.roots + e;
     v.comp_first = t.comp_first + e;
     v.comp_box = t.comp_box + e;
-    v.lidx = t.lidx + (long long)frame * t.lidx_pitch;
+    v.gidx = t.gidx + (long long)frame * t.gidx_pitch;
+    v.gw = t.gw;
     v.arena = t.arena + (long long)frame * t.arena_cap;
     v.arena_cap = t.arena_cap;
     v.cand = t.cand + (long long)frame * t.cand_cap;
@@ -116,45 +121,56 @@ __device__ __forceinline__ FrameView make_view(const LevelBatch& lb, const CompT
     return v;
 }
 
-// P1 and P2 are one kernel of their own, one 1024-thread workgroup per frame (so that workgroup-scope
-// atomics suffice, see above): at full resolution a noisy frame has tens of thousands of hot
-// pixels, nearly all of them isolated, which P1 flags so that P2 skips them.
+// P0, P1 and P2 are one kernel of their own, one 1024-thread workgroup per frame (so that
+// workgroup-scope atomics suffice, see above): at full resolution a noisy frame has tens of thousands
+// of hot pixels, nearly all of them isolated, which P1 flags so that P2 skips them.
 constexpr int CCL_THREADS = 1024;
-constexpr int kSingletonFlag = 0x40000000;  // in hot_pix[]: the pixel has no hot 4-neighbour
-// P1: union-find over the hot list (left / up neighbours); P2: flatten (parent[i] = root of i),
-// per-root pixel count, bounding box and smallest raster index.  One kernel, one workgroup per
-// frame, a workgroup barrier between the phases.
+// P0: reset the per-entry tables (the pixel kernel only writes the hot list and the pixel -> index
+// map); P1: union-find over the hot list (left / up neighbours); P2: flatten (parent[i] = root of i),
+// per-root pixel count, bounding box and smallest raster position.  Workgroup barriers in between.
 __global__ __launch_bounds__(CCL_THREADS) void cc_label_kernel(LevelBatch lb, CompTables t, int frame0) {
     const int frame = frame0 + blockIdx.y;
     if (t.hot_cnt[frame] > t.cap) return;  // overflow is reported by the per-frame kernel
     const FrameView v = make_view(lb, t, frame);
     const int w = v.w;
     for (int i = threadIdx.x; i < v.n; i += CCL_THREADS) {
-        const int p = v.hot_pix[i];
+        v.parent[i] = i;
+        v.comp_cnt[i] = 0;
+        v.comp_box[i] = make_int4(0x7fffffff, 0x7fffffff, -1, -1);
+        v.roots[i] = 0x7fffffff;
+        v.comp_first[i] = 0x7fffffff;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < v.n; i += CCL_THREADS) {
+        const uint32_t e = v.hot_xy[i];
+        if (e == kHotDead) continue;  // unused slot: flagged already (bit 31), P2 skips it
+        const int x = (int)(e & 0xffffu), y = (int)(e >> 16);
+        const int p = y * w + x;
         // all four neighbours lie inside the image (p is in [7,w-7) x [7,h-7)); the frame is zero
         const bool l = v.d[p - 1] > kRespMin, u = v.d[p - w] > kRespMin;
         const bool r = v.d[p + 1] > kRespMin, dn = v.d[p + w] > kRespMin;
-        if (l) uf_unite(v.parent, i, v.lidx[p - 1]);
-        if (u) uf_unite(v.parent, i, v.lidx[p - w]);
+        // the hot pixels of an aligned group of 8 are consecutive list entries in ascending x
+        if (l) uf_unite(v.parent, i, (x & 7) ? i - 1 : hot_index_of(v.gidx, v.gw, x - 1, y));
+        if (u) uf_unite(v.parent, i, hot_index_of(v.gidx, v.gw, x, y - 1));
         // An isolated hot pixel is a finished super-component of size one: flag it so that P2 does
         // not spend five atomics on it (at full resolution most hot pixels are isolated noise).
-        if (!(l || u || r || dn)) v.hot_pix[i] = p | kSingletonFlag;
+        if (!(l || u || r || dn)) v.hot_xy[i] = e | kHotSingleton;
     }
     __syncthreads();  // every union of the frame is done (the tables are only touched by this workgroup)
     for (int i = threadIdx.x; i < v.n; i += CCL_THREADS) {
-        const int p = v.hot_pix[i];
-        if (p & kSingletonFlag) continue;  // its own root, count 0: never a blob, never shared
+        const uint32_t e = v.hot_xy[i];
+        if (e & kHotSingleton) continue;  // its own root, count 0: never a blob, never shared
         const int r = uf_root(v.parent, i);
         // other threads may still walk through i: r is an ancestor, so their walks stay valid
         __hip_atomic_store(v.parent + i, r, MRG_WG);
-        const int y = p / w, x = p - y * w;
+        const int x = (int)(e & 0xffffu), y = (int)(e >> 16);
         int* box = reinterpret_cast<int*>(v.comp_box + r);
         wg_min(box + 0, x);
         wg_min(box + 1, y);
         wg_max(box + 2, x);
         wg_max(box + 3, y);
         wg_add(v.comp_cnt + r, 1);
-        wg_min(v.comp_first + r, p);
+        wg_min(v.comp_first + r, (int)e);  // (y << 16) | x orders like the raster index
     }
 }
 
@@ -162,6 +178,40 @@ void launch_cc_label(const LevelBatch& lb, const CompTables& t, int frame0, int 
     if (nframes <= 0) return;
     const dim3 grid(1, nframes);
     hipLaunchKernelGGL(cc_label_kernel, grid, dim3(CCL_THREADS), 0, s, lb, t, frame0);
+}
+
+// Hot list of a CALLER-SUPPLIED response (mrgingham_amd_cc_on_response_batch, the entry point the
+// rule tests drive): copies it into the level scratch the way the component search expects it --
+// negatives clamped to 0 (find_chessboard_corners.cc:527-529), the 7-pixel frame zero (:506) -- and
+// appends the hot pixels exactly as the ChESS epilogue does (same list / map format).
+// One wave = 64 aligned groups of 8 pixels of one row.
+__global__ __launch_bounds__(256) void hot_from_response_kernel(const int16_t* src, LevelBatch lb, CompTables t,
+                                                                int frame0) {
+    const int frame = frame0 + blockIdx.z;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= lb.h) return;  // wave-uniform
+    const int w = lb.w, h = lb.h;
+    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 8;
+    const int16_t* in = src + (long long)frame * w * h + (long long)y * w;
+    int16_t* out = lb.resp + (long long)frame * lb.resp_pitch + (long long)y * w;
+    const bool row_in = y >= kMargin && y < h - kMargin;
+    uint32_t bits = 0;
+    for (int i = 0; i < 8; ++i) {
+        const int x = x0 + i;
+        if (x >= w) break;
+        int v = in[x];
+        if (v < 0 || !row_in || x < kMargin || x >= w - kMargin) v = 0;
+        out[x] = (int16_t)v;
+        bits |= (uint32_t)(v > kRespMin) << i;
+    }
+    append_groups_wave(t, frame, bits, ((uint32_t)y << 16) | (uint32_t)x0);
+}
+
+void launch_hot_from_response(const int16_t* src, const LevelBatch& lb, const CompTables& t, int frame0, int nframes,
+                              hipStream_t s) {
+    if (nframes <= 0 || lb.w <= 0 || lb.h <= 0) return;
+    const dim3 grid((t.gw + 63) / 64, (lb.h + 3) / 4, nframes);
+    hipLaunchKernelGGL(hot_from_response_kernel, grid, dim3(256), 0, s, src, lb, t, frame0);
 }
 
 struct Blob {
@@ -278,7 +328,7 @@ __device__ void bitonic_sort(unsigned long long* keys, int n_pad) {
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(CC_THREADS) void cc_detect_kernel(LevelBatch lb, CompTables t, int level,
                                                                DetectOut out, int frame0) {
-    __shared__ int s_nroots, s_ncand;
+    __shared__ int s_nroots, s_ncand, s_arena_full;
     __shared__ unsigned long long s_arena_top;
     // latency-bound and tiny next to the pixel kernels it shares CUs with: take issue priority
     __builtin_amdgcn_s_setprio(3);
@@ -291,7 +341,7 @@ __global__ __launch_bounds__(CC_THREADS) void cc_detect_kernel(LevelBatch lb, Co
         return;
     }
     const FrameView v = make_view(lb, t, frame);
-    if (threadIdx.x == 0) { s_nroots = 0; s_ncand = 0; s_arena_top = 0; }
+    if (threadIdx.x == 0) { s_nroots = 0; s_ncand = 0; s_arena_top = 0; s_arena_full = 0; }
     __syncthreads();
 
     // P3a: compact the roots.  A super-component of a single hot pixel can only ever give a
@@ -308,12 +358,13 @@ __global__ __launch_bounds__(CC_THREADS) void cc_detect_kernel(LevelBatch lb, Co
         const int4 box = v.comp_box[r];
         const int cnt = v.comp_cnt[r];
         const unsigned long long off = atomicAdd(&s_arena_top, (unsigned long long)(4 * cnt + 1));
+        if (off + (unsigned long long)(4 * cnt + 1) > (unsigned long long)v.arena_cap) { s_arena_full = 1; continue; }
         uint32_t* stk = v.arena + off;
         // seeds live in [8, w-8) x [8, h-8) (:332-333)
         const int ylo = max(box.y, kMargin + 1), yhi = min(box.w, h - kMargin - 2);
         const int xlo = max(box.x, kMargin + 1), xhi = min(box.z, w - kMargin - 2);
         int left = cnt;  // hot pixels of this super-component not consumed yet
-        auto fill_from = [&](int x, int y, int p) {
+        auto fill_from = [&](int x, int y) {
             stk[0] = (uint32_t)x | ((uint32_t)y << 16);  // :338
             Blob b;
             left -= drain_lifo(v.d, w, h, stk, 1, b);
@@ -323,7 +374,7 @@ __global__ __launch_bounds__(CC_THREADS) void cc_detect_kernel(LevelBatch lb, Co
             if (c < v.cand_cap) {
                 Cand cd;
                 cd.sum_rx = b.srx; cd.sum_ry = b.sry; cd.sum_r = b.sr;
-                cd.seed = p;
+                cd.seed = (y << 16) | x;  // orders like the raster index of the seed
                 cd.x_peak = (uint16_t)b.xpk; cd.y_peak = (uint16_t)b.ypk;
                 cd.ok = 1; cd.pad = 0;
                 v.cand[c] = cd;
@@ -333,20 +384,19 @@ __global__ __launch_bounds__(CC_THREADS) void cc_detect_kernel(LevelBatch lb, Co
         // pixel may seed, fill from it straight away; in the common case the fill consumes every
         // hot pixel of the super-component and no scan of the bounding box is needed at all.
         {
-            const int p = v.comp_first[r];
-            const int y = p / w, x = p - y * w;
-            if (x >= xlo && x <= xhi && y >= ylo && y <= yhi) fill_from(x, y, p);
+            const int e = v.comp_first[r];
+            const int y = e >> 16, x = e & 0xffff;
+            if (x >= xlo && x <= xhi && y >= ylo && y <= yhi) fill_from(x, y);
         }
         for (int y = ylo; y <= yhi && left > 0; ++y)
             for (int x = xlo; x <= xhi && left > 0; ++x) {
-                const int p = y * w + x;
-                if (!(v.d[p] > kRespMin)) continue;      // is_valid(.., NULL), :335
-                if (v.parent[v.lidx[p]] != r) continue;  // someone else's super-component
-                fill_from(x, y, p);
+                if (!(v.d[y * w + x] > kRespMin)) continue;                  // is_valid(.., NULL), :335
+                if (v.parent[hot_index_of(v.gidx, v.gw, x, y)] != r) continue;  // someone else's super-component
+                fill_from(x, y);
             }
     }
     __syncthreads();
-    if (s_ncand > v.cand_cap) {
+    if (s_ncand > v.cand_cap || s_arena_full) {
         if (threadIdx.x == 0) { wg_or(v.status, kStatusCandOverflow); out.counts[frame] = -1; }
         return;
     }
@@ -401,7 +451,7 @@ void launch_cc_detect(const LevelBatch& lb, const CompTables& t, int level, cons
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, CompTables t, int level,
                                                                RefineIO io, int frame0) {
-    __shared__ int s_changed, s_nref;
+    __shared__ int s_changed, s_nref, s_arena_full;
     __shared__ unsigned long long s_arena_top;
     __builtin_amdgcn_s_setprio(3);
     const int frame = frame0 + blockIdx.x;
@@ -413,8 +463,8 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, Co
         return;
     }
     const FrameView v = make_view(lb, t, frame);
-    if (threadIdx.x == 0) { s_changed = 0; s_nref = 0; s_arena_top = 0; }
-    __syncthreads();  // v.roots[] was preset to INT_MAX by the ChESS kernel: it is the claim table here
+    if (threadIdx.x == 0) { s_changed = 0; s_nref = 0; s_arena_top = 0; s_arena_full = 0; }
+    __syncthreads();  // v.roots[] was preset to INT_MAX by cc_label_kernel: it is the claim table here
 
     const int w = v.w, h = v.h;
     const int npts = min(io.npoints[frame], io.pitch);
@@ -444,7 +494,7 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, Co
                     const int p = sy * w + sx;
                     if (!(v.d[p] > kRespMin)) continue;
                     seeds[9 * i + ns] = (uint32_t)sx | ((uint32_t)sy << 16);
-                    sroot[9 * i + ns] = v.parent[v.lidx[p]];
+                    sroot[9 * i + ns] = v.parent[hot_index_of(v.gidx, v.gw, sx, sy)];
                     ++ns;
                 }
         }
@@ -491,6 +541,7 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, Co
     for (int i = threadIdx.x; i < npts; i += CC_THREADS) {
         if (nseeds[i] < 0 || leader[i] != i) continue;
         const unsigned long long off = atomicAdd(&s_arena_top, (unsigned long long)(need[i] + 10));
+        if (off + (unsigned long long)(need[i] + 10) > (unsigned long long)v.arena_cap) { s_arena_full = 1; continue; }
         uint32_t* stk = v.arena + off;
         for (int j = i; j < npts; ++j) {
             if (nseeds[j] < 0 || leader[j] != i) continue;
@@ -509,7 +560,10 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, Co
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0 && io.nrefined) io.nrefined[frame] = s_nref;
+    if (threadIdx.x == 0) {
+        if (s_arena_full) wg_or(v.status, kStatusCandOverflow);  // points refined so far stay refined; the call fails
+        if (io.nrefined) io.nrefined[frame] = s_arena_full ? -1 : s_nref;
+    }
 }
 
 void launch_cc_refine(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io, int frame0,

@@ -17,35 +17,26 @@
 //     Y = sum_i max(t1_i, t2_i),  X = sum_i max(a_i,c_i) + max(b_i,d_i)
 //   and response = 2*(Y-X) - |M - local_mean|,  M = sum of the 16 samples.
 #include "common.h"
+#include "hotlist.h"
 #include "kernels.h"
 
 namespace mrg {
 
 // ---------------------------------------------------------------------------
-// Shared epilogue: append the hot pixels of a wave to the frame's hot list.
-// Must be called by all 64 lanes of a wave (uniform control flow).
+// v0 epilogue: a wave holds 64 consecutive pixels of one row (x0 a multiple of 64), one per lane.
+// The first lane of every aligned group of 8 appends the group.  Uniform control flow required.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void append_hot(bool hot, int p, const CompTables& t, int frame) {
+__device__ __forceinline__ void append_hot_row64(bool hot, int x, int y, const CompTables& t, int frame) {
     const unsigned long long m = __ballot(hot);
     if (m == 0) return;
     const int lane = __lane_id();
-    const int leader = __ffsll((long long)m) - 1;
     int base = 0;
-    if (lane == leader) base = atomicAdd(t.hot_cnt + frame, __popcll(m));
-    base = __shfl(base, leader);
-    if (hot) {
-        const int idx = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (idx < t.cap) {
-            const long long e = (long long)frame * t.cap + idx;
-            t.hot_pix[e] = p;
-            t.parent[e] = idx;
-            t.comp_cnt[e] = 0;
-            t.comp_box[e] = make_int4(0x7fffffff, 0x7fffffff, -1, -1);
-            t.roots[e] = 0x7fffffff;
-            t.comp_first[e] = 0x7fffffff;
-            t.lidx[(long long)frame * t.lidx_pitch + p] = idx;
-        }
-    }
+    if (lane == 0) base = atomicAdd(t.hot_cnt + frame, __popcll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+    const uint32_t bits = (uint32_t)(m >> (lane & 56)) & 0xffu;
+    if ((lane & 7) == 0 && bits)
+        write_group_direct(t, frame, base + __popcll(m & ((1ull << lane) - 1ull)), bits,
+                           ((uint32_t)y << 16) | (uint32_t)x);
 }
 
 // ---------------------------------------------------------------------------
@@ -102,7 +93,7 @@ __global__ __launch_bounds__(256) void chess_v0_kernel(LevelBatch lb, CompTables
         if (!interior) r = 0;
         if (CLAMP) r = max(r, 0);
         if (inimg) resp[(long long)y * w + x] = (int16_t)r;
-        if (HOT) append_hot(interior && r > kRespMin, y * w + x, t, frame);
+        if (HOT) append_hot_row64(interior && r > kRespMin, x, y, t, frame);
     }
 }
 
@@ -255,42 +246,53 @@ __device__ __forceinline__ void load12(uint32_t (&R)[12], const char* p) {
 // Hot pixels of a workgroup are collected in LDS and appended to the frame's
 // list with ONE global atomic per workgroup: per-pixel (even per-wave) returning
 // atomics on the frame counter serialise and were costing more than the response
-// itself on the small pyramid levels.
-constexpr int V1_HOTBUF = 768;  // entries; overflow falls back to direct appends
+// itself on the small pyramid levels.  Entries are (y << 16) | x.
+constexpr int V1_HOTBUF = 768;  // entries; what does not fit is appended directly (one atomic per lane)
 
-__device__ __forceinline__ void write_hot_entry(const CompTables& t, int frame, int idx, int p) {
-    if (idx >= t.cap) return;
-    const long long e = (long long)frame * t.cap + idx;
-    t.hot_pix[e] = p;
-    t.parent[e] = idx;
-    t.comp_cnt[e] = 0;
-    t.comp_box[e] = make_int4(0x7fffffff, 0x7fffffff, -1, -1);
-    t.roots[e] = 0x7fffffff;
-    t.comp_first[e] = 0x7fffffff;
-    t.lidx[(long long)frame * t.lidx_pitch + p] = idx;
-}
-
-// All lanes of the wave call this; `bits` has bit i set when pixel p0+i of the lane is hot.
-__device__ __forceinline__ void collect_hot(uint32_t bits, int p0, int* hotbuf, int* hotcnt, const CompTables& t,
-                                            int frame) {
+// All lanes of the wave call this; `bits` has bit i set when pixel xy0 + i of the lane is hot.
+__device__ __forceinline__ void collect_hot(uint32_t bits, uint32_t xy0, uint32_t* hotbuf, int* hotcnt,
+                                            const CompTables& t, int frame) {
     const int cnt = __popc(bits);  // 0..8
-    int prefix = 0, total = 0;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const unsigned long long m = __ballot((cnt >> b) & 1);
-        prefix += (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0)) << b;
-        total += __popcll(m) << b;
-    }
+    int prefix, total;
+    wave_prefix_0to8(cnt, prefix, total);
     int base = 0;
     if (__lane_id() == 0) base = atomicAdd(hotcnt, total);  // LDS atomic
     base = __builtin_amdgcn_readfirstlane(base);
+    if (cnt == 0) return;
     int k = base + prefix;
-    while (bits) {
-        const int i = __ffs(bits) - 1;
-        bits &= bits - 1;
-        if (k < V1_HOTBUF) hotbuf[k] = p0 + i;
-        else write_hot_entry(t, frame, atomicAdd(t.hot_cnt + frame, 1), p0 + i);  // rare: buffer full
-        ++k;
+    if (k + cnt <= V1_HOTBUF) {
+        while (bits) {
+            const int i = __ffs(bits) - 1;
+            bits &= bits - 1;
+            hotbuf[k++] = xy0 + (uint32_t)i;
+        }
+    } else {
+        // rare: the buffer is full.  The lane's group goes straight to the list (its entries must stay
+        // consecutive); the buffer slots it had reserved are flushed as unused list slots.
+        for (int j = k; j < k + cnt && j < V1_HOTBUF; ++j) hotbuf[j] = kHotDead;
+        write_group_direct(t, frame, atomicAdd(t.hot_cnt + frame, cnt), bits, xy0);
+    }
+}
+
+// Flush of the workgroup's buffer: one global atomic, coalesced list writes; the first entry of every
+// 8-pixel group also writes the group's pixel -> index record.  Called by all 256 threads.
+__device__ __forceinline__ void flush_hot(const uint32_t* hotbuf, int* hotcnt, const CompTables& t, int frame) {
+    __syncthreads();
+    const int n = min(*hotcnt, V1_HOTBUF);
+    if (n <= 0) return;
+    __syncthreads();
+    if (threadIdx.x == 0) *hotcnt = atomicAdd(t.hot_cnt + frame, n);
+    __syncthreads();
+    const int gbase = *hotcnt;
+    uint32_t* hot = t.hot_xy + (long long)frame * t.cap;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const uint32_t e = hotbuf[i];
+        if (gbase + i < t.cap) hot[gbase + i] = e;
+        if (e == kHotDead || (i > 0 && (hotbuf[i - 1] >> 3) == (e >> 3))) continue;
+        uint32_t mask = 0;
+        for (int j = i; j < n && (hotbuf[j] >> 3) == (e >> 3); ++j) mask |= 1u << (hotbuf[j] & 7u);
+        t.gidx[(long long)frame * t.gidx_pitch + (long long)(e >> 16) * t.gw + ((e & 0xffffu) >> 3)] =
+            make_uint2((uint32_t)(gbase + i), mask);
     }
 }
 
@@ -322,8 +324,8 @@ __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTa
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6, half = lane >> 5, lx = lane & 31;
-    int* hotbuf = reinterpret_cast<int*>(lds + 2 * V1_PLANE);
-    int* hotcnt = hotbuf + V1_HOTBUF;
+    uint32_t* hotbuf = reinterpret_cast<uint32_t*>(lds + 2 * V1_PLANE);
+    int* hotcnt = reinterpret_cast<int*>(hotbuf + V1_HOTBUF);
     if (HOT && tid == 0) *hotcnt = 0;
     // staging role: 8 rows x 18 chunks = 144 threads
     const bool stager = tid < V1_RB * V1_NCH;
@@ -444,7 +446,7 @@ __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTa
                     const int v = (int)((out[i >> 1] >> (16 * (i & 1))) & 0xffffu);
                     bits |= (uint32_t)(v > kRespMin && live) << i;
                 }
-                collect_hot(bits, yy * w + x0, hotbuf, hotcnt, t, frame);
+                collect_hot(bits, ((uint32_t)yy << 16) | (uint32_t)x0, hotbuf, hotcnt, t, frame);
             }
         }
 
@@ -473,18 +475,7 @@ __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTa
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     }
-    if (HOT) {
-        // flush the workgroup's hot pixels: one global atomic, then coalesced table writes
-        __syncthreads();
-        const int n = min(*hotcnt, V1_HOTBUF);
-        if (n > 0) {
-            __syncthreads();
-            if (tid == 0) *hotcnt = atomicAdd(t.hot_cnt + frame, n);
-            __syncthreads();
-            const int gbase = *hotcnt;
-            for (int i = tid; i < n; i += 256) write_hot_entry(t, frame, gbase + i, hotbuf[i]);
-        }
-    }
+    if (HOT) flush_hot(hotbuf, hotcnt, t, frame);
 }
 
 template <bool CLAMP, bool HOT, bool W16>

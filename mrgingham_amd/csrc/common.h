@@ -35,15 +35,21 @@ struct LevelBatch {
 // only pixels that can seed, join or extend a component.
 struct CompTables {
     int cap;                  // hot-pixel capacity per frame
-    int32_t* hot_cnt;         // [nframes]     number of hot pixels found (may exceed cap)
-    int32_t* hot_pix;         // [nframes*cap] linear pixel index y*w+x
+    int32_t* hot_cnt;         // [nframes]     number of hot-list entries made (may exceed cap)
+    uint32_t* hot_xy;         // [nframes*cap] the hot list: pixel as (y << 16) | x; kHotDead = unused slot
     int32_t* parent;          // [nframes*cap] union-find forest over hot-list indices
     int32_t* comp_cnt;        // [nframes*cap] hot pixels per super-component (at its root)
     int4* comp_box;           // [nframes*cap] (xmin, ymin, xmax, ymax) at the root
     int32_t* roots;           // [nframes*cap] compacted root list / claim table (refine)
-    int32_t* comp_first;      // [nframes*cap] smallest raster index of the super-component (at its root)
-    int32_t* lidx;            // [nframes*w0*h0] pixel -> hot-list index (sparse writes)
-    long long lidx_pitch;     // elements between frames
+    int32_t* comp_first;      // [nframes*cap] smallest (y << 16) | x of the super-component (at its root)
+    // pixel -> hot-list index, one entry per aligned group of 8 pixels of a row: .x = list index of the
+    // group's first hot pixel, .y = 8-bit mask of its hot pixels.  The hot pixels of a group are
+    // consecutive list entries in ascending x, so index(x, y) = .x + popcount(.y & ((1 << (x & 7)) - 1)).
+    // Written only for groups that have a hot pixel, read only at pixels known to be hot: never
+    // initialised.  1 byte per pixel (a dense int32-per-pixel index took 4).
+    uint2* gidx;              // [nframes*gidx_pitch]
+    long long gidx_pitch;     // entries between frames = gw * h
+    int gw;                   // groups per row = ceil(w / 8)
     uint32_t* arena;          // [nframes*arena_cap] DFS stacks
     long long arena_cap;      // entries per frame
     int cand_cap;             // candidate capacity per frame
@@ -57,13 +63,15 @@ struct CompTables {
 // variance test and the ordering by seed (find_chessboard_corners.cc:193-209).
 struct Cand {
     unsigned long long sum_rx, sum_ry, sum_r;
-    int32_t seed;             // raster index of the seed pixel (output order key)
+    int32_t seed;             // (y << 16) | x of the seed pixel: orders like its raster index (output order key)
     uint16_t x_peak, y_peak;
     int32_t ok;               // set by the variance stage
     int32_t pad;
 };
 
 enum : int { kStatusHotOverflow = 1, kStatusCandOverflow = 2 };
+constexpr uint32_t kHotDead = 0xffffffffu;       // hot list slot that holds no pixel
+constexpr uint32_t kHotSingleton = 0x80000000u;  // flag in hot_xy[]: the pixel has no hot 4-neighbour
 
 #define MRG_HIP_CHECK(expr)                                                                          \
     do {                                                                                             \

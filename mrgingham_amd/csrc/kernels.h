@@ -57,6 +57,8 @@ struct RefineIO {
     uint32_t* seeds;         // [nframes*pitch*9]
     int32_t* sroot;          // [nframes*pitch*9] root of each seed's super-component
 };
+void launch_hot_from_response(const int16_t* src, const LevelBatch& lb, const CompTables& t, int frame0, int nframes,
+                              hipStream_t s);
 void launch_cc_detect(const LevelBatch& lb, const CompTables& t, int level, const DetectOut& out, int frame0,
                       int nframes, hipStream_t s);
 void launch_cc_refine(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io, int frame0,

@@ -1,0 +1,155 @@
+"""The HIP component-search kernels (cc_label / cc_detect / cc_refine, csrc/cc.hip) driven with
+HAND-BUILT and random sparse responses through mrgingham_amd_cc_on_response_batch: every rule of
+find_chessboard_corners.cc:159-267 / :284-397 is met on purpose here, not only when a natural image
+happens to produce it.  Expectations: the hand-derived values of tests/cc_cases.py AND the oracle on
+the same buffers, bit-exact (integers and order; refined doubles compared for equality)."""
+import numpy as np
+import pytest
+import torch
+
+import mrgingham_amd
+from oracle import oracle
+
+import cc_cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def det():
+    d = mrgingham_amd.Detector(0)
+    yield d
+    d.close()
+
+
+def _detect(det, ds, imgs, level=0, capacity=4096):
+    xy, cnt = det.cc_detect_on_response(torch.from_numpy(np.stack(ds)).cuda(), torch.from_numpy(np.stack(imgs)).cuda(),
+                                        level=level, capacity=capacity)
+    xy, cnt = xy.cpu().numpy(), cnt.cpu().numpy()
+    return [xy[f, :cnt[f]] for f in range(len(ds))]
+
+
+def test_handbuilt_detect_rules_one_frame_at_a_time(det):
+    for name, d, img, expected in cc_cases.detect_cases():
+        got = _detect(det, [d], [img])[0]
+        want = oracle.cc_detect_on_response(d, img)
+        assert np.array_equal(got, want), name
+        if expected is not None:
+            assert got.tolist() == expected, name
+
+
+def test_handbuilt_detect_rules_as_one_batch(det):
+    cases = cc_cases.detect_cases()
+    got = _detect(det, [c[1] for c in cases], [c[2] for c in cases])
+    for (name, d, img, expected), g in zip(cases, got):
+        assert np.array_equal(g, oracle.cc_detect_on_response(d, img)), name
+
+
+def test_detect_does_not_modify_the_callers_response_and_clamps(det):
+    name, d, img, expected = cc_cases.detect_cases()[1]
+    d = d.copy()
+    d[5, 5] = 900          # outside [7, w-7) x [7, h-7): structurally zero in the reference (:506)
+    d[20, 22] = -300       # negative: clamped (:527-529); would otherwise never matter
+    dd = torch.from_numpy(d[None]).cuda()
+    before = dd.clone()
+    xy, cnt = det.cc_detect_on_response(dd, torch.from_numpy(img[None]).cuda())
+    assert torch.equal(dd, before)
+    assert xy[0, :int(cnt[0])].cpu().tolist() == expected
+
+
+@pytest.mark.parametrize("level", [0, 1, 3])
+def test_detect_level_scaling(det, level):
+    name, d, img, _ = cc_cases.detect_cases()[1]
+    got = _detect(det, [d], [img], level=level)[0]
+    assert np.array_equal(got, oracle.cc_detect_on_response(d, img, level=level))
+
+
+@pytest.mark.parametrize("shape,nblobs,noise", [((48, 64), 12, 0.0), ((96, 131), 60, 0.002), ((97, 129), 80, 0.01),
+                                                ((240, 333), 300, 0.004), ((64, 1001), 200, 0.003),
+                                                ((600, 77), 150, 0.003), ((15, 15), 3, 0.1), ((16, 40), 6, 0.05)])
+def test_random_sparse_responses(det, shape, nblobs, noise):
+    h, w = shape
+    rng = np.random.RandomState(h * 1009 + w)
+    B = 6
+    ds = [cc_cases.random_sparse_response(rng, h, w, nblobs, noise) for _ in range(B)]
+    imgs = [cc_cases.flat_img(h, w) if f % 3 else (rng.randint(0, 256, size=(h, w)).astype(np.uint8)) for f in range(B)]
+    imgs[1] = (rng.randint(0, 40, size=(h, w)) + 100).astype(np.uint8)     # low variance: sigma ~ 11.5 < 20
+    got = _detect(det, ds, imgs, capacity=8192)
+    total = 0
+    for f in range(B):
+        want = oracle.cc_detect_on_response(ds[f], imgs[f])
+        assert np.array_equal(got[f], want), (shape, f, len(got[f]), len(want))
+        total += len(want)
+    if h >= 48:
+        assert total > 0
+
+
+def test_dense_texture_response(det):
+    """Every other pixel hot: one huge super-component per frame (tables at one entry per pixel)."""
+    h, w = 64, 96
+    rng = np.random.RandomState(5)
+    d = rng.randint(16, 400, size=(h, w)).astype(np.int16)
+    img = cc_cases.flat_img(h, w)
+    det.set_option("hot_capacity_shift", 0)
+    try:
+        got = _detect(det, [d], [img])[0]
+    finally:
+        det.set_option("hot_capacity_shift", 3)
+    assert np.array_equal(got, oracle.cc_detect_on_response(d, img))
+
+
+def test_capacity_overflow_is_reported(det):
+    h, w = 64, 96
+    d = np.full((h, w), 100, np.int16)
+    with pytest.raises(RuntimeError, match="overflowed"):
+        _detect(det, [d], [cc_cases.flat_img(h, w)])
+    # and the context recovers
+    name, d, img, expected = cc_cases.detect_cases()[1]
+    assert _detect(det, [d], [img])[0].tolist() == expected
+
+
+def _refine(det, pts, lv, d, img, level):
+    P = max(1, len(lv))
+    tp = torch.zeros((1, P, 2), dtype=torch.float64)
+    tl = torch.zeros((1, P), dtype=torch.int8)
+    tp[0, :len(lv)] = torch.from_numpy(np.asarray(pts, np.float64).reshape(-1, 2))
+    tl[0, :len(lv)] = torch.from_numpy(np.asarray(lv, np.int8))
+    tp, tl = tp.cuda(), tl.cuda()
+    n = torch.tensor([len(lv)], dtype=torch.int32).cuda()
+    nref = det.cc_refine_on_response(torch.from_numpy(d[None]).cuda(), torch.from_numpy(img[None]).cuda(), level,
+                                     tp, tl, n)
+    return tp[0, :len(lv)].cpu().numpy(), tl[0, :len(lv)].cpu().numpy(), int(nref[0])
+
+
+def test_handbuilt_refine_rules(det):
+    for name, pts, lv, d, img, level, expected in cc_cases.refine_cases():
+        gp, gl, gn = _refine(det, pts, lv, d, img, level)
+        wp, wl, wn = oracle.cc_refine_on_response(pts, lv, d, img, level)
+        assert gn == wn and np.array_equal(gl, wl) and np.array_equal(gp, wp), name
+        if expected is not None:
+            ep, el, en = expected
+            assert gn == en and gl.tolist() == el and np.array_equal(gp, ep), name
+
+
+@pytest.mark.parametrize("shape,level", [((96, 131), 0), ((240, 333), 1), ((97, 129), 2)])
+def test_random_refine_against_oracle(det, shape, level):
+    h, w = shape
+    rng = np.random.RandomState(h + 31 * w + level)
+    for trial in range(4):
+        d = cc_cases.random_sparse_response(rng, h, w, 60 + 40 * trial, 0.003)
+        img = cc_cases.flat_img(h, w) if trial % 2 else rng.randint(0, 256, size=(h, w)).astype(np.uint8)
+        # points: near hot pixels (full-resolution coordinates), duplicates, far-away, out-of-image
+        ys, xs = np.nonzero(d > 15)
+        k = min(len(xs), 120)
+        sel = rng.choice(len(xs), size=k, replace=True)
+        scale = float(1 << level)
+        pts = np.stack([(xs[sel] + rng.uniform(-1.6, 1.6, k) + 0.5) * scale - 0.5,
+                        (ys[sel] + rng.uniform(-1.6, 1.6, k) + 0.5) * scale - 0.5], axis=1)
+        pts = np.concatenate([pts, pts[:10], [[-5.0, -5.0], [w * scale + 3, h * scale + 3], [0.0, 0.0]]])
+        lv = np.full(len(pts), level + 1, np.int8)
+        lv[::7] = level + 2                              # not refinable at this level
+        lv[3::11] = level                                # already there
+        gp, gl, gn = _refine(det, pts, lv, d, img, level)
+        wp, wl, wn = oracle.cc_refine_on_response(pts, lv, d, img, level)
+        assert gn == wn and np.array_equal(gl, wl) and np.array_equal(gp, wp), (shape, level, trial)
+        assert wn > 0

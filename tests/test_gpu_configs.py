@@ -1,0 +1,99 @@
+"""BASELINE.json's configurations AS STATED, under -m gpu:
+  C3  64 x 4096x3072 frames with a 14x14 board, chain 3 -> 0 (checked bit-exactly against the oracle on
+      a sample of the frames, by properties on all of them);
+  C4  one GPU's shard of the 2048-frame job: 256 frames of 4096x3072 in ONE call, both scratch sets
+      resident (properties: batch-size independence, determinism, sample vs the oracle);
+  C5  in miniature lives in tests/test_gpu_parallel.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+import mrgingham_amd
+from mrgingham_amd import synth
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+W, H = 4096, 3072
+
+
+@pytest.fixture(scope="module")
+def det():
+    d = mrgingham_amd.Detector(0)
+    yield d
+    d.close()
+
+
+def _check_against_oracle(frame_u8, pts, lv, n, start_level=3):
+    wp, wl = oracle.chain(frame_u8, start_level)
+    assert n == len(wp)
+    assert np.array_equal(lv[:n], wl)
+    assert np.abs(pts[:n] - wp).max(initial=0.0) <= 1e-4      # north star tolerance ...
+    assert np.array_equal(pts[:n], wp)                        # ... and in fact identical doubles
+
+
+def test_c3_as_stated_14x14_board_chain(det):
+    B = 64
+    frames = synth.board_batch(B, W, H, gridn=14, seed0=100, device="cuda")
+    pts, lv, npts = det.chain(frames, start_level=3, max_points=512)
+    pts, lv, npts = pts.cpu().numpy(), lv.cpu().numpy(), npts.cpu().numpy()
+    for f in (0, 17, 63):                                      # bit-exact sample
+        _check_against_oracle(frames[f].cpu().numpy(), pts[f], lv[f], int(npts[f]))
+    for f in range(B):
+        n = int(npts[f])
+        assert 196 <= n <= 512, (f, n)
+        assert int((lv[f, :n] == 0).sum()) >= 196, f           # the 14x14 grid refines down to level 0
+    # every level of the stated 4-level pyramid finds the 196 corners on its own as well
+    for level in (0, 1, 2):
+        xy, counts = det.detect(frames[:4], level, capacity=1024)
+        assert (counts.cpu().numpy() >= 196).all(), level
+        want = oracle.find_corners(frames[1].cpu().numpy(), level)
+        assert int(counts[1]) == len(want) and np.array_equal(xy[1, :len(want)].cpu().numpy(), want)
+
+
+def test_c4_shard_256_frames_in_one_call(det):
+    B = 256
+    base = synth.board_batch(32, W, H, gridn=10, seed0=500, device="cuda")
+    frames = torch.empty((B, H, W), dtype=torch.uint8, device="cuda")
+    for k in range(B // 32):                                   # 32 distinct frames, 8 rotations of the order
+        frames[k * 32:(k + 1) * 32] = torch.roll(base, shifts=k, dims=0)
+    del base
+    out = det.chain(frames, start_level=3, max_points=256)
+    pts, lv, npts = [t.cpu().numpy() for t in out]
+    assert (npts >= 100).all()
+    # sample vs the oracle
+    for f in (0, 101, 255):
+        _check_against_oracle(frames[f].cpu().numpy(), pts[f], lv[f], int(npts[f]))
+    # batch-size independence: the same frames as four calls of 64 give the same lists
+    for k in range(4):
+        p2, l2, n2 = det.chain(frames[k * 64:(k + 1) * 64], start_level=3, max_points=256)
+        assert np.array_equal(n2.cpu().numpy(), npts[k * 64:(k + 1) * 64])
+        for f in range(64):
+            n = int(npts[k * 64 + f])
+            assert np.array_equal(p2[f, :n].cpu().numpy(), pts[k * 64 + f, :n])
+            assert np.array_equal(l2[f, :n].cpu().numpy(), lv[k * 64 + f, :n])
+    # the same frame at different positions of the batch gives the same list (frame 0 == frame 33 == ...)
+    for k in range(1, B // 32):
+        a, b = 0, k * 32 + k
+        n = int(npts[a])
+        assert int(npts[b]) == n and np.array_equal(pts[a, :n], pts[b, :n]) and np.array_equal(lv[a, :n], lv[b, :n])
+    # both scratch sets of the 256-frame shard are resident, and well below what a dense
+    # int32-per-pixel index alone used to take for them (4 B/px * 1.33 * 256 frames * 2 sets = 34 GB)
+    gib = det.scratch_bytes() / 2**30
+    assert gib < 120, gib
+    print(f"scratch for 256 frames of {W}x{H}, both sets: {gib:.1f} GiB")
+
+
+def test_scratch_for_64_frames():
+    d = mrgingham_amd.Detector(0)
+    try:
+        frames = synth.board_batch(2, W, H, gridn=10, seed0=1, device="cuda").repeat(32, 1, 1)
+        d.chain(frames, start_level=3, max_points=256)
+        gib = d.scratch_bytes() / 2**30
+        print(f"scratch for 64 frames of {W}x{H}, both sets: {gib:.2f} GiB")
+        # round 1 held 4 B/px of dense index per level and set: 64 * 12.58 MB * 4 * 1.33 * 2 = 8.6 GB for
+        # that table alone, ~31 GiB in total; the bound below fails if anything of that size comes back
+        assert gib < 20, gib
+    finally:
+        d.close()

@@ -139,89 +139,39 @@ def test_detect_error_paths():
     assert len(oracle.find_corners(np.zeros((10, 10), np.uint8), 0)) == 0
 
 
-# ---- hand-built responses exercising the fill rules ------------------------
-
-def _flat_img(h, w, var=True):
-    img = np.zeros((h, w), np.uint8)
-    if var:
-        img[:, ::2] = 255          # every 21x21 window has variance ~ 127^2 > 400
-    return img
-
+# ---- hand-built responses exercising the fill rules (tests/cc_cases.py; the GPU suite runs the
+# same buffers through the HIP kernels) ------------------------------------------------------
 
 def test_cc_rules_on_handbuilt_responses():
-    h, w = 48, 64
-    img = _flat_img(h, w)
-
-    def run(d, image=img):
-        return oracle.cc_detect_on_response(d, image)
-
-    # single pixel: N < 2 rejected (find_chessboard_corners.cc:205)
-    d = np.zeros((h, w), np.int16); d[20, 20] = 500
-    assert len(run(d)) == 0
-    # two pixels, peak > 120: accepted, weighted centroid (:262-263), *1000 rounding (:350-351)
-    d = np.zeros((h, w), np.int16); d[20, 20] = 300; d[20, 21] = 100
-    out = run(d)
-    assert out.tolist() == [[int(0.5 + (300 * 20 + 100 * 21) / 400 * 1000), 20000]]
-    # peak must be strictly > 120 (:206)
-    d = np.zeros((h, w), np.int16); d[20, 20] = 120; d[20, 21] = 100
-    assert len(run(d)) == 0
-    d[20, 20] = 121
-    assert len(run(d)) == 1
-    # responses <= 15 neither seed nor extend (:169)
-    d = np.zeros((h, w), np.int16); d[20, 20] = 300; d[20, 21] = 15; d[20, 22] = 300
-    assert len(run(d)) == 0                                 # two isolated single pixels
-    d[20, 21] = 16                                          # > 15 but not > 300>>4 = 18 (:27)
-    assert len(run(d)) == 0
-    d[20, 20] = 300; d[20, 21] = 19; d[20, 22] = 300
-    assert len(run(d)) == 1
-    # low variance window rejects (:207, :50-88)
-    d = np.zeros((h, w), np.int16); d[20, 20] = 300; d[20, 21] = 100
-    assert len(run(d, _flat_img(h, w, var=False))) == 0
-    # window leaving the image rejects (:52-57): peak at x = 9 < 10
-    d = np.zeros((h, w), np.int16); d[20, 9] = 300; d[20, 10] = 100
-    assert len(run(d)) == 0
-    d = np.zeros((h, w), np.int16); d[20, 10] = 300; d[20, 11] = 100
-    assert len(run(d)) == 1
-    # touching the margin invalidates but still consumes (:216-221, :259)
-    d = np.zeros((h, w), np.int16); d[20, 7] = 300; d[20, 8] = 300; d[20, 9] = 300; d[20, 10] = 300; d[20, 11] = 300
-    assert len(run(d)) == 0
-    # ratio-of-max rule is order dependent (:27, :170): seed 100 first, then 2000 raises the bar
-    d = np.zeros((h, w), np.int16)
-    d[20, 20] = 100; d[20, 21] = 2000; d[21, 20] = 100
-    # raster seed (20,20): push (21,20),(19,20),(20,21),(20,19) -> pops (20,21)... order of pops:
-    # y-1 first (zero), then y+1 = (21,20)? no: LIFO of +x,-x,+y,-y -> pops -y,+y,-x,+x.
-    # (20,21) is x=21,y=20 = +x, popped LAST, so (x=20,y=21) [+y] is accumulated at max=100.
-    out = run(d)
-    sw = 100 + 100 + 2000
-    assert out.tolist() == [[int(0.5 + (100 * 20 + 100 * 20 + 2000 * 21) / sw * 1000),
-                             int(0.5 + (100 * 20 + 100 * 21 + 2000 * 20) / sw * 1000)]]
-    # now make the big one pop first: put it at -y of the seed; then the 100s are below 2000>>4=125
-    d = np.zeros((h, w), np.int16)
-    d[20, 20] = 130; d[19, 20] = 0; d[21, 20] = 2000; d[20, 21] = 100
-    # pops: -y (0, skipped: not pushed), +y (2000) accumulated -> max 2000, threshold 125;
-    # its neighbours pushed; later (21,20)=100 <= 125 zeroed without being accumulated.
-    out = run(d)
-    sw = 130 + 2000
-    assert out.tolist() == [[20000, int(0.5 + (130 * 20 + 2000 * 21) / sw * 1000)]]
+    import cc_cases
+    cases = cc_cases.detect_cases()
+    assert len(cases) >= 25
+    for name, d, img, expected in cases:
+        out = oracle.cc_detect_on_response(d, img)
+        if expected is not None:
+            assert out.tolist() == expected, name
 
 
 def test_refine_rules():
-    h, w = 48, 64
-    img = _flat_img(h, w)
-    d = np.zeros((h, w), np.int16); d[20, 20] = 300; d[20, 21] = 100
-    pts = np.array([[20.2, 19.8], [100.0, 60.0]])   # full-resolution coordinates (:367-372)
-    # refine at level 0 only touches points whose level is 1 (:362)
-    p2, lv, n = oracle.cc_refine_on_response(pts, np.array([1, 2], np.int8), d, img, 0)
-    assert n == 1 and lv.tolist() == [0, 2]
-    assert p2[0, 0] == (300 * 20 + 100 * 21) / 400 and p2[0, 1] == 20.0
-    assert p2[1].tolist() == [100.0, 60.0]
-    # seed neighbourhood is 3x3 around the rounded point (:371-382): 2 px away finds nothing
-    p3, lv3, n3 = oracle.cc_refine_on_response(np.array([[23.0, 20.0]]), np.array([1], np.int8), d, img, 0)
-    assert n3 == 0 and lv3.tolist() == [1] and p3.tolist() == [[23.0, 20.0]]
-    # the response buffer mutates between points (:358-396): second identical point finds nothing
-    p4, lv4, n4 = oracle.cc_refine_on_response(np.array([[20.0, 20.0], [20.0, 20.0]]), np.array([1, 1], np.int8),
-                                               d, img, 0)
-    assert n4 == 1 and lv4.tolist() == [0, 1]
+    import cc_cases
+    for name, pts, lv, d, img, level, expected in cc_cases.refine_cases():
+        p2, l2, n = oracle.cc_refine_on_response(pts, lv, d, img, level)
+        if expected is not None:
+            ep, el, en = expected
+            assert n == en and l2.tolist() == el and np.array_equal(p2, ep), name
+    # two points sharing one blob: exactly one of them is refined, and it is the first
+    name, pts, lv, d, img, level, _ = [c for c in cc_cases.refine_cases() if c[0].startswith("two points share")][0]
+    p2, l2, n = oracle.cc_refine_on_response(pts, lv, d, img, level)
+    assert n == 1 and l2.tolist() == [0, 1]
+
+
+def test_random_sparse_responses_are_nontrivial():
+    """The random generator of the GPU rule tests produces accepted AND rejected blobs."""
+    import cc_cases
+    rng = np.random.RandomState(0)
+    d = cc_cases.random_sparse_response(rng, 96, 131, 60, noise=0.002)
+    out = oracle.cc_detect_on_response(d, cc_cases.flat_img(96, 131))
+    assert 3 < len(out) < 60
 
 
 # ----------------------------------------------------------------------------- preprocessing (row (f)-2)
