@@ -21,7 +21,14 @@ frames.  Rank 0 prints ONE JSON line.
                 with hipEvents on the stream each launch ran on.
   cpu_baseline  the C oracle (a port of the reference's algorithm) running the
                 same schedule on a bounded sample of the same frames, one frame
-                per host thread at a time like the reference CLI's --jobs.
+                per host thread at a time like the reference CLI's --jobs: T = 1
+                and T = all physical cores, both as numbers.
+  end_to_end    (N = 1) the same step fed from PINNED HOST memory: H2D of the
+                batch on two copy streams (double-buffered device frames) ->
+                chain -> D2H of the packed corner lists; never `value`.
+
+`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment)
+starts the N ranks itself, one process per GPU, on a free local port.
 """
 import argparse
 import json
@@ -43,48 +50,147 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 WORKLOADS = {
     # name: (W, H, gridn, start_level, batch)
-    "c3_4096x3072_chain": (4096, 3072, 10, 3, 64),
+    "c3_4096x3072_chain": (4096, 3072, 10, 3, 64),          # the size and board BASELINE.json's metric names
+    "c3_4096x3072_14x14_chain": (4096, 3072, 14, 3, 64),    # configs[2] as stated: 14x14 board
     "c2_1920x1080_level0": (1920, 1080, 10, 0, 64),
     "c1_640x480_chain": (640, 480, 10, 3, 64),
 }
 
 
+def physical_cores():
+    """(physical cores, logical cpus, model name) of this host from /proc/cpuinfo."""
+    logical = os.cpu_count() or 1
+    cores, model, phys, core = set(), "unknown", None, None
+    try:
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core))
+                phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    try:
+        logical = min(logical, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    n = len(cores) if cores else max(1, logical // 2)
+    return min(n, logical), logical, model
+
+
 def cpu_baseline(frames_host, start_level, cpu_seconds=15.0):
-    """Oracle (kind "port") on the host cores: frame-parallel threads, one frame per thread at a
-    time (the reference CLI's --jobs model), over a bounded sample worth ~cpu_seconds of CPU work."""
+    """Oracle (kind "port") on the host cores, frame-parallel like the reference CLI's --jobs
+    (mrgingham-from-image.cc:50, :374-379): T = 1 and T = all PHYSICAL cores, each over a bounded
+    sample of the batch (about cpu_seconds of CPU work for the parallel leg)."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle
     oracle.lib()
-    ncores = os.cpu_count() or 1
+    ncores, nlogical, model = physical_cores()
     n = len(frames_host)
     oracle.chain(frames_host[0], start_level)               # warm (page in the library, the frame)
     t0 = time.perf_counter()
-    oracle.chain(frames_host[0], start_level)               # one frame sizes the sample
-    t1 = time.perf_counter() - t0
-    nsample = int(min(max(ncores, cpu_seconds / max(t1, 1e-4)), 50 * ncores))
+    n1 = 0
+    while n1 < 3 or (time.perf_counter() - t0 < 2.0 and n1 < 64):   # T = 1: a few frames, ~2 s
+        oracle.chain(frames_host[n1 % n], start_level)
+        n1 += 1
+    t1 = (time.perf_counter() - t0) / n1
+    nsample = int(min(max(2 * ncores, cpu_seconds / max(t1, 1e-4)), 50 * ncores))
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=ncores) as ex:      # ctypes releases the GIL
         list(ex.map(lambda i: oracle.chain(frames_host[i % n], start_level), range(nsample)))
     dt = time.perf_counter() - t0
-    model = "unknown"
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                model = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
-    extra = ""
-    if oracle.have_reference_build():                       # the upstream ChESS.c itself, for scale
+    out = {"value": nsample / dt, "unit": "frames/s", "cores": ncores, "kind": "port",
+           "physical_cores": ncores, "logical_cpus": nlogical, "cpu_model": model,
+           "t1_frames_s": 1.0 / t1, "tall_frames_s": nsample / dt, "threads_all": ncores,
+           "sample": f"T=1: {n1} frames back to back on one thread ({t1 * 1e3:.0f} ms per frame); T={ncores} "
+                     f"(one thread per physical core, one frame per thread at a time): {nsample} frame passes over "
+                     f"{n} distinct frames of the batch in {dt:.1f} s; every pass is the full "
+                     f"detect(L{start_level})+refine chain of the C oracle (a port, gcc -O3)",
+           "what": "`value` = tall_frames_s = the stated CPU baseline: the oracle port, whole chain, all physical "
+                   "cores.  The upstream ChESS.c built as shipped (oracle/_ref) is timed beside it for scale only."}
+    if oracle.have_reference_build():                       # the upstream ChESS.c itself, level 0 only
+        oracle.ref_chess_response_5(frames_host[0])
         t0 = time.perf_counter()
         oracle.ref_chess_response_5(frames_host[0])
-        extra = (f"; upstream ChESS.c (oracle/_ref) level-0 response alone: "
-                 f"{(time.perf_counter() - t0) * 1e3:.0f} ms per frame on 1 thread")
-    return {"value": nsample / dt, "unit": "frames/s", "cores": min(ncores, nsample), "kind": "port",
-            "sample": f"{nsample} frame passes over {n} distinct frames of the batch, full "
-                      f"detect(L{start_level})+refine chain, {min(ncores, nsample)} threads x 1 frame each at a "
-                      f"time, {nsample * t1:.0f} s of CPU work; cpu: {model}; 1 frame on 1 thread: "
-                      f"{t1 * 1e3:.0f} ms{extra}"}
+        out["upstream_chess_level0_ms_per_frame_t1"] = (time.perf_counter() - t0) * 1e3
+    return out
+
+
+def end_to_end(det, frames, start_level, P, steps=12, warmup=3):
+    """The step fed from pinned host memory (SURVEY.md 8d's second rate): host batch -> H2D on one of
+    two copy streams into one of two device buffers -> chain on the context's streams -> packed corner
+    lists D2H on a third stream; uploads of step i+1 overlap the kernels of step i."""
+    from mrgingham_amd import parallel
+    B, H, W = frames.shape
+    dev = frames.device
+    host = torch.empty((B, H, W), dtype=torch.uint8, pin_memory=True)
+    host.copy_(frames)
+    dbuf = [torch.empty_like(frames) for _ in range(2)]
+    packs = [parallel.packed_outputs(B, P, dev) for _ in range(2)]
+    hout = [torch.empty(packs[0][0].numel(), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+    up = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    down = torch.cuda.Stream(dev)
+    done = [None, None]
+    torch.cuda.synchronize()
+
+    def step(i):
+        b = i & 1
+        with torch.cuda.stream(up[b]):
+            if done[b] is not None:
+                up[b].wait_event(done[b])                    # the chain that read dbuf[b] / wrote packs[b] is complete
+            dbuf[b].copy_(host, non_blocking=True)
+        det.after_stream(up[b])                              # the chain starts behind the upload, on the device
+        det.chain(dbuf[b], start_level=start_level, max_points=P, out=packs[b][1:], sync=False)
+        det.stream_wait(down)
+        with torch.cuda.stream(down):
+            hout[b].copy_(packs[b][0], non_blocking=True)
+            done[b] = torch.cuda.Event()
+            done[b].record(down)
+
+    for i in range(warmup):
+        step(i)
+    det.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(warmup, warmup + steps):
+        step(i)
+    det.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    npts = parallel.unpack_outputs(hout[(warmup + steps - 1) & 1], B, P)[2]
+    return {"value": B * steps / dt, "unit": "frames/s", "h2d_GBs": B * H * W * steps / dt / 1e9,
+            "d2h_bytes_per_step": int(packs[0][0].numel()), "steps": steps, "ms_per_step": dt / steps * 1e3,
+            "frames_with_points_last_step": int((npts > 0).sum()),
+            "what": "pinned host batch -> H2D (2 copy streams, double-buffered) -> chain -> corner lists D2H to "
+                    "pinned host; PCIe-bound (the link, not the kernels)"}
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one process per GPU,
+    rendezvous on a free local port) and wait for them; rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    return rc
 
 
 def main():
@@ -102,7 +208,17 @@ def main():
                     help="render only this many distinct frames and repeat them to fill the batch (used for the "
                          "rocprofv3 --pmc passes, where tracing the ~37k tiny kernels of the frame generator is "
                          "the bottleneck); default: every frame distinct")
+    ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="with one rank: still create the (one-rank) RCCL group and issue the gather every step")
+    ap.add_argument("--prime", type=int, default=30,
+                    help="untimed set-up passes before the W warm-up steps (scratch allocation, clock ramp); reported")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} HIP device(s) here")
+        sys.exit(launch_ranks(args.gpus))                    # no launcher: start the ranks ourselves
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,10 +226,17 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: mrgingham_amd has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    collective = world > 1 or args.force_gather
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
 
     import mrgingham_amd
     from mrgingham_amd import parallel, synth
@@ -139,7 +262,7 @@ def main():
     NBUF = 3
     packs = [parallel.packed_outputs(batch, P, dev) for _ in range(NBUF)]   # (pack, points, levels, npoints)
     outs = [p[1:] for p in packs]
-    gathered = [torch.empty((world, packs[0][0].numel()), dtype=torch.uint8, device=dev) if (world > 1 and rank == 0)
+    gathered = [torch.empty((world, packs[0][0].numel()), dtype=torch.uint8, device=dev) if (collective and rank == 0)
                 else None for _ in range(NBUF)]
     consumed = [None] * NBUF
     torch.cuda.synchronize()
@@ -151,9 +274,9 @@ def main():
         if consumed[k] is not None:
             consumed[k].synchronize()                        # gather of three steps ago: long done
         pts, lv, npts = det.chain(frames, start_level=start_level, max_points=P, out=outs[k], sync=False)
-        if world > 1:
+        if collective:
             det.stream_wait()                                # torch's stream waits for this step on the device
-            parallel.gather_packed(packs[k][0], dst=0, out=gathered[k])    # the ONE collective of the path
+            parallel.gather_packed(packs[k][0], dst=0, out=gathered[k], force=True)   # the ONE collective of the path
             consumed[k] = torch.cuda.Event()
             consumed[k].record()
         return npts
@@ -161,10 +284,18 @@ def main():
     def fence():
         det.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
+    for _ in range(args.prime):                              # set-up: first call allocates the scratch
+        step()
+    fence()
+    ranks_seen = 1
+    if collective:
+        seen = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(seen)
+        ranks_seen = int(seen.item())
     for _ in range(args.warmup):
         step()
     det.set_kernel_timing(True)
@@ -178,12 +309,18 @@ def main():
     det.set_kernel_timing(False)
     kern_ms, nlaunch = det.chess_kernel_ms()
 
-    if world > 1:
+    if collective:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
     found = int((npts >= gridn * gridn).sum().item())
+    gather_ok = None
+    if collective and rank == 0:                             # what rank 0 received equals what the ranks produced
+        last = (nstep[0] - 1) % NBUF
+        gp, gl, gn = parallel.unpack_outputs(gathered[last], batch, P)
+        gather_ok = bool(torch.equal(gn[0], packs[last][3]) and torch.equal(gp[0], packs[last][1]))
+        assert gather_ok, "gathered corner lists differ from rank 0's own"
     if rank == 0:
         total_frames = world * batch * args.steps
         # level-0 ChESS launches per step = number of stream chunks; frames per launch follows
@@ -208,6 +345,7 @@ def main():
             "value": total_frames / dt,
             "unit": "frames/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
@@ -218,7 +356,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {batch} frames/GPU of {W}x{H} u8, {gridn}x{gridn} board, "
                                    f"detect at level {start_level} + refine to level 0, corner lists "
-                                   f"{'gathered to rank 0' if world > 1 else 'left on the device'}",
+                                   f"{'gathered to rank 0' if collective else 'left on the device'}",
                        "frames_per_gpu": batch, "width": W, "height": H, "gridn": gridn,
                        "start_level": start_level, "parallelism": f"frames sharded x{world}",
                        "frames_with_full_grid_last_step": found},
@@ -229,11 +367,21 @@ def main():
                          "bytes_per_launch": alg_bytes, "avg_launch_ms": kern_ms,
                          "launches_timed": nlaunch},
         }
-        if not args.no_cpu_baseline:
-            nhost = min(batch, 2 * (os.cpu_count() or 1))
+        res["gather_checked"] = gather_ok
+        res["setup_prime_steps"] = args.prime
+        res["timed_region_s"] = dt
+        res["notes"] = ("steps are queued back to back (streaming pipeline); the first few dozen passes of a process "
+                        "run ~5-7 % below the steady state (clock ramp), which is why `setup_prime_steps` untimed "
+                        "set-up passes precede the W warm-up steps; a timed region shorter than ~0.1 s still "
+                        "under-reads the steady state slightly")
+        res["scratch_GiB"] = det.scratch_bytes() / 2**30
+        if world == 1 and not args.no_end_to_end:
+            res["end_to_end"] = end_to_end(det, frames, start_level, P)
+        if world == 1 and not args.no_cpu_baseline:
+            nhost = min(batch, 64)
             res["cpu_baseline"] = cpu_baseline(frames[:nhost].cpu().numpy(), start_level)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -207,6 +207,16 @@ bool find_chessboard_corners_from_image_file_C(const char* filename, int image_p
 bool find_chessboard_from_image_file_C(const char* filename, const int gridn, int image_pyramid_level, bool debug,
                                        bool (*add_points)(double* xy, int N, void* cookie), void* cookie);
 
+/* The image decoder behind the two functions above and the command-line tool, on its own (host only, no
+ * device needed): binary PGM (8 / 16 bit) and non-interlaced PNG.  `out` (may be NULL: sizes only)
+ * receives width*height grey bytes.  16-bit samples: cli_scaling = 0 keeps the high byte, what
+ * cv::imread(IMREAD_GRAYSCALE) gives the file entry points; 1 rescales by 255/65535 with rounding, what
+ * the CLI's convertTo does (mrgingham-from-image.cc:85-92).  Returns 0; -1 unreadable, unsupported or
+ * malformed file (never throws, never reads or writes out of bounds on a crafted file; sides above
+ * 32767 are rejected); -2 out_capacity too small (sizes are still reported). */
+int mrgingham_amd_read_image(const char* filename, int cli_scaling, uint8_t* out, size_t out_capacity, int* width,
+                             int* height, int* depth);
+
 /* The same preprocessing for one HOST image (out: dense width x height bytes, host): what the Python
  * recipe of find_board.docstring:8-10 does with cv2 before find_board.  Uses the calling thread's
  * context.  Returns 0, or -2 on an argument or device error. */
@@ -257,6 +267,11 @@ int mrgingham_amd_sync(mrgingham_amd_ctx* ctx);
  * the component kernels of call N finish, on alternating scratch sets), so give each call in
  * flight its own output buffers. */
 int mrgingham_amd_stream_wait(mrgingham_amd_ctx* ctx, void* stream);
+
+/* The other direction: the NEXT detect / refine / chain call queued on the context starts only after
+ * everything queued so far on `stream` (e.g. the host-to-device copy of its frames on a copy stream)
+ * has completed.  Does not block the host. */
+int mrgingham_amd_after_stream(mrgingham_amd_ctx* ctx, void* stream);
 
 /* Average duration in milliseconds of the dominant kernel (the level-0 ChESS
  * response kernel) over the launches issued since the last call, measured with

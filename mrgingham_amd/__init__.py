@@ -12,7 +12,7 @@ memory and streams.
     board = mrgingham.find_board(image, gridn=10)               # float64[100, 2] or None
 """
 from .api import (ChESS_response_5, find_points, find_chessboard_corners, refine_points, find_board, find_chessboard,
-                  find_grid_from_points, preprocess, Detector, level_dims)
+                  find_grid_from_points, preprocess, read_image, Detector, level_dims)
 
 __all__ = ["ChESS_response_5", "find_points", "find_chessboard_corners", "refine_points", "find_board",
-           "find_chessboard", "find_grid_from_points", "preprocess", "Detector", "level_dims"]
+           "find_chessboard", "find_grid_from_points", "preprocess", "read_image", "Detector", "level_dims"]

@@ -31,8 +31,8 @@ EXPORTS = [
     "mrgingham_amd_preprocess_batch", "mrgingham_amd_process_image", "mrgingham_amd_preprocess_image",
     "find_chessboard_corners_from_image_file_C", "find_chessboard_from_image_file_C",
     "mrgingham_amd_detect_batch", "mrgingham_amd_refine_batch", "mrgingham_amd_chain_batch",
-    "mrgingham_amd_find_boards_batch", "mrgingham_amd_cc_on_response_batch", "mrgingham_amd_scratch_bytes",
-    "mrgingham_amd_set_option", "mrgingham_amd_sync", "mrgingham_amd_stream_wait", "mrgingham_amd_set_kernel_timing",
+    "mrgingham_amd_find_boards_batch", "mrgingham_amd_cc_on_response_batch", "mrgingham_amd_scratch_bytes", "mrgingham_amd_read_image",
+    "mrgingham_amd_set_option", "mrgingham_amd_sync", "mrgingham_amd_stream_wait", "mrgingham_amd_after_stream", "mrgingham_amd_set_kernel_timing",
     "mrgingham_amd_chess_kernel_ms",
 ]
 
@@ -94,11 +94,14 @@ def lib():
     L.mrgingham_amd_find_boards_batch.argtypes = [c_vp, FP, c_int, c_int, c_vp, c_vp, c_int]
     L.mrgingham_amd_cc_on_response_batch.argtypes = [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp,
                                                      c_vp, c_vp, c_vp, c_int, c_vp]
+    L.mrgingham_amd_read_image.argtypes = [ctypes.c_char_p, c_int, c_vp, ctypes.c_size_t, ctypes.POINTER(c_int),
+                                           ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     L.mrgingham_amd_scratch_bytes.argtypes = [c_vp]
     L.mrgingham_amd_scratch_bytes.restype = ctypes.c_longlong
     L.mrgingham_amd_set_option.argtypes = [c_vp, ctypes.c_char_p, c_int]
     L.mrgingham_amd_sync.argtypes = [c_vp]
     L.mrgingham_amd_stream_wait.argtypes = [c_vp, c_vp]
+    L.mrgingham_amd_after_stream.argtypes = [c_vp, c_vp]
     L.mrgingham_amd_set_kernel_timing.argtypes = [c_vp, c_int]
     L.mrgingham_amd_set_kernel_timing.restype = None
     L.mrgingham_amd_chess_kernel_ms.argtypes = [c_vp, ctypes.POINTER(c_int)]

@@ -5,6 +5,7 @@ behaviour: mrgingham_pywrap.c:40-112 ChESS_response_5, :128-212 find_points).
 `Detector` is the batch interface over device-resident torch tensors.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -104,6 +105,23 @@ def refine_points(points, levels, image, image_pyramid_level):
                                                                 lv.ctypes.data, len(lv), int(image_pyramid_level),
                                                                 False)
     return pts, lv, n
+
+
+def read_image(filename, cli_scaling=False):
+    """Decode a binary PGM or non-interlaced PNG to uint8 [H, W] with the library's own decoder (host only).
+    16-bit files: the high byte (cv::imread(IMREAD_GRAYSCALE)) or, with cli_scaling, the CLI's
+    convertTo(255/65535).  None when the file is unreadable, unsupported or malformed."""
+    L = _lib.lib()
+    w, h, d = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    name = os.fsencode(filename)
+    if L.mrgingham_amd_read_image(name, int(bool(cli_scaling)), None, 0, ctypes.byref(w), ctypes.byref(h),
+                                  ctypes.byref(d)) != 0:
+        return None
+    out = np.empty((h.value, w.value), dtype=np.uint8)
+    if L.mrgingham_amd_read_image(name, int(bool(cli_scaling)), out.ctypes.data, out.size, ctypes.byref(w),
+                                  ctypes.byref(h), ctypes.byref(d)) != 0:
+        return None
+    return out
 
 
 def find_grid_from_points(points_scaled, gridn=10):
@@ -221,6 +239,13 @@ class Detector:
         t = self.torch
         st = t.cuda.current_stream(self.device) if stream is None else stream
         self._check(self.L.mrgingham_amd_stream_wait(self.ctx, st.cuda_stream))
+
+    def after_stream(self, stream=None):
+        """The next queued call starts after what is queued so far on a torch stream (default: the
+        current one), e.g. the upload of its frames; on the device, the host is not blocked."""
+        t = self.torch
+        st = t.cuda.current_stream(self.device) if stream is None else stream
+        self._check(self.L.mrgingham_amd_after_stream(self.ctx, st.cuda_stream))
 
     def chess_response(self, frames, level=0, clamp=False, out=None):
         """Dense int16 response [B,h,w] (border zero).  Runs on torch's current stream."""

@@ -113,6 +113,7 @@ struct mrgingham_amd_ctx {
     // Level scratch exists twice: call N+1 fills set (N+1)%2 on the pixel stream while the
     // component stream still works through call N in the other set.
     hipEvent_t ev_cc_done[2] = {};
+    hipEvent_t ev_ext = nullptr;  // mrgingham_amd_after_stream
     bool cc_pending[2] = {false, false};
     int cur = 0;  // scratch set of the call being queued
     std::string err;
@@ -120,7 +121,7 @@ struct mrgingham_amd_ctx {
     bool use_v0 = false;  // reference-shaped ChESS kernel instead of the tuned one
     // levels 3..1 of a chain in one launch (set_option "multi_level_launch"): +1.5 % chain rate, but the
     // component chains then start later and overlap the level-0 launch more (+5 % on that launch): off
-    bool multi_level = false;
+    int multi_level = 0;  // 0 = one launch per level; 1 = levels 3..1 in one launch; 2 = levels 0..3 in one launch
     // component-chain schedule of chain_batch: 0 = every level's component kernels start as soon as
     // that level's response is done; 1 = levels 1 and 0 wait for the level-0 response (they then run
     // underneath the NEXT call's pyramid and small levels instead of underneath this call's level 0)
@@ -314,18 +315,19 @@ static CompTables tables_of(mrgingham_amd_ctx* ctx, int level) {
     return t;
 }
 
+static hipEvent_t timing_event(mrgingham_amd_ctx* ctx) {
+    hipEvent_t e;
+    if (!ctx->event_pool.empty()) { e = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
+    else hipEventCreate(&e);
+    return e;
+}
+
 static void launch_chess_any(mrgingham_amd_ctx* ctx, const LevelBatch& lb, const CompTables& t, int n, bool clamp,
                              bool hot, hipStream_t s, bool time_it) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (time_it && ctx->timing) {
-        auto get = [ctx]() {
-            hipEvent_t e;
-            if (!ctx->event_pool.empty()) { e = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
-            else hipEventCreate(&e);
-            return e;
-        };
-        e0 = get();
-        e1 = get();
+        e0 = timing_event(ctx);
+        e1 = timing_event(ctx);
         hipEventRecord(e0, s);
     }
     if (lb.w > 0 && lb.h > 0 && n > 0) {
@@ -518,6 +520,7 @@ void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx) {
         if (e) hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_cc_done)
         if (e) hipEventDestroy(e);
+    if (ctx->ev_ext) hipEventDestroy(ctx->ev_ext);
     if (ctx->pix) hipStreamDestroy(ctx->pix);
     for (hipStream_t c : ctx->ccs)
         if (c) hipStreamDestroy(c);
@@ -557,8 +560,9 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
         return 0;
     }
     if (!strcmp(name, "chess_v0")) { ctx->use_v0 = value != 0; return 0; }
-    if (!strcmp(name, "multi_level_launch")) { ctx->multi_level = value != 0; return 0; }
+    if (!strcmp(name, "multi_level_launch")) { ctx->multi_level = value < 0 ? 0 : value > 2 ? 2 : value; return 0; }
     if (!strcmp(name, "cc_schedule")) { ctx->cc_schedule = value; return 0; }
+    if (!strcmp(name, "chess_stage")) { mrg::chess_stage_override = value; return 0; }
     if (!strcmp(name, "chess_seg")) { mrg::chess_seg_override = value > 0 ? value : 0; return 0; }
     return MRGINGHAM_AMD_ERR_ARG;
 }
@@ -622,6 +626,16 @@ int mrgingham_amd_stream_wait(mrgingham_amd_ctx* ctx, void* stream) {
     MRG_HIP_CHECK(hipSetDevice(ctx->device));
     for (int set = 0; set < 2; ++set)  // consecutive calls finish on different component streams
         if (ctx->cc_pending[set]) MRG_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, ctx->ev_cc_done[set], 0));
+    return MRGINGHAM_AMD_OK;
+}
+
+int mrgingham_amd_after_stream(mrgingham_amd_ctx* ctx, void* stream) {
+    if (!ctx) return MRGINGHAM_AMD_ERR_ARG;
+    MRG_HIP_CHECK(hipSetDevice(ctx->device));
+    if (!ctx->ev_ext) MRG_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_ext, hipEventDisableTiming));
+    MRG_HIP_CHECK(hipEventRecord(ctx->ev_ext, (hipStream_t)stream));
+    // every kernel of a call is ordered behind the pixel stream's work of that call
+    MRG_HIP_CHECK(hipStreamWaitEvent(ctx->pix, ctx->ev_ext, 0));
     return MRGINGHAM_AMD_OK;
 }
 
@@ -831,28 +845,42 @@ int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames
     // pixel stream: every level image in one pass over the frames, then the responses top-down
     queue_level_images(ctx, fr, start_level);
     LevelBatch lbs[kMaxLevel + 1];
-    // levels 3 (or the top), 2, 1 in one launch when the shapes allow it, then level 0
+    // levels 3 (or the top), 2, 1 -- or all of them, level 0 included -- in one launch when the shapes
+    // allow it
     bool merged = false;
     const int top = start_level < 3 ? start_level : 3;
-    if (top >= 2 && !ctx->use_v0 && ctx->multi_level) {
-        LevelBatch mlb[3];
-        CompTables mt[3];
+    const int lowest = ctx->multi_level == 2 ? 0 : 1;  // lowest level inside the merged launch
+    if (top - lowest >= 1 && !ctx->use_v0 && ctx->multi_level) {
+        LevelBatch mlb[4];
+        CompTables mt[4];
         int n = 0;
-        for (int L = 1; L <= top; ++L, ++n) {  // largest level first
+        for (int L = lowest; L <= top; ++L, ++n) {  // largest level first
             mlb[n] = level_batch_of(ctx, fr, L);
             mt[n] = tables_of(ctx, L);
         }
-        for (int L = start_level; L > top; --L) lbs[L] = queue_level_chess(ctx, fr, L);
-        merged = launch_chess_multi(mlb, mt, n, fr->nframes, ctx->pix);
+        // decided BEFORE anything is queued: a level must not be appended to its hot list twice
+        if (chess_multi_ok(mlb, n, fr->nframes)) {
+            for (int L = start_level; L > top; --L) lbs[L] = queue_level_chess(ctx, fr, L);
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (lowest == 0 && ctx->timing) {
+                e0 = timing_event(ctx);
+                e1 = timing_event(ctx);
+                hipEventRecord(e0, ctx->pix);
+            }
+            merged = launch_chess_multi(mlb, mt, n, fr->nframes, ctx->pix);
+            if (e0) {
+                hipEventRecord(e1, ctx->pix);
+                ctx->events.emplace_back(e0, e1);
+            }
+        }
         if (merged)
-            for (int L = top; L >= 1; --L) {
-                lbs[L] = mlb[L - 1];
+            for (int L = top; L >= lowest; --L) {
+                lbs[L] = mlb[L - lowest];
                 hipEventRecord(ctx->ev_pix[L], ctx->pix);
                 if (fr->nframes > ctx->pending_frames[ctx->cur][L]) ctx->pending_frames[ctx->cur][L] = fr->nframes;
             }
     }
-    for (int L = merged ? 0 : start_level; L >= 0; --L)
-        if (!merged || L == 0) lbs[L] = queue_level_chess(ctx, fr, L);
+    for (int L = merged ? lowest - 1 : start_level; L >= 0; --L) lbs[L] = queue_level_chess(ctx, fr, L);
     // component stream: detect at the top (mrgingham.cc:50), candidates -> corners
     // (find_grid.cc:353-354), then refine level by level (mrgingham.cc:87-99)
     MRG_HIP_CHECK(hipStreamWaitEvent(cur_cc(ctx), ctx->ev_pix[ctx->cc_schedule == 2 ? 0 : start_level], 0));
@@ -962,6 +990,36 @@ static int upload_frame(mrgingham_amd_ctx* ctx, const void* host, int rows, int 
     return 0;
 }
 
+// Every candidate of ONE frame that already lives on the device (dense or strided), with the retry of
+// the reference-symbol wrappers: a frame whose hot list or candidate table overflows the default
+// capacity is re-run with one table entry per pixel.  Returns false on a device / argument error.
+static bool detect_one_frame_all(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr1, int level,
+                                 std::vector<int32_t>& xy, int32_t* count_out) {
+    const int saved_shift = ctx->cap_shift;
+    bool ok = false;
+    int32_t count = 0;
+    for (int attempt = 0; attempt < 2 && !ok; ++attempt) {
+        if (ensure_level(ctx, level, 1, fr1->width, fr1->height, 0) || ensure_points(ctx, 1, 1)) break;
+        const int cap = ctx->lvs[0][level].cand_cap;
+        if (ensure(ctx, ctx->io_out, (size_t)cap * 8 + 64) || ensure(ctx, ctx->io_counts, 64)) break;
+        if (mrgingham_amd_detect_batch(ctx, fr1, level, (int32_t*)ctx->io_out.p, cap, (int32_t*)ctx->io_counts.p)) break;
+        const int rc = mrgingham_amd_sync(ctx);
+        if (rc == MRGINGHAM_AMD_ERR_CAPACITY && attempt == 0) {
+            ctx->cap_shift = 0;  // adversarial texture: retry with a table entry for every pixel
+            continue;
+        }
+        if (rc) break;
+        if (hipMemcpy(&count, ctx->io_counts.p, sizeof(count), hipMemcpyDeviceToHost) != hipSuccess) break;
+        xy.resize((size_t)(count > 0 ? count : 0) * 2);
+        if (count > 0 && hipMemcpy(xy.data(), ctx->io_out.p, (size_t)count * 8, hipMemcpyDeviceToHost) != hipSuccess)
+            break;
+        ok = true;
+    }
+    ctx->cap_shift = saved_shift;
+    *count_out = count;
+    return ok;
+}
+
 void mrgingham_ChESS_response_5(int16_t* response, const uint8_t* image, int w, int h, int stride) {
     if (w < 15 || h < 15) return;  // no interior: the reference's loops do not execute (ChESS.c:62-63)
     mrgingham_amd_ctx* ctx = thread_ctx();
@@ -1011,35 +1069,11 @@ bool find_chessboard_corners_from_image_array_C(int Nrows, int Ncols, int stride
     mrgingham_amd_ctx* ctx = thread_ctx();
     if (!ctx) return false;
     hipSetDevice(ctx->device);
-    const int saved_shift = ctx->cap_shift;
     std::vector<int32_t> xy;
     int32_t count = 0;
-    bool ok = false;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        mrgingham_amd_frames fr;
-        if (upload_frame(ctx, imagebuffer, Nrows, Ncols, stride, &fr)) break;
-        if (ensure_level(ctx, image_pyramid_level, 1, Ncols, Nrows, 0)) break;
-        if (ensure_points(ctx, 1, 1)) break;
-        const int cap = ctx->lvs[0][image_pyramid_level].cand_cap;
-        if (ensure(ctx, ctx->io_out, (size_t)cap * 8 + 64) || ensure(ctx, ctx->io_counts, 64)) break;
-        if (mrgingham_amd_detect_batch(ctx, &fr, image_pyramid_level, (int32_t*)ctx->io_out.p, cap,
-                                       (int32_t*)ctx->io_counts.p))
-            break;
-        const int rc = mrgingham_amd_sync(ctx);
-        if (rc == MRGINGHAM_AMD_ERR_CAPACITY && attempt == 0) {
-            ctx->cap_shift = 0;  // adversarial texture: retry with a table entry for every pixel
-            continue;
-        }
-        if (rc) break;
-        if (hipMemcpy(&count, ctx->io_counts.p, sizeof(count), hipMemcpyDeviceToHost) != hipSuccess) break;
-        if (count > 0) {
-            xy.resize((size_t)count * 2);
-            if (hipMemcpy(xy.data(), ctx->io_out.p, (size_t)count * 8, hipMemcpyDeviceToHost) != hipSuccess) break;
-        }
-        ok = true;
-        break;
-    }
-    ctx->cap_shift = saved_shift;
+    mrgingham_amd_frames fr;
+    const bool ok = upload_frame(ctx, imagebuffer, Nrows, Ncols, stride, &fr) == 0 &&
+                    detect_one_frame_all(ctx, &fr, image_pyramid_level, xy, &count);
     if (!ok || count <= 0) return false;  // bridge.cc:61: nothing found -> false, add_points not called
     return (*add_points)(xy.data(), (int)count, 1. / kGridScale, cookie);  // bridge.cc:66-69
 }
@@ -1112,7 +1146,6 @@ static int find_board_on_device(mrgingham_amd_ctx* ctx, const char* who, const m
                                 int image_pyramid_level, bool do_refine, std::vector<PointD>& board,
                                 std::vector<signed char>& lv) {
     const int Nrows = fr->height, Ncols = fr->width;
-    const int saved_shift = ctx->cap_shift;
     const int N = gridn * gridn;
     std::vector<int32_t> xy;
     bool found = false;
@@ -1123,23 +1156,7 @@ static int find_board_on_device(mrgingham_amd_ctx* ctx, const char* who, const m
     for (; level >= last && !found; --level) {
         if (!check_level_and_layout(who, Nrows, Ncols, fr->stride, level)) continue;
         int32_t count = 0;
-        bool ok = false;
-        for (int attempt = 0; attempt < 2 && !ok; ++attempt) {
-            if (ensure_level(ctx, level, 1, Ncols, Nrows, N) || ensure_points(ctx, 1, N)) break;
-            const int cap = ctx->lvs[0][level].cand_cap;
-            if (ensure(ctx, ctx->io_out, (size_t)cap * 8 + (size_t)N * 17 + 256) || ensure(ctx, ctx->io_counts, 64)) break;
-            if (mrgingham_amd_detect_batch(ctx, fr, level, (int32_t*)ctx->io_out.p, cap, (int32_t*)ctx->io_counts.p))
-                break;
-            const int rc = mrgingham_amd_sync(ctx);
-            if (rc == MRGINGHAM_AMD_ERR_CAPACITY && attempt == 0) { ctx->cap_shift = 0; continue; }
-            if (rc) break;
-            if (hipMemcpy(&count, ctx->io_counts.p, sizeof(count), hipMemcpyDeviceToHost) != hipSuccess) break;
-            xy.resize((size_t)(count > 0 ? count : 0) * 2);
-            if (count > 0 && hipMemcpy(xy.data(), ctx->io_out.p, (size_t)count * 8, hipMemcpyDeviceToHost) != hipSuccess)
-                break;
-            ok = true;
-        }
-        ctx->cap_shift = saved_shift;
+        const bool ok = detect_one_frame_all(ctx, fr, level, xy, &count);
         if (!ok || count < N) continue;
         std::vector<PointI> cand((size_t)count);
         for (int i = 0; i < count; ++i) cand[i] = PointI{xy[2 * i], xy[2 * i + 1]};
@@ -1189,7 +1206,8 @@ bool find_chessboard_from_image_array_C(int Nrows, int Ncols, int stride, char* 
 /* The reference's file entry points: find_chessboard_corners_from_image_file
  * (find_chessboard_corners.cc:623-648) and find_chessboard_from_image_file (mrgingham.cc:145-170) are
  * cv::imread(GRAYSCALE) followed by the array functions.  Here the file is decoded by csrc/image_io
- * (binary PGM, non-interlaced PNG; 16-bit samples are reduced to 8 bit) -- same results as the array
+ * (binary PGM, non-interlaced PNG; 16-bit samples are reduced to their high byte, as cv::imread without
+ * IMREAD_ANYDEPTH does) -- same results as the array
  * functions on the decoded pixels, same "Couldn't open image" failure. */
 static bool load_gray8(const char* who, const char* filename, mrg::Image& im, std::vector<uint8_t>& tmp,
                        const uint8_t** px) {
@@ -1198,12 +1216,33 @@ static bool load_gray8(const char* who, const char* filename, mrg::Image& im, st
         return false;
     }
     if (im.depth == 16) {
-        mrg::to_8bit(im, tmp);
+        mrg::to_8bit_imread(im, tmp);  // cv::imread(GRAYSCALE) keeps the high byte; the CLI's own path rescales
         *px = tmp.data();
     } else {
         *px = im.px8.data();
     }
     return true;
+}
+
+int mrgingham_amd_read_image(const char* filename, int cli_scaling, uint8_t* out, size_t out_capacity, int* width,
+                             int* height, int* depth) {
+    mrg::Image im;
+    if (!filename || !mrg::read_image(filename, im)) return -1;
+    if (width) *width = im.w;
+    if (height) *height = im.h;
+    if (depth) *depth = im.depth;
+    const size_t n = (size_t)im.w * im.h;
+    if (!out) return 0;
+    if (out_capacity < n) return -2;
+    if (im.depth == 16) {
+        std::vector<uint8_t> tmp;
+        if (cli_scaling) mrg::to_8bit(im, tmp);
+        else mrg::to_8bit_imread(im, tmp);
+        memcpy(out, tmp.data(), n);
+    } else {
+        memcpy(out, im.px8.data(), n);
+    }
+    return 0;
 }
 
 bool find_chessboard_corners_from_image_file_C(const char* filename, int image_pyramid_level, bool debug,
@@ -1347,13 +1386,34 @@ int mrgingham_amd_find_boards_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_
             cur_idx = open;
         }
         const int nb = (int)cur_idx.size();
-        if ((rc = mrgingham_amd_detect_batch(ctx, &cur, L, (int32_t*)d_xy.p, cap, (int32_t*)d_cnt.p)) ||
-            (rc = mrgingham_amd_sync(ctx))) break;
+        if ((rc = mrgingham_amd_detect_batch(ctx, &cur, L, (int32_t*)d_xy.p, cap, (int32_t*)d_cnt.p))) break;
+        rc = mrgingham_amd_sync(ctx);
+        if (rc == MRGINGHAM_AMD_ERR_CAPACITY) rc = 0;  // the frames concerned report count -1: handled below
+        if (rc) break;
         if (hipMemcpy(h_cnt.data(), d_cnt.p, (size_t)nb * 4, hipMemcpyDeviceToHost) != hipSuccess ||
             hipMemcpy(h_xy.data(), d_xy.p, (size_t)nb * cap * 8, hipMemcpyDeviceToHost) != hipSuccess) {
             rc = fail(ctx, MRGINGHAM_AMD_ERR_DEVICE, "candidate download failed");
             break;
         }
+        // Frames with more candidates than the batch buffer keeps (clutter), or whose component tables
+        // overflowed (dense texture): the reference runs the grid finder on ALL candidates
+        // (mrgingham.cc:50-51), so these are re-run one by one with exact capacity (and the
+        // one-entry-per-pixel retry), on the calling thread's single-frame context.
+        std::vector<std::vector<int32_t>> big(nb);
+        for (int k = 0; k < nb && !rc; ++k) {
+            if (h_found_level[cur_idx[k]] >= 0 || (h_cnt[k] >= 0 && h_cnt[k] <= cap)) continue;
+            mrgingham_amd_ctx* one = thread_ctx();
+            if (!one) { rc = fail(ctx, MRGINGHAM_AMD_ERR_DEVICE, "no single-frame context"); break; }
+            const mrgingham_amd_frames f1{cur.frames + (size_t)k * cur.frame_pitch, cur.frame_pitch, 1, cur.width,
+                                          cur.height, cur.stride};
+            int32_t n1 = 0;
+            if (!detect_one_frame_all(one, &f1, L, big[k], &n1)) {
+                rc = fail(ctx, MRGINGHAM_AMD_ERR_DEVICE, "frame %d, level %d: full-capacity detect failed", cur_idx[k], L);
+                break;
+            }
+            h_cnt[k] = n1;
+        }
+        if (rc) break;
         lap("detect+D2H", L, nb);
         // (b) grid finder on host threads (mrgingham.cc:51), for the frames still without a board
         std::vector<char> found_now(nb, 0);
@@ -1362,10 +1422,11 @@ int mrgingham_amd_find_boards_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_
             for (int k; (k = next.fetch_add(1)) < nb;) {
                 const int f = cur_idx[k];
                 if (h_found_level[f] >= 0) continue;
-                const int n = h_cnt[k] < cap ? h_cnt[k] : cap;  // more candidates than `cap`: clutter, no board
-                if (n < N || h_cnt[k] > cap) continue;
+                const int n = h_cnt[k];
+                if (n < N) continue;
+                const int32_t* src = big[k].empty() ? &h_xy[(size_t)k * cap * 2] : big[k].data();
                 std::vector<PointI> cand((size_t)n);
-                for (int i = 0; i < n; ++i) cand[i] = PointI{h_xy[((size_t)k * cap + i) * 2], h_xy[((size_t)k * cap + i) * 2 + 1]};
+                for (int i = 0; i < n; ++i) cand[i] = PointI{src[2 * i], src[2 * i + 1]};
                 std::vector<PointD> board;
                 if (find_grid_from_points(board, cand, gridn) && (int)board.size() == N) {
                     memcpy(h_boards + (size_t)f * N * 2, board.data(), sizeof(double) * 2 * N);
@@ -1416,7 +1477,26 @@ int mrgingham_amd_find_boards_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_
         for (int l = L - 1; l >= 0 && !rc; --l)  // (refining past "nothing refined" is a no-op, mrgingham.cc:97-98)
             rc = mrgingham_amd_refine_batch(ctx, rb, l, (double*)d_pts.p, (signed char*)d_lv.p, (const int32_t*)d_np.p,
                                             N, nullptr);
-        if (rc || (rc = mrgingham_amd_sync(ctx))) break;
+        if (!rc) rc = mrgingham_amd_sync(ctx);
+        if (rc == MRGINGHAM_AMD_ERR_CAPACITY) {
+            // a frame of the refine batch overflowed the default tables at some level: refine the boards
+            // found at this level one frame at a time (that path retries with one entry per pixel)
+            rc = 0;
+            mrgingham_amd_ctx* one = thread_ctx();
+            if (!one) { rc = fail(ctx, MRGINGHAM_AMD_ERR_DEVICE, "no single-frame context"); break; }
+            for (int k = 0; k < nr; ++k) {
+                if (!h_np[k]) continue;
+                const mrgingham_amd_frames f1{rb->frames + (size_t)k * rb->frame_pitch, rb->frame_pitch, 1, rb->width,
+                                              rb->height, rb->stride};
+                double* bp = h_boards + (size_t)ridx[k] * N * 2;  // still the unrefined grid
+                std::vector<signed char> lv1((size_t)N, (signed char)L);
+                for (int l = L - 1; l >= 0; --l)
+                    if (refine_on_device(one, &f1, bp, lv1.data(), N, l) <= 0) break;
+            }
+            lap("refine 1-by-1", L, nr);
+            continue;
+        }
+        if (rc) break;
         if (hipMemcpy(h_pts.data(), d_pts.p, (size_t)nr * N * 16, hipMemcpyDeviceToHost) != hipSuccess) {
             rc = fail(ctx, MRGINGHAM_AMD_ERR_DEVICE, "board download failed");
             break;

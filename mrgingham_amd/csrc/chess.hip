@@ -223,6 +223,70 @@ __device__ __forceinline__ void stage_store(char* lds, int slot, int ch, const S
     *reinterpret_cast<uint4*>(p + V1_PLANE + 16) = d;
 }
 
+// ---------------------------------------------------------------------------
+// Typed staging: `buffer_load_format_d16_xyzw` through an 8_8_8_8 UINT buffer descriptor turns 4 bytes
+// into two packed-u16 pair registers in the texture unit, i.e. the P0 plane entries with no VALU work
+// at all (the v_perm path above spends 16 v_perm_b32 per 16 pixels on it).  Probed on the chip
+// (tools/ubench/typed_load.hip): element addresses need no alignment, and an element that is out of
+// range of the descriptor (negative offsets included) reads as 0 instead of faulting.  A staging task
+// is one aligned group of 8 window pixels ("oct") of one row: 36 octs x 8 rows = 288 tasks per
+// iteration for 256 threads, every wave takes part.
+//   STAGE_TYPED2: P1 (odd pairs) comes from two more typed loads at byte offset +1 / +5;
+//   STAGE_TYPED1: P1 is built from the P0 registers with four v_alignbit_b32 plus one byte load.
+// Works for any width: what a row holds beyond the frame (the next row's pixels) only ever reaches
+// outputs the interior mask zeroes.
+// ---------------------------------------------------------------------------
+enum : int { STAGE_GENERIC = 0, STAGE_PERM16 = 1, STAGE_TYPED2 = 2, STAGE_TYPED1 = 3 };
+using i32x4 = int __attribute__((ext_vector_type(4)));
+using u16x4 = unsigned short __attribute__((ext_vector_type(4)));
+__device__ u16x4 buffer_load_u8x4_as_u16x4(i32x4 rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.buffer.load.format.v4i16");
+__device__ unsigned char buffer_load_u8(i32x4 rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.buffer.load.i8");
+
+__device__ __forceinline__ i32x4 typed_rsrc(const uint8_t* base, uint32_t bytes) {
+    // word 3: dst_sel x,y,z,w = R,G,B,A (4,5,6,7); num_format UINT (4) << 12; data_format 8_8_8_8 (10) << 15
+    constexpr uint32_t w3 = (4u | (5u << 3) | (6u << 6) | (7u << 9)) | (4u << 12) | (10u << 15);
+    const uint64_t a = (uint64_t)base;
+    return i32x4{(int)(uint32_t)a, (int)(uint32_t)(a >> 32), (int)bytes, (int)w3};
+}
+
+struct OctRegs {
+    uint2 p0a, p0b;  // pairs (I0,I1) (I2,I3) | (I4,I5) (I6,I7)
+    uint2 p1a, p1b;  // TYPED2: pairs (I1,I2) (I3,I4) | (I5,I6) (I7,I8)
+    uint32_t next;   // TYPED1: I8
+};
+
+template <int STAGE>
+__device__ __forceinline__ OctRegs oct_load(const i32x4& rsrc, int voff) {
+    OctRegs o;
+    o.p0a = __builtin_bit_cast(uint2, buffer_load_u8x4_as_u16x4(rsrc, voff, 0, 0));
+    o.p0b = __builtin_bit_cast(uint2, buffer_load_u8x4_as_u16x4(rsrc, voff + 4, 0, 0));
+    if (STAGE == STAGE_TYPED2) {
+        o.p1a = __builtin_bit_cast(uint2, buffer_load_u8x4_as_u16x4(rsrc, voff + 1, 0, 0));
+        o.p1b = __builtin_bit_cast(uint2, buffer_load_u8x4_as_u16x4(rsrc, voff + 5, 0, 0));
+        o.next = 0;
+    } else {
+        o.next = buffer_load_u8(rsrc, voff + 8, 0, 0);
+        o.p1a = o.p1b = make_uint2(0, 0);
+    }
+    return o;
+}
+
+template <int STAGE>
+__device__ __forceinline__ void oct_store(char* lds, int slot, int oct, const OctRegs& o) {
+    char* p = lds + slot * V1_ROWB + oct * 16;
+    *reinterpret_cast<uint4*>(p) = make_uint4(o.p0a.x, o.p0a.y, o.p0b.x, o.p0b.y);
+    if (STAGE == STAGE_TYPED2) {
+        *reinterpret_cast<uint4*>(p + V1_PLANE) = make_uint4(o.p1a.x, o.p1a.y, o.p1b.x, o.p1b.y);
+    } else {
+        // (hi half of one pair, lo half of the next) = v_alignbit_b32(next, this, 16)
+        *reinterpret_cast<uint4*>(p + V1_PLANE) =
+            make_uint4(__builtin_amdgcn_alignbit(o.p0a.y, o.p0a.x, 16), __builtin_amdgcn_alignbit(o.p0b.x, o.p0a.y, 16),
+                       __builtin_amdgcn_alignbit(o.p0b.y, o.p0b.x, 16), __builtin_amdgcn_alignbit(o.next, o.p0b.y, 16));
+    }
+}
+
 // 12 dwords D[-4..7] around the lane's 4 dwords of one (plane,row).
 // The empty asm statements make each 16-byte value opaque, so hipcc keeps the
 // aligned, bank-conflict-free ds_read_b128 instead of narrowing it to the few
@@ -298,7 +362,7 @@ __device__ __forceinline__ void flush_hot(const uint32_t* hotbuf, int* hotcnt, c
 
 // The body of the kernel for workgroup `bid` of `nwg` of one level (the multi-level launch below runs
 // several levels in one grid).
-template <bool CLAMP, bool HOT, bool W16>
+template <bool CLAMP, bool HOT, int STAGE>
 __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTables& t, int frame0, int seg, unsigned bid,
                                               unsigned nwg_level, char* lds) {
     // XCD-aware work order: workgroup b is dispatched to XCD b % 8 (observed, used
@@ -327,15 +391,45 @@ __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTa
     uint32_t* hotbuf = reinterpret_cast<uint32_t*>(lds + 2 * V1_PLANE);
     int* hotcnt = reinterpret_cast<int*>(hotbuf + V1_HOTBUF);
     if (HOT && tid == 0) *hotcnt = 0;
-    // staging role: 8 rows x 18 chunks = 144 threads
+    constexpr bool W16 = STAGE == STAGE_PERM16;
+    constexpr bool TYPED = STAGE == STAGE_TYPED2 || STAGE == STAGE_TYPED1;
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    // staging role (v_perm paths): 8 rows x 18 chunks = 144 threads
     const bool stager = tid < V1_RB * V1_NCH;
     const int st_row = tid / V1_NCH, st_ch = tid - st_row * V1_NCH;
     const int st_gx = strip_x - V1_HL + 16 * st_ch;
     const int st_gx_c = min(max(st_gx, 0), max(w - 16, 0));  // W16: clamped chunk start / following pixel
     const int st_nx_c = min(max(st_gx + 16, 0), w - 1);
+    // staging role (typed paths): 8 rows x 36 octs = 288 tasks; thread tid takes task tid, and wave 0
+    // also takes tasks 256..287 (both of its half-waves do the same 32, so the branch is wave-uniform)
+    constexpr int NOCT = V1_WIN / 8;  // 36
+    const int oc_row0 = tid / NOCT, oc_c0 = tid - oc_row0 * NOCT;
+    const int oc_t1 = 256 + (lane & 31);
+    const int oc_row1 = oc_t1 / NOCT, oc_c1 = oc_t1 - oc_row1 * NOCT;
+    const int oc_v0 = oc_row0 * stride + strip_x - V1_HL + 8 * oc_c0;  // + (group's first row) * stride
+    const int oc_v1 = oc_row1 * stride + strip_x - V1_HL + 8 * oc_c1;
+    i32x4 rsrc = {0, 0, 0, 0};
+    if (TYPED) {
+        // this frame and whatever of the batch follows it, up to 2 GB: rows above frame 0 and below
+        // the last frame are out of range and read as 0; between frames the neighbour's pixels are
+        // read, which is as good (they only reach masked outputs)
+        const long long rest = (long long)(lb.nframes - 1 - frame) * lb.img_pitch + (long long)(h - 1) * stride + w;
+        rsrc = typed_rsrc(img, (uint32_t)(rest < 0x7fffffffLL ? rest : 0x7fffffffLL));
+    }
 
     // prologue: row groups G0..G2 = rows ys-5 .. ys+18
-    if (stager) {
+    if (TYPED) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const int r0 = ys - 5 + V1_RB * g;
+            const OctRegs a = oct_load<STAGE>(rsrc, oc_v0 + r0 * stride);
+            oct_store<STAGE>(lds, (r0 + oc_row0 + 64) & (V1_NR - 1), oc_c0, a);
+            if (wvu == 0) {
+                const OctRegs b = oct_load<STAGE>(rsrc, oc_v1 + r0 * stride);
+                oct_store<STAGE>(lds, (r0 + oc_row1 + 64) & (V1_NR - 1), oc_c1, b);
+            }
+        }
+    } else if (stager) {
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
             const int r = ys - 5 + V1_RB * g + st_row;
@@ -362,7 +456,6 @@ __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTa
     // constant.  A wave covers rows yy = y + 2*wv + half; for even dy the slot of half 1 is the
     // slot of half 0 plus one (never wraps, the base slot is even), for odd dy (+-5) the two
     // half-waves get separately wrapped uniform slots, selected with a mask.
-    const int wvu = __builtin_amdgcn_readfirstlane(wv);
     const uint32_t lane_off = 16u + 16u * lx;                      // D[-4] of the lane within a row
     const uint32_t lane_off_h = lane_off + (half ? V1_ROWB : 0u);  // + the half-wave's row
     const uint32_t halfmask = half ? 0xffffffffu : 0u;
@@ -372,9 +465,16 @@ __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTa
     for (int y = ys; y < ye; y += V1_RB, ++grp) {
         // prefetch the group needed two iterations from now (rows y+19 .. y+26)
         StageRegs pre;
-        const int pr = ys - 5 + V1_RB * grp + st_row;
-        if (stager) pre = W16 ? stage_load_fast(img, stride, h, pr, st_gx_c, st_nx_c)
-                              : stage_load(img, stride, w, h, pr, st_gx);
+        OctRegs opre0, opre1;
+        const int pr0 = ys - 5 + V1_RB * grp;  // first row of the group (uniform)
+        const int pr = pr0 + st_row;
+        if (TYPED) {
+            opre0 = oct_load<STAGE>(rsrc, oc_v0 + pr0 * stride);
+            if (wvu == 0) opre1 = oct_load<STAGE>(rsrc, oc_v1 + pr0 * stride);
+        } else if (stager) {
+            pre = W16 ? stage_load_fast(img, stride, h, pr, st_gx_c, st_nx_c)
+                      : stage_load(img, stride, w, h, pr, st_gx);
+        }
 
         const int s0 = y + 2 * wvu + 64;  // uniform, even
         const int yy = s0 - 64 + half;
@@ -455,7 +555,10 @@ __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTa
         // The waves that stage are the last to reach the barrier (16 v_perm + four 13-cycle LDS stores
         // more than the others), and the rest of the workgroup waits for them: issue priority for
         // exactly that stretch (-1.2 ... -2.6 % on the launch, A/B on three boxes).
-        if (stager) {
+        if (TYPED) {
+            oct_store<STAGE>(lds, (pr0 + oc_row0 + 64) & (V1_NR - 1), oc_c0, opre0);
+            if (wvu == 0) oct_store<STAGE>(lds, (pr0 + oc_row1 + 64) & (V1_NR - 1), oc_c1, opre1);
+        } else if (stager) {
             __builtin_amdgcn_s_setprio(2);
             stage_store(lds, (pr + 64) & (V1_NR - 1), st_ch, pre);
             __builtin_amdgcn_s_setprio(0);
@@ -478,33 +581,40 @@ __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTa
     if (HOT) flush_hot(hotbuf, hotcnt, t, frame);
 }
 
-template <bool CLAMP, bool HOT, bool W16>
+template <bool CLAMP, bool HOT, int STAGE>
 __global__ __launch_bounds__(256) void chess_v1_kernel(LevelBatch lb, CompTables t, int frame0, int seg) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    chess_v1_body<CLAMP, HOT, W16>(lb, t, frame0, seg, blockIdx.x, gridDim.x, lds);
+    chess_v1_body<CLAMP, HOT, STAGE>(lb, t, frame0, seg, blockIdx.x, gridDim.x, lds);
 }
 
 // Several pyramid levels of the same batch in ONE grid (clamp + hot list, widths that are multiples
 // of 16): the small levels have too few workgroups to fill the chip on their own, and every kernel
 // boundary on the pixel stream costs 7-12 us (end-of-kernel cache write-back + dispatch).  The
 // levels are laid out largest first, so the small ones fill the tail of the large one.
+constexpr int kMultiMax = 4;
 struct ChessMulti {
-    LevelBatch lb[3];
-    CompTables t[3];
-    int first_wg[4];  // workgroup range of level slot k is [first_wg[k], first_wg[k+1])
-    int seg[3];
+    LevelBatch lb[kMultiMax];
+    CompTables t[kMultiMax];
+    int first_wg[kMultiMax];  // first workgroup of level slot k (a multiple of 8: workgroup b runs on XCD b % 8,
+    int nwg[kMultiMax];       // and the XCD-aware work order of the body counts from the slot's first workgroup)
+    int seg[kMultiMax];
     int n;
 };
 __global__ __launch_bounds__(256, 4) void chess_v1_multi_kernel(ChessMulti a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int b = blockIdx.x;
-    const int k = (a.n > 2 && b >= a.first_wg[2]) ? 2 : (a.n > 1 && b >= a.first_wg[1]) ? 1 : 0;  // uniform
-    chess_v1_body<true, true, true>(a.lb[k], a.t[k], 0, a.seg[k], (unsigned)(b - a.first_wg[k]),
-                                    (unsigned)(a.first_wg[k + 1] - a.first_wg[k]), lds);
+    int k = 0;  // uniform
+#pragma unroll
+    for (int j = 1; j < kMultiMax; ++j)
+        if (j < a.n && b >= a.first_wg[j]) k = j;
+    const int rel = b - a.first_wg[k];
+    if (rel >= a.nwg[k]) return;  // padding between slots
+    chess_v1_body<true, true, STAGE_PERM16>(a.lb[k], a.t[k], 0, a.seg[k], (unsigned)rel, (unsigned)a.nwg[k], lds);
 }
 
 
 int chess_seg_override = 0;  // tuning hook (mrgingham_amd_set_option "chess_seg"): 0 = automatic
+int chess_stage_override = 0;  // tuning hook "chess_stage": 0 = automatic, 2 / 3 = typed staging, -1 = generic
 
 static int pick_segment(int w, int h, int nframes) {
     if (chess_seg_override > 0) return (chess_seg_override + 7) / 8 * 8;
@@ -524,30 +634,52 @@ void launch_chess(const LevelBatch& lb, const CompTables& t, int frame0, int nfr
     dim3 grid(((lb.w + V1_SW - 1) / V1_SW) * ((lb.h + seg - 1) / seg) * nframes);
     const size_t lds = 2 * V1_PLANE + (hot ? (V1_HOTBUF + 4) * sizeof(int) : 0);
     const bool w16 = lb.w >= 16 && lb.w % 16 == 0;
+    // staging path: chess_stage_override (tuning hook "chess_stage") 0 = automatic
+    int stage = w16 ? STAGE_PERM16 : STAGE_GENERIC;
+    const bool typed_ok = (long long)lb.h * lb.img_stride < 0x7fffffffLL && lb.img_pitch >= 0;
+    if (chess_stage_override == STAGE_TYPED2 || chess_stage_override == STAGE_TYPED1) {
+        if (typed_ok) stage = chess_stage_override;
+    } else if (chess_stage_override == -1) {
+        stage = STAGE_GENERIC;
+    }
 #define MRG_LAUNCH(C, H, A) hipLaunchKernelGGL((chess_v1_kernel<C, H, A>), grid, dim3(256), lds, s, lb, t, frame0, seg)
-    if (hot) { if (w16) MRG_LAUNCH(true, true, true); else MRG_LAUNCH(true, true, false); }
-    else if (clamp) { if (w16) MRG_LAUNCH(true, false, true); else MRG_LAUNCH(true, false, false); }
-    else { if (w16) MRG_LAUNCH(false, false, true); else MRG_LAUNCH(false, false, false); }
+#define MRG_LAUNCH_ST(C, H)                                             \
+    switch (stage) {                                                    \
+        case STAGE_PERM16: MRG_LAUNCH(C, H, STAGE_PERM16); break;       \
+        case STAGE_TYPED2: MRG_LAUNCH(C, H, STAGE_TYPED2); break;       \
+        case STAGE_TYPED1: MRG_LAUNCH(C, H, STAGE_TYPED1); break;       \
+        default: MRG_LAUNCH(C, H, STAGE_GENERIC); break;                \
+    }
+    if (hot) { MRG_LAUNCH_ST(true, true) }
+    else if (clamp) { MRG_LAUNCH_ST(true, false) }
+    else { MRG_LAUNCH_ST(false, false) }
+#undef MRG_LAUNCH_ST
 #undef MRG_LAUNCH
 }
 
 // Levels lbs[0..n) (n <= 3, largest first) of one batch in one launch; returns false when the shapes do
 // not qualify (then the caller launches them one by one).
+bool chess_multi_ok(const LevelBatch* lbs, int n, int nframes) {
+    if (n < 2 || n > kMultiMax || nframes <= 0) return false;
+    for (int k = 0; k < n; ++k)
+        if (lbs[k].w < 16 || lbs[k].w % 16 != 0 || lbs[k].h <= 0) return false;
+    return true;
+}
+
 bool launch_chess_multi(const LevelBatch* lbs, const CompTables* ts, int n, int nframes, hipStream_t s) {
-    if (n < 2 || n > 3 || nframes <= 0) return false;
+    if (!chess_multi_ok(lbs, n, nframes)) return false;
     ChessMulti a;
     a.n = n;
     int total = 0;
-    for (int k = 0; k < n; ++k) {
-        if (lbs[k].w < 16 || lbs[k].w % 16 != 0 || lbs[k].h <= 0) return false;
-        a.lb[k] = lbs[k];
-        a.t[k] = ts[k];
-        a.seg[k] = pick_segment(lbs[k].w, lbs[k].h, nframes);
+    for (int k = 0; k < kMultiMax; ++k) {
+        const int j = k < n ? k : 0;
+        a.lb[k] = lbs[j];
+        a.t[k] = ts[j];
+        a.seg[k] = pick_segment(lbs[j].w, lbs[j].h, nframes);
         a.first_wg[k] = total;
-        total += ((lbs[k].w + V1_SW - 1) / V1_SW) * ((lbs[k].h + a.seg[k] - 1) / a.seg[k]) * nframes;
+        a.nwg[k] = k < n ? ((lbs[j].w + V1_SW - 1) / V1_SW) * ((lbs[j].h + a.seg[k] - 1) / a.seg[k]) * nframes : 0;
+        total += (a.nwg[k] + 7) / 8 * 8;
     }
-    for (int k = n; k <= 3; ++k) a.first_wg[k] = total;
-    for (int k = n; k < 3; ++k) { a.lb[k] = lbs[0]; a.t[k] = ts[0]; a.seg[k] = a.seg[0]; }
     const size_t lds = 2 * V1_PLANE + (V1_HOTBUF + 4) * sizeof(int);
     hipLaunchKernelGGL(chess_v1_multi_kernel, dim3(total), dim3(256), lds, s, a);
     return true;

@@ -10,6 +10,10 @@
 
 namespace mrg {
 
+// Largest side the library accepts anywhere (int16 coordinates, find_chessboard_corners.cc:91): checked
+// BEFORE anything is allocated or indexed from a header field of an untrusted file.
+constexpr int kMaxSide = 32767;
+
 static bool read_file(const char* path, std::vector<uint8_t>& buf) {
     FILE* f = fopen(path, "rb");
     if (!f) return false;
@@ -41,7 +45,7 @@ static bool decode_pgm(const std::vector<uint8_t>& b, Image& im) {
     if (!next_int(w) || !next_int(h) || !next_int(maxval)) return false;
     if (p >= b.size()) return false;
     ++p;  // the single whitespace after maxval
-    if (w <= 0 || h <= 0 || maxval <= 0 || maxval > 65535) return false;
+    if (w <= 0 || h <= 0 || w > kMaxSide || h > kMaxSide || maxval <= 0 || maxval > 65535) return false;
     const size_t n = (size_t)w * h;
     im.w = w; im.h = h;
     if (maxval < 256) {
@@ -64,20 +68,28 @@ static bool decode_png(const std::vector<uint8_t>& b, Image& im) {
     if (b.size() < 8 + 25 || memcmp(b.data(), sig, 8)) return false;
     size_t p = 8;
     int w = 0, h = 0, bits = 0, ctype = -1, interlace = 0;
+    bool have_ihdr = false;
     std::vector<uint8_t> idat, plte;
     while (p + 12 <= b.size()) {
         const uint32_t len = be32(&b[p]);
         const char* type = (const char*)&b[p + 4];
         if (p + 12 + (size_t)len > b.size()) return false;
         const uint8_t* d = &b[p + 8];
-        if (!memcmp(type, "IHDR", 4) && len >= 13) {
-            w = (int)be32(d); h = (int)be32(d + 4); bits = d[8]; ctype = d[9]; interlace = d[12];
-        } else if (!memcmp(type, "PLTE", 4)) plte.assign(d, d + len);
+        if (!memcmp(type, "IHDR", 4)) {
+            // exactly one IHDR, first, 13 bytes; sides within the library's limit (a crafted header must
+            // not size the buffers below)
+            if (have_ihdr || p != 8 || len != 13) return false;
+            const uint32_t uw = be32(d), uh = be32(d + 4);
+            if (uw == 0 || uh == 0 || uw > (uint32_t)kMaxSide || uh > (uint32_t)kMaxSide) return false;
+            w = (int)uw; h = (int)uh; bits = d[8]; ctype = d[9]; interlace = d[12];
+            have_ihdr = true;
+        } else if (!have_ihdr) return false;  // any other chunk before IHDR
+        else if (!memcmp(type, "PLTE", 4)) plte.assign(d, d + len);
         else if (!memcmp(type, "IDAT", 4)) idat.insert(idat.end(), d, d + len);
         else if (!memcmp(type, "IEND", 4)) break;
         p += 12 + (size_t)len;
     }
-    if (w <= 0 || h <= 0 || interlace != 0 || (bits != 8 && bits != 16)) return false;
+    if (!have_ihdr || idat.empty() || interlace != 0 || (bits != 8 && bits != 16)) return false;
     int ch;
     switch (ctype) {
         case 0: ch = 1; break;
@@ -140,11 +152,21 @@ static bool decode_png(const std::vector<uint8_t>& b, Image& im) {
 }
 
 bool read_image(const char* path, Image& im) {
-    std::vector<uint8_t>& b = im.file;
-    if (!read_file(path, b) || b.size() < 8) return false;
-    if (b[0] == 'P' && b[1] == '5') return decode_pgm(b, im);
-    if (b[0] == 0x89 && b[1] == 'P') return decode_png(b, im);
-    return false;
+    // never throws: the callers are extern "C" entry points and detached worker threads
+    try {
+        std::vector<uint8_t>& b = im.file;
+        if (!read_file(path, b) || b.size() < 8) return false;
+        if (b[0] == 'P' && b[1] == '5') return decode_pgm(b, im);
+        if (b[0] == 0x89 && b[1] == 'P') return decode_png(b, im);
+        return false;
+    } catch (...) {  // std::bad_alloc / length_error on a file that claims more than can be held
+        return false;
+    }
+}
+
+void to_8bit_imread(const Image& im, std::vector<uint8_t>& out) {
+    out.resize(im.px16.size());
+    for (size_t k = 0; k < out.size(); ++k) out[k] = (uint8_t)(im.px16[k] >> 8);
 }
 
 void to_8bit(const Image& im, std::vector<uint8_t>& out) {

@@ -21,5 +21,8 @@ struct Image {
 bool read_image(const char* path, Image& im);
 // 16 -> 8 bit the way the reference CLI does it: convertTo(CV_8U, 255./65535.) (mrgingham-from-image.cc:91)
 void to_8bit(const Image& im, std::vector<uint8_t>& out);
+// 16 -> 8 bit the way cv::imread(IMREAD_GRAYSCALE) without IMREAD_ANYDEPTH does it (the reference's file
+// entry points, find_chessboard_corners.cc:637-639, mrgingham.cc:158-160): the high byte
+void to_8bit_imread(const Image& im, std::vector<uint8_t>& out);
 
 }  // namespace mrg

@@ -10,8 +10,10 @@ void launch_chess_v0(const LevelBatch& lb, const CompTables& t, int frame0, int 
 void launch_chess(const LevelBatch& lb, const CompTables& t, int frame0, int nframes, bool clamp, bool hot,
                   hipStream_t s);
 
+bool chess_multi_ok(const LevelBatch* lbs, int n, int nframes);
 bool launch_chess_multi(const LevelBatch* lbs, const CompTables* ts, int n, int nframes, hipStream_t s);
 extern int chess_seg_override;
+extern int chess_stage_override;
 
 // decimate.hip
 struct FrameBatch {

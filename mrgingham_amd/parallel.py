@@ -65,11 +65,17 @@ def unpack_outputs(pack, nframes, max_points):
     return points, levels, npoints
 
 
-def gather_packed(pack, dst=0, group=None, out=None):
+def gather_packed(pack, dst=0, group=None, out=None, force=False):
     """THE collective of the path: one gather of every rank's packed corner lists to `dst`
     (-> uint8 [world, nbytes] there, None elsewhere).  `out` may be a preallocated [world, nbytes]
-    buffer on `dst`."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    buffer on `dst`.  With one rank there is nothing to exchange and no collective is issued, unless
+    `force` (used to run the collective's code path on a one-GPU box).
+
+    The buffers are fixed-pitch (64 frames x 256 points x 17 B + counts = 0.28 MB per rank): the call
+    needs no sizes on the host, so it is queued behind the step on the device and the pipeline never
+    stalls.  `gather_exact` below moves only the live records but has to read the counts on the host
+    first -- a round trip that costs more than the 0.2 MB it saves."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return pack.unsqueeze(0)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     bufs = None
@@ -79,6 +85,43 @@ def gather_packed(pack, dst=0, group=None, out=None):
         bufs = list(out.unbind(0))
     dist.gather(pack, bufs, dst=dst, group=group)
     return out if rank == dst else None
+
+
+def gather_exact(points, levels, npoints, dst=0, group=None):
+    """Exact-size form of the exchange (counts first, then grouped send / recv -- there is
+    no gatherv): every rank compacts its live corners into records (frame, x, y, level), the record
+    counts are all-gathered (one int64 per rank), then every rank but `dst` sends exactly its records
+    and `dst` posts the matching receives in one batch (ncclGroupStart .. ncclSend / ncclRecv ..
+    ncclGroupEnd under RCCL).  Returns on `dst` a list over ranks of (frame int32 [n], xy f64 [n,2],
+    level int8 [n]) with frame numbered within the rank's shard, in frame-major then reference order;
+    None elsewhere.  Synchronises the host with the device (the counts)."""
+    B, P = levels.shape
+    live = torch.arange(P, device=npoints.device).unsqueeze(0) < npoints.clamp(max=P).unsqueeze(1)   # [B,P]
+    fidx = torch.arange(B, device=npoints.device, dtype=torch.float64).unsqueeze(1).expand(B, P)[live]
+    rec = torch.stack([fidx, points[..., 0][live], points[..., 1][live], levels[live].to(torch.float64)], dim=1)
+    rec = rec.contiguous()                                                                  # f64 [n, 4]
+
+    def unpack(r):
+        return r[:, 0].to(torch.int32), r[:, 1:3].contiguous(), r[:, 3].to(torch.int8)
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [unpack(rec)]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n_here = torch.tensor([rec.shape[0]], dtype=torch.int64, device=rec.device)
+    counts = [torch.zeros_like(n_here) for _ in range(world)]
+    dist.all_gather(counts, n_here, group=group)
+    counts = [int(c.item()) for c in counts]
+    if rank == dst:
+        bufs = [rec if r == dst else torch.empty((counts[r], 4), dtype=torch.float64, device=rec.device)
+                for r in range(world)]
+        ops = [dist.P2POp(dist.irecv, bufs[r], r, group) for r in range(world) if r != dst and counts[r] > 0]
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        return [unpack(b) for b in bufs]
+    if counts[rank] > 0:
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, rec, dst, group)]):
+            w.wait()
+    return None
 
 
 # ---------------------------------------------------------------------------

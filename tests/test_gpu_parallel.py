@@ -1,0 +1,126 @@
+"""The multi-GPU path on whatever GPUs this box has: bench.py's own step (chain -> stream_wait -> the one
+gather over RCCL) launched exactly the way the driver launches it -- `python bench.py --gpus N` with no
+launcher in the environment -- with one rank (collective forced through a one-rank RCCL group) and,
+when a second device is present, two.  Plus BASELINE config 5 at its stated resolutions on one rank:
+mixed 1-12 MP stream, LPT plan for 8 ranks, per-frame adaptive pyramid depth (find_boards)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import mrgingham_amd
+from mrgingham_amd import parallel, synth
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]              # ONE json line, from rank 0
+    return json.loads(lines[0])
+
+
+SMALL = ["--workload", "c1_640x480_chain", "--steps", "6", "--warmup", "2", "--prime", "3", "--no-cpu-baseline",
+         "--no-end-to-end"]
+
+
+def test_bench_step_with_the_collective_on_one_rank():
+    res = _bench("--gpus", "1", "--force-gather", *SMALL)
+    assert res["n_gpus"] == 1 and res["ranks_seen"] == 1 and res["steps"] == 6
+    assert res["gather_checked"] is True                   # rank 0 compared what it received with what it sent
+    assert "gathered to rank 0" in res["config"]["workload"]
+    assert res["roofline"]["launches_timed"] == 6 and res["value"] > 0
+
+
+def test_bench_under_a_launcher_environment():
+    """RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the environment, as torch.distributed.run sets them."""
+    res = _bench("--gpus", "1", *SMALL, env_extra={"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0",
+                                                   "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"})
+    assert res["n_gpus"] == 1 and res["ranks_seen"] == 1
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two HIP devices")
+def test_bench_launches_its_own_two_ranks():
+    res = _bench("--gpus", "2", *SMALL)
+    assert res["n_gpus"] == 2 and res["ranks_seen"] == 2
+    assert res["scaling"] == "weak"
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), *SMALL],
+                       capture_output=True, text=True, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert r.returncode != 0 and "HIP device" in r.stderr
+
+
+def test_bench_end_to_end_leg_small():
+    res = _bench("--gpus", "1", "--workload", "c1_640x480_chain", "--steps", "4", "--warmup", "1", "--prime", "2",
+                 "--no-cpu-baseline")
+    e = res["end_to_end"]
+    assert e["value"] > 0 and e["h2d_GBs"] > 0 and e["frames_with_points_last_step"] == 64
+
+
+def test_exact_size_gather_matches_the_padded_one_on_device():
+    det = mrgingham_amd.Detector(0)
+    try:
+        frames = synth.board_batch(3, 640, 480, gridn=10, seed0=0, device="cuda")
+        pts, lv, npts = det.chain(frames, 3, 256)
+        (f, xy, l), = parallel.gather_exact(pts, lv, npts)
+        k = 0
+        for b in range(3):
+            n = int(npts[b])
+            assert f[k:k + n].tolist() == [b] * n
+            assert torch.equal(xy[k:k + n], pts[b, :n]) and torch.equal(l[k:k + n], lv[b, :n])
+            k += n
+        assert k == len(f)
+    finally:
+        det.close()
+
+
+def test_c5_mixed_stream_at_baseline_resolutions_one_rank_of_eight():
+    """BASELINE config 5 as stated (mixed 1-12 MP stream, per-frame adaptive pyramid depth, load balanced
+    over 8 GPUs), on the one GPU there is: the 8-rank LPT plan is computed, rank 3's share is run as one
+    find_boards batch per resolution, and every board equals what the single-frame path gives."""
+    import random
+    rnd = random.Random(11)
+    res = [(1280, 800), (1920, 1080), (2560, 1440), (4096, 2160), (4096, 3072)]
+    sizes = [res[rnd.randrange(5)] for _ in range(64)]
+    costs = [parallel.frame_cost(w, h) for (w, h) in sizes]
+    plan = parallel.lpt_assign(costs, 8)
+    loads = [sum(costs[i] for i in p) for p in plan]
+    assert max(loads) / (sum(loads) / 8) < 1.15                        # balanced to within 15 %
+    det = mrgingham_amd.Detector(0)
+    try:
+        nfound = 0
+        for (w, h), idx in parallel.plan_mixed_stream(sizes, 8, 3).items():
+            frames = torch.stack([synth.board_frame(w, h, 10, seed=i, device="cuda") for i in idx])
+            boards, found = det.find_boards(frames, gridn=10)
+            for j, i in enumerate(idx):
+                img = frames[j].cpu().numpy()
+                want = mrgingham_amd.find_board(img, gridn=10)
+                if want is None:
+                    assert found[j] < 0, (w, h, i)
+                    continue
+                assert found[j] >= 0 and np.array_equal(boards[j], want), (w, h, i)
+                nfound += 1
+                # the level the batch stopped at is the first of 3, 2, 1, 0 with a grid (mrgingham.cc:127-138):
+                # no grid among the oracle's candidates of any higher level
+                for L in range(3, int(found[j]), -1):
+                    cand = oracle.find_corners(img, L)
+                    assert len(cand) < 100 or mrgingham_amd.find_grid_from_points(cand, 10) is None
+        assert nfound >= 4
+    finally:
+        det.close()

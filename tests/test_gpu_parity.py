@@ -341,11 +341,12 @@ def test_dependent_calls_without_sync_are_ordered(det):
             assert torch.equal(out2[0][f, :k], rp[f, :k])
 
 
-def test_multi_level_launch_option_gives_the_same_chain():
-    """set_option("multi_level_launch", 1): levels 3, 2, 1 of a chain share one grid."""
+@pytest.mark.parametrize("mode", [1, 2])
+def test_multi_level_launch_option_gives_the_same_chain(mode):
+    """set_option("multi_level_launch", 1): levels 3, 2, 1 of a chain share one grid; 2: level 0 as well."""
     d2 = mrgingham_amd.Detector(0)
     try:
-        d2.set_option("multi_level_launch", 1)
+        d2.set_option("multi_level_launch", mode)
         frames = np.stack([synth.board_frame(1280, 960, 10, s).numpy() for s in (0, 3)] +
                           [synth.noise_frame(1280, 960, 2, smooth=1).numpy()])
         d = _cuda(frames)

@@ -50,6 +50,22 @@ def _worker(rank, world, port, ret):
         ret.put(ok2)
     else:
         assert got is None
+    # exact-size form: counts first, then grouped send / recv of exactly the live records
+    ex = parallel.gather_exact(pts, lv, npts, dst=0)
+    if rank == 0:
+        ok3 = len(ex) == world
+        for r in range(world):
+            f, xy, l = ex[r]
+            n_r = [r + 1, r + 2, r + 3]
+            want_f = sum(([k] * n for k, n in enumerate(n_r)), [])
+            rp = torch.arange(B * P * 2, dtype=torch.float64).reshape(B, P, 2) + 1000 * r
+            rl = (torch.arange(B * P, dtype=torch.int64).reshape(B, P) % 4).to(torch.int8) - r
+            ok3 &= f.tolist() == want_f and xy.shape == (sum(n_r), 2)
+            ok3 &= bool(torch.equal(xy, torch.cat([rp[k, :n] for k, n in enumerate(n_r)])))
+            ok3 &= bool(torch.equal(l, torch.cat([rl[k, :n] for k, n in enumerate(n_r)])))
+        ret.put(ok3)
+    else:
+        assert ex is None
     dist.barrier()
     dist.destroy_process_group()
 
@@ -72,7 +88,7 @@ def test_gather_corner_lists_world2_gloo():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
     for p in procs:
         p.start()
-    ok = ret.get(timeout=120) and ret.get(timeout=120)
+    ok = ret.get(timeout=120) and ret.get(timeout=120) and ret.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
