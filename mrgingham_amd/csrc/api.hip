@@ -126,9 +126,10 @@ struct mrgingham_amd_ctx {
     // that level's response is done; 1 = levels 1 and 0 wait for the level-0 response (they then run
     // underneath the NEXT call's pyramid and small levels instead of underneath this call's level 0)
     int cc_schedule = 0;
+    bool cc_lds = true;  // component search out of LDS for frames with few hot pixels (option "cc_lds")
 
     mrg::LevelScratch lvs[2][mrg::kMaxLevel + 1];
-    mrg::DevBuf counters2[2];  // per scratch set: hot_cnt words [level][counters_nf], then status words [level][counters_nf]
+    mrg::DevBuf counters2[2];  // per scratch set: hot_cnt words [level][counters_nf], then status words, then path words
     int counters_nf = 0;
     struct PointScratch { mrg::DevBuf leader, need, nseeds, seeds, sroot, cand_xy, cand_counts; } pts[2];  // per scratch set
     mrg::DevBuf aux_img, io_frame, io_out, io_counts;
@@ -237,7 +238,7 @@ static int ensure_level_set(mrgingham_amd_ctx* ctx, int set, int level, int nfra
         MRG_HIP_CHECK(hipDeviceSynchronize());
         const int cnf = nframes + nframes / 8 + 8;
         for (int k = 0; k < 2; ++k) {
-            if ((rc = ensure(ctx, ctx->counters2[k], (size_t)(kMaxLevel + 1) * 2 * cnf * 4))) return rc;
+            if ((rc = ensure(ctx, ctx->counters2[k], (size_t)(kMaxLevel + 1) * 3 * cnf * 4))) return rc;
             MRG_HIP_CHECK(hipMemset(ctx->counters2[k].p, 0, ctx->counters2[k].bytes));
         }
         ctx->counters_nf = cnf;
@@ -291,6 +292,10 @@ static int32_t* status_of(mrgingham_amd_ctx* ctx, int level) {
     return (int32_t*)ctx->counters2[ctx->cur].p + (size_t)(kMaxLevel + 1 + level) * ctx->counters_nf;
 }
 
+static int32_t* path_of(mrgingham_amd_ctx* ctx, int level) {
+    return (int32_t*)ctx->counters2[ctx->cur].p + (size_t)(2 * (kMaxLevel + 1) + level) * ctx->counters_nf;
+}
+
 static CompTables tables_of(mrgingham_amd_ctx* ctx, int level) {
     const LevelScratch& L = cur_levels(ctx)[level];
     CompTables t;
@@ -312,6 +317,8 @@ static CompTables tables_of(mrgingham_amd_ctx* ctx, int level) {
     t.sortkeys = (unsigned long long*)L.sortkeys.p;
     t.sort_cap = L.sort_cap;
     t.status = status_of(ctx, level);
+    t.path = path_of(ctx, level);
+    t.lds_path = ctx->cc_lds ? 1 : 0;
     return t;
 }
 
@@ -562,6 +569,7 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
     if (!strcmp(name, "chess_v0")) { ctx->use_v0 = value != 0; return 0; }
     if (!strcmp(name, "multi_level_launch")) { ctx->multi_level = value < 0 ? 0 : value > 2 ? 2 : value; return 0; }
     if (!strcmp(name, "cc_schedule")) { ctx->cc_schedule = value; return 0; }
+    if (!strcmp(name, "cc_lds")) { ctx->cc_lds = value != 0; return 0; }
     if (!strcmp(name, "chess_stage")) { mrg::chess_stage_override = value; return 0; }
     if (!strcmp(name, "chess_seg")) { mrg::chess_seg_override = value > 0 ? value : 0; return 0; }
     return MRGINGHAM_AMD_ERR_ARG;

@@ -130,6 +130,7 @@ constexpr int CCL_THREADS = 1024;
 // per-root pixel count, bounding box and smallest raster position.  Workgroup barriers in between.
 __global__ __launch_bounds__(CCL_THREADS) void cc_label_kernel(LevelBatch lb, CompTables t, int frame0) {
     const int frame = frame0 + blockIdx.y;
+    if (t.lds_path && t.path[frame]) return;  // done out of LDS
     if (t.hot_cnt[frame] > t.cap) return;  // overflow is reported by the per-frame kernel
     const FrameView v = make_view(lb, t, frame);
     const int w = v.w;
@@ -173,6 +174,11 @@ __global__ __launch_bounds__(CCL_THREADS) void cc_label_kernel(LevelBatch lb, Co
         wg_min(v.comp_first + r, (int)e);  // (y << 16) | x orders like the raster index
     }
 }
+
+void launch_cc_detect_lds(const LevelBatch& lb, const CompTables& t, int level, const DetectOut& out, int frame0,
+                          int nframes, hipStream_t s);
+void launch_cc_refine_lds(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io, int frame0,
+                          int nframes, hipStream_t s);
 
 void launch_cc_label(const LevelBatch& lb, const CompTables& t, int frame0, int nframes, hipStream_t s) {
     if (nframes <= 0) return;
@@ -323,6 +329,38 @@ __device__ void bitonic_sort(unsigned long long* keys, int n_pad) {
         }
 }
 
+// Candidates in output order -> coordinates (the reference's exact double expressions), and the chain's
+// hand-over to the refinement.  keys[k] & 0xffffffff indexes v.cand; all threads of the workgroup call it.
+__device__ __forceinline__ void emit_detect_outputs(const FrameView& v, const unsigned long long* keys, int nvalid,
+                                                    int level, const DetectOut& out, int frame) {
+    const double scale = (double)(uint16_t)(1u << level);  // :319
+    int32_t* oxy = out.xy + (long long)frame * out.capacity * 2;
+    const int nout = nvalid < out.capacity ? nvalid : out.capacity;
+    // the chain's hand-over to refinement, fused: every candidate becomes a corner at this level
+    // ((double)x / 1000, find_grid.cc:353-354; level tags, mrgingham.cc:81-85)
+    const int npt = out.points ? (nout < out.points_pitch ? nout : out.points_pitch) : 0;
+    double* opt = out.points ? out.points + (long long)frame * out.points_pitch * 2 : nullptr;
+    signed char* olv = out.points ? out.levels + (long long)frame * out.points_pitch : nullptr;
+    for (int k = threadIdx.x; k < nout; k += CC_THREADS) {
+        const Cand& cd = v.cand[(uint32_t)(keys[k] & 0xffffffffu)];
+        const double cx = (double)cd.sum_rx / (double)cd.sum_r;  // :262-263
+        const double cy = (double)cd.sum_ry / (double)cd.sum_r;
+        const double px = rescale_coord(cx, scale), py = rescale_coord(cy, scale);  // :346
+        const int ix = (int)(0.5 + px * kGridScale), iy = (int)(0.5 + py * kGridScale);  // :350-351
+        oxy[2 * k + 0] = ix;
+        oxy[2 * k + 1] = iy;
+        if (k < npt) {
+            opt[2 * k + 0] = (double)ix / kGridScale;
+            opt[2 * k + 1] = (double)iy / kGridScale;
+            olv[k] = (signed char)level;
+        }
+    }
+    if (threadIdx.x == 0) {
+        out.counts[frame] = nvalid;
+        if (out.points) out.npoints[frame] = npt;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Detect: process_connected_components, points_scaled_out branch (:330-355)
 // ---------------------------------------------------------------------------
@@ -333,6 +371,7 @@ __global__ __launch_bounds__(CC_THREADS) void cc_detect_kernel(LevelBatch lb, Co
     // latency-bound and tiny next to the pixel kernels it shares CUs with: take issue priority
     __builtin_amdgcn_s_setprio(3);
     const int frame = frame0 + blockIdx.x;
+    if (t.lds_path && t.path[frame]) return;  // done out of LDS
     if (t.hot_cnt[frame] > t.cap) {  // table overflow: report, produce nothing
         if (threadIdx.x == 0) {
             wg_or(t.status + frame, kStatusHotOverflow);
@@ -410,38 +449,13 @@ __global__ __launch_bounds__(CC_THREADS) void cc_detect_kernel(LevelBatch lb, Co
     for (int i = nvalid + threadIdx.x; i < n_pad; i += CC_THREADS) v.sortkeys[i] = ~0ull;
     __syncthreads();
     bitonic_sort(v.sortkeys, n_pad);
-
-    const double scale = (double)(uint16_t)(1u << level);  // :319
-    int32_t* oxy = out.xy + (long long)frame * out.capacity * 2;
-    const int nout = nvalid < out.capacity ? nvalid : out.capacity;
-    // the chain's hand-over to refinement, fused: every candidate becomes a corner at this level
-    // ((double)x / 1000, find_grid.cc:353-354; level tags, mrgingham.cc:81-85)
-    const int npt = out.points ? (nout < out.points_pitch ? nout : out.points_pitch) : 0;
-    double* opt = out.points ? out.points + (long long)frame * out.points_pitch * 2 : nullptr;
-    signed char* olv = out.points ? out.levels + (long long)frame * out.points_pitch : nullptr;
-    for (int k = threadIdx.x; k < nout; k += CC_THREADS) {
-        const Cand& cd = v.cand[(uint32_t)(v.sortkeys[k] & 0xffffffffu)];
-        const double cx = (double)cd.sum_rx / (double)cd.sum_r;  // :262-263
-        const double cy = (double)cd.sum_ry / (double)cd.sum_r;
-        const double px = rescale_coord(cx, scale), py = rescale_coord(cy, scale);  // :346
-        const int ix = (int)(0.5 + px * kGridScale), iy = (int)(0.5 + py * kGridScale);  // :350-351
-        oxy[2 * k + 0] = ix;
-        oxy[2 * k + 1] = iy;
-        if (k < npt) {
-            opt[2 * k + 0] = (double)ix / kGridScale;
-            opt[2 * k + 1] = (double)iy / kGridScale;
-            olv[k] = (signed char)level;
-        }
-    }
-    if (threadIdx.x == 0) {
-        out.counts[frame] = nvalid;
-        if (out.points) out.npoints[frame] = npt;
-    }
+    emit_detect_outputs(v, v.sortkeys, nvalid, level, out, frame);
 }
 
 void launch_cc_detect(const LevelBatch& lb, const CompTables& t, int level, const DetectOut& out, int frame0,
                       int nframes, hipStream_t s) {
     if (nframes <= 0) return;
+    launch_cc_detect_lds(lb, t, level, out, frame0, nframes, s);
     launch_cc_label(lb, t, frame0, nframes, s);
     hipLaunchKernelGGL(cc_detect_kernel, dim3(nframes), dim3(CC_THREADS), 0, s, lb, t, level, out, frame0);
 }
@@ -455,6 +469,7 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, Co
     __shared__ unsigned long long s_arena_top;
     __builtin_amdgcn_s_setprio(3);
     const int frame = frame0 + blockIdx.x;
+    if (t.lds_path && t.path[frame]) return;  // done out of LDS
     if (t.hot_cnt[frame] > t.cap) {
         if (threadIdx.x == 0) {
             wg_or(t.status + frame, kStatusHotOverflow);
@@ -569,8 +584,415 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, Co
 void launch_cc_refine(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io, int frame0,
                       int nframes, hipStream_t s) {
     if (nframes <= 0) return;
+    launch_cc_refine_lds(lb, t, level, io, frame0, nframes, s);
     launch_cc_label(lb, t, frame0, nframes, s);
     hipLaunchKernelGGL(cc_refine_kernel, dim3(nframes), dim3(CC_THREADS), 0, s, lb, t, level, io, frame0);
+}
+
+
+// ===========================================================================
+// LDS path.  A calibration frame has ~10^3 hot pixels per pyramid level (a dozen per corner), and the
+// kernels above spend their time in chains of dependent global accesses (2-3 us each underneath a
+// bandwidth-saturating pixel kernel): 50-100 us for the labelling, 100-260 us for the fills.  When a
+// frame's hot list fits -- at most LN entries -- the whole search runs out of LDS instead: the list, the
+// response VALUES of the listed pixels (the only responses the search ever uses, see (1) at the top), a
+// hash map pixel -> entry for the neighbour lookups, labels, and the LIFOs.  Same sequence of
+// operations as above, hence the same results bit for bit; the dense response is only read (once per
+// hot pixel), never written.  Frames that do not fit (hot pixels, components or LIFO demand) are left
+// to the global-memory kernels through CompTables::path.
+//
+// LDS per workgroup: 39 968 B, so that a workgroup fits next to three resident ChESS workgroups
+// (163 840 - 3 * 39 952 B) as soon as a fourth one retires.
+// ===========================================================================
+constexpr int LN = 2048;      // hot-list entries
+constexpr int LHASH = 4096;   // 16-bit hash slots (load factor <= 0.5)
+constexpr int LSTK = 5120;    // 16-bit LIFO words shared by the fills of a frame
+constexpr int LROOTS = 512;   // super-components with >= 2 pixels (detect)
+constexpr int LEPT = LN / CC_THREADS;  // list entries per thread
+
+struct LdsCC {
+    uint32_t xy[LN];              // (y << 16) | x, kHotDead for an unused slot
+    int16_t val[LN];              // clamped response of the pixel; 0 once consumed by a fill
+    int16_t lab[LN];              // smallest list index of the pixel's super-component
+    uint32_t hashw[LHASH / 2];    // two 16-bit slots per word: list index, 0xffff = empty
+    union {
+        int16_t stk[LSTK];        // LIFOs (list indices)
+        int32_t acc[LN];          // per-root accumulators / claim table, before the fills
+        unsigned long long keys[LSTK / 4];  // sort keys, after the fills
+    } u;
+    union {
+        struct { int16_t root[LROOTS], cnt[LROOTS], need[LROOTS]; uint32_t first[LROOTS]; } r;  // detect
+        int16_t need16[LN];       // refine: LIFO demand of the super-component, at its root
+    } w;
+    int nroots, ncand, top, total, changed, nref, pad0, pad1;
+};
+static_assert(sizeof(LdsCC) <= 39968, "must fit beside three ChESS workgroups");
+
+__device__ __forceinline__ uint32_t lds_hash(uint32_t e) { return (e * 0x9E3779B1u) >> 20; }  // 12 bits
+
+__device__ __forceinline__ void lds_insert(LdsCC& L, uint32_t e, int i) {
+    uint32_t s = lds_hash(e);
+    while (true) {
+        uint32_t* wp = &L.hashw[s >> 1];
+        const int sh = (int)(s & 1u) * 16;
+        const uint32_t old = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (((old >> sh) & 0xffffu) == 0xffffu) {
+            const uint32_t nw = (old & ~(0xffffu << sh)) | ((uint32_t)i << sh);
+            if (atomicCAS(wp, old, nw) == old) return;  // else: the word changed under us, look again
+        } else {
+            s = (s + 1u) & (LHASH - 1);
+        }
+    }
+}
+
+// list index of pixel e, or -1 when it is not hot
+__device__ __forceinline__ int lds_find(const LdsCC& L, uint32_t e) {
+    uint32_t s = lds_hash(e);
+    while (true) {
+        const uint32_t v = (L.hashw[s >> 1] >> ((s & 1u) * 16)) & 0xffffu;
+        if (v == 0xffffu) return -1;
+        if (L.xy[v] == e) return (int)v;
+        s = (s + 1u) & (LHASH - 1);
+    }
+}
+
+// follow_connected_component (:236-256) on the LDS tables; the LIFO holds list indices.
+__device__ __forceinline__ int drain_lds(LdsCC& L, int w, int h, int16_t* stk, int sp, Blob& b) {
+    b.srx = b.sry = b.sr = 0;
+    b.npix = 0;
+    b.rmax = 0;
+    b.xpk = b.ypk = 0;
+    b.touched = false;
+    int consumed = 0;
+    while (sp > 0) {
+        const int i = stk[--sp];
+        const int v = L.val[i];
+        if (v <= 0) continue;  // visited already
+        const uint32_t e = L.xy[i];
+        const int x = (int)(e & 0xffffu), y = (int)(e >> 16);
+        // the four lookups do not depend on v: issued together
+        const int jxp = lds_find(L, e + 1u), jxm = lds_find(L, e - 1u);
+        const int jyp = lds_find(L, e + 0x10000u), jym = lds_find(L, e - 0x10000u);
+        L.val[i] = 0;  // :245 / :250
+        ++consumed;    // every listed pixel is hot
+        if (!(v > (b.rmax >> 4))) continue;                    // :159-171 with :27 (v > 15 holds)
+        if (v > b.rmax) { b.rmax = v; b.xpk = x; b.ypk = y; }  // :176-181, first maximum wins
+        b.srx += (unsigned long long)(v * x);
+        b.sry += (unsigned long long)(v * y);
+        b.sr += (unsigned long long)v;
+        b.npix++;
+        // :252-255 then :216-226; a neighbour is worth pushing only while it is hot and unvisited
+        if (x + 1 >= w - kMargin) b.touched = true;
+        else if (jxp >= 0 && L.val[jxp] > 0) stk[sp++] = (int16_t)jxp;
+        if (x - 1 < kMargin) b.touched = true;
+        else if (jxm >= 0 && L.val[jxm] > 0) stk[sp++] = (int16_t)jxm;
+        if (y + 1 >= h - kMargin) b.touched = true;
+        else if (jyp >= 0 && L.val[jyp] > 0) stk[sp++] = (int16_t)jyp;
+        if (y - 1 < kMargin) b.touched = true;
+        else if (jym >= 0 && L.val[jym] > 0) stk[sp++] = (int16_t)jym;
+    }
+    return consumed;
+}
+
+// Load the frame's hot list into LDS, label the super-components (lab = smallest list index) and leave in
+// L.u.acc, at every root, (pixels of the super-component) | (sum of hot-neighbour counts << 12): the
+// latter bounds the pushes of any fill of it.  Returns false (uniformly) when the frame does not
+// fit.  All threads call it.
+__device__ __forceinline__ bool lds_load_and_label(LdsCC& L, const FrameView& v, int nraw, int cap) {
+    const int tid = threadIdx.x;
+    if (nraw > cap || nraw > LN) return false;
+    const int n = nraw, w = v.w;
+    for (int k = tid; k < LHASH / 2; k += CC_THREADS) L.hashw[k] = 0xffffffffu;
+    if (tid == 0) { L.nroots = 0; L.ncand = 0; L.top = 0; L.total = 0; L.changed = 0; L.nref = 0; }
+    __syncthreads();
+    uint32_t own[LEPT];
+#pragma unroll
+    for (int k = 0; k < LEPT; ++k) {
+        const int i = tid + CC_THREADS * k;
+        own[k] = kHotDead;
+        if (i < n) {
+            const uint32_t e = v.hot_xy[i];
+            own[k] = e;
+            L.xy[i] = e;
+            L.lab[i] = (int16_t)i;
+            L.u.acc[i] = 0;
+            if (e != kHotDead) {
+                L.val[i] = v.d[(int)(e >> 16) * w + (int)(e & 0xffffu)];
+                lds_insert(L, e, i);
+            } else {
+                L.val[i] = 0;
+            }
+        }
+    }
+    __syncthreads();
+    short nb[LEPT][4];
+#pragma unroll
+    for (int k = 0; k < LEPT; ++k) {
+        const uint32_t e = own[k];
+        const bool live = e != kHotDead;
+        nb[k][0] = live ? (short)lds_find(L, e + 1u) : (short)-1;
+        nb[k][1] = live ? (short)lds_find(L, e - 1u) : (short)-1;
+        nb[k][2] = live ? (short)lds_find(L, e + 0x10000u) : (short)-1;
+        nb[k][3] = live ? (short)lds_find(L, e - 0x10000u) : (short)-1;
+    }
+    // min-label propagation with shortcutting; labels only ever decrease and always name a member of
+    // the same super-component, so unsynchronised reads within a round are harmless
+    while (true) {
+        bool ch = false;
+#pragma unroll
+        for (int k = 0; k < LEPT; ++k) {
+            if (own[k] == kHotDead) continue;
+            const int i = tid + CC_THREADS * k;
+            const int cur = L.lab[i];
+            int m = cur;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (nb[k][q] >= 0) m = min(m, (int)L.lab[nb[k][q]]);
+            m = min(m, (int)L.lab[m]);
+            if (m < cur) { L.lab[i] = (int16_t)m; ch = true; }
+        }
+        if (ch) L.changed = 1;
+        __syncthreads();
+        const int c = L.changed;
+        __syncthreads();
+        if (!c) break;
+        if (tid == 0) L.changed = 0;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < LEPT; ++k) {
+        if (own[k] == kHotDead) continue;
+        const int i = tid + CC_THREADS * k;
+        const int deg = (nb[k][0] >= 0) + (nb[k][1] >= 0) + (nb[k][2] >= 0) + (nb[k][3] >= 0);
+        atomicAdd(&L.u.acc[L.lab[i]], 1 + (deg << 12));
+    }
+    __syncthreads();
+    return true;
+}
+
+__global__ __launch_bounds__(CC_THREADS) void cc_detect_lds_kernel(LevelBatch lb, CompTables t, int level,
+                                                                   DetectOut out, int frame0) {
+    __shared__ LdsCC L;
+    __builtin_amdgcn_s_setprio(3);
+    const int frame = frame0 + blockIdx.x, tid = threadIdx.x;
+    const int nraw = t.hot_cnt[frame];
+    FrameView v = make_view(lb, t, frame);
+    if (!lds_load_and_label(L, v, nraw, t.cap)) {
+        if (tid == 0) t.path[frame] = 0;
+        return;
+    }
+    const int n = nraw, w = v.w, h = v.h;
+    // roots with >= 2 pixels (a single hot pixel can only give a one-pixel blob, :205)
+    for (int i = tid; i < n; i += CC_THREADS) {
+        if (L.xy[i] == kHotDead || L.lab[i] != i) continue;
+        const int a = L.u.acc[i], cnt = a & 0xfff, need = (a >> 12) + 1;
+        if (cnt < kBlobMinPixels) continue;
+        const int r = atomicAdd(&L.nroots, 1);
+        atomicAdd(&L.total, need);
+        if (r < LROOTS) { L.w.r.root[r] = (int16_t)i; L.w.r.cnt[r] = (int16_t)cnt; L.w.r.need[r] = (int16_t)need; }
+    }
+    __syncthreads();
+    if (L.nroots > LROOTS || L.total > LSTK) {  // does not fit: nothing has been modified
+        if (tid == 0) t.path[frame] = 0;
+        return;
+    }
+    const int nroots = L.nroots;
+    // smallest raster position of every super-component: the first seed the raster scan meets
+    for (int i = tid; i < n; i += CC_THREADS) L.u.acc[i] = 0x7fffffff;
+    __syncthreads();
+    for (int i = tid; i < n; i += CC_THREADS)
+        if (L.xy[i] != kHotDead) atomicMin(&L.u.acc[L.lab[i]], (int)L.xy[i]);
+    __syncthreads();
+    for (int r = tid; r < nroots; r += CC_THREADS) L.w.r.first[r] = (uint32_t)L.u.acc[L.w.r.root[r]];
+    __syncthreads();  // the accumulators are dead: their storage becomes the LIFOs
+    if (tid == 0) t.path[frame] = 1;
+
+    // seeds live in [8, w-8) x [8, h-8) (:332-333)
+    auto seedable = [&](uint32_t e) {
+        const int x = (int)(e & 0xffffu), y = (int)(e >> 16);
+        return x > kMargin && x < w - kMargin - 1 && y > kMargin && y < h - kMargin - 1;
+    };
+    for (int r = tid; r < nroots; r += CC_THREADS) {
+        const int root = L.w.r.root[r];
+        int left = L.w.r.cnt[r];
+        int16_t* stk = L.u.stk + atomicAdd(&L.top, (int)L.w.r.need[r]);
+        uint32_t seed = L.w.r.first[r];
+        bool have = seedable(seed);
+        while (true) {
+            if (!have) {
+                // the raster scan goes on: the smallest position among what is left of this
+                // super-component (rare: the first fill usually consumes all of it)
+                uint32_t best = kHotDead;
+                for (int i = 0; i < n; ++i)
+                    if (L.lab[i] == root && L.val[i] > 0 && seedable(L.xy[i])) best = min(best, L.xy[i]);
+                if (best == kHotDead) break;
+                seed = best;
+            }
+            have = false;
+            stk[0] = (int16_t)lds_find(L, seed);  // :338
+            Blob b;
+            left -= drain_lds(L, w, h, stk, 1, b);
+            if (blob_passes_cheap_tests(b) && window_variance_high(v.img, v.img_stride, w, h, b.xpk, b.ypk)) {  // :207
+                const int c = atomicAdd(&L.ncand, 1);
+                if (c < v.cand_cap) {
+                    Cand cd;
+                    cd.sum_rx = b.srx; cd.sum_ry = b.sry; cd.sum_r = b.sr;
+                    cd.seed = (int32_t)seed;
+                    cd.x_peak = (uint16_t)b.xpk; cd.y_peak = (uint16_t)b.ypk;
+                    cd.ok = 1; cd.pad = 0;
+                    v.cand[c] = cd;
+                }
+            }
+            if (left <= 0) break;
+        }
+    }
+    __syncthreads();
+    const int nvalid = L.ncand;  // <= LN / 2 <= LSTK / 4 keys, <= cand_cap (>= 1024)
+    // order by seed position = the reference's output order (:332-353), sorted in LDS
+    int n_pad = 1;
+    while (n_pad < nvalid) n_pad <<= 1;
+    for (int c = tid; c < n_pad; c += CC_THREADS)
+        L.u.keys[c] = c < nvalid ? (((unsigned long long)(uint32_t)v.cand[c].seed << 32) | (uint32_t)c) : ~0ull;
+    __syncthreads();
+    bitonic_sort(L.u.keys, n_pad);
+    emit_detect_outputs(v, L.u.keys, nvalid, level, out, frame);
+}
+
+__global__ __launch_bounds__(CC_THREADS) void cc_refine_lds_kernel(LevelBatch lb, CompTables t, int level,
+                                                                   RefineIO io, int frame0) {
+    __shared__ LdsCC L;
+    __builtin_amdgcn_s_setprio(3);
+    const int frame = frame0 + blockIdx.x, tid = threadIdx.x;
+    const int nraw = t.hot_cnt[frame];
+    FrameView v = make_view(lb, t, frame);
+    if (!lds_load_and_label(L, v, nraw, t.cap)) {
+        if (tid == 0) t.path[frame] = 0;
+        return;
+    }
+    const int n = nraw, w = v.w, h = v.h;
+    // LIFO demand of every super-component at its root, then the accumulators become the claim table
+    for (int i = tid; i < n; i += CC_THREADS) {
+        const int a = L.u.acc[i];
+        L.w.need16[i] = (int16_t)((a >> 12) + 1);
+    }
+    __syncthreads();
+    int32_t* claim = L.u.acc;
+    for (int i = tid; i < n; i += CC_THREADS) claim[i] = 0x7fffffff;
+
+    const int npts = min(io.npoints[frame], io.pitch);
+    const long long pb = (long long)frame * io.pitch;
+    double* pts = io.points + 2 * pb;
+    signed char* lv = io.levels + pb;
+    int32_t* leader = io.leader + pb;
+    int32_t* need = io.need + pb;
+    int32_t* nseeds = io.nseeds + pb;
+    uint32_t* seeds = io.seeds + 9 * pb;  // here: list indices
+    int32_t* sroot = io.sroot + 9 * pb;
+    const uint16_t coord_scale = (uint16_t)(1u << level);
+
+    // R1: seeds of every refinable point (:362-382), in the reference's push order
+    for (int i = tid; i < npts; i += CC_THREADS) {
+        int ns = -1;  // -1: not refinable at this level
+        if (lv[i] == level + 1) {
+            ns = 0;
+            const double lx = rescale_coord(pts[2 * i + 0], 1.0 / coord_scale);  // :369
+            const double ly = rescale_coord(pts[2 * i + 1], 1.0 / coord_scale);
+            const int x = (int)(lx + 0.5), y = (int)(ly + 0.5);  // :371-372
+            for (int dx = -1; dx <= 1; ++dx)
+                for (int dy = -1; dy <= 1; ++dy) {
+                    const int sx = (int16_t)(x + dx), sy = (int16_t)(y + dy);  // is_valid takes int16_t
+                    if (sx < 0 || sx >= w || sy < 0 || sy >= h) continue;
+                    const int j = lds_find(L, ((uint32_t)sy << 16) | (uint32_t)sx);  // hot <=> listed (nothing consumed yet)
+                    if (j < 0) continue;
+                    seeds[9 * i + ns] = (uint32_t)j;
+                    sroot[9 * i + ns] = L.lab[j];
+                    ++ns;
+                }
+        }
+        nseeds[i] = ns;
+        leader[i] = i;
+        need[i] = 0;
+    }
+    __syncthreads();
+
+    // R2: points whose seeds share a super-component are replayed in index order by one lane:
+    // propagate the minimum point index over the bipartite graph points <-> super-components
+    while (true) {
+        for (int i = tid; i < npts; i += CC_THREADS) {
+            const int ns = nseeds[i];
+            if (ns <= 0) continue;
+            int m = leader[i];
+            for (int k = 0; k < ns; ++k)
+                m = min(m, __hip_atomic_load(&claim[sroot[9 * i + k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            bool changed = m < leader[i];
+            for (int k = 0; k < ns; ++k)
+                if (atomicMin(&claim[sroot[9 * i + k]], m) > m) changed = true;
+            leader[i] = m;
+            if (changed) L.changed = 1;
+        }
+        __syncthreads();
+        const int changed = L.changed;
+        __syncthreads();
+        if (!changed) break;
+        if (tid == 0) L.changed = 0;
+        __syncthreads();
+    }
+
+    // R3: LIFO demand of each group = sum over its super-components, each counted once
+    for (int i = tid; i < npts; i += CC_THREADS) {
+        const int ns = nseeds[i];
+        if (ns >= 0 && leader[i] == i) atomicAdd(&L.total, 10);
+        for (int k = 0; k < ns; ++k) {
+            const int root = sroot[9 * i + k], ld = leader[i];
+            if (atomicCAS(&claim[root], ld, ld | 0x40000000) == ld) {
+                wg_add(need + ld, (int)L.w.need16[root]);
+                atomicAdd(&L.total, (int)L.w.need16[root]);
+            }
+        }
+    }
+    __syncthreads();
+    if (L.total > LSTK) {  // does not fit: no point, no response has been modified
+        if (tid == 0) t.path[frame] = 0;
+        return;
+    }
+    if (tid == 0) t.path[frame] = 1;
+    __syncthreads();  // the claim table is dead: its storage becomes the LIFOs
+
+    // R4: one lane per group, members in index order (:358); accepted points are written in place
+    for (int i = tid; i < npts; i += CC_THREADS) {
+        if (nseeds[i] < 0 || leader[i] != i) continue;
+        int16_t* stk = L.u.stk + atomicAdd(&L.top, aload(need + i) + 10);
+        for (int j = i; j < npts; ++j) {
+            if (nseeds[j] < 0 || leader[j] != i) continue;
+            const int ns = nseeds[j];
+            for (int k = 0; k < ns; ++k) stk[k] = (int16_t)seeds[9 * j + k];
+            Blob b;
+            drain_lds(L, w, h, stk, ns, b);
+            if (!blob_passes_cheap_tests(b)) continue;
+            if (!window_variance_high(v.img, v.img_stride, w, h, b.xpk, b.ypk)) continue;  // :207
+            const double cx = (double)b.srx / (double)b.sr;  // :262-263
+            const double cy = (double)b.sry / (double)b.sr;
+            pts[2 * j + 0] = rescale_coord(cx, (double)coord_scale);  // :390
+            pts[2 * j + 1] = rescale_coord(cy, (double)coord_scale);
+            lv[j] = (signed char)level;  // :393
+            atomicAdd(&L.nref, 1);
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && io.nrefined) io.nrefined[frame] = L.nref;
+}
+
+
+void launch_cc_detect_lds(const LevelBatch& lb, const CompTables& t, int level, const DetectOut& out, int frame0,
+                          int nframes, hipStream_t s) {
+    if (!t.lds_path || nframes <= 0) return;
+    hipLaunchKernelGGL(cc_detect_lds_kernel, dim3(nframes), dim3(CC_THREADS), 0, s, lb, t, level, out, frame0);
+}
+
+void launch_cc_refine_lds(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io, int frame0,
+                          int nframes, hipStream_t s) {
+    if (!t.lds_path || nframes <= 0) return;
+    hipLaunchKernelGGL(cc_refine_lds_kernel, dim3(nframes), dim3(CC_THREADS), 0, s, lb, t, level, io, frame0);
 }
 
 }  // namespace mrg

@@ -57,6 +57,10 @@ struct CompTables {
     unsigned long long* sortkeys; // [nframes*cand_cap_pow2]
     int sort_cap;             // power of two >= cand_cap
     int32_t* status;          // [nframes] bit 0: hot table overflow, bit 1: candidate overflow
+    // Component search out of LDS (cc.hip, "LDS path"): path[f] = 1 when frame f was handled there, 0 when
+    // it is left to the global-memory kernels (more hot pixels / components than the LDS tables hold).
+    int32_t* path;            // [nframes]
+    int lds_path;             // 0: the LDS kernels are not launched and path[] is not consulted
 };
 
 // A component that passed the size / peak / margin tests and waits for the

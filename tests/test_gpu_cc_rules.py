@@ -15,9 +15,12 @@ import cc_cases
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def det():
+@pytest.fixture(scope="module", params=["lds", "global"])
+def det(request):
+    """Both implementations of the search: out of LDS (frames with <= 2048 hot pixels; larger ones fall
+    through to the other) and the global-memory kernels alone (option cc_lds = 0)."""
     d = mrgingham_amd.Detector(0)
+    d.set_option("cc_lds", 1 if request.param == "lds" else 0)
     yield d
     d.close()
 

@@ -262,6 +262,25 @@ def test_chain_batch_matches_oracle(det, golden_dir):
     assert np.array_equal(oracle.chain(frames[0], 3)[0], z["chain3_pts_board10_640x480_s0"])
 
 
+def test_global_memory_component_kernels_alone_give_the_same_chain():
+    """option cc_lds = 0: every frame through the global-memory kernels (the fallback of the LDS path)."""
+    d2 = mrgingham_amd.Detector(0)
+    try:
+        d2.set_option("cc_lds", 0)
+        frames = np.stack([synth.board_frame(1280, 960, 10, s).numpy() for s in (0, 3)] +
+                          [synth.noise_frame(1280, 960, 2, smooth=1).numpy()])
+        d = _cuda(frames)
+        for start in (3, 1):
+            pts, lv, npts = d2.chain(d, start_level=start, max_points=8192)
+            for f in range(len(frames)):
+                wp, wl = oracle.chain(frames[f], start)
+                n = int(npts[f])
+                assert n == len(wp), (start, f)
+                assert np.array_equal(pts[f, :n].cpu().numpy(), wp) and np.array_equal(lv[f, :n].cpu().numpy(), wl)
+    finally:
+        d2.close()
+
+
 def test_back_to_back_batches_without_sync(det):
     """Queued calls reuse the level scratch: the pixel stream of call N+1 must wait for the
     component stream of call N (results equal the synchronous ones)."""
