@@ -251,7 +251,12 @@ long long mrgingham_amd_scratch_bytes(const mrgingham_amd_ctx* ctx);
 /* Tunables outside the reference's surface.  Known names:
  *   "hot_capacity_shift"  per-frame capacity of the hot-pixel / component tables is
  *                         (width*height) >> shift entries (default 3; 0 = one per pixel)
- *   "chess_v0"            1 = use the plain reference-shaped ChESS kernel (cross-check) */
+ *   "chess_v0"            1 = use the plain reference-shaped ChESS kernel (cross-check)
+ *   "multi_level_launch"  chain_batch: 0 = one ChESS launch per pyramid level, 1 (default) = levels 3..1 in one
+ *                         launch, 2 = all levels in one launch
+ *   "cc_lds"              1 (default) = component search out of LDS for frames with at most 2048 hot pixels
+ *                         (the global-memory kernels take the others), 0 = global-memory kernels only
+ *   "cc_schedule", "chess_seg", "chess_stage"   experiment hooks (tools/interference_ab.py, tools/stage_ab.py) */
 int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value);
 
 /* Wait for everything queued on the context's streams; returns the first

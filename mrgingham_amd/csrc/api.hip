@@ -121,12 +121,15 @@ struct mrgingham_amd_ctx {
     bool use_v0 = false;  // reference-shaped ChESS kernel instead of the tuned one
     // levels 3..1 of a chain in one launch (set_option "multi_level_launch"): +1.5 % chain rate, but the
     // component chains then start later and overlap the level-0 launch more (+5 % on that launch): off
-    int multi_level = 0;  // 0 = one launch per level; 1 = levels 3..1 in one launch; 2 = levels 0..3 in one launch
+    // chain_batch: 0 = one ChESS launch per level; 1 = levels 3..1 in one launch (default: two kernel
+    // boundaries fewer per step, 1.129 -> 1.113 ms per 64 frames of 4096x3072); 2 = levels 0..3 in one
+    // launch (measured slower: 1.171 ms)
+    int multi_level = 1;
     // component-chain schedule of chain_batch: 0 = every level's component kernels start as soon as
     // that level's response is done; 1 = levels 1 and 0 wait for the level-0 response (they then run
     // underneath the NEXT call's pyramid and small levels instead of underneath this call's level 0)
     int cc_schedule = 0;
-    bool cc_lds = true;  // component search out of LDS for frames with few hot pixels (option "cc_lds")
+    int cc_lds = 1;  // component search out of LDS for frames with few hot pixels (option "cc_lds"; bits 1-3: timing ablations)
 
     mrg::LevelScratch lvs[2][mrg::kMaxLevel + 1];
     mrg::DevBuf counters2[2];  // per scratch set: hot_cnt words [level][counters_nf], then status words, then path words
@@ -318,7 +321,7 @@ static CompTables tables_of(mrgingham_amd_ctx* ctx, int level) {
     t.sort_cap = L.sort_cap;
     t.status = status_of(ctx, level);
     t.path = path_of(ctx, level);
-    t.lds_path = ctx->cc_lds ? 1 : 0;
+    t.lds_path = ctx->cc_lds;
     return t;
 }
 
@@ -569,7 +572,7 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
     if (!strcmp(name, "chess_v0")) { ctx->use_v0 = value != 0; return 0; }
     if (!strcmp(name, "multi_level_launch")) { ctx->multi_level = value < 0 ? 0 : value > 2 ? 2 : value; return 0; }
     if (!strcmp(name, "cc_schedule")) { ctx->cc_schedule = value; return 0; }
-    if (!strcmp(name, "cc_lds")) { ctx->cc_lds = value != 0; return 0; }
+    if (!strcmp(name, "cc_lds")) { ctx->cc_lds = value; return 0; }
     if (!strcmp(name, "chess_stage")) { mrg::chess_stage_override = value; return 0; }
     if (!strcmp(name, "chess_seg")) { mrg::chess_seg_override = value > 0 ? value : 0; return 0; }
     return MRGINGHAM_AMD_ERR_ARG;

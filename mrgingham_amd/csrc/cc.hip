@@ -621,10 +621,12 @@ struct LdsCC {
         unsigned long long keys[LSTK / 4];  // sort keys, after the fills
     } u;
     union {
-        struct { int16_t root[LROOTS], cnt[LROOTS], need[LROOTS]; uint32_t first[LROOTS]; } r;  // detect
+        // detect, per super-component with >= 2 pixels: list index of its root (later: offset of its member
+        // list), pixel count, offset of its LIFO, smallest raster position
+        struct { int16_t root[LROOTS], cnt[LROOTS], soff[LROOTS]; uint32_t first[LROOTS]; } r;
         int16_t need16[LN];       // refine: LIFO demand of the super-component, at its root
     } w;
-    int nroots, ncand, top, total, changed, nref, pad0, pad1;
+    int nroots, ncand, top, total, changed, nref, mtop, pad1;
 };
 static_assert(sizeof(LdsCC) <= 39968, "must fit beside three ChESS workgroups");
 
@@ -703,7 +705,7 @@ __device__ __forceinline__ bool lds_load_and_label(LdsCC& L, const FrameView& v,
     if (nraw > cap || nraw > LN) return false;
     const int n = nraw, w = v.w;
     for (int k = tid; k < LHASH / 2; k += CC_THREADS) L.hashw[k] = 0xffffffffu;
-    if (tid == 0) { L.nroots = 0; L.ncand = 0; L.top = 0; L.total = 0; L.changed = 0; L.nref = 0; }
+    if (tid == 0) { L.nroots = 0; L.ncand = 0; L.top = 0; L.total = 0; L.changed = 0; L.nref = 0; L.mtop = 0; }
     __syncthreads();
     uint32_t own[LEPT];
 #pragma unroll
@@ -782,17 +784,19 @@ __global__ __launch_bounds__(CC_THREADS) void cc_detect_lds_kernel(LevelBatch lb
         return;
     }
     const int n = nraw, w = v.w, h = v.h;
-    // roots with >= 2 pixels (a single hot pixel can only give a one-pixel blob, :205)
+    if (t.lds_path & 8) { if (tid == 0) { t.path[frame] = 1; out.counts[frame] = 0; } return; }  // ablation (timing only)
+    // roots with >= 2 pixels (a single hot pixel can only give a one-pixel blob, :205); each gets a LIFO of
+    // (sum of hot-neighbour counts + 1) words, which bounds the pushes of all fills of it together
     for (int i = tid; i < n; i += CC_THREADS) {
         if (L.xy[i] == kHotDead || L.lab[i] != i) continue;
         const int a = L.u.acc[i], cnt = a & 0xfff, need = (a >> 12) + 1;
         if (cnt < kBlobMinPixels) continue;
         const int r = atomicAdd(&L.nroots, 1);
-        atomicAdd(&L.total, need);
-        if (r < LROOTS) { L.w.r.root[r] = (int16_t)i; L.w.r.cnt[r] = (int16_t)cnt; L.w.r.need[r] = (int16_t)need; }
+        const int so = atomicAdd(&L.top, need);
+        if (r < LROOTS) { L.w.r.root[r] = (int16_t)i; L.w.r.cnt[r] = (int16_t)cnt; L.w.r.soff[r] = (int16_t)so; }
     }
     __syncthreads();
-    if (L.nroots > LROOTS || L.total > LSTK) {  // does not fit: nothing has been modified
+    if (L.nroots > LROOTS || L.top > LSTK) {  // does not fit: nothing has been modified
         if (tid == 0) t.path[frame] = 0;
         return;
     }
@@ -804,6 +808,29 @@ __global__ __launch_bounds__(CC_THREADS) void cc_detect_lds_kernel(LevelBatch lb
         if (L.xy[i] != kHotDead) atomicMin(&L.u.acc[L.lab[i]], (int)L.xy[i]);
     __syncthreads();
     for (int r = tid; r < nroots; r += CC_THREADS) L.w.r.first[r] = (uint32_t)L.u.acc[L.w.r.root[r]];
+    __syncthreads();
+    // member lists (list indices of the pixels of a super-component, unordered): what the "raster scan goes
+    // on" step below walks instead of the whole hot list.  They take over the storage of the labels.
+    int mylab[LEPT];
+#pragma unroll
+    for (int k = 0; k < LEPT; ++k) {
+        const int i = tid + CC_THREADS * k;
+        mylab[k] = (i < n && L.xy[i] != kHotDead) ? (int)L.lab[i] : -1;
+    }
+    for (int i = tid; i < n; i += CC_THREADS) L.u.acc[i] = -1;
+    __syncthreads();
+    for (int r = tid; r < nroots; r += CC_THREADS) {
+        const int mo = atomicAdd(&L.mtop, (int)L.w.r.cnt[r]);
+        L.u.acc[L.w.r.root[r]] = mo;      // running write position of this list
+        L.w.r.root[r] = (int16_t)mo;      // the root's list index is not needed any more
+    }
+    __syncthreads();
+    int16_t* members = L.lab;
+#pragma unroll
+    for (int k = 0; k < LEPT; ++k) {
+        if (mylab[k] < 0 || L.u.acc[mylab[k]] < 0) continue;  // (acc only grows: a list's slot stays >= 0)
+        members[atomicAdd(&L.u.acc[mylab[k]], 1)] = (int16_t)(tid + CC_THREADS * k);
+    }
     __syncthreads();  // the accumulators are dead: their storage becomes the LIFOs
     if (tid == 0) t.path[frame] = 1;
 
@@ -813,26 +840,31 @@ __global__ __launch_bounds__(CC_THREADS) void cc_detect_lds_kernel(LevelBatch lb
         return x > kMargin && x < w - kMargin - 1 && y > kMargin && y < h - kMargin - 1;
     };
     for (int r = tid; r < nroots; r += CC_THREADS) {
-        const int root = L.w.r.root[r];
-        int left = L.w.r.cnt[r];
-        int16_t* stk = L.u.stk + atomicAdd(&L.top, (int)L.w.r.need[r]);
+        const int cnt = L.w.r.cnt[r], mo = L.w.r.root[r];
+        int left = cnt;
+        int16_t* stk = L.u.stk + L.w.r.soff[r];
         uint32_t seed = L.w.r.first[r];
         bool have = seedable(seed);
         while (true) {
             if (!have) {
-                // the raster scan goes on: the smallest position among what is left of this
-                // super-component (rare: the first fill usually consumes all of it)
+                // the raster scan goes on: the smallest seedable position among what is left of this
+                // super-component (pixels below the running-maximum threshold are consumed but not
+                // expanded, so the fringe of a blob is often left over)
                 uint32_t best = kHotDead;
-                for (int i = 0; i < n; ++i)
-                    if (L.lab[i] == root && L.val[i] > 0 && seedable(L.xy[i])) best = min(best, L.xy[i]);
+                for (int q = 0; q < cnt; ++q) {
+                    const int i = members[mo + q];
+                    if (L.val[i] > 0 && seedable(L.xy[i])) best = min(best, L.xy[i]);
+                }
                 if (best == kHotDead) break;
                 seed = best;
             }
             have = false;
             stk[0] = (int16_t)lds_find(L, seed);  // :338
             Blob b;
-            left -= drain_lds(L, w, h, stk, 1, b);
-            if (blob_passes_cheap_tests(b) && window_variance_high(v.img, v.img_stride, w, h, b.xpk, b.ypk)) {  // :207
+            if (t.lds_path & 4) { b.touched = true; left = 0; }  // ablation (timing only)
+            else left -= drain_lds(L, w, h, stk, 1, b);
+            if (blob_passes_cheap_tests(b) &&
+                ((t.lds_path & 2) || window_variance_high(v.img, v.img_stride, w, h, b.xpk, b.ypk))) {  // :207
                 const int c = atomicAdd(&L.ncand, 1);
                 if (c < v.cand_cap) {
                     Cand cd;
@@ -858,96 +890,131 @@ __global__ __launch_bounds__(CC_THREADS) void cc_detect_lds_kernel(LevelBatch lb
     emit_detect_outputs(v, L.u.keys, nvalid, level, out, frame);
 }
 
+constexpr int LPTS = 512;                    // points per frame the LDS refine kernel takes
+constexpr int LPPT = LPTS / CC_THREADS;     // points per thread
+
 __global__ __launch_bounds__(CC_THREADS) void cc_refine_lds_kernel(LevelBatch lb, CompTables t, int level,
                                                                    RefineIO io, int frame0) {
     __shared__ LdsCC L;
     __builtin_amdgcn_s_setprio(3);
     const int frame = frame0 + blockIdx.x, tid = threadIdx.x;
     const int nraw = t.hot_cnt[frame];
+    const int npts = min(io.npoints[frame], io.pitch);
     FrameView v = make_view(lb, t, frame);
-    if (!lds_load_and_label(L, v, nraw, t.cap)) {
+    if (npts > LPTS || !lds_load_and_label(L, v, nraw, t.cap)) {
         if (tid == 0) t.path[frame] = 0;
         return;
     }
     const int n = nraw, w = v.w, h = v.h;
     // LIFO demand of every super-component at its root, then the accumulators become the claim table
-    for (int i = tid; i < n; i += CC_THREADS) {
-        const int a = L.u.acc[i];
-        L.w.need16[i] = (int16_t)((a >> 12) + 1);
-    }
+    for (int i = tid; i < n; i += CC_THREADS) L.w.need16[i] = (int16_t)((L.u.acc[i] >> 12) + 1);
     __syncthreads();
     int32_t* claim = L.u.acc;
     for (int i = tid; i < n; i += CC_THREADS) claim[i] = 0x7fffffff;
+    // the group leader of every point, -1 for a point that is not refinable at this level: behind
+    // need16[] in the same union (LN * 2 bytes used of 5120), npts <= LPTS entries
+    int16_t* lead16 = L.w.need16 + LN;
+    static_assert(sizeof(L.w) >= (size_t)LN * 2 + (size_t)LPTS * 2, "lead16 must fit behind need16");
 
-    const int npts = min(io.npoints[frame], io.pitch);
     const long long pb = (long long)frame * io.pitch;
     double* pts = io.points + 2 * pb;
     signed char* lv = io.levels + pb;
-    int32_t* leader = io.leader + pb;
-    int32_t* need = io.need + pb;
+    uint32_t* seeds = io.seeds + 9 * pb;  // here: list indices, read back by the group's leader lane
     int32_t* nseeds = io.nseeds + pb;
-    uint32_t* seeds = io.seeds + 9 * pb;  // here: list indices
-    int32_t* sroot = io.sroot + 9 * pb;
     const uint16_t coord_scale = (uint16_t)(1u << level);
 
-    // R1: seeds of every refinable point (:362-382), in the reference's push order
-    for (int i = tid; i < npts; i += CC_THREADS) {
-        int ns = -1;  // -1: not refinable at this level
-        if (lv[i] == level + 1) {
+    // R1: seeds of every refinable point (:362-382), in the reference's push order.  A thread owns points
+    // tid and tid + 256 and keeps their seed roots, seed counts and leaders in registers.
+    int ns_[LPPT], lead_[LPPT], need_[LPPT];
+    short sroot_[LPPT][9];
+#pragma unroll
+    for (int q = 0; q < LPPT; ++q) {
+        const int i = tid + CC_THREADS * q;
+        int ns = -1;  // -1: not refinable at this level (or no such point)
+        if (i < npts && lv[i] == level + 1) {
             ns = 0;
             const double lx = rescale_coord(pts[2 * i + 0], 1.0 / coord_scale);  // :369
             const double ly = rescale_coord(pts[2 * i + 1], 1.0 / coord_scale);
             const int x = (int)(lx + 0.5), y = (int)(ly + 0.5);  // :371-372
+#pragma unroll
             for (int dx = -1; dx <= 1; ++dx)
+#pragma unroll
                 for (int dy = -1; dy <= 1; ++dy) {
                     const int sx = (int16_t)(x + dx), sy = (int16_t)(y + dy);  // is_valid takes int16_t
-                    if (sx < 0 || sx >= w || sy < 0 || sy >= h) continue;
-                    const int j = lds_find(L, ((uint32_t)sy << 16) | (uint32_t)sx);  // hot <=> listed (nothing consumed yet)
-                    if (j < 0) continue;
-                    seeds[9 * i + ns] = (uint32_t)j;
-                    sroot[9 * i + ns] = L.lab[j];
-                    ++ns;
+                    int j = -1;
+                    if (sx >= 0 && sx < w && sy >= 0 && sy < h)
+                        j = lds_find(L, ((uint32_t)sy << 16) | (uint32_t)sx);  // hot <=> listed (nothing consumed yet)
+                    if (j >= 0) {
+                        seeds[9 * i + ns] = (uint32_t)j;
+#pragma unroll
+                        for (int k = 0; k < 9; ++k)  // static register index
+                            if (k == ns) sroot_[q][k] = L.lab[j];
+                        ++ns;
+                    }
                 }
+            nseeds[i] = ns;
         }
-        nseeds[i] = ns;
-        leader[i] = i;
-        need[i] = 0;
+        ns_[q] = ns;
+        lead_[q] = i;
+        need_[q] = 0;
     }
     __syncthreads();
 
     // R2: points whose seeds share a super-component are replayed in index order by one lane:
     // propagate the minimum point index over the bipartite graph points <-> super-components
     while (true) {
-        for (int i = tid; i < npts; i += CC_THREADS) {
-            const int ns = nseeds[i];
-            if (ns <= 0) continue;
-            int m = leader[i];
-            for (int k = 0; k < ns; ++k)
-                m = min(m, __hip_atomic_load(&claim[sroot[9 * i + k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-            bool changed = m < leader[i];
-            for (int k = 0; k < ns; ++k)
-                if (atomicMin(&claim[sroot[9 * i + k]], m) > m) changed = true;
-            leader[i] = m;
-            if (changed) L.changed = 1;
+        bool changed = false;
+#pragma unroll
+        for (int q = 0; q < LPPT; ++q) {
+            if (ns_[q] <= 0) continue;
+            int m = lead_[q];
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                if (k < ns_[q])
+                    m = min(m, __hip_atomic_load(&claim[sroot_[q][k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            changed |= m < lead_[q];
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                if (k < ns_[q] && atomicMin(&claim[sroot_[q][k]], m) > m) changed = true;
+            lead_[q] = m;
         }
+        if (changed) L.changed = 1;
         __syncthreads();
-        const int changed = L.changed;
+        const int c = L.changed;
         __syncthreads();
-        if (!changed) break;
+        if (!c) break;
         if (tid == 0) L.changed = 0;
         __syncthreads();
     }
+#pragma unroll
+    for (int q = 0; q < LPPT; ++q) {
+        const int i = tid + CC_THREADS * q;
+        if (i < npts) lead16[i] = (int16_t)(ns_[q] < 0 ? -1 : lead_[q]);
+    }
 
-    // R3: LIFO demand of each group = sum over its super-components, each counted once
-    for (int i = tid; i < npts; i += CC_THREADS) {
-        const int ns = nseeds[i];
-        if (ns >= 0 && leader[i] == i) atomicAdd(&L.total, 10);
-        for (int k = 0; k < ns; ++k) {
-            const int root = sroot[9 * i + k], ld = leader[i];
-            if (atomicCAS(&claim[root], ld, ld | 0x40000000) == ld) {
-                wg_add(need + ld, (int)L.w.need16[root]);
-                atomicAdd(&L.total, (int)L.w.need16[root]);
-            }
+    // R3: LIFO demand of each group = sum over its super-components, each counted once; groups take
+    // their LIFOs in the order of a running counter
+    int32_t* gneed = io.need + pb;  // per leader
+#pragma unroll
+    for (int q = 0; q < LPPT; ++q) {
+        const int i = tid + CC_THREADS * q;
+        if (i < npts) gneed[i] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < LPPT; ++q) {
+        if (ns_[q] < 0) continue;
+        const int i = tid + CC_THREADS * q, ld = lead_[q];
+        int add = ld == i ? 10 : 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            if (k >= ns_[q]) continue;
+            const int root = sroot_[q][k];
+            if (atomicCAS(&claim[root], ld, ld | 0x40000000) == ld) add += (int)L.w.need16[root];
+        }
+        if (add) {
+            wg_add(gneed + ld, add);
+            atomicAdd(&L.total, add);
         }
     }
     __syncthreads();
@@ -959,13 +1026,15 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_lds_kernel(LevelBatch lb
     __syncthreads();  // the claim table is dead: its storage becomes the LIFOs
 
     // R4: one lane per group, members in index order (:358); accepted points are written in place
-    for (int i = tid; i < npts; i += CC_THREADS) {
-        if (nseeds[i] < 0 || leader[i] != i) continue;
-        int16_t* stk = L.u.stk + atomicAdd(&L.top, aload(need + i) + 10);
+#pragma unroll
+    for (int q = 0; q < LPPT; ++q) {
+        const int i = tid + CC_THREADS * q;
+        if (ns_[q] < 0 || lead_[q] != i) continue;
+        int16_t* stk = L.u.stk + atomicAdd(&L.top, aload(gneed + i));
         for (int j = i; j < npts; ++j) {
-            if (nseeds[j] < 0 || leader[j] != i) continue;
-            const int ns = nseeds[j];
-            for (int k = 0; k < ns; ++k) stk[k] = (int16_t)seeds[9 * j + k];
+            if (lead16[j] != i) continue;
+            const int ns = j == i ? ns_[q] : aload(nseeds + j);
+            for (int k = 0; k < ns; ++k) stk[k] = (int16_t)__hip_atomic_load(&seeds[9 * j + k], MRG_WG);
             Blob b;
             drain_lds(L, w, h, stk, ns, b);
             if (!blob_passes_cheap_tests(b)) continue;
@@ -981,7 +1050,6 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_lds_kernel(LevelBatch lb
     __syncthreads();
     if (tid == 0 && io.nrefined) io.nrefined[frame] = L.nref;
 }
-
 
 void launch_cc_detect_lds(const LevelBatch& lb, const CompTables& t, int level, const DetectOut& out, int frame0,
                           int nframes, hipStream_t s) {

@@ -360,9 +360,10 @@ def test_dependent_calls_without_sync_are_ordered(det):
             assert torch.equal(out2[0][f, :k], rp[f, :k])
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_multi_level_launch_option_gives_the_same_chain(mode):
-    """set_option("multi_level_launch", 1): levels 3, 2, 1 of a chain share one grid; 2: level 0 as well."""
+    """set_option("multi_level_launch", ..): 0 = one ChESS launch per level; 1 (the default) = levels 3, 2, 1
+    of a chain share one grid; 2 = level 0 as well."""
     d2 = mrgingham_amd.Detector(0)
     try:
         d2.set_option("multi_level_launch", mode)
