@@ -85,6 +85,13 @@ bool find_chessboard_from_image_array_C(int Nrows, int Ncols, int stride, char* 
  * (rows top to bottom, each left to right).  false when no grid is found. */
 bool mrgingham_amd_find_grid_from_points(const int* xy_scaled, int npoints, int gridn, double* xy_out);
 
+/* TEST HOOK: the same with the parts of the visiting order that cannot be checked against the
+ * reference's boost::polygon graph perturbed -- ring_seed != 0 starts every site's neighbour ring at a
+ * pseudo-random position, last_match != 0 takes the last neighbour that continues a sequence instead of
+ * the first (find_grid.cc:216-222).  tests/test_grid.py asserts the results do not change. */
+bool mrgingham_amd_find_grid_from_points_perturbed(const int* xy_scaled, int npoints, int gridn, double* xy_out,
+                                                   unsigned ring_seed, int last_match);
+
 /* ------------------------------------------------------------------------ */
 /* (2) Batch API over device-resident frames                                */
 /* ------------------------------------------------------------------------ */

@@ -133,6 +133,16 @@ def find_grid_from_points(points_scaled, gridn=10):
     return out if ok else None
 
 
+def find_grid_from_points_perturbed(points_scaled, gridn=10, ring_seed=0, last_match=False):
+    """Test hook: find_grid_from_points with the neighbour-ring start of every site randomised (ring_seed != 0)
+    and / or the last instead of the first matching neighbour taken along a sequence."""
+    pts = np.ascontiguousarray(points_scaled, dtype=np.int32).reshape(-1, 2)
+    out = np.empty((gridn * gridn, 2), dtype=np.float64)
+    ok = _lib.lib().mrgingham_amd_find_grid_from_points_perturbed(pts.ctypes.data, len(pts), int(gridn),
+                                                                 out.ctypes.data, int(ring_seed), int(bool(last_match)))
+    return out if ok else None
+
+
 def preprocess(image, clahe=True, blur_radius=1):
     """The CLI's preprocessing of an 8-bit image on the GPU (mrgingham-from-image.cc:71-111; the cv2
     recipe of find_board.docstring:8-10): normalize + CLAHE(8) when `clahe`, then a box blur of

@@ -1149,6 +1149,15 @@ bool mrgingham_amd_find_grid_from_points(const int* xy_scaled, int npoints, int 
     return true;
 }
 
+/* Test hook: the same with the visiting order perturbed (grid.h, GridPerturbation). */
+bool mrgingham_amd_find_grid_from_points_perturbed(const int* xy_scaled, int npoints, int gridn, double* xy_out,
+                                                   unsigned ring_seed, int last_match) {
+    g_grid_perturbation = GridPerturbation{ring_seed, last_match != 0};
+    const bool ok = mrgingham_amd_find_grid_from_points(xy_scaled, npoints, gridn, xy_out);
+    g_grid_perturbation = GridPerturbation{0u, false};
+    return ok;
+}
+
 // mrgingham::find_chessboard_from_image_array (mrgingham.cc:38-140) on ONE frame that already lives
 // on the device (dense, stride == width): detector and refinement on the GPU, grid finder on the
 // host.  Returns the level the grid was found at, or -1.  `lv` receives the per-corner refinement

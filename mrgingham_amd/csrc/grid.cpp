@@ -31,6 +31,13 @@
 
 namespace mrg {
 
+// Test hook (mrgingham_amd_find_grid_from_points_perturbed): the two things about the reference's visiting
+// order that cannot be checked against boost here.  ring_seed != 0 starts every site's neighbour ring at a
+// pseudo-random position (boost's incident_edge() start is an implementation detail); last_match takes the
+// LAST neighbour that continues a sequence instead of the first (find_grid.cc:216-222).  The tests assert
+// that neither changes any result.
+thread_local GridPerturbation g_grid_perturbation{0u, false};
+
 namespace {
 
 using i64 = long long;
@@ -299,7 +306,14 @@ bool for_each_adjacent(const SiteGraph& g, const std::vector<PointI>& pts, int c
     const Ring& r = g.ring[c];
     const int deg = (int)r.nbr.size();
     const PointI& pt = pts[c];
-    for (int k = 0; k < deg; ++k) {
+    int start = 0;
+    if (g_grid_perturbation.ring_seed && deg > 0) {
+        uint32_t hsh = (uint32_t)c * 2654435761u ^ g_grid_perturbation.ring_seed;
+        hsh ^= hsh >> 15; hsh *= 0x2c1b3c6du; hsh ^= hsh >> 12;
+        start = (int)(hsh % (uint32_t)deg);
+    }
+    for (int kk = 0; kk < deg; ++kk) {
+        const int k = (kk + start) % deg;
         const int b = r.nbr[k];
         if (visit(b, PointI{pts[b].x - pt.x, pts[b].y - pt.y})) return true;
         if (deg < 2) continue;
@@ -350,6 +364,8 @@ struct SeqStats {  // HypothesisStatistics, :166-172
 
 // get_adjacent_cell_along_sequence, :209-312: the first neighbour continuing the sequence, or -1
 int next_along_sequence(const AdjLists& adj, int c, SeqStats& st) {
+    const Adj* chosen = nullptr;
+    double chosen_ratio = 0.0;
     for (const Adj& a : adj[c]) {
         const double cos_err = ((double)st.delta_last.x * (double)a.delta.x + (double)st.delta_last.y * (double)a.delta.y) /
                                (st.last_len * a.len);
@@ -360,13 +376,16 @@ int next_along_sequence(const AdjLists& adj, int c, SeqStats& st) {
             const double dev = ratio - st.ratio_sum / (double)st.ratio_n;
             if (dev < -kLenRatioDev || dev > kLenRatioDev) continue;
         }
-        st.ratio_sum += ratio;
-        st.ratio_n++;
-        st.delta_last = a.delta;
-        st.last_len = a.len;
-        return a.site;
+        chosen = &a;
+        chosen_ratio = ratio;
+        if (!g_grid_perturbation.last_match) break;  // the reference: the first match (:216-222)
     }
-    return -1;
+    if (!chosen) return -1;
+    st.ratio_sum += chosen_ratio;
+    st.ratio_n++;
+    st.delta_last = chosen->delta;
+    st.last_len = chosen->len;
+    return chosen->site;
 }
 
 struct Sequence {  // CandidateSequence, :148-162

@@ -11,4 +11,8 @@ struct PointD { double x, y; };     // corner, pixel coordinates (point.hh:11-15
 // gridn*gridn corners in board order (rows top to bottom, each left to right) to `out`.
 bool find_grid_from_points(std::vector<PointD>& out, const std::vector<PointI>& pts, int gridn);
 
+// visiting-order perturbations for the insensitivity tests (see grid.cpp); thread-local, default off
+struct GridPerturbation { unsigned ring_seed; bool last_match; };
+extern thread_local GridPerturbation g_grid_perturbation;
+
 }  // namespace mrg

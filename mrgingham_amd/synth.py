@@ -91,3 +91,26 @@ def noise_frame(W, H, seed=0, smooth=0, device="cpu"):
     for _ in range(smooth):
         img = box_blur3(img)
     return img.to(torch.uint8)
+
+
+def board_lattice(W, H, gridn=10, seed=0):
+    """Analytic positions of the gridn x gridn interior X-corners of board_frame(W, H, gridn, seed), from the
+    renderer's own geometry (no detector involved): float64 numpy [gridn, gridn, 2] of (x, y) in the
+    detector's convention (integer coordinates at pixel centres), rows in the order of the board's v axis
+    (top to bottom for the +0.1 rad rotation), columns along u (left to right)."""
+    import numpy as np
+    ncell = gridn + 3
+    cell = (8 * 65536 * 8 * H) // (10 * ncell)
+    half = (ncell * cell) // 2
+    s = int(_mix(torch.tensor(seed * 7919 + 13, dtype=torch.int64)).item())
+    ox, oy = s & 63, (s >> 6) & 63
+    out = np.empty((gridn, gridn, 2), dtype=np.float64)
+    det = float(_COS_Q16) ** 2 + float(_SIN_Q16) ** 2
+    for b in range(gridn):
+        for a in range(gridn):
+            bu, bv = (a + 2) * cell - half, (b + 2) * cell - half       # X-corners sit on cell boundaries 2 .. gridn+1
+            dx = (_COS_Q16 * bu - _SIN_Q16 * bv) / det                   # 1/8-pixel units from the image centre
+            dy = (_SIN_Q16 * bu + _COS_Q16 * bv) / det
+            out[b, a, 0] = (dx + 4 * W + ox) / 8.0 - 0.5                 # continuous position -> pixel-centre convention
+            out[b, a, 1] = (dy + 4 * H + oy) / 8.0 - 0.5
+    return out

@@ -11,7 +11,25 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 
-def _expected_board(img, gridn, level):
+def _lattice_order(cand, lattice):
+    """The candidates in the order of the lattice the frame was rendered from (synth.board_lattice), or None
+    when some lattice point does not have exactly one candidate within 0.4 pitches."""
+    c = cand.astype(np.float64) / 1000.0
+    r2 = (0.4 * np.linalg.norm(lattice[0, 1] - lattice[0, 0])) ** 2
+    out = []
+    for p in lattice.reshape(-1, 2):
+        near = np.nonzero(((c - p) ** 2).sum(1) <= r2)[0]
+        if len(near) != 1:
+            return None
+        out.append(c[near[0]])
+    return np.array(out)
+
+
+def _expected_board(img, gridn, level, lattice=None):
+    """Expected corners: the ORACLE's candidates and refinement.  With `lattice` (synthetic frames) the board
+    -- which candidates, in which order -- comes from the geometry the frame was rendered from, not from
+    the product's grid finder; the finder (CPU entry point) is then only asked WHETHER it accepts a level
+    (its refusals at coarse levels are pinned geometrically in tests/test_grid.py)."""
     levels = [level] if level >= 0 else [3, 2, 1, 0]
     for L in levels:
         cand = oracle.find_corners(img, L)
@@ -20,6 +38,10 @@ def _expected_board(img, gridn, level):
         grid = mrgingham_amd.find_grid_from_points(cand, gridn)
         if grid is None:
             continue
+        if lattice is not None:
+            want = _lattice_order(cand, lattice)
+            assert want is not None and np.array_equal(grid, want), L   # the accepted board IS the rendered lattice
+            grid = want
         pts, lv = grid.copy(), np.full(gridn * gridn, L, np.int8)
         for l in range(L - 1, -1, -1):
             pts, lv, n = oracle.refine_corners(pts, lv, img, l)
@@ -34,8 +56,9 @@ def _expected_board(img, gridn, level):
 def test_find_board_matches_composed_oracle(case):
     w, h, gridn, seed = case
     img = synth.board_frame(w, h, gridn, seed).numpy()
+    lattice = synth.board_lattice(w, h, gridn, seed)
     for level in (-1, 0, 1, 2):
-        want, found_at = _expected_board(img, gridn, level)
+        want, found_at = _expected_board(img, gridn, level, lattice)
         got = mrgingham_amd.find_board(img, image_pyramid_level=level, gridn=gridn)
         if want is None:
             assert got is None, (case, level)
