@@ -230,6 +230,11 @@ int mrgingham_amd_read_image(const char* filename, int cli_scaling, uint8_t* out
 int mrgingham_amd_preprocess_image(const uint8_t* image, int width, int height, int stride, int do_clahe,
                                    int blur_radius, uint8_t* out);
 
+/* The 16-bit branch of the tool's preprocessing for one HOST image (mrgingham-from-image.cc:85-111; `stride`
+ * in elements): out receives width*height bytes.  Returns 0, or -2. */
+int mrgingham_amd_preprocess_image16(const uint16_t* image, int width, int height, int stride, int do_clahe,
+                                     int blur_radius, uint8_t* out);
+
 /* What one worker of the reference CLI does with one decoded 8-bit image
  * (mrgingham-from-image.cc:71-111, :160-171): [normalize + CLAHE(8)] -> box blur of
  * blur_radius -> find_chessboard_from_image_array(gridn, image_pyramid_level), with the
@@ -240,6 +245,21 @@ int mrgingham_amd_preprocess_image(const uint8_t* image, int width, int height, 
 int mrgingham_amd_process_image(const uint8_t* image, int width, int height, int stride, int do_clahe,
                                 int blur_radius, int gridn, int image_pyramid_level, int do_refine,
                                 double* xy_out, signed char* levels_out);
+
+/* The same with the tool's whole option set, and for 16-bit images (mrgingham-from-image.cc:85-92:
+ * cv::normalize to 0..65535 and CLAHE on 16 bits when do_clahe, then convertTo(CV_8U, 255/65535)).
+ * bits = 8 or 16; `stride` in ELEMENTS.  debug != 0 writes the reference's dumps: the preprocessed
+ * image as /tmp/<basename of filename>_preprocessed.png (:113-148) and, per detector / refinement pass,
+ * the level image, the normalised ChESS responses and a self-plotting corner vnlog
+ * (find_chessboard_corners.cc:282-315, :453-459, :513-541) -- same names, same messages on stderr. */
+typedef struct mrgingham_amd_cli_options {
+    int do_clahe, blur_radius, gridn, image_pyramid_level, do_refine, do_blobs, debug;
+    int debug_sequence_x, debug_sequence_y; /* accepted; the grid finder's own dumps are not produced */
+    const char* filename;                   /* names the debug dumps only; may be NULL */
+} mrgingham_amd_cli_options;
+int mrgingham_amd_process_image_ex(const void* image, int bits, int width, int height, int stride,
+                                   const mrgingham_amd_cli_options* options, double* xy_out,
+                                   signed char* levels_out);
 
 /* Batch form of the full detector (what find_chessboard_from_image_array_C does per frame, for
  * image_pyramid_level < 0 the reference's default "first level of 3,2,1,0 at which the grid finder

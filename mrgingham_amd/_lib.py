@@ -28,7 +28,7 @@ EXPORTS = [
     "mrgingham_amd_find_grid_from_points", "mrgingham_amd_find_grid_from_points_perturbed", "mrgingham_amd_create", "mrgingham_amd_destroy",
     "mrgingham_amd_last_error", "mrgingham_amd_abi_version", "mrgingham_amd_device_count", "mrgingham_amd_level_dims",
     "mrgingham_amd_chess_response_batch", "mrgingham_amd_decimate_batch", "mrgingham_amd_box_blur_batch",
-    "mrgingham_amd_preprocess_batch", "mrgingham_amd_process_image", "mrgingham_amd_preprocess_image",
+    "mrgingham_amd_preprocess_batch", "mrgingham_amd_process_image", "mrgingham_amd_process_image_ex", "mrgingham_amd_preprocess_image16", "mrgingham_amd_preprocess_image",
     "find_chessboard_corners_from_image_file_C", "find_chessboard_from_image_file_C",
     "mrgingham_amd_detect_batch", "mrgingham_amd_refine_batch", "mrgingham_amd_chain_batch",
     "mrgingham_amd_find_boards_batch", "mrgingham_amd_cc_on_response_batch", "mrgingham_amd_scratch_bytes", "mrgingham_amd_read_image",

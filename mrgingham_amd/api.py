@@ -161,6 +161,24 @@ def preprocess(image, clahe=True, blur_radius=1):
     return out
 
 
+def preprocess16(image16, clahe=True, blur_radius=1):
+    """The CLI's preprocessing of a 16-bit image on the GPU (mrgingham-from-image.cc:85-111): normalize to
+    0..65535 and CLAHE(8) on 16 bits when `clahe`, convertTo 8 bit with 255/65535, box blur.  -> uint8 [H, W]."""
+    _require_device()
+    image16 = np.ascontiguousarray(image16)
+    if image16.dtype != np.uint16 or image16.ndim != 2:
+        raise RuntimeError("preprocess16 takes a 2-D uint16 array")
+    H, W = image16.shape
+    out = np.empty((H, W), dtype=np.uint8)
+    L = _lib.lib()
+    L.mrgingham_amd_preprocess_image16.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                   ctypes.c_int, ctypes.c_void_p]
+    if L.mrgingham_amd_preprocess_image16(image16.ctypes.data, W, H, W, int(bool(clahe)), int(blur_radius),
+                                          out.ctypes.data) != 0:
+        raise RuntimeError("mrgingham_amd: 16-bit preprocessing failed (bad arguments or no device)")
+    return out
+
+
 def find_board(image, image_pyramid_level=-1, gridn=10, blobs=False, debug=False, debug_sequence=None):
     """The full detector: float64 (gridn*gridn, 2) board corners, or None (mrgingham_pywrap.c:227-337).
 

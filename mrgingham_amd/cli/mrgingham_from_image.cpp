@@ -11,8 +11,8 @@
 // codec build, so byte-identity with cv::imread on colour files is not claimed.
 //
 // Preprocessing (normalize + CLAHE(8), box blur) and detection run on the GPU through
-// mrgingham_amd_process_image; 16-bit input is reduced to 8 bit on the host the way the reference
-// does (convertTo(CV_8U, 255/65535), :91) and is only accepted together with --noclahe.
+// mrgingham_amd_process_image_ex, for 8- and 16-bit images alike (16 bit: normalize to 0..65535, CLAHE on
+// 16 bits, convertTo(CV_8U, 255/65535), :85-92).
 #include <getopt.h>
 #include <glob.h>
 #include <pthread.h>
@@ -37,6 +37,7 @@ struct Options {
     glob_t globbed;
     int jobs = 1, blur_radius = 1, gridn = 10, level = -1;
     bool doclahe = true, do_refine = true, debug = false;
+    int debug_sequence_x = -1, debug_sequence_y = -1;
 } opt;
 
 const char* kUsage =
@@ -58,14 +59,15 @@ const char* kUsage =
     "  --no-refine     keep the corners of the level the board was found at\n"
     "  --jobs N, -j N  worker threads (image i is handled by worker i mod N)\n"
     "  --blobs         circle grids: not supported by this build\n"
-    "  --debug, --debug-sequence x,y   accepted; no intermediate dumps are written\n";
+    "  --debug         one image only: write the preprocessed image, the level images, the ChESS\n"
+    "                  responses and the corner vnlogs to /tmp like the reference does\n"
+    "  --debug-sequence x,y   accepted (the grid finder's own dumps are not produced)\n";
 
 void* worker(void* arg) {
     const int ijob = (int)(intptr_t)arg;
     const int N = opt.gridn * opt.gridn;
     std::vector<double> xy((size_t)N * 2);
     std::vector<signed char> lv((size_t)N);
-    std::vector<uint8_t> tmp8;
     Image im;  // reused: its buffers keep their pages from image to image
     for (int i = ijob; i < (int)opt.globbed.gl_pathc; i += opt.jobs) {
         const char* filename = opt.globbed.gl_pathv[i];
@@ -77,22 +79,20 @@ void* worker(void* arg) {
             funlockfile(stdout);
             break;
         }
-        const uint8_t* px = im.px8.data();
-        if (im.depth == 16) {
-            if (opt.doclahe) {
-                fprintf(stderr, "Couldn't process image '%s': 16-bit images are only handled with --noclahe by this build\n", filename);
-                flockfile(stdout);
-                printf("## Couldn't process image '%s': 16-bit images are only handled with --noclahe by this build\n", filename);
-                printf("%s - - -\n", filename);
-                funlockfile(stdout);
-                break;
-            }
-            // image0.convertTo(image1, CV_8U, 255./65535.), mrgingham-from-image.cc:91
-            mrg::to_8bit(im, tmp8);
-            px = tmp8.data();
-        }
-        const int level = mrgingham_amd_process_image(px, im.w, im.h, im.w, opt.doclahe, opt.blur_radius, opt.gridn,
-                                                      opt.level, opt.do_refine, xy.data(), lv.data());
+        mrgingham_amd_cli_options o{};
+        o.do_clahe = opt.doclahe;
+        o.blur_radius = opt.blur_radius;
+        o.gridn = opt.gridn;
+        o.image_pyramid_level = opt.level;
+        o.do_refine = opt.do_refine;
+        o.debug = opt.debug;
+        o.debug_sequence_x = opt.debug_sequence_x;
+        o.debug_sequence_y = opt.debug_sequence_y;
+        o.filename = filename;
+        // 8- and 16-bit images go to the device as they are (mrgingham-from-image.cc:71-92)
+        const int level = im.depth == 16
+                              ? mrgingham_amd_process_image_ex(im.px16.data(), 16, im.w, im.h, im.w, &o, xy.data(), lv.data())
+                              : mrgingham_amd_process_image_ex(im.px8.data(), 8, im.w, im.h, im.w, &o, xy.data(), lv.data());
         flockfile(stdout);
         if (level >= 0)  // mrgingham-from-image.cc:174-183
             for (int k = 0; k < N; ++k)
@@ -130,6 +130,8 @@ int main(int argc, char* argv[]) {
                     fprintf(stderr, kUsage, argv[0]);
                     return -1;
                 }
+                opt.debug_sequence_x = x;
+                opt.debug_sequence_y = y;
                 break;
             }
             case 'N': opt.gridn = atoi(optarg); break;

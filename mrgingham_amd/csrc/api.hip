@@ -136,7 +136,7 @@ struct mrgingham_amd_ctx {
     int counters_nf = 0;
     struct PointScratch { mrg::DevBuf leader, need, nseeds, seeds, sroot, cand_xy, cand_counts; } pts[2];  // per scratch set
     mrg::DevBuf aux_img, io_frame, io_out, io_counts;
-    mrg::DevBuf pre_scratch, pre_tmp, pre_out;
+    mrg::DevBuf pre_scratch, pre_tmp, pre_out, pre16_scratch, io_frame16, dbg_img, dbg_resp;
     mrg::DevBuf fb_xy, fb_cnt, fb_pts, fb_lv, fb_np, fb_frames, fb_frames2;  // find_boards_batch: candidates, counts, boards, levels, point counts
     HostPool pool;  // preprocessing: extrema + tile histograms + LUTs, CLAHE output before the blur
     int pts_nframes = 0, pts_pitch = 0;
@@ -520,7 +520,7 @@ void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx) {
     for (auto& ps : ctx->pts)
         for (DevBuf* b : {&ps.leader, &ps.need, &ps.nseeds, &ps.seeds, &ps.sroot, &ps.cand_xy, &ps.cand_counts})
             if (b->p) hipFree(b->p);
-    DevBuf* bufs[] = {&ctx->counters2[0], &ctx->counters2[1], &ctx->io_counts, &ctx->aux_img, &ctx->io_frame, &ctx->io_out, &ctx->pre_scratch, &ctx->pre_tmp, &ctx->pre_out,
+    DevBuf* bufs[] = {&ctx->counters2[0], &ctx->counters2[1], &ctx->io_counts, &ctx->aux_img, &ctx->io_frame, &ctx->io_out, &ctx->pre_scratch, &ctx->pre_tmp, &ctx->pre_out, &ctx->pre16_scratch, &ctx->io_frame16, &ctx->dbg_img, &ctx->dbg_resp,
                       &ctx->fb_xy, &ctx->fb_cnt, &ctx->fb_pts, &ctx->fb_lv, &ctx->fb_np, &ctx->fb_frames, &ctx->fb_frames2};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
@@ -1001,11 +1001,69 @@ static int upload_frame(mrgingham_amd_ctx* ctx, const void* host, int rows, int 
     return 0;
 }
 
+// The reference's --debug dumps of one detector / refinement pass (find_chessboard_corners.cc:282-315,
+// :453-459, :513-541): the level image, the ChESS response normalised to 0..255 (raw, and with the
+// negatives clamped), and a self-plotting vnlog of the corners.  Same file names, same messages.  The
+// response PNGs follow cv::normalize(.., 0, 255, NORM_MINMAX) on CV_16S (single-precision scale and
+// shift, round half to even) and imwrite's saturating conversion to 8 bit.
+static void write_debug_dumps(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr1, int level, bool refinement,
+                              const char* debug_image_filename, const double* pts_xy, int npts) {
+    int w, h;
+    if (level_dims(fr1->width, fr1->height, level, &w, &h) || w <= 0 || h <= 0) return;
+    const size_t n = (size_t)w * h;
+    char name[300];
+    std::vector<uint8_t> img8(n);
+    std::vector<int16_t> resp(n);
+    if (ensure(ctx, ctx->dbg_img, n + 64) || ensure(ctx, ctx->dbg_resp, n * 2 + 64)) return;
+    if (!refinement) {  // apply_image_pyramid_scaling dumps once per detector call (:453-459)
+        if (mrgingham_amd_decimate_batch(ctx, fr1, level, (uint8_t*)ctx->dbg_img.p, ctx->pix) ||
+            hipMemcpyAsync(img8.data(), ctx->dbg_img.p, n, hipMemcpyDeviceToHost, ctx->pix) != hipSuccess ||
+            hipStreamSynchronize(ctx->pix) != hipSuccess)
+            return;
+        snprintf(name, sizeof(name), "/tmp/mrgingham-scaled-processed-level%d.png", level);
+        if (write_png_gray8(name, img8.data(), w, h)) fprintf(stderr, "Wrote scaled,processed image to %s\n", name);
+    }
+    for (int positive = 0; positive < 2; ++positive) {
+        if (mrgingham_amd_chess_response_batch(ctx, fr1, level, positive, (int16_t*)ctx->dbg_resp.p, ctx->pix) ||
+            hipMemcpyAsync(resp.data(), ctx->dbg_resp.p, n * 2, hipMemcpyDeviceToHost, ctx->pix) != hipSuccess ||
+            hipStreamSynchronize(ctx->pix) != hipSuccess)
+            return;
+        int lo = 32767, hi = -32768;
+        for (int16_t v : resp) { lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+        const double scale = 255.0 * (hi - lo > 2.220446049250313e-16 ? 1.0 / (double)(hi - lo) : 0.0);
+        const double shift = 0.0 - (double)lo * scale;
+        const float a = (float)scale, b = (float)shift;
+        for (size_t i = 0; i < n; ++i) {
+            const float prod = (float)resp[i] * a;
+            const float r = rintf(prod + b);
+            img8[i] = (uint8_t)(r < 0.f ? 0.f : (r > 255.f ? 255.f : r));
+        }
+        snprintf(name, sizeof(name), "/tmp/mrgingham-chess-response%s-level%d%s.png", refinement ? "-refinement" : "", level,
+                 positive ? "-positive" : "");
+        if (write_png_gray8(name, img8.data(), w, h))
+            fprintf(stderr, positive ? "Wrote positive-only, normalized ChESS response to %s\n"
+                                     : "Wrote a normalized ChESS response to %s\n", name);
+    }
+    if (refinement) snprintf(name, sizeof(name), "/tmp/mrgingham-1-corners-refinement-level%d.vnl", level);
+    else snprintf(name, sizeof(name), "/tmp/mrgingham-1-corners.vnl");
+    fprintf(stderr, "Writing self-plotting corner dump to %s\n", name);
+    FILE* fp = fopen(name, "w");
+    if (!fp) return;
+    if (debug_image_filename)
+        fprintf(fp, "#!/usr/bin/feedgnuplot --dom --with 'points pt 7 ps 2' --square --image %s\n", debug_image_filename);
+    else
+        fprintf(fp, "#!/usr/bin/feedgnuplot --dom --square --set 'yr [:] rev'\n");
+    fprintf(fp, "# x y\n");
+    for (int i = 0; i < npts; ++i) fprintf(fp, "%f %f\n", pts_xy[2 * i], pts_xy[2 * i + 1]);
+    fclose(fp);
+}
+
 // Every candidate of ONE frame that already lives on the device (dense or strided), with the retry of
 // the reference-symbol wrappers: a frame whose hot list or candidate table overflows the default
 // capacity is re-run with one table entry per pixel.  Returns false on a device / argument error.
 static bool detect_one_frame_all(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr1, int level,
-                                 std::vector<int32_t>& xy, int32_t* count_out) {
+                                 std::vector<int32_t>& xy, int32_t* count_out, bool debug = false,
+                                 const char* debug_image_filename = nullptr) {
     const int saved_shift = ctx->cap_shift;
     bool ok = false;
     int32_t count = 0;
@@ -1028,6 +1086,13 @@ static bool detect_one_frame_all(mrgingham_amd_ctx* ctx, const mrgingham_amd_fra
     }
     ctx->cap_shift = saved_shift;
     *count_out = count;
+    if (ok && debug) {
+        // the dump lists the corners in full-resolution pixels (:346-348); from the *1000 integers here,
+        // i.e. to three decimals
+        std::vector<double> p((size_t)(count > 0 ? count : 0) * 2);
+        for (size_t i = 0; i < p.size(); ++i) p[i] = (double)xy[i] / kGridScale;
+        write_debug_dumps(ctx, fr1, level, false, debug_image_filename, p.data(), count > 0 ? count : 0);
+    }
     return ok;
 }
 
@@ -1070,7 +1135,6 @@ bool find_chessboard_corners_from_image_array_C(int Nrows, int Ncols, int stride
                                                 int image_pyramid_level, bool doblobs, bool debug,
                                                 bool (*add_points)(int* xy, int N, double scale, void* cookie),
                                                 void* cookie) {
-    (void)debug;  // the reference's /tmp debug dumps are not produced
     if (doblobs) {
         fprintf(stderr, "mrgingham_amd: the blob detector (find_blobs.cc) is not part of this library\n");
         return false;
@@ -1084,14 +1148,17 @@ bool find_chessboard_corners_from_image_array_C(int Nrows, int Ncols, int stride
     int32_t count = 0;
     mrgingham_amd_frames fr;
     const bool ok = upload_frame(ctx, imagebuffer, Nrows, Ncols, stride, &fr) == 0 &&
-                    detect_one_frame_all(ctx, &fr, image_pyramid_level, xy, &count);
+                    detect_one_frame_all(ctx, &fr, image_pyramid_level, xy, &count, debug, nullptr);
     if (!ok || count <= 0) return false;  // bridge.cc:61: nothing found -> false, add_points not called
     return (*add_points)(xy.data(), (int)count, 1. / kGridScale, cookie);  // bridge.cc:66-69
 }
 
 // Refinement of host-side points against a frame that already lives on the device (one frame).
 static int refine_on_device(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, double* points_xy,
-                            signed char* level, int Npoints, int image_pyramid_level) {
+                            signed char* level, int Npoints, int image_pyramid_level, bool debug = false,
+                            const char* debug_image_filename = nullptr) {
+    std::vector<signed char> level_before;
+    if (debug) level_before.assign(level, level + Npoints);
     const int saved_shift = ctx->cap_shift;
     int32_t nrefined = 0;
     bool ok = false;
@@ -1119,13 +1186,18 @@ static int refine_on_device(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* 
         break;
     }
     ctx->cap_shift = saved_shift;
+    if (ok && debug) {  // the points refined by this pass, in index order (:390-392)
+        std::vector<double> p;
+        for (int i = 0; i < Npoints; ++i)
+            if (level[i] != level_before[i]) { p.push_back(points_xy[2 * i]); p.push_back(points_xy[2 * i + 1]); }
+        write_debug_dumps(ctx, fr, image_pyramid_level, true, debug_image_filename, p.data(), (int)(p.size() / 2));
+    }
     return ok && nrefined > 0 ? nrefined : 0;
 }
 
 int refine_chessboard_corners_from_image_array_C(int Nrows, int Ncols, int stride, char* imagebuffer,
                                                  double* points_xy, signed char* level, int Npoints,
                                                  int image_pyramid_level, bool debug) {
-    (void)debug;
     if (Nrows < 0 || Ncols < 0 || stride < Ncols || !imagebuffer || Npoints < 0) return 0;
     if (Npoints > 0 && (!points_xy || !level)) return 0;
     if (!check_level_and_layout(__func__, Nrows, Ncols, stride, image_pyramid_level)) return 0;
@@ -1135,7 +1207,7 @@ int refine_chessboard_corners_from_image_array_C(int Nrows, int Ncols, int strid
     hipSetDevice(ctx->device);
     mrgingham_amd_frames fr;
     if (upload_frame(ctx, imagebuffer, Nrows, Ncols, stride, &fr)) return 0;
-    return refine_on_device(ctx, &fr, points_xy, level, Npoints, image_pyramid_level);
+    return refine_on_device(ctx, &fr, points_xy, level, Npoints, image_pyramid_level, debug, nullptr);
 }
 
 /* C face of mrgingham::find_grid_from_points (mrgingham.hh:83-87; find_grid.cc:1216-1445): host only. */
@@ -1164,7 +1236,8 @@ bool mrgingham_amd_find_grid_from_points_perturbed(const int* xy_scaled, int npo
 // level; without do_refine nothing is refined and every entry is the found level.
 static int find_board_on_device(mrgingham_amd_ctx* ctx, const char* who, const mrgingham_amd_frames* fr, int gridn,
                                 int image_pyramid_level, bool do_refine, std::vector<PointD>& board,
-                                std::vector<signed char>& lv) {
+                                std::vector<signed char>& lv, bool debug = false,
+                                const char* debug_image_filename = nullptr) {
     const int Nrows = fr->height, Ncols = fr->width;
     const int N = gridn * gridn;
     std::vector<int32_t> xy;
@@ -1176,7 +1249,7 @@ static int find_board_on_device(mrgingham_amd_ctx* ctx, const char* who, const m
     for (; level >= last && !found; --level) {
         if (!check_level_and_layout(who, Nrows, Ncols, fr->stride, level)) continue;
         int32_t count = 0;
-        const bool ok = detect_one_frame_all(ctx, fr, level, xy, &count);
+        const bool ok = detect_one_frame_all(ctx, fr, level, xy, &count, debug, debug_image_filename);
         if (!ok || count < N) continue;
         std::vector<PointI> cand((size_t)count);
         for (int i = 0; i < count; ++i) cand[i] = PointI{xy[2 * i], xy[2 * i + 1]};
@@ -1189,7 +1262,7 @@ static int find_board_on_device(mrgingham_amd_ctx* ctx, const char* who, const m
     // refine towards level 0 while something still refines (mrgingham.cc:81-99)
     if (do_refine)
         for (int l = level - 1; l >= 0; --l)
-            if (refine_on_device(ctx, fr, &board[0].x, lv.data(), N, l) <= 0) break;
+            if (refine_on_device(ctx, fr, &board[0].x, lv.data(), N, l, debug, debug_image_filename) <= 0) break;
     return level;
 }
 
@@ -1200,7 +1273,7 @@ bool find_chessboard_from_image_array_C(int Nrows, int Ncols, int stride, char* 
                                         int image_pyramid_level, bool doblobs, bool debug, int debug_sequence_x,
                                         int debug_sequence_y,
                                         bool (*add_points)(double* xy, int N, void* cookie), void* cookie) {
-    (void)debug; (void)debug_sequence_x; (void)debug_sequence_y;
+    (void)debug_sequence_x; (void)debug_sequence_y;  // the grid finder's own dumps are not produced
     if (doblobs) {
         fprintf(stderr, "mrgingham_amd: the blob detector (find_blobs.cc) is not part of this library\n");
         return false;
@@ -1218,7 +1291,8 @@ bool find_chessboard_from_image_array_C(int Nrows, int Ncols, int stride, char* 
     if (upload_frame(ctx, imagebuffer, Nrows, Ncols, stride, &fr)) return false;
     std::vector<PointD> board;
     std::vector<signed char> lv;
-    if (find_board_on_device(ctx, __func__, &fr, gridn, image_pyramid_level, true, board, lv) < 0) return false;
+    if (find_board_on_device(ctx, __func__, &fr, gridn, image_pyramid_level, true, board, lv, debug, nullptr) < 0)
+        return false;
     static_assert(sizeof(PointD) == 2 * sizeof(double), "add_points() takes interleaved doubles");
     return (*add_points)(&board[0].x, gridn * gridn, cookie);  // bridge.cc:133-137
 }
@@ -1310,33 +1384,113 @@ int mrgingham_amd_preprocess_image(const uint8_t* image, int width, int height, 
  * find_chessboard_from_image_array.  The frame is uploaded once; preprocessing, detector and
  * refinement run on the device, the grid finder on the host.  Returns the level the board was found
  * at (>= 0), -1 when no board was found, -2 on an argument / device error. */
-int mrgingham_amd_process_image(const uint8_t* image, int width, int height, int stride, int do_clahe,
-                                int blur_radius, int gridn, int image_pyramid_level, int do_refine, double* xy_out,
-                                signed char* levels_out) {
-    if (!image || width <= 0 || height <= 0 || stride < width || gridn < 2 || !xy_out || blur_radius < 0) return -2;
-    if (image_pyramid_level > 10) {
+int mrgingham_amd_preprocess_image16(const uint16_t* image, int width, int height, int stride, int do_clahe,
+                                     int blur_radius, uint8_t* out) {
+    if (!image || !out || width <= 0 || height <= 0 || stride < width || blur_radius < 0 || width > 32767 || height > 32767)
+        return -2;
+    mrgingham_amd_ctx* ctx = thread_ctx();
+    if (!ctx) return -2;
+    hipSetDevice(ctx->device);
+    const size_t npx = (size_t)width * height;
+    if (ensure(ctx, ctx->io_frame16, npx * 2 + 64) || ensure(ctx, ctx->pre_tmp, npx + 64) || ensure(ctx, ctx->pre_out, npx + 64) ||
+        ensure(ctx, ctx->pre16_scratch, preprocess16_scratch_bytes(1, width, height)))
+        return -2;
+    if (hipMemcpy2DAsync(ctx->io_frame16.p, (size_t)width * 2, image, (size_t)stride * 2, (size_t)width * 2, height,
+                         hipMemcpyHostToDevice, ctx->pix) != hipSuccess)
+        return -2;
+    uint8_t* eight = (uint8_t*)(blur_radius > 0 ? ctx->pre_tmp.p : ctx->pre_out.p);
+    if (!launch_preprocess16((const uint16_t*)ctx->io_frame16.p, (long long)npx, 1, width, height, width, do_clahe != 0,
+                             8.0, eight, ctx->pre16_scratch.p, ctx->pix))
+        return -2;
+    if (blur_radius > 0) {
+        const mrgingham_amd_frames fr{eight, (int64_t)npx, 1, width, height, width};
+        if (mrgingham_amd_box_blur_batch(ctx, &fr, blur_radius, (uint8_t*)ctx->pre_out.p, ctx->pix)) return -2;
+    }
+    if (hipMemcpyAsync(out, ctx->pre_out.p, npx, hipMemcpyDeviceToHost, ctx->pix) != hipSuccess ||
+        hipStreamSynchronize(ctx->pix) != hipSuccess)
+        return -2;
+    return 0;
+}
+
+int mrgingham_amd_process_image_ex(const void* image, int bits, int width, int height, int stride,
+                                   const mrgingham_amd_cli_options* o, double* xy_out, signed char* levels_out) {
+    if (!image || !o || (bits != 8 && bits != 16) || width <= 0 || height <= 0 || stride < width || o->gridn < 2 ||
+        !xy_out || o->blur_radius < 0 || width > 32767 || height > 32767)
+        return -2;
+    if (o->image_pyramid_level > 10) {
         fprintf(stderr, "mrgingham_amd: %s(): Got an unreasonable image_pyramid_level = %d. Sorry.\n", __func__,
-                image_pyramid_level);
+                o->image_pyramid_level);
+        return -2;
+    }
+    if (o->do_blobs) {
+        fprintf(stderr, "mrgingham_amd: the blob detector (find_blobs.cc) is not part of this library\n");
         return -2;
     }
     mrgingham_amd_ctx* ctx = thread_ctx();
     if (!ctx) return -2;
     hipSetDevice(ctx->device);
+    const size_t npx = (size_t)width * height;
     mrgingham_amd_frames fr;
-    if (upload_frame(ctx, image, height, width, stride, &fr)) return -2;
-    if (do_clahe || blur_radius > 0) {
-        if (ensure(ctx, ctx->pre_out, (size_t)width * height + 64)) return -2;
-        if (mrgingham_amd_preprocess_batch(ctx, &fr, do_clahe, blur_radius, (uint8_t*)ctx->pre_out.p, ctx->pix))
+    if (bits == 8) {
+        if (upload_frame(ctx, image, height, width, stride, &fr)) return -2;
+        if (o->do_clahe || o->blur_radius > 0) {
+            if (ensure(ctx, ctx->pre_out, npx + 64)) return -2;
+            if (mrgingham_amd_preprocess_batch(ctx, &fr, o->do_clahe, o->blur_radius, (uint8_t*)ctx->pre_out.p, ctx->pix))
+                return -2;
+            fr.frames = (const uint8_t*)ctx->pre_out.p;  // same stream as the detector's pixel kernels
+        }
+    } else {
+        // mrgingham-from-image.cc:85-92: [normalize to 0..65535 + CLAHE on 16 bits] -> convertTo(CV_8U, 255/65535)
+        if (ensure(ctx, ctx->io_frame16, npx * 2 + 64) || ensure(ctx, ctx->pre_tmp, npx + 64) ||
+            ensure(ctx, ctx->pre_out, npx + 64) ||
+            ensure(ctx, ctx->pre16_scratch, preprocess16_scratch_bytes(1, width, height)))
             return -2;
-        fr.frames = (const uint8_t*)ctx->pre_out.p;  // same stream as the detector's pixel kernels
+        if (hipMemcpy2DAsync(ctx->io_frame16.p, (size_t)width * 2, image, (size_t)stride * 2, (size_t)width * 2, height,
+                             hipMemcpyHostToDevice, ctx->pix) != hipSuccess)
+            return -2;
+        uint8_t* eight = (uint8_t*)(o->blur_radius > 0 ? ctx->pre_tmp.p : ctx->pre_out.p);
+        if (!launch_preprocess16((const uint16_t*)ctx->io_frame16.p, (long long)npx, 1, width, height, width,
+                                 o->do_clahe != 0, 8.0, eight, ctx->pre16_scratch.p, ctx->pix))
+            return -2;
+        fr = mrgingham_amd_frames{eight, (int64_t)npx, 1, width, height, width};
+        if (o->blur_radius > 0) {
+            if (mrgingham_amd_box_blur_batch(ctx, &fr, o->blur_radius, (uint8_t*)ctx->pre_out.p, ctx->pix)) return -2;
+            fr.frames = (const uint8_t*)ctx->pre_out.p;
+        }
+    }
+    if (o->debug) {  // mrgingham-from-image.cc:113-148: /tmp/<basename without extension>_preprocessed.png
+        const char* fn = o->filename ? o->filename : "image";
+        const char* slash = strrchr(fn, '/');
+        std::string base = slash ? slash + 1 : fn;
+        const size_t dot = base.rfind('.');
+        if (dot != std::string::npos) base.resize(dot);
+        const std::string outname = "/tmp/" + base + "_preprocessed.png";
+        std::vector<uint8_t> host(npx);
+        if (hipMemcpy2DAsync(host.data(), width, fr.frames, fr.stride, width, height, hipMemcpyDeviceToHost, ctx->pix) ==
+                hipSuccess &&
+            hipStreamSynchronize(ctx->pix) == hipSuccess && write_png_gray8(outname.c_str(), host.data(), width, height))
+            fprintf(stderr, "Wrote preprocessed image to %s\n", outname.c_str());
     }
     std::vector<PointD> board;
     std::vector<signed char> lv;
-    const int level = find_board_on_device(ctx, __func__, &fr, gridn, image_pyramid_level, do_refine != 0, board, lv);
+    const int level = find_board_on_device(ctx, __func__, &fr, o->gridn, o->image_pyramid_level, o->do_refine != 0,
+                                           board, lv, o->debug != 0, o->filename);
     if (level < 0) return -1;
-    memcpy(xy_out, &board[0].x, sizeof(double) * 2 * (size_t)gridn * gridn);
-    if (levels_out) memcpy(levels_out, lv.data(), (size_t)gridn * gridn);
+    memcpy(xy_out, &board[0].x, sizeof(double) * 2 * (size_t)o->gridn * o->gridn);
+    if (levels_out) memcpy(levels_out, lv.data(), (size_t)o->gridn * o->gridn);
     return level;
+}
+
+int mrgingham_amd_process_image(const uint8_t* image, int width, int height, int stride, int do_clahe,
+                                int blur_radius, int gridn, int image_pyramid_level, int do_refine, double* xy_out,
+                                signed char* levels_out) {
+    mrgingham_amd_cli_options o{};
+    o.do_clahe = do_clahe;
+    o.blur_radius = blur_radius;
+    o.gridn = gridn;
+    o.image_pyramid_level = image_pyramid_level;
+    o.do_refine = do_refine;
+    return mrgingham_amd_process_image_ex(image, 8, width, height, stride, &o, xy_out, levels_out);
 }
 
 /* Batch form of the full detector (the reference's default schedule, image_pyramid_level < 0, per

@@ -164,6 +164,44 @@ bool read_image(const char* path, Image& im) {
     }
 }
 
+bool write_png_gray8(const char* path, const uint8_t* px, int w, int h) {
+    if (!path || !px || w <= 0 || h <= 0) return false;
+    try {
+        std::vector<uint8_t> raw((size_t)(w + 1) * h);
+        for (int y = 0; y < h; ++y) {
+            raw[(size_t)(w + 1) * y] = 0;  // filter type "none"
+            memcpy(&raw[(size_t)(w + 1) * y + 1], px + (size_t)w * y, (size_t)w);
+        }
+        uLongf clen = compressBound((uLong)raw.size());
+        std::vector<uint8_t> comp(clen);
+        if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 3) != Z_OK) return false;
+        FILE* f = fopen(path, "wb");
+        if (!f) return false;
+        auto chunk = [&](const char* type, const uint8_t* d, uint32_t n) {
+            uint8_t hdr[8] = {(uint8_t)(n >> 24), (uint8_t)(n >> 16), (uint8_t)(n >> 8), (uint8_t)n,
+                              (uint8_t)type[0], (uint8_t)type[1], (uint8_t)type[2], (uint8_t)type[3]};
+            uLong crc = crc32(0L, hdr + 4, 4);
+            if (n) crc = crc32(crc, d, n);
+            const uint8_t tail[4] = {(uint8_t)(crc >> 24), (uint8_t)(crc >> 16), (uint8_t)(crc >> 8), (uint8_t)crc};
+            fwrite(hdr, 1, 8, f);
+            if (n) fwrite(d, 1, n, f);
+            fwrite(tail, 1, 4, f);
+        };
+        static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+        fwrite(sig, 1, 8, f);
+        const uint8_t ihdr[13] = {(uint8_t)(w >> 24), (uint8_t)(w >> 16), (uint8_t)(w >> 8), (uint8_t)w,
+                                  (uint8_t)(h >> 24), (uint8_t)(h >> 16), (uint8_t)(h >> 8), (uint8_t)h, 8, 0, 0, 0, 0};
+        chunk("IHDR", ihdr, 13);
+        chunk("IDAT", comp.data(), (uint32_t)clen);
+        chunk("IEND", nullptr, 0);
+        const bool ok = !ferror(f);
+        fclose(f);
+        return ok;
+    } catch (...) {
+        return false;
+    }
+}
+
 void to_8bit_imread(const Image& im, std::vector<uint8_t>& out) {
     out.resize(im.px16.size());
     for (size_t k = 0; k < out.size(); ++k) out[k] = (uint8_t)(im.px16[k] >> 8);

@@ -25,4 +25,7 @@ void to_8bit(const Image& im, std::vector<uint8_t>& out);
 // entry points, find_chessboard_corners.cc:637-639, mrgingham.cc:158-160): the high byte
 void to_8bit_imread(const Image& im, std::vector<uint8_t>& out);
 
+// 8-bit grey PNG (what the reference's --debug dumps are written with cv::imwrite)
+bool write_png_gray8(const char* path, const uint8_t* px, int w, int h);
+
 }  // namespace mrg

@@ -35,6 +35,11 @@ size_t clahe_scratch_bytes(int nframes);
 bool launch_clahe(const FrameBatch& in, int nframes, double clip_limit, bool do_normalize, uint8_t* out,
                   void* scratch, hipStream_t s);
 
+// preprocess16.hip: the CLI's 16-bit branch (normalize to 0..65535, CLAHE on 16 bits, convertTo 8 bit)
+size_t preprocess16_scratch_bytes(int nframes, int w, int h);
+bool launch_preprocess16(const uint16_t* frames, long long pitch, int nframes, int w, int h, int stride, bool do_clahe,
+                         double clip_limit, uint8_t* out8, void* scratch, hipStream_t s);
+
 // cc.hip
 struct DetectOut {
     int32_t* xy;      // [nframes*capacity*2]

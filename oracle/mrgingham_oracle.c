@@ -332,6 +332,137 @@ int oracle_clahe(uint8_t* out, const uint8_t* in, int w, int h, int stride, doub
     return 0;
 }
 
+/* ---- the CLI's 16-bit branch (mrgingham-from-image.cc:85-92): normalize to 0..65535, CLAHE on 16 bits
+ * (OpenCV's CLAHE_CalcLut_Body<ushort, 65536, 0> / CLAHE_Interpolation_Body<ushort, 0>: the 8-bit
+ * algorithm with 65536 bins), convertTo(CV_8U, 255/65535).  stride in ELEMENTS.  Parity unpinned. ---- */
+static uint16_t sat_u16_rint(float v)
+{
+    const float r = rintf(v);
+    return (uint16_t)(r < 0.f ? 0.f : (r > 65535.f ? 65535.f : r));
+}
+
+void oracle_normalize16(uint16_t* out, const uint16_t* in, int w, int h, int stride)
+{
+    int vmin = 65535, vmax = 0;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const int v = in[(size_t)y * stride + x];
+            if (v < vmin) vmin = v;
+            if (v > vmax) vmax = v;
+        }
+    const double smin = vmin, smax = vmax;
+    const double scale = 65535.0 * (smax - smin > 2.220446049250313e-16 ? 1. / (smax - smin) : 0.);
+    const double shift = 0.0 - smin * scale;
+    const float a = (float)scale, b = (float)shift;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const float prod = (float)in[(size_t)y * stride + x] * a; /* its own rounding step: no fused multiply-add */
+            out[(size_t)y * w + x] = sat_u16_rint(prod + b);
+        }
+}
+
+int oracle_clahe16(uint16_t* out, const uint16_t* in, int w, int h, int stride, double clip_limit)
+{
+    enum { BINS = 65536 };
+    int ew = w, eh = h;
+    if (w % CLAHE_TILES != 0 || h % CLAHE_TILES != 0) {
+        ew = w + (CLAHE_TILES - w % CLAHE_TILES);
+        eh = h + (CLAHE_TILES - h % CLAHE_TILES);
+    }
+    const int tw = ew / CLAHE_TILES, th = eh / CLAHE_TILES;
+    if (tw <= 0 || th <= 0) return -1;
+    const long long area = (long long)tw * th;
+    const float lut_scale = (float)(BINS - 1) / (float)area;
+    int clip = 0;
+    if (clip_limit > 0.0) {
+        clip = (int)(clip_limit * (double)area / BINS);
+        if (clip < 1) clip = 1;
+    }
+    uint16_t* lut = (uint16_t*)malloc((size_t)CLAHE_TILES * CLAHE_TILES * BINS * sizeof(uint16_t));
+    int* hist = (int*)malloc((size_t)BINS * sizeof(int));
+    if (!lut || !hist) { free(lut); free(hist); return -1; }
+    for (int ty = 0; ty < CLAHE_TILES; ty++)
+        for (int tx = 0; tx < CLAHE_TILES; tx++) {
+            memset(hist, 0, (size_t)BINS * sizeof(int));
+            for (int y = ty * th; y < (ty + 1) * th; y++) {
+                const uint16_t* row = in + (size_t)reflect101(y, h) * stride;
+                for (int x = tx * tw; x < (tx + 1) * tw; x++) hist[row[reflect101(x, w)]]++;
+            }
+            if (clip > 0) {
+                long long clipped = 0;
+                for (int i = 0; i < BINS; i++)
+                    if (hist[i] > clip) {
+                        clipped += hist[i] - clip;
+                        hist[i] = clip;
+                    }
+                const int batch = (int)(clipped / BINS);
+                int residual = (int)(clipped - (long long)batch * BINS);
+                for (int i = 0; i < BINS; i++) hist[i] += batch;
+                if (residual != 0) {
+                    const int step = BINS / residual > 1 ? BINS / residual : 1;
+                    for (int i = 0; i < BINS && residual > 0; i += step, residual--) hist[i]++;
+                }
+            }
+            uint16_t* tl = lut + (size_t)(ty * CLAHE_TILES + tx) * BINS;
+            long long sum = 0;
+            for (int i = 0; i < BINS; i++) {
+                sum += hist[i];
+                tl[i] = sat_u16_rint((float)sum * lut_scale);
+            }
+        }
+    const float inv_tw = 1.0f / (float)tw, inv_th = 1.0f / (float)th;
+    for (int y = 0; y < h; y++) {
+        const float tyf = (float)y * inv_th - 0.5f;
+        int ty1 = (int)floorf(tyf), ty2 = ty1 + 1;
+        const float ya = tyf - (float)ty1, ya1 = 1.0f - ya;
+        if (ty1 < 0) ty1 = 0;
+        if (ty2 > CLAHE_TILES - 1) ty2 = CLAHE_TILES - 1;
+        for (int x = 0; x < w; x++) {
+            const float txf = (float)x * inv_tw - 0.5f;
+            int tx1 = (int)floorf(txf), tx2 = tx1 + 1;
+            const float xa = txf - (float)tx1, xa1 = 1.0f - xa;
+            if (tx1 < 0) tx1 = 0;
+            if (tx2 > CLAHE_TILES - 1) tx2 = CLAHE_TILES - 1;
+            const int v = in[(size_t)y * stride + x];
+            const float l11 = lut[(size_t)(ty1 * CLAHE_TILES + tx1) * BINS + v];
+            const float l12 = lut[(size_t)(ty1 * CLAHE_TILES + tx2) * BINS + v];
+            const float l21 = lut[(size_t)(ty2 * CLAHE_TILES + tx1) * BINS + v];
+            const float l22 = lut[(size_t)(ty2 * CLAHE_TILES + tx2) * BINS + v];
+            const float p11 = l11 * xa1, p12 = l12 * xa, p21 = l21 * xa1, p22 = l22 * xa;
+            const float top = (p11 + p12) * ya1, bot = (p21 + p22) * ya;
+            out[(size_t)y * w + x] = sat_u16_rint(top + bot);
+        }
+    }
+    free(lut);
+    free(hist);
+    return 0;
+}
+
+/* mrgingham-from-image.cc:85-111 for a 16-bit frame -> the 8-bit image the detector sees */
+int oracle_preprocess16(uint8_t* out, const uint16_t* in, int w, int h, int stride, int do_clahe, int blur_radius)
+{
+    const size_t n = (size_t)w * h;
+    uint16_t* a = (uint16_t*)malloc(n * 2 + 2);
+    uint16_t* b = (uint16_t*)malloc(n * 2 + 2);
+    uint8_t* c = (uint8_t*)malloc(n + 1);
+    if (!a || !b || !c) { free(a); free(b); free(c); return -1; }
+    const uint16_t* src = in;
+    int sstride = stride;
+    if (do_clahe) {
+        oracle_normalize16(a, in, w, h, stride);
+        if (oracle_clahe16(b, a, w, h, w, 8.0) != 0) { free(a); free(b); free(c); return -1; }
+        src = b;
+        sstride = w;
+    }
+    const float k = (float)(255. / 65535.);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) c[(size_t)y * w + x] = sat_u8_rint((float)src[(size_t)y * sstride + x] * k);
+    if (blur_radius > 0) oracle_box_blur(out, c, w, h, w, blur_radius);
+    else memcpy(out, c, n);
+    free(a); free(b); free(c);
+    return 0;
+}
+
 /* mrgingham-from-image.cc:71-111 for an 8-bit frame: [normalize + CLAHE(8)] then box blur. */
 int oracle_preprocess(uint8_t* out, const uint8_t* in, int w, int h, int stride, int do_clahe, int blur_radius)
 {

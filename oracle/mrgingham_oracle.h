@@ -27,6 +27,11 @@ void oracle_normalize_minmax(uint8_t* out, const uint8_t* in, int w, int h, int 
 int oracle_clahe(uint8_t* out, const uint8_t* in, int w, int h, int stride, double clip_limit);
 int oracle_preprocess(uint8_t* out, const uint8_t* in, int w, int h, int stride, int do_clahe, int blur_radius);
 
+/* the 16-bit branch (mrgingham-from-image.cc:85-92); stride in elements */
+void oracle_normalize16(uint16_t* out, const uint16_t* in, int w, int h, int stride);
+int oracle_clahe16(uint16_t* out, const uint16_t* in, int w, int h, int stride, double clip_limit);
+int oracle_preprocess16(uint8_t* out, const uint16_t* in, int w, int h, int stride, int do_clahe, int blur_radius);
+
 /* Clamped (negatives -> 0, border zero) response and the level image the
  * connected-component stage sees (find_chessboard_corners.cc:495-529). */
 int oracle_clamped_response(int16_t* resp_out, uint8_t* level_image_out, const uint8_t* image, int H, int W,

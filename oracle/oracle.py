@@ -143,6 +143,19 @@ def preprocess(image, clahe=True, blur_radius=1):
     return out
 
 
+def preprocess16(image16, clahe=True, blur_radius=1):
+    """mrgingham-from-image.cc:85-111 for a 16-bit frame -> the uint8 image the detector sees."""
+    image16 = np.ascontiguousarray(image16, dtype=np.uint16)
+    H, W = image16.shape
+    out = np.empty((H, W), dtype=np.uint8)
+    L = lib()
+    L.oracle_preprocess16.argtypes = [_u8p, ctypes.POINTER(ctypes.c_uint16)] + [ctypes.c_int] * 5
+    if L.oracle_preprocess16(out.ctypes.data_as(_u8p), image16.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), W, H, W,
+                             int(bool(clahe)), int(blur_radius)) != 0:
+        raise RuntimeError("oracle_preprocess16 failed")
+    return out
+
+
 def clamped_response(image, level):
     image, H, W, stride = _img2d(image)
     w, h = level_dims(W, H, level)

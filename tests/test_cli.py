@@ -102,7 +102,7 @@ def test_cli_without_a_gpu_fails_loudly(tmp_path):
 def _expected(img, gridn, level, clahe, blur, refine=True):
     import mrgingham_amd
     from oracle import oracle
-    pre = oracle.preprocess(img, clahe=clahe, blur_radius=blur)
+    pre = (oracle.preprocess16 if img.dtype == np.uint16 else oracle.preprocess)(img, clahe=clahe, blur_radius=blur)
     for L in ([level] if level >= 0 else [3, 2, 1, 0]):
         cand = oracle.find_corners(pre, L)
         if cand is None or len(cand) < gridn * gridn:
@@ -177,12 +177,75 @@ def test_cli_rgb_png_16bit_pgm_and_unreadable_file(tmp_path):
     for name in (p_rgb, p_16):
         g = np.array([(x, y) for x, y, _ in got[name]])
         assert g.shape == (100, 2) and np.abs(g - want).max() < 1e-6, name
-    r = _run(p_16)                                                           # 16 bit needs --noclahe in this build
-    assert r.returncode == 0 and _parse(r.stdout)[p_16] == [None] and "16-bit" in r.stderr
+    # 16 bit WITH the contrast step: normalize to 0..65535, CLAHE on 16 bits, convertTo 8 bit (:85-92)
+    rng = np.random.RandomState(4)
+    img16 = (img.astype(np.float64) * 120 + 9000 + rng.randint(0, 120, img.shape)).astype(np.uint16)   # a dim 16-bit frame
+    p_dim = str(tmp_path / "d_dim16.pgm")
+    _write_pgm(p_dim, img16, maxval=65535)
+    r = _run(p_dim)
+    assert r.returncode == 0, r.stderr
+    want16, lv16 = _expected(img16, 10, -1, True, 1)
+    g = np.array([(x, y) for x, y, _ in _parse(r.stdout)[p_dim]])
+    assert want16 is not None and g.shape == (100, 2) and np.abs(g - want16).max() < 1e-6
     r = _run(p_bad, p_rgb)                                                   # one worker: the bad file ends it (:58-68)
     assert r.returncode == 0 and "Couldn't open image" in r.stderr
     got = _parse(r.stdout)
     assert got[p_bad] == [None] and p_rgb not in got
+
+
+@pytest.mark.gpu
+def test_preprocess16_matches_the_oracle_on_ragged_sizes():
+    """The 16-bit branch alone (mrgingham-from-image.cc:85-92) through process_image_ex's debug dump would be
+    indirect; compare the preprocessed 8-bit image itself via the --debug PNG on three sizes."""
+    import mrgingham_amd
+    from oracle import oracle
+    rng = np.random.RandomState(8)
+    for (h, w) in [(64, 64), (61, 77), (240, 333)]:
+        img16 = (rng.rand(h, w) * 30000 + 2000).astype(np.uint16)
+        img16[h // 4:h // 2, w // 4:w // 2] += 20000
+        for clahe, blur in [(True, 1), (True, 0), (False, 2)]:
+            got = mrgingham_amd.api.preprocess16(img16, clahe=clahe, blur_radius=blur)
+            assert np.array_equal(got, oracle.preprocess16(img16, clahe=clahe, blur_radius=blur)), (h, w, clahe, blur)
+
+
+@pytest.mark.gpu
+def test_cli_debug_dumps(tmp_path):
+    """--debug: the preprocessed image, per pass the level image / normalised responses / corner vnlog, with
+    the reference's file names and messages (mrgingham-from-image.cc:113-148; find_chessboard_corners.cc:282-315,
+    :453-459, :513-541)."""
+    import glob
+    import mrgingham_amd
+    from mrgingham_amd import synth
+    from oracle import oracle
+    for f in glob.glob("/tmp/mrgingham-*") + glob.glob("/tmp/dbgboard_preprocessed.png"):
+        os.remove(f)
+    img = synth.board_frame(640, 480, 10, 3).numpy()
+    p = str(tmp_path / "dbgboard.pgm")
+    _write_pgm(p, img)
+    r = _run("--debug", "--level", "1", p)
+    assert r.returncode == 0, r.stderr
+    assert len(_parse(r.stdout)[p]) == 100
+    for msg in ("Wrote preprocessed image to /tmp/dbgboard_preprocessed.png",
+                "Wrote scaled,processed image to /tmp/mrgingham-scaled-processed-level1.png",
+                "Wrote a normalized ChESS response to /tmp/mrgingham-chess-response-level1.png",
+                "Wrote positive-only, normalized ChESS response to /tmp/mrgingham-chess-response-level1-positive.png",
+                "Writing self-plotting corner dump to /tmp/mrgingham-1-corners.vnl",
+                "Wrote a normalized ChESS response to /tmp/mrgingham-chess-response-refinement-level0.png",
+                "Writing self-plotting corner dump to /tmp/mrgingham-1-corners-refinement-level0.vnl"):
+        assert msg in r.stderr, msg
+    pre = oracle.preprocess(img, clahe=True, blur_radius=1)
+    assert np.array_equal(mrgingham_amd.read_image("/tmp/dbgboard_preprocessed.png"), pre)
+    assert np.array_equal(mrgingham_amd.read_image("/tmp/mrgingham-scaled-processed-level1.png"), oracle.decimate(pre, 1))
+    resp, _ = oracle.clamped_response(pre, 1)
+    want = np.rint((resp.astype(np.float32) * np.float32(255.0 / resp.max()))).astype(np.uint8)   # min is 0 after the clamp
+    assert np.array_equal(mrgingham_amd.read_image("/tmp/mrgingham-chess-response-level1-positive.png"), want)
+    lines = open("/tmp/mrgingham-1-corners.vnl").read().splitlines()
+    assert lines[0].startswith("#!/usr/bin/feedgnuplot") and p in lines[0] and lines[1] == "# x y"
+    cand = oracle.find_corners(pre, 1)
+    got = np.array([[float(t) for t in ln.split()] for ln in lines[2:]])
+    assert np.array_equal(np.round(got * 1000).astype(np.int64), cand.astype(np.int64))
+    ref = open("/tmp/mrgingham-1-corners-refinement-level0.vnl").read().splitlines()
+    assert len(ref) == 2 + 100
 
 
 @pytest.mark.gpu
