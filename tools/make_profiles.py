@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turns gpurun_out/<tag>/ (written by tools/collect_profiles.sh on the GPU box) into the committed
-summaries under profiles/:  python tools/make_profiles.py r01d"""
+summaries under profiles/:  python tools/make_profiles.py r02a [r02]   (second argument: file prefix = round)"""
 import json
 import os
 import re
@@ -8,6 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
+RND = sys.argv[2] if len(sys.argv) > 2 else tag[:3]
 R = os.path.join(ROOT, "gpurun_out", tag)
 P = os.path.join(ROOT, "profiles")
 rd = lambda n: open(os.path.join(R, n)).read()
@@ -15,11 +16,11 @@ strip = lambda t: re.sub(r"/tmp/[^ ]*?/gpurun_out/", "gpurun_out/", t)
 
 # 1. kernel trace of the bench command
 tb, b = json.loads(rd("trace_bench.json")), json.loads(rd("bench.json"))
-hdr = (f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline   (round 1, final kernels; tools/collect_profiles.sh {tag})\n"
+hdr = (f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline   (round {RND[1:]}, final kernels; tools/collect_profiles.sh {tag})\n"
        f"# bench.py under the tracer: {tb['value']:.0f} frames/s, {tb['ms_per_step']:.3f} ms/step, level-0 ChESS launch {tb['roofline']['avg_launch_ms']*1e3:.1f} us by hipEvents (trace below: avg over 25 launches incl. warmup)\n"
        f"# bench.py with its defaults (200 steps) without the tracer, same box, same build: {b['value']:.0f} frames/s, {b['ms_per_step']:.3f} ms/step, level-0 ChESS launch {b['roofline']['avg_launch_ms']*1e3:.1f} us -> {b['roofline']['achieved']:.0f} GB/s = {b['roofline']['frac']*100:.1f} % of 8 TB/s\n")
-open(os.path.join(P, "r01_bench_kernel_trace.txt"), "w").write(hdr + strip(rd("bench_kernel_trace.txt")))
-open(os.path.join(P, "r01_bench.json"), "w").write(rd("bench.json"))
+open(os.path.join(P, f"{RND}_bench_kernel_trace.txt"), "w").write(hdr + strip(rd("bench_kernel_trace.txt")))
+open(os.path.join(P, f"{RND}_bench.json"), "w").write(rd("bench.json"))
 
 # 2. EA traffic of the bench command, separate passes
 parts = []
@@ -27,9 +28,9 @@ for n, title in [("pmc_rd", "pass 1: --pmc TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_E
                  ("pmc_wr", "pass 2: --pmc TCC_EA0_WRREQ TCC_EA0_WRREQ_64B"), ("pmc_fetch", "pass 3: --pmc FETCH_SIZE"),
                  ("pmc_write", "pass 4: --pmc WRITE_SIZE")]:
     parts.append(f"## {title}\n" + rd(n + ".txt"))
-open(os.path.join(P, "r01_bench_pmc_ea_traffic.txt"), "w").write(
+open(os.path.join(P, f"{RND}_bench_pmc_ea_traffic.txt"), "w").write(
     "# rocprofv3 --pmc ... --kernel-trace --output-format csv -- python bench.py --distinct 4 --steps 3 --warmup 1 --no-cpu-baseline\n"
-    "# separate passes, counters only; means over the dispatches of each kernel (tools/pmc_summary.py); final round-1 kernels\n" + "\n".join(parts))
+    f"# separate passes, counters only; means over the dispatches of each kernel (tools/pmc_summary.py); final round-{RND[1:]} kernels\n" + "\n".join(parts))
 
 
 def grab(fn, kernel_grid, ctr):
@@ -38,24 +39,27 @@ def grab(fn, kernel_grid, ctr):
     return float(re.search(re.escape(ctr) + r"\s+mean\s+([0-9.]+)", blk).group(1))
 
 
-kg = "chess_v1_kernel<true, true, true>  grid=3145728"
+kg = "chess_v1_kernel<true, true, 1>  grid=3145728"
 rdb = 128 * grab("pmc_rd", kg, "TCC_EA0_RDREQ_128B") + 64 * grab("pmc_rd", kg, "TCC_EA0_RDREQ_64B") + 32 * grab("pmc_rd", kg, "TCC_EA0_RDREQ_32B")
 wr64, wrall = grab("pmc_wr", kg, "TCC_EA0_WRREQ_64B"), grab("pmc_wr", kg, "TCC_EA0_WRREQ ")
 wrb = 64 * wr64 + 32 * (wrall - wr64)
 px = 64 * 4096 * 3072
 j = json.load(open(os.path.join(P, "chess_l0_traffic.json")))
+j["kernel"] = "mrg::chess_v1_kernel<true, true, 1> (CLAMP, HOT, STAGE_PERM16)"
+j["source"] = f"profiles/{RND}_bench_pmc_ea_traffic.txt"
+j["_comment"] = j["_comment"].replace("round 1, profiles/r01_bench_pmc_ea_traffic.txt", f"round {RND[1:]}, profiles/{RND}_bench_pmc_ea_traffic.txt")
 j.update(read_bytes=int(rdb), write_bytes=int(wrb), fetch_size_kib_raw=grab("pmc_fetch", kg, "FETCH_SIZE"),
          write_size_kib_raw=grab("pmc_write", kg, "WRITE_SIZE"), bytes_per_pixel=round((rdb + wrb) / px, 4))
 json.dump(j, open(os.path.join(P, "chess_l0_traffic.json"), "w"), indent=1)
 print(f"level-0 ChESS: read {rdb/1e6:.1f} MB + written {wrb/1e6:.1f} MB per launch = {(rdb+wrb)/px:.4f} B/px")
 
 # 3. issue / wait / LDS counters of the level-0 response kernel alone
-open(os.path.join(P, "r01_chess_l0_sq_counters.txt"), "w").write(
+open(os.path.join(P, f"{RND}_chess_l0_sq_counters.txt"), "w").write(
     "# rocprofv3 --pmc <SQ counters> --kernel-trace --output-format csv -- python tools/chess_l0_alone.py   (32 frames 4096x3072, clamp kernel without the hot list; two passes)\n"
     "# per wave-iteration (512 px): divide by the number of wave-iterations (pixels / 512); SQ_* cycle counters are in quad-cycles (DESIGN.md section 7)\n"
     + rd("pmc_sq1.txt") + rd("pmc_sq2.txt"))
 
 # 4. preprocessing kernels
-open(os.path.join(P, "r01_preprocess_kernel_trace.txt"), "w").write(
+open(os.path.join(P, f"{RND}_preprocess_kernel_trace.txt"), "w").write(
     "# rocprofv3 --kernel-trace --stats -- python tools/preprocess_bench.py   (64 frames 4096x3072; clahe+blur, clahe only, blur only; row (f)-2)\n"
     + strip(rd("preprocess_kernel_trace.txt")) + "\n" + rd("prebench.txt"))
