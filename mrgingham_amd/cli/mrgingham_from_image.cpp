@@ -36,7 +36,7 @@ using mrg::read_image;
 struct Options {
     glob_t globbed;
     int jobs = 1, blur_radius = 1, gridn = 10, level = -1;
-    bool doclahe = true, do_refine = true, debug = false;
+    bool doclahe = true, do_refine = true, debug = false, doblobs = false;
     int debug_sequence_x = -1, debug_sequence_y = -1;
 } opt;
 
@@ -58,7 +58,7 @@ const char* kUsage =
     "  --level L       pyramid level to search at; default -1 = try 3, 2, 1, 0 in turn\n"
     "  --no-refine     keep the corners of the level the board was found at\n"
     "  --jobs N, -j N  worker threads (image i is handled by worker i mod N)\n"
-    "  --blobs         circle grids: not supported by this build\n"
+    "  --blobs         find a grid of dark circles instead of a chessboard (no --level, no refinement)\n"
     "  --debug         one image only: write the preprocessed image, the level images, the ChESS\n"
     "                  responses and the corner vnlogs to /tmp like the reference does\n"
     "  --debug-sequence x,y   accepted (the grid finder's own dumps are not produced)\n";
@@ -85,6 +85,7 @@ void* worker(void* arg) {
         o.gridn = opt.gridn;
         o.image_pyramid_level = opt.level;
         o.do_refine = opt.do_refine;
+        o.do_blobs = opt.doblobs;
         o.debug = opt.debug;
         o.debug_sequence_x = opt.debug_sequence_x;
         o.debug_sequence_y = opt.debug_sequence_y;
@@ -96,7 +97,7 @@ void* worker(void* arg) {
         flockfile(stdout);
         if (level >= 0)  // mrgingham-from-image.cc:174-183
             for (int k = 0; k < N; ++k)
-                printf("%s %f %f %d\n", filename, xy[2 * k], xy[2 * k + 1], opt.do_refine ? (int)lv[k] : level);
+                printf("%s %f %f %d\n", filename, xy[2 * k], xy[2 * k + 1], (opt.do_refine && !opt.doblobs) ? (int)lv[k] : level);
         else
             printf("%s - - -\n", filename);
         funlockfile(stdout);
@@ -154,10 +155,12 @@ int main(int argc, char* argv[]) {
         fprintf(stderr, kUsage, argv[0]);
         return 1;
     }
-    if (doblobs) {
-        fprintf(stderr, "ERROR: --blobs (circle grids, find_blobs.cc) is not part of this build\n");
+    if (doblobs && opt.level >= 0) {  // mrgingham-from-image.cc:305-309
+        fprintf(stderr, "ERROR: 'image_pyramid_level' only implemented for chessboards.\n");
         return 1;
     }
+    opt.doblobs = doblobs;
+    if (doblobs) opt.level = 0;
     if (opt.gridn < 2) {
         fprintf(stderr, "--gridn value must be >= 2\n");
         return 1;

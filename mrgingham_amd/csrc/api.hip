@@ -136,7 +136,7 @@ struct mrgingham_amd_ctx {
     int counters_nf = 0;
     struct PointScratch { mrg::DevBuf leader, need, nseeds, seeds, sroot, cand_xy, cand_counts; } pts[2];  // per scratch set
     mrg::DevBuf aux_img, io_frame, io_out, io_counts;
-    mrg::DevBuf pre_scratch, pre_tmp, pre_out, pre16_scratch, io_frame16, dbg_img, dbg_resp;
+    mrg::DevBuf pre_scratch, pre_tmp, pre_out, pre16_scratch, io_frame16, dbg_img, dbg_resp, blob_scratch;
     mrg::DevBuf fb_xy, fb_cnt, fb_pts, fb_lv, fb_np, fb_frames, fb_frames2;  // find_boards_batch: candidates, counts, boards, levels, point counts
     HostPool pool;  // preprocessing: extrema + tile histograms + LUTs, CLAHE output before the blur
     int pts_nframes = 0, pts_pitch = 0;
@@ -520,7 +520,7 @@ void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx) {
     for (auto& ps : ctx->pts)
         for (DevBuf* b : {&ps.leader, &ps.need, &ps.nseeds, &ps.seeds, &ps.sroot, &ps.cand_xy, &ps.cand_counts})
             if (b->p) hipFree(b->p);
-    DevBuf* bufs[] = {&ctx->counters2[0], &ctx->counters2[1], &ctx->io_counts, &ctx->aux_img, &ctx->io_frame, &ctx->io_out, &ctx->pre_scratch, &ctx->pre_tmp, &ctx->pre_out, &ctx->pre16_scratch, &ctx->io_frame16, &ctx->dbg_img, &ctx->dbg_resp,
+    DevBuf* bufs[] = {&ctx->counters2[0], &ctx->counters2[1], &ctx->io_counts, &ctx->aux_img, &ctx->io_frame, &ctx->io_out, &ctx->pre_scratch, &ctx->pre_tmp, &ctx->pre_out, &ctx->pre16_scratch, &ctx->io_frame16, &ctx->dbg_img, &ctx->dbg_resp, &ctx->blob_scratch,
                       &ctx->fb_xy, &ctx->fb_cnt, &ctx->fb_pts, &ctx->fb_lv, &ctx->fb_np, &ctx->fb_frames, &ctx->fb_frames2};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
@@ -1131,15 +1131,37 @@ static bool check_level_and_layout(const char* fn, int Nrows, int Ncols, int str
     return true;
 }
 
+// find_blobs_from_image_array (find_blobs.cc:14-46) on a frame that lives on the device as `fr` (one frame) and
+// on the host as h_img: candidates as (x, y) * 1000 ints.
+static bool blobs_on_device(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, const uint8_t* h_img, int h_stride,
+                            std::vector<int32_t>& xy) {
+    if (ensure(ctx, ctx->blob_scratch, blob_scratch_bytes(fr->width, fr->height, nullptr))) return false;
+    std::string err;
+    if (!blob_detect(fr->frames, fr->stride, h_img, h_stride, fr->width, fr->height, ctx->blob_scratch.p, ctx->pix, xy, err)) {
+        fail(ctx, MRGINGHAM_AMD_ERR_CAPACITY, "%s", err.c_str());
+        return false;
+    }
+    return true;
+}
+
 bool find_chessboard_corners_from_image_array_C(int Nrows, int Ncols, int stride, char* imagebuffer,
                                                 int image_pyramid_level, bool doblobs, bool debug,
                                                 bool (*add_points)(int* xy, int N, double scale, void* cookie),
                                                 void* cookie) {
-    if (doblobs) {
-        fprintf(stderr, "mrgingham_amd: the blob detector (find_blobs.cc) is not part of this library\n");
-        return false;
-    }
     if (Nrows < 0 || Ncols < 0 || stride < Ncols || !imagebuffer || !add_points) return false;
+    if (doblobs) {  // bridge.cc:50-55: the blob detector, level 0 only; always "found", possibly with 0 points
+        if (image_pyramid_level != 0) return false;
+        mrgingham_amd_ctx* bctx = thread_ctx();
+        if (!bctx) return false;
+        hipSetDevice(bctx->device);
+        mrgingham_amd_frames bfr;
+        std::vector<int32_t> bxy;
+        if (upload_frame(bctx, imagebuffer, Nrows, Ncols, stride, &bfr) ||
+            !blobs_on_device(bctx, &bfr, (const uint8_t*)imagebuffer, stride, bxy))
+            return false;
+        int32_t none[2] = {0, 0};
+        return (*add_points)(bxy.empty() ? none : bxy.data(), (int)(bxy.size() / 2), 1. / kGridScale, cookie);
+    }
     if (!check_level_and_layout(__func__, Nrows, Ncols, stride, image_pyramid_level)) return false;
     mrgingham_amd_ctx* ctx = thread_ctx();
     if (!ctx) return false;
@@ -1274,11 +1296,23 @@ bool find_chessboard_from_image_array_C(int Nrows, int Ncols, int stride, char* 
                                         int debug_sequence_y,
                                         bool (*add_points)(double* xy, int N, void* cookie), void* cookie) {
     (void)debug_sequence_x; (void)debug_sequence_y;  // the grid finder's own dumps are not produced
-    if (doblobs) {
-        fprintf(stderr, "mrgingham_amd: the blob detector (find_blobs.cc) is not part of this library\n");
-        return false;
-    }
     if (Nrows < 0 || Ncols < 0 || stride < Ncols || !imagebuffer || !add_points || gridn < 2) return false;
+    if (doblobs) {  // bridge.cc:104-113: find_circle_grid_from_image_array = blobs + grid finder, no refinement
+        if (image_pyramid_level != 0) return false;
+        mrgingham_amd_ctx* bctx = thread_ctx();
+        if (!bctx) return false;
+        hipSetDevice(bctx->device);
+        mrgingham_amd_frames bfr;
+        std::vector<int32_t> bxy;
+        if (upload_frame(bctx, imagebuffer, Nrows, Ncols, stride, &bfr) ||
+            !blobs_on_device(bctx, &bfr, (const uint8_t*)imagebuffer, stride, bxy))
+            return false;
+        std::vector<PointI> cand(bxy.size() / 2);
+        for (size_t i = 0; i < cand.size(); ++i) cand[i] = PointI{bxy[2 * i], bxy[2 * i + 1]};
+        std::vector<PointD> grid;
+        if (!find_grid_from_points(grid, cand, gridn) || (int)grid.size() != gridn * gridn) return false;
+        return (*add_points)(&grid[0].x, gridn * gridn, cookie);
+    }
     if (image_pyramid_level > 10) {
         fprintf(stderr, "mrgingham_amd: %s(): Got an unreasonable image_pyramid_level = %d. Sorry.\n", __func__,
                 image_pyramid_level);
@@ -1422,10 +1456,6 @@ int mrgingham_amd_process_image_ex(const void* image, int bits, int width, int h
                 o->image_pyramid_level);
         return -2;
     }
-    if (o->do_blobs) {
-        fprintf(stderr, "mrgingham_amd: the blob detector (find_blobs.cc) is not part of this library\n");
-        return -2;
-    }
     mrgingham_amd_ctx* ctx = thread_ctx();
     if (!ctx) return -2;
     hipSetDevice(ctx->device);
@@ -1473,6 +1503,21 @@ int mrgingham_amd_process_image_ex(const void* image, int bits, int width, int h
     }
     std::vector<PointD> board;
     std::vector<signed char> lv;
+    if (o->do_blobs) {
+        // mrgingham-from-image.cc:153-160: find_circle_grid_from_image_array on the preprocessed image, "level" 0
+        std::vector<uint8_t> host(npx);
+        std::vector<int32_t> bxy;
+        if (hipMemcpy2DAsync(host.data(), width, fr.frames, fr.stride, width, height, hipMemcpyDeviceToHost, ctx->pix) !=
+                hipSuccess ||
+            hipStreamSynchronize(ctx->pix) != hipSuccess || !blobs_on_device(ctx, &fr, host.data(), width, bxy))
+            return -2;
+        std::vector<PointI> cand(bxy.size() / 2);
+        for (size_t i = 0; i < cand.size(); ++i) cand[i] = PointI{bxy[2 * i], bxy[2 * i + 1]};
+        if (!find_grid_from_points(board, cand, o->gridn) || (int)board.size() != o->gridn * o->gridn) return -1;
+        memcpy(xy_out, &board[0].x, sizeof(double) * 2 * (size_t)o->gridn * o->gridn);
+        if (levels_out) memset(levels_out, 0, (size_t)o->gridn * o->gridn);
+        return 0;
+    }
     const int level = find_board_on_device(ctx, __func__, &fr, o->gridn, o->image_pyramid_level, o->do_refine != 0,
                                            board, lv, o->debug != 0, o->filename);
     if (level < 0) return -1;

@@ -1,5 +1,8 @@
 // Launchers of the HIP kernels (host side declarations).
 #pragma once
+#include <string>
+#include <vector>
+
 #include "common.h"
 
 namespace mrg {
@@ -39,6 +42,15 @@ bool launch_clahe(const FrameBatch& in, int nframes, double clip_limit, bool do_
 size_t preprocess16_scratch_bytes(int nframes, int w, int h);
 bool launch_preprocess16(const uint16_t* frames, long long pitch, int nframes, int w, int h, int stride, bool do_clahe,
                          double clip_limit, uint8_t* out8, void* scratch, hipStream_t s);
+
+// blobs.hip: cv::SimpleBlobDetector as find_blobs.cc:14-46 configures it (device border following, host filters)
+struct BlobScratchLayout {
+    int wpr, cand_cap, rec_cap, pts_cap;
+    size_t o_counters, o_bits, o_cand, o_recs, o_pts;
+};
+size_t blob_scratch_bytes(int w, int h, BlobScratchLayout* lay);
+bool blob_detect(const uint8_t* d_img, int d_stride, const uint8_t* h_img, int h_stride, int w, int h, void* scratch,
+                 hipStream_t s, std::vector<int32_t>& xy_out, std::string& err);
 
 // cc.hip
 struct DetectOut {

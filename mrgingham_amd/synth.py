@@ -114,3 +114,37 @@ def board_lattice(W, H, gridn=10, seed=0):
             out[b, a, 0] = (dx + 4 * W + ox) / 8.0 - 0.5                 # continuous position -> pixel-centre convention
             out[b, a, 1] = (dy + 4 * H + oy) / 8.0 - 0.5
     return out
+
+
+def dots_frame(W, H, gridn=10, seed=0, noise=True, device="cpu"):
+    """A circle-grid target (what the reference's blob path is for): gridn x gridn dark discs on a light
+    board, same placement, rotation and noise model as board_frame.  uint8 [H, W]."""
+    dev = torch.device(device)
+    ncell = gridn + 3
+    cell = (8 * 65536 * 8 * H) // (10 * ncell)
+    half = (ncell * cell) // 2
+    s = int(_mix(torch.tensor(seed * 7919 + 13, dtype=torch.int64)).item())
+    ox, oy = s & 63, (s >> 6) & 63
+    ys = torch.arange(H, dtype=torch.int64, device=dev).view(H, 1)
+    xs = torch.arange(W, dtype=torch.int64, device=dev).view(1, W)
+    acc = torch.zeros((H, W), dtype=torch.int64, device=dev)
+    r2 = (cell * 3 // 10) ** 2                                  # disc radius = 0.3 cell
+    for j in range(4):
+        dy = 8 * ys + (2 * j + 1) - 4 * H - oy
+        for i in range(4):
+            dx = 8 * xs + (2 * i + 1) - 4 * W - ox
+            bu = _COS_Q16 * dx + _SIN_Q16 * dy + half
+            bv = -_SIN_Q16 * dx + _COS_Q16 * dy + half
+            inside = (bu >= 0) & (bu < ncell * cell) & (bv >= 0) & (bv < ncell * cell)
+            # nearest lattice node a*cell, a in 2 .. gridn+1
+            a = torch.div(bu + cell // 2, cell, rounding_mode="floor").clamp(2, gridn + 1)
+            b = torch.div(bv + cell // 2, cell, rounding_mode="floor").clamp(2, gridn + 1)
+            du, dv = bu - a * cell, bv - b * cell
+            disc = (du * du + dv * dv) <= r2
+            acc += torch.where(inside, torch.where(disc, 25, 215), 120)
+    img = (acc + 8) >> 4
+    if noise:
+        hsh = _mix((ys * W + xs) * 2654435761 + (seed + 1) * 40503)
+        n = (hsh & 7) + ((hsh >> 3) & 7) + ((hsh >> 6) & 7) + ((hsh >> 9) & 7) - 14
+        img = (img + (n >> 1)).clamp(0, 255)
+    return box_blur3(img).to(torch.uint8)

@@ -54,6 +54,11 @@ int oracle_cc_detect_on_response(int32_t* xy_out, int cap, int16_t* d, const uin
 int oracle_cc_refine_on_response(double* xy, signed char* level_of_point, int npoints, int16_t* d,
                                  const uint8_t* level_image, int w, int h, int level);
 
+/* find_blobs_from_image_array (find_blobs.cc:14-46): cv::SimpleBlobDetector keypoints as (x, y) * 1000 ints
+ * (blobs_oracle.c; OpenCV arithmetic, parity unpinned).  Returns the number of blobs; the first
+ * min(N, cap) are stored. */
+int oracle_find_blobs(int32_t* xy_out, int cap, const uint8_t* image, int w, int h, int stride);
+
 #ifdef __cplusplus
 }
 #endif

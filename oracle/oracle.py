@@ -23,8 +23,8 @@ _i8p = ctypes.POINTER(ctypes.c_int8)
 
 def build(force=False):
     """Compile the restatement (and oracle/_ref when /root/reference exists)."""
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(
-            os.path.join(_HERE, "mrgingham_oracle.c")):
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(
+            os.path.getmtime(os.path.join(_HERE, f)) for f in ("mrgingham_oracle.c", "blobs_oracle.c")):
         subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
     elif not os.path.exists(_REF) and os.path.exists("/root/reference/ChESS.c"):
         subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
@@ -218,6 +218,20 @@ def cc_refine_on_response(points, levels, resp, level_image, level):
     n = lib().oracle_cc_refine_on_response(pts.ctypes.data_as(_f64p), lv.ctypes.data_as(_i8p), len(lv),
                                            d.ctypes.data_as(_i16p), img.ctypes.data_as(_u8p), w, h, level)
     return pts, lv, n
+
+
+def find_blobs(image):
+    """find_blobs_from_image_array (find_blobs.cc:14-46) -> int32 (N,2) of (x,y)*1000 in keypoint order."""
+    image, H, W, stride = _img2d(image)
+    L = lib()
+    L.oracle_find_blobs.argtypes = [_i32p, ctypes.c_int, _u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    cap = 4096
+    while True:
+        out = np.empty((cap, 2), dtype=np.int32)
+        n = L.oracle_find_blobs(out.ctypes.data_as(_i32p), cap, image.ctypes.data_as(_u8p), W, H, stride)
+        if n <= cap:
+            return out[:n].copy()
+        cap = n
 
 
 def chain(image, start_level=3):

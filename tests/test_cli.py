@@ -74,8 +74,8 @@ def test_cli_argument_errors(tmp_path):
     assert r.returncode == 1 and "The job count must be a positive integer" in r.stderr
     r = _run("--gridn", "1", "x*.pgm")
     assert r.returncode == 1 and "--gridn value must be >= 2" in r.stderr
-    r = _run("--blobs", "x*.pgm")
-    assert r.returncode == 1 and "blobs" in r.stderr
+    r = _run("--blobs", "--level", "0", "x*.pgm")
+    assert r.returncode == 1 and "'image_pyramid_level' only implemented for chessboards" in r.stderr   # :305-309
     r = _run("--debug-sequence", "nonsense", "x*.pgm")
     assert r.returncode != 0 and "could not parse 'x,y'" in r.stderr
     r = _run("--frobnicate", "x*.pgm")

@@ -1,0 +1,117 @@
+"""Rows a-19 / (f)-4: the blob path, find_blobs_from_image_array (find_blobs.cc:14-46) = cv::SimpleBlobDetector
+with mrgingham's parameters, through the reference's own entry points (find_points(blobs=True),
+find_board(blobs=True), the tool's --blobs).  Expected values: oracle/blobs_oracle.c, the sequential
+restatement of OpenCV's published algorithm (parity unpinned: OpenCV is not available here).  Everything
+is compared exactly -- the keypoints are (x, y) * 1000 integers, in the detector's output order."""
+import subprocess
+
+import numpy as np
+import pytest
+
+import mrgingham_amd
+from mrgingham_amd import synth
+from oracle import oracle
+
+from test_cli import CLI, _parse, _write_pgm
+
+pytestmark = pytest.mark.gpu
+
+
+def _blobs(img):
+    return np.round(mrgingham_amd.find_points(img, image_pyramid_level=0, blobs=True) * 1000).astype(np.int64)
+
+
+@pytest.mark.parametrize("case", [(640, 480, 10, 0), (800, 600, 7, 2), (1280, 960, 10, 5), (333, 251, 4, 1)])
+def test_circle_grids(case):
+    w, h, gridn, seed = case
+    img = synth.dots_frame(w, h, gridn, seed).numpy()
+    want = oracle.find_blobs(img)
+    got = _blobs(img)
+    assert np.array_equal(got, want.astype(np.int64)), case
+    assert len(want) >= gridn * gridn
+    # the discs sit on the lattice the frame was rendered from
+    lat = synth.board_lattice(w, h, gridn, seed).reshape(-1, 2)
+    d = np.sqrt(((lat[:, None, :] - got[None, :, :] / 1000.0) ** 2).sum(-1))
+    assert d.min(1).max() < 0.25
+
+
+def test_find_board_with_blobs_orders_the_grid():
+    w, h, gridn, seed = 800, 600, 10, 3
+    img = synth.dots_frame(w, h, gridn, seed).numpy()
+    board = mrgingham_amd.find_board(img, image_pyramid_level=0, gridn=gridn, blobs=True)
+    assert board is not None and board.shape == (gridn * gridn, 2)
+    want = mrgingham_amd.find_grid_from_points(oracle.find_blobs(img), gridn)      # bridge.cc:104-113: no refinement
+    assert np.array_equal(board, want)
+    lat = synth.board_lattice(w, h, gridn, seed).reshape(-1, 2)
+    assert np.abs(board - lat).max() < 0.25                                          # and in the lattice's order
+    assert mrgingham_amd.find_board(img, image_pyramid_level=0, gridn=gridn + 1, blobs=True) is None
+
+
+def _shapes(h, w):
+    """Hand-made shapes that exercise the filters: discs of several sizes, a ring (its outer border has a dark
+    centre), a bar (inertia), an L (convexity), blobs that touch the frame, tiny specks (area), a big square
+    (area >= 80000 at some thresholds), a soft-edged disc (different contours per threshold)."""
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.full((h, w), 200, np.float64)
+
+    def disc(cx, cy, r, v=30.0, soft=0.0):
+        d = np.sqrt((xx - cx) ** 2 + (yy - cy) ** 2)
+        if soft > 0:
+            img[:] = np.minimum(img, v + (200 - v) * np.clip((d - r) / soft, 0, 1))
+        else:
+            img[d <= r] = v
+    disc(60, 60, 12); disc(120, 60, 6); disc(160, 60, 2.2); disc(200, 60, 4.5); disc(260, 60, 25)
+    disc(70, 150, 18, soft=12); disc(150, 150, 10, v=120); disc(210, 150, 10, v=180)
+    d = np.sqrt((xx - 300) ** 2 + (yy - 150) ** 2)
+    img[(d <= 22) & (d >= 12)] = 40                                   # ring
+    img[220:228, 40:160] = 20                                         # bar, 8 x 120: inertia ratio below 0.1
+    img[250:300, 200:212] = 25; img[288:300, 200:260] = 25            # L shape: convexity below 0.95
+    disc(0, 240, 14); disc(w - 1, 100, 9); disc(180, h - 1, 11)       # cut by the frame
+    img[10:12, 300:303] = 10                                          # speck
+    if h > 330 and w > 420:
+        img[h - 320:h - 10, w - 310:w - 20] = 60                      # 310 x 290 = 89900 px: above maxArea
+        disc(w - 160, h - 160, 30, v=230)                             # a light disc inside it: a hole of a dark blob
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("shape", [(320, 360), (400, 640), (697, 811)])
+def test_filters_on_hand_made_shapes(shape):
+    h, w = shape
+    img = _shapes(h, w)
+    want = oracle.find_blobs(img)
+    assert np.array_equal(_blobs(img), want.astype(np.int64)), shape
+    assert 4 <= len(want) <= 16
+
+
+@pytest.mark.parametrize("seed,smooth", [(0, 1), (1, 2), (2, 3), (3, 4)])
+def test_noise_frames(seed, smooth):
+    """Smoothed noise: thousands of ragged borders per threshold, nearly all rejected -- the same few survive."""
+    img = synth.noise_frame(320, 240, seed, smooth=smooth).numpy()
+    assert np.array_equal(_blobs(img), oracle.find_blobs(img).astype(np.int64)), (seed, smooth)
+
+
+def test_degenerate_frames():
+    for img in (np.zeros((64, 64), np.uint8), np.full((64, 64), 255, np.uint8), np.zeros((1, 1), np.uint8),
+                (np.indices((40, 50)).sum(0) % 2 * 255).astype(np.uint8)):
+        got = mrgingham_amd.find_points(img, image_pyramid_level=0, blobs=True)
+        want = oracle.find_blobs(img)
+        assert got.shape == (len(want), 2) and np.array_equal(np.round(got * 1000).astype(np.int64), want.astype(np.int64))
+    with pytest.raises(RuntimeError):
+        mrgingham_amd.find_points(np.zeros((64, 64), np.uint8), image_pyramid_level=1, blobs=True)
+
+
+def test_cli_blobs(tmp_path):
+    """--blobs: preprocessing (CLAHE + blur) -> blobs -> grid finder; level column 0, no refinement
+    (mrgingham-from-image.cc:153-160, :174-183)."""
+    w, h, gridn, seed = 800, 600, 10, 1
+    img = synth.dots_frame(w, h, gridn, seed).numpy()
+    p = str(tmp_path / "dots.pgm")
+    _write_pgm(p, img)
+    r = subprocess.run([CLI, "--blobs", "--gridn", str(gridn), p], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    rows = _parse(r.stdout)[p]
+    pre = oracle.preprocess(img, clahe=True, blur_radius=1)
+    want = mrgingham_amd.find_grid_from_points(oracle.find_blobs(pre), gridn)
+    assert want is not None and len(rows) == gridn * gridn
+    g = np.array([(x, y) for x, y, _ in rows])
+    assert np.abs(g - want).max() < 1e-6 and all(lv == 0 for _, _, lv in rows)

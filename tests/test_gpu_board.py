@@ -81,7 +81,7 @@ def test_find_board_negative_and_argument_paths():
     assert mrgingham_amd.find_board(np.zeros((64, 64), np.uint8)) is None
     img = synth.board_frame(640, 480, 10, 0).numpy()
     assert mrgingham_amd.find_board(img, gridn=12) is None                # wrong board size
-    assert mrgingham_amd.find_board(img, blobs=True, image_pyramid_level=0) is None
+    assert mrgingham_amd.find_board(img, blobs=True, image_pyramid_level=0) is None   # a chessboard is not a circle grid
     assert mrgingham_amd.find_board(img, image_pyramid_level=11) is None
     with pytest.raises(RuntimeError, match="gridn"):
         mrgingham_amd.find_board(img, gridn=1)

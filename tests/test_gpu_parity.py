@@ -169,7 +169,8 @@ def test_find_points_error_and_empty_paths():
     assert np.array_equal(_as_int(a), oracle.find_corners(wide[:, :160], 1))
     assert mrgingham_amd.find_points(np.zeros((10, 10), np.uint8)).shape == (0, 2)  # no interior at all
     assert mrgingham_amd.find_points(np.zeros((64, 64), np.uint8)).shape == (0, 2)  # nothing found
-    assert mrgingham_amd.find_points(img, blobs=True).shape == (0, 2)               # blob path not provided
+    assert np.array_equal(np.round(mrgingham_amd.find_points(img, blobs=True) * 1000).astype(np.int64),
+                          oracle.find_blobs(img).astype(np.int64))                   # the blob path (find_blobs.cc)
     with pytest.raises(RuntimeError):
         mrgingham_amd.find_points(img, image_pyramid_level=1, blobs=True)           # mrgingham_pywrap.c:153-157
     with pytest.raises(RuntimeError):
