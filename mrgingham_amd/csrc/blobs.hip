@@ -33,7 +33,8 @@ namespace {
 
 constexpr int kNumThresh = 17;            // 50, 60, .. 210 (minThreshold 50, maxThreshold 220, step 10)
 constexpr int kThresh0 = 50, kThreshStep = 10;
-constexpr int kMaxBorder = 1 << 18;       // lanes give up on longer borders (see blob_follow)
+constexpr int kMaxBorder = 1 << 16;       // lanes give up on longer borders ...
+constexpr int kMaxExtent = 2048;          // ... and on borders that stray this far from their start (see blob_follow)
 
 struct BitPlanes {
     const uint32_t* bits;  // [kNumThresh][h][wpr]
@@ -47,6 +48,38 @@ struct BitPlanes {
 // direction codes of the border follower: 0 = +x, then counter-clockwise on the screen (y down)
 __device__ __constant__ int kDX[8] = {1, 1, 0, -1, -1, -1, 0, 1};
 __device__ __constant__ int kDY[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+
+// bits (x-1, x, x+1) of row y of plane t, 0 outside the image
+__device__ __forceinline__ uint32_t row3(const BitPlanes& bp, int t, int x, int y) {
+    if ((unsigned)y >= (unsigned)bp.h) return 0u;
+    const uint32_t* row = bp.bits + ((long long)t * bp.h + y) * bp.wpr;
+    const int wx = x >> 5, b = x & 31;
+    const uint32_t cur = row[wx];
+    if (b == 0) return ((cur << 1) | (wx > 0 ? row[wx - 1] >> 31 : 0u)) & 7u;
+    if (b == 31) return ((cur >> 30) | (wx + 1 < bp.wpr ? (row[wx + 1] & 1u) << 2 : 0u)) & 7u;
+    return (cur >> (b - 1)) & 7u;
+}
+
+// The 8 neighbours of (x, y) as a mask, bit s = the pixel in direction s: three independent loads, after
+// which every search of the follower is register work.
+__device__ __forceinline__ uint32_t neighbours(const BitPlanes& bp, int t, int x, int y) {
+    const uint32_t up = row3(bp, t, x, y - 1), mid = row3(bp, t, x, y), dn = row3(bp, t, x, y + 1);
+    return ((mid >> 2) & 1u) | (((up >> 2) & 1u) << 1) | (((up >> 1) & 1u) << 2) | ((up & 1u) << 3) |
+           ((mid & 1u) << 4) | ((dn & 1u) << 5) | (((dn >> 1) & 1u) << 6) | (((dn >> 2) & 1u) << 7);
+}
+
+// first set direction going clockwise (decreasing code) from `from` (exclusive, wrapping back to it); -1 if none
+__device__ __forceinline__ int first_cw(uint32_t m, int from) {
+    if (!m) return -1;
+    // rotate so that direction from-1 becomes bit 7, from-2 bit 6, ...: bit (7 - k) <-> direction from-1-k
+    const uint32_t r = ((m | (m << 8)) >> (from & 7)) & 0xffu;  // bit j = direction from + j; from-1-k = from + (7-k)
+    return (from + (31 - __clz((int)r))) & 7;
+}
+// first set direction going counter-clockwise (increasing code) from s + 1
+__device__ __forceinline__ int first_ccw(uint32_t m, int s) {
+    const uint32_t r = ((m | (m << 8)) >> ((s + 1) & 7)) & 0xffu;  // bit j = direction s + 1 + j
+    return (s + 1 + (__ffs((int)r) - 1)) & 7;
+}
 
 // one thread = 32 pixels of a row -> one word of each of the 17 planes
 __global__ __launch_bounds__(256) void blob_bitplanes_kernel(const uint8_t* img, int stride, int w, int h, int wpr,
@@ -72,9 +105,11 @@ __global__ __launch_bounds__(256) void blob_bitplanes_kernel(const uint8_t* img,
 // whose left neighbour is 0 (outer-type start), a white pixel whose right neighbour is 0 and inside the
 // image (hole-type start: the scan never looks at the zero pad).  key = (y << 16 | x << 1 | type): raster
 // order, outer-type first at the same pixel.
-__global__ __launch_bounds__(256) void blob_candidates_kernel(BitPlanes bp, int t, uint32_t* cand, int cand_cap,
-                                                              int* cand_cnt) {
-    const int wx = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+__global__ __launch_bounds__(256) void blob_candidates_kernel(BitPlanes bp, uint32_t* cand_all, int cand_cap,
+                                                              int* cand_cnt_all) {
+    const int wx = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, t = blockIdx.z;
+    uint32_t* cand = cand_all + (long long)t * cand_cap;
+    int* cand_cnt = cand_cnt_all + t;
     if (wx >= bp.wpr) return;
     const uint32_t* row = bp.bits + ((long long)t * bp.h + y) * bp.wpr;
     const uint32_t cur = row[wx];
@@ -107,41 +142,33 @@ struct BlobContour {      // one followed border that passed the area filter
     long long a00, a10, a01, a20, a11, a02;  // contourMoments sums
 };
 
-// Direction from pixel (x, y) to its predecessor on the border, the way icvFetchContour finds it from a
-// start: search clockwise (decreasing code) from `from`; -1: no neighbour at all (single pixel).
-__device__ __forceinline__ int first_clockwise(const BitPlanes& bp, int t, int x, int y, int from) {
-    int s = from;
-    do {
-        s = (s - 1) & 7;
-        if (bp.at(t, x + kDX[s], y + kDY[s])) return s;
-    } while (s != from);
-    return -1;
-}
-
-// Follows the border that starts at candidate `key` exactly like icvFetchContour (CHAIN_APPROX_NONE).
+// Follows the border that starts at candidate `key` exactly like icvFetchContour (CHAIN_APPROX_NONE): from the
+// start, the predecessor is the first white neighbour clockwise from west (outer start) or east (hole start);
+// then, at every point, the next one is the first white neighbour counter-clockwise from the direction we
+// came from, until the start is reached again from that predecessor.
 // WRITE = false: returns false as soon as another start of the same border with a smaller key is met (that
 // lane owns the border) or the border is longer than kMaxBorder; otherwise fills the sums and the length.
 // WRITE = true: stores the points ((y << 16) | x) to `pts`.
-// kMaxBorder: a border that passes the filters has area < 80000 and fills >= 95 % of its convex hull with
-// an inertia ratio >= 0.1; what such a border can spend on detours is bounded by the 5 % of hull area it
-// may waste, far below 2^18 steps -- longer borders (image-wide background ridges in noise) can only be
-// rejected, and following them to the end in one lane would take seconds.
+// kMaxBorder / kMaxExtent: a border that passes the filters encloses less than 80000 px^2, fills >= 95 % of its
+// convex hull (hull area H < 84211) and has an inertia ratio >= 0.1.  A convex region of area H that is D
+// pixels long is at most 2H/D wide, so its inertia ratio is of the order (2H/D^2)^2: at D = 2048 that is
+// below 0.002 -- such a border cannot pass.  And what a passing border can spend on detours is bounded by
+// the 5 % of hull area it may waste (each step of a detour wastes about half a pixel): about 10^4 steps on
+// top of a perimeter of at most a few thousand, far below 2^16.  Longer or wider borders (the image
+// frame, background ridges in noise) can only be rejected, and following them to the end in one lane
+// would take most of the call.
 template <bool WRITE>
 __device__ __forceinline__ bool blob_follow(const BitPlanes& bp, int t, uint32_t key, BlobContour& c, uint32_t* pts) {
     const int x0 = (int)((key >> 1) & 0x7fffu), y0 = (int)(key >> 16), is_hole = (int)(key & 1u);
-    int s = first_clockwise(bp, t, x0, y0, is_hole ? 0 : 4);
+    uint32_t m = neighbours(bp, t, x0, y0);
+    int s = first_cw(m, is_hole ? 0 : 4);
     if (s < 0) return false;  // a single pixel: area 0, never a blob
     const int x1 = x0 + kDX[s], y1 = y0 + kDY[s];  // the predecessor of the start on the border
     int x3 = x0, y3 = y0, n = 0;
     unsigned long long a00 = 0, a10 = 0, a01 = 0, a20 = 0, a11 = 0, a02 = 0;  // wrap-around integers: exact results
     for (;;) {
-        int x4, y4;
-        for (;;) {  // counter-clockwise search for the next border point
-            s = (s + 1) & 7;
-            x4 = x3 + kDX[s];
-            y4 = y3 + kDY[s];
-            if (bp.at(t, x4, y4)) break;
-        }
+        s = first_ccw(m, s);  // the next border point
+        const int x4 = x3 + kDX[s], y4 = y3 + kDY[s];
         if (WRITE) {
             pts[n] = ((uint32_t)y3 << 16) | (uint32_t)x3;
         } else {
@@ -157,20 +184,17 @@ __device__ __forceinline__ bool blob_follow(const BitPlanes& bp, int t, uint32_t
         }
         ++n;
         if (x4 == x0 && y4 == y0 && x3 == x1 && y3 == y1) break;  // closed
-        if (n >= kMaxBorder) return false;
-        // now at (x4, y4), having come from direction `back`
+        if (n >= kMaxBorder || abs(x4 - x0) > kMaxExtent || abs(y4 - y0) > kMaxExtent) return false;
+        // now at (x4, y4), having come from direction s + 4
         x3 = x4;
         y3 = y4;
         s = (s + 4) & 7;
+        m = neighbours(bp, t, x3, y3);
         if (!WRITE) {
             // is this pixel a start of the same border that the raster scan meets earlier?
-            const uint32_t here = ((uint32_t)y3 << 16) | ((uint32_t)x3 << 1);
-            if (here < (key & ~1u) || (here == (key & ~1u) && is_hole)) {
-                if (!bp.at(t, x3 - 1, y3) && first_clockwise(bp, t, x3, y3, 4) == s) return false;
-            }
-            if (here < (key & ~1u)) {
-                if (x3 < bp.w - 1 && !bp.at(t, x3 + 1, y3) && first_clockwise(bp, t, x3, y3, 0) == s) return false;
-            }
+            const uint32_t here = ((uint32_t)y3 << 16) | ((uint32_t)x3 << 1), mine = key & ~1u;
+            if ((here < mine || (here == mine && is_hole)) && !(m & 0x10u) && first_cw(m, 4) == s) return false;
+            if (here < mine && x3 < bp.w - 1 && !(m & 1u) && first_cw(m, 0) == s) return false;
         }
     }
     c.n = n;
@@ -179,9 +203,11 @@ __device__ __forceinline__ bool blob_follow(const BitPlanes& bp, int t, uint32_t
     return true;
 }
 
-__global__ __launch_bounds__(256) void blob_trace_kernel(BitPlanes bp, int t, const uint32_t* cand, const int* cand_cnt,
+__global__ __launch_bounds__(256) void blob_trace_kernel(BitPlanes bp, const uint32_t* cand_all, const int* cand_cnt_all,
                                                          int cand_cap, BlobContour* recs, int rec_cap, int* counters) {
-    const int ncand = min(*cand_cnt, cand_cap);
+    const int t = blockIdx.y;
+    const uint32_t* cand = cand_all + (long long)t * cand_cap;
+    const int ncand = min(cand_cnt_all[t], cand_cap);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < ncand; i += gridDim.x * 256) {
         BlobContour c;
         c.key = cand[i];
@@ -318,7 +344,7 @@ size_t blob_scratch_bytes(int w, int h, BlobScratchLayout* lay) {
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     L.o_counters = take(64 * sizeof(int));
     L.o_bits = take((size_t)kNumThresh * h * L.wpr * 4);
-    L.o_cand = take((size_t)L.cand_cap * 4);
+    L.o_cand = take((size_t)kNumThresh * L.cand_cap * 4);
     L.o_recs = take((size_t)L.rec_cap * sizeof(BlobContour));
     L.o_pts = take((size_t)L.pts_cap * 4);
     if (lay) *lay = L;
@@ -343,11 +369,11 @@ bool blob_detect(const uint8_t* d_img, int d_stride, const uint8_t* h_img, int h
     hipMemsetAsync(counters, 0, 64 * sizeof(int), s);
     const dim3 grid_rows((L.wpr + 255) / 256, h);
     hipLaunchKernelGGL(blob_bitplanes_kernel, grid_rows, dim3(256), 0, s, d_img, d_stride, w, h, L.wpr, bits);
-    for (int t = 0; t < kNumThresh; ++t) {
-        hipLaunchKernelGGL(blob_candidates_kernel, grid_rows, dim3(256), 0, s, bp, t, cand, L.cand_cap, counters + 2 + t);
-        hipLaunchKernelGGL(blob_trace_kernel, dim3(1024), dim3(256), 0, s, bp, t, (const uint32_t*)cand,
-                           (const int*)(counters + 2 + t), L.cand_cap, recs, L.rec_cap, counters);
-    }
+    // every plane at once: the planes are independent, and a launch lasts as long as its longest border
+    hipLaunchKernelGGL(blob_candidates_kernel, dim3(grid_rows.x, grid_rows.y, kNumThresh), dim3(256), 0, s, bp, cand,
+                       L.cand_cap, counters + 2);
+    hipLaunchKernelGGL(blob_trace_kernel, dim3(256, kNumThresh), dim3(256), 0, s, bp, (const uint32_t*)cand,
+                       (const int*)(counters + 2), L.cand_cap, recs, L.rec_cap, counters);
     hipLaunchKernelGGL(blob_points_kernel, dim3(256), dim3(256), 0, s, bp, (const BlobContour*)recs, L.rec_cap,
                        (const int*)counters, pts, L.pts_cap);
     int hc[64];

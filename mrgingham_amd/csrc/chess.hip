@@ -635,8 +635,11 @@ void launch_chess(const LevelBatch& lb, const CompTables& t, int frame0, int nfr
     const size_t lds = 2 * V1_PLANE + (hot ? (V1_HOTBUF + 4) * sizeof(int) : 0);
     const bool w16 = lb.w >= 16 && lb.w % 16 == 0;
     // staging path: chess_stage_override (tuning hook "chess_stage") 0 = automatic
-    int stage = w16 ? STAGE_PERM16 : STAGE_GENERIC;
+    // widths that are a multiple of 16 take the v_perm staging (fastest there: 624 vs 637-644 us per 64 frames of
+    // 4096x3072); every other width takes the typed staging, which needs no edge handling at all (4090x3070:
+    // 0.377 ms per 32 frames against 0.552 ms with the generic staging)
     const bool typed_ok = (long long)lb.h * lb.img_stride < 0x7fffffffLL && lb.img_pitch >= 0;
+    int stage = w16 ? STAGE_PERM16 : (typed_ok ? STAGE_TYPED1 : STAGE_GENERIC);
     if (chess_stage_override == STAGE_TYPED2 || chess_stage_override == STAGE_TYPED1) {
         if (typed_ok) stage = chess_stage_override;
     } else if (chess_stage_override == -1) {

@@ -16,6 +16,6 @@ for (W, H, B) in [(4096, 3072, 64), (1920, 1080, 64), (640, 480, 64)]:
         for _ in range(n):
             boards, found = det.find_boards(frames, gridn=10, nthreads=nthreads)
         dt = (time.perf_counter() - t0) / n
-        print(f"{W}x{H} x{B}  grid-finder threads {(str(nthreads) if nthreads else "auto"):>4s}: {dt*1e3:8.2f} ms per batch -> {B/dt:8.0f} frames/s; "
+        print(f"{W}x{H} x{B}  grid-finder threads {(str(nthreads) if nthreads else 'auto'):>4s}: {dt*1e3:8.2f} ms per batch -> {B/dt:8.0f} frames/s; "
               f"found at levels {np.bincount(found[found >= 0], minlength=4).tolist()}, not found {int((found < 0).sum())}")
     del frames
