@@ -272,6 +272,11 @@ int mrgingham_amd_find_boards_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_
                                     int image_pyramid_level, double* h_boards, signed char* h_found_level,
                                     int nthreads);
 
+/* TEST HOOK: which implementation of the component search handled each frame of the most recent call at
+ * `level`: h_paths[f] = 1 out of LDS, 0 the global-memory kernels (more than 2048 hot pixels, more than 512
+ * multi-pixel components / points, or more LIFO demand than the LDS tables hold).  Synchronises. */
+int mrgingham_amd_debug_paths(mrgingham_amd_ctx* ctx, int level, int nframes, int32_t* h_paths);
+
 /* Device memory the context currently holds (level scratch of both sets, point scratch, staging). */
 long long mrgingham_amd_scratch_bytes(const mrgingham_amd_ctx* ctx);
 

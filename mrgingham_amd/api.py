@@ -406,6 +406,13 @@ class Detector:
                                                            found.ctypes.data, int(nthreads)))
         return boards, found
 
+    def debug_paths(self, level, nframes):
+        """Test hook: per frame of the most recent call at `level`, 1 = component search out of LDS, 0 = the
+        global-memory kernels."""
+        out = np.zeros((nframes,), dtype=np.int32)
+        self._check(self.L.mrgingham_amd_debug_paths(self.ctx, int(level), int(nframes), out.ctypes.data))
+        return out
+
     def scratch_bytes(self):
         """Device memory the context holds right now."""
         return int(self.L.mrgingham_amd_scratch_bytes(self.ctx))

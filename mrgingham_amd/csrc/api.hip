@@ -537,6 +537,15 @@ void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx) {
     delete ctx;
 }
 
+int mrgingham_amd_debug_paths(mrgingham_amd_ctx* ctx, int level, int nframes, int32_t* h_paths) {
+    if (!ctx || !h_paths || level < 0 || level > kMaxLevel || nframes < 0 || nframes > ctx->counters_nf)
+        return MRGINGHAM_AMD_ERR_ARG;
+    MRG_HIP_CHECK(hipSetDevice(ctx->device));
+    MRG_HIP_CHECK(hipDeviceSynchronize());
+    MRG_HIP_CHECK(hipMemcpy(h_paths, path_of(ctx, level), sizeof(int32_t) * (size_t)nframes, hipMemcpyDeviceToHost));
+    return MRGINGHAM_AMD_OK;
+}
+
 long long mrgingham_amd_scratch_bytes(const mrgingham_amd_ctx* ctx) {
     if (!ctx) return 0;
     long long total = 0;
@@ -573,6 +582,7 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
     if (!strcmp(name, "multi_level_launch")) { ctx->multi_level = value < 0 ? 0 : value > 2 ? 2 : value; return 0; }
     if (!strcmp(name, "cc_schedule")) { ctx->cc_schedule = value; return 0; }
     if (!strcmp(name, "cc_lds")) { ctx->cc_lds = value; return 0; }
+    if (!strcmp(name, "chess_multi_min_blocks")) { mrg::chess_multi_min_blocks = value; return 0; }
     if (!strcmp(name, "chess_stage")) { mrg::chess_stage_override = value; return 0; }
     if (!strcmp(name, "chess_seg")) { mrg::chess_seg_override = value > 0 ? value : 0; return 0; }
     return MRGINGHAM_AMD_ERR_ARG;

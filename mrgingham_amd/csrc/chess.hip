@@ -614,15 +614,17 @@ __global__ __launch_bounds__(256, 4) void chess_v1_multi_kernel(ChessMulti a) {
 
 
 int chess_seg_override = 0;  // tuning hook (mrgingham_amd_set_option "chess_seg"): 0 = automatic
+int chess_multi_min_blocks = 2048;  // tuning hook "chess_multi_min_blocks": per-level block target inside a merged launch
 int chess_stage_override = 0;  // tuning hook "chess_stage": 0 = automatic, 2 / 3 = typed staging, -1 = generic
 
-static int pick_segment(int w, int h, int nframes) {
+static int pick_segment(int w, int h, int nframes, int min_blocks = 2048) {
     if (chess_seg_override > 0) return (chess_seg_override + 7) / 8 * 8;
-    // tall segments amortise the 10-row halo; short ones fill the 256 CUs when the batch is small
+    // tall segments amortise the 10-row halo and the three-group prologue; short ones fill the 256 CUs
+    // when the batch is small
     const long long strips = (w + V1_SW - 1) / V1_SW;
     for (int seg : {256, 128, 64, 32}) {
         const long long blocks = strips * ((h + seg - 1) / seg) * nframes;
-        if (blocks >= 2048 || seg == 32) return seg;
+        if (blocks >= min_blocks || seg == 32) return seg;
     }
     return 32;
 }
@@ -678,7 +680,9 @@ bool launch_chess_multi(const LevelBatch* lbs, const CompTables* ts, int n, int 
         const int j = k < n ? k : 0;
         a.lb[k] = lbs[j];
         a.t[k] = ts[j];
-        a.seg[k] = pick_segment(lbs[j].w, lbs[j].h, nframes);
+        // inside a merged launch the largest level fills the chip; the smaller ones only need enough
+        // workgroups to pack its tail, so they can afford taller segments than on their own
+        a.seg[k] = pick_segment(lbs[j].w, lbs[j].h, nframes, k == 0 ? 2048 : chess_multi_min_blocks);
         a.first_wg[k] = total;
         a.nwg[k] = k < n ? ((lbs[j].w + V1_SW - 1) / V1_SW) * ((lbs[j].h + a.seg[k] - 1) / a.seg[k]) * nframes : 0;
         total += (a.nwg[k] + 7) / 8 * 8;

@@ -17,6 +17,7 @@ bool chess_multi_ok(const LevelBatch* lbs, int n, int nframes);
 bool launch_chess_multi(const LevelBatch* lbs, const CompTables* ts, int n, int nframes, hipStream_t s);
 extern int chess_seg_override;
 extern int chess_stage_override;
+extern int chess_multi_min_blocks;
 
 // decimate.hip
 struct FrameBatch {

@@ -156,3 +156,61 @@ def test_random_refine_against_oracle(det, shape, level):
         wp, wl, wn = oracle.cc_refine_on_response(pts, lv, d, img, level)
         assert gn == wn and np.array_equal(gl, wl) and np.array_equal(gp, wp), (shape, level, trial)
         assert wn > 0
+
+
+# ----------------------------------------------------------------------------- which implementation ran
+
+def _blob_field(h, w, nblobs, size, rng):
+    """`nblobs` separate blobs of `size` hot pixels each (a row of pixels), on a grid, all accepted-looking."""
+    d = np.zeros((h, w), np.int16)
+    per_row = (w - 40) // (size + 3)
+    for k in range(nblobs):
+        y = 12 + 3 * (k // per_row)
+        x = 12 + (size + 3) * (k % per_row)
+        assert y < h - 12
+        d[y, x:x + size] = rng.randint(130, 400, size)
+    return d
+
+
+def test_every_fallback_reason_of_the_lds_path():
+    """Frames that fit are handled out of LDS; each reason for leaving a frame to the global-memory kernels is
+    met on purpose -- hot pixels, multi-pixel components, LIFO demand, points -- in ONE batch with frames that
+    fit, and every frame equals the oracle."""
+    det = mrgingham_amd.Detector(0)
+    try:
+        rng = np.random.RandomState(3)
+        h, w = 400, 600
+        frames = {
+            "fits": _blob_field(h, w, 100, 6, rng),                    # 600 hot pixels, 100 components
+            "2049+ hot pixels": _blob_field(h, w, 300, 8, rng),          # 2400 hot
+            "513+ components": _blob_field(h, w, 600, 3, rng),           # 1800 hot, 600 components
+            "LIFO demand": np.zeros((h, w), np.int16),                   # one solid 44 x 44 block: 1936 hot, degree sum 7568
+            "fits too": _blob_field(h, w, 40, 12, rng),
+        }
+        frames["LIFO demand"][100:144, 100:144] = rng.randint(200, 300, (44, 44))
+        names = list(frames)
+        ds = [frames[n] for n in names]
+        img = cc_cases.flat_img(h, w)
+        got = _detect(det, ds, [img] * len(ds), capacity=2048)
+        paths = det.debug_paths(0, len(ds))
+        assert paths.tolist() == [1, 0, 0, 0, 1], dict(zip(names, paths.tolist()))
+        for n, d, g in zip(names, ds, got):
+            want = oracle.cc_detect_on_response(d, img)
+            assert np.array_equal(g, want), n
+            assert len(want) > 0 or n == "LIFO demand"
+        # refine: more than 512 points per frame goes to the global-memory kernels, 512 stay in LDS
+        d = frames["fits"]
+        ys, xs = np.nonzero(d > 15)
+        for npts, want_path in [(512, 1), (513, 0)]:
+            sel = rng.choice(len(xs), size=npts, replace=True)
+            pts = np.stack([xs[sel] + rng.uniform(-1, 1, npts), ys[sel] + rng.uniform(-1, 1, npts)], axis=1)
+            lv = np.ones(npts, np.int8)
+            tp = torch.from_numpy(pts[None].copy()).cuda()
+            tl = torch.from_numpy(lv[None].copy()).cuda()
+            n = torch.tensor([npts], dtype=torch.int32).cuda()
+            nref = det.cc_refine_on_response(torch.from_numpy(d[None]).cuda(), torch.from_numpy(img[None]).cuda(), 0, tp, tl, n)
+            assert det.debug_paths(0, 1).tolist() == [want_path], npts
+            wp, wl, wn = oracle.cc_refine_on_response(pts, lv, d, img, 0)
+            assert int(nref[0]) == wn and np.array_equal(tl[0].cpu().numpy(), wl) and np.array_equal(tp[0].cpu().numpy(), wp)
+    finally:
+        det.close()

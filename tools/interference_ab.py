@@ -48,6 +48,9 @@ settings = [
     ("multi-level + schedule 1 + cc 2 CU/XCD", {"OPTIONS": "multi_level_launch=1,cc_schedule=1", "MRGINGHAM_AMD_CC_CUS": "2"}),
     ("all four levels in one launch", {"OPTIONS": "multi_level_launch=2"}),
     ("all four levels in one launch + schedule 1", {"OPTIONS": "multi_level_launch=2,cc_schedule=1"}),
+    ("merged small levels: min blocks 1024", {"OPTIONS": "chess_multi_min_blocks=1024"}),
+    ("merged small levels: min blocks 512", {"OPTIONS": "chess_multi_min_blocks=512"}),
+    ("merged small levels: min blocks 256", {"OPTIONS": "chess_multi_min_blocks=256"}),
     ("baseline again", {}),
 ]
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
