@@ -775,7 +775,7 @@ __device__ __forceinline__ bool lds_load_and_label(LdsCC& L, const FrameView& v,
 __global__ __launch_bounds__(CC_THREADS) void cc_detect_lds_kernel(LevelBatch lb, CompTables t, int level,
                                                                    DetectOut out, int frame0) {
     __shared__ LdsCC L;
-    __builtin_amdgcn_s_setprio(3);
+    if (!(t.lds_path & 16)) __builtin_amdgcn_s_setprio(3);
     const int frame = frame0 + blockIdx.x, tid = threadIdx.x;
     const int nraw = t.hot_cnt[frame];
     FrameView v = make_view(lb, t, frame);
@@ -896,7 +896,7 @@ constexpr int LPPT = LPTS / CC_THREADS;     // points per thread
 __global__ __launch_bounds__(CC_THREADS) void cc_refine_lds_kernel(LevelBatch lb, CompTables t, int level,
                                                                    RefineIO io, int frame0) {
     __shared__ LdsCC L;
-    __builtin_amdgcn_s_setprio(3);
+    if (!(t.lds_path & 16)) __builtin_amdgcn_s_setprio(3);
     const int frame = frame0 + blockIdx.x, tid = threadIdx.x;
     const int nraw = t.hot_cnt[frame];
     const int npts = min(io.npoints[frame], io.pitch);

@@ -51,6 +51,7 @@ settings = [
     ("merged small levels: min blocks 1024", {"OPTIONS": "chess_multi_min_blocks=1024"}),
     ("merged small levels: min blocks 512", {"OPTIONS": "chess_multi_min_blocks=512"}),
     ("merged small levels: min blocks 256", {"OPTIONS": "chess_multi_min_blocks=256"}),
+    ("LDS search without s_setprio 3", {"OPTIONS": "cc_lds=17"}),
     ("baseline again", {}),
 ]
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
