@@ -604,13 +604,16 @@ void launch_cc_refine(const LevelBatch& lb, const CompTables& t, int level, cons
 // LDS per workgroup: 39 968 B, so that a workgroup fits next to three resident ChESS workgroups
 // (163 840 - 3 * 39 952 B) as soon as a fourth one retires.
 // ===========================================================================
-constexpr int LN = 2048;      // hot-list entries
-constexpr int LHASH = 4096;   // 16-bit hash slots (load factor <= 0.5)
-constexpr int LSTK = 5120;    // 16-bit LIFO words shared by the fills of a frame
-constexpr int LROOTS = 512;   // super-components with >= 2 pixels (detect)
-constexpr int LEPT = LN / CC_THREADS;  // list entries per thread
-
-struct LdsCC {
+// Table sizes for N hot-list entries.  N = 2048 is the size every frame is tried at (39 968 B); N = 4096
+// (79 904 B: TWO workgroup slots of the pixel kernel) is launched only while the stream has frames that
+// need it (a 14x14 board has ~2600 hot pixels at level 0), see launch_cc_detect_lds.
+template <int N>
+struct LdsCCT {
+    static constexpr int LN = N;              // hot-list entries
+    static constexpr int LHASH = 2 * N;       // 16-bit hash slots (load factor <= 0.5)
+    static constexpr int LSTK = 5 * N / 2;    // 16-bit LIFO words shared by the fills of a frame
+    static constexpr int LROOTS = N / 4;      // super-components with >= 2 pixels (detect)
+    static constexpr int LEPT = N / CC_THREADS;  // list entries per thread
     uint32_t xy[LN];              // (y << 16) | x, kHotDead for an unused slot
     int16_t val[LN];              // clamped response of the pixel; 0 once consumed by a fill
     int16_t lab[LN];              // smallest list index of the pixel's super-component
@@ -628,12 +631,17 @@ struct LdsCC {
     } w;
     int nroots, ncand, top, total, changed, nref, mtop, pad1;
 };
-static_assert(sizeof(LdsCC) <= 39968, "must fit beside three ChESS workgroups");
+constexpr int LPTS = 512;                    // points per frame the LDS refine kernel takes
+constexpr int LPPT = LPTS / CC_THREADS;     // points per thread
+static_assert(sizeof(LdsCCT<2048>) <= 39968, "must fit beside three ChESS workgroups");
+static_assert(sizeof(LdsCCT<4096>) <= 2 * 39952, "must fit beside two ChESS workgroups");
 
-__device__ __forceinline__ uint32_t lds_hash(uint32_t e) { return (e * 0x9E3779B1u) >> 20; }  // 12 bits
+template <class LdsCC>
+__device__ __forceinline__ uint32_t lds_hash(uint32_t e) { return ((e * 0x9E3779B1u) >> 16) & (uint32_t)(LdsCC::LHASH - 1); }
 
+template <class LdsCC>
 __device__ __forceinline__ void lds_insert(LdsCC& L, uint32_t e, int i) {
-    uint32_t s = lds_hash(e);
+    uint32_t s = lds_hash<LdsCC>(e);
     while (true) {
         uint32_t* wp = &L.hashw[s >> 1];
         const int sh = (int)(s & 1u) * 16;
@@ -642,23 +650,25 @@ __device__ __forceinline__ void lds_insert(LdsCC& L, uint32_t e, int i) {
             const uint32_t nw = (old & ~(0xffffu << sh)) | ((uint32_t)i << sh);
             if (atomicCAS(wp, old, nw) == old) return;  // else: the word changed under us, look again
         } else {
-            s = (s + 1u) & (LHASH - 1);
+            s = (s + 1u) & (uint32_t)(LdsCC::LHASH - 1);
         }
     }
 }
 
 // list index of pixel e, or -1 when it is not hot
+template <class LdsCC>
 __device__ __forceinline__ int lds_find(const LdsCC& L, uint32_t e) {
-    uint32_t s = lds_hash(e);
+    uint32_t s = lds_hash<LdsCC>(e);
     while (true) {
         const uint32_t v = (L.hashw[s >> 1] >> ((s & 1u) * 16)) & 0xffffu;
         if (v == 0xffffu) return -1;
         if (L.xy[v] == e) return (int)v;
-        s = (s + 1u) & (LHASH - 1);
+        s = (s + 1u) & (uint32_t)(LdsCC::LHASH - 1);
     }
 }
 
 // follow_connected_component (:236-256) on the LDS tables; the LIFO holds list indices.
+template <class LdsCC>
 __device__ __forceinline__ int drain_lds(LdsCC& L, int w, int h, int16_t* stk, int sp, Blob& b) {
     b.srx = b.sry = b.sr = 0;
     b.npix = 0;
@@ -697,10 +707,12 @@ __device__ __forceinline__ int drain_lds(LdsCC& L, int w, int h, int16_t* stk, i
 }
 
 // Load the frame's hot list into LDS, label the super-components (lab = smallest list index) and leave in
-// L.u.acc, at every root, (pixels of the super-component) | (sum of hot-neighbour counts << 12): the
+// L.u.acc, at every root, (pixels of the super-component) | (sum of hot-neighbour counts << 13): the
 // latter bounds the pushes of any fill of it.  Returns false (uniformly) when the frame does not
 // fit.  All threads call it.
+template <class LdsCC>
 __device__ __forceinline__ bool lds_load_and_label(LdsCC& L, const FrameView& v, int nraw, int cap) {
+    constexpr int LN = LdsCC::LN, LHASH = LdsCC::LHASH, LEPT = LdsCC::LEPT;
     const int tid = threadIdx.x;
     if (nraw > cap || nraw > LN) return false;
     const int n = nraw, w = v.w;
@@ -766,21 +778,38 @@ __device__ __forceinline__ bool lds_load_and_label(LdsCC& L, const FrameView& v,
         if (own[k] == kHotDead) continue;
         const int i = tid + CC_THREADS * k;
         const int deg = (nb[k][0] >= 0) + (nb[k][1] >= 0) + (nb[k][2] >= 0) + (nb[k][3] >= 0);
-        atomicAdd(&L.u.acc[L.lab[i]], 1 + (deg << 12));
+        atomicAdd(&L.u.acc[L.lab[i]], 1 + (deg << 13));
     }
     __syncthreads();
     return true;
 }
 
+// What a declining kernel leaves behind: the frame stays with the next implementation (path 0), and -- when
+// the larger LDS tables could take it -- a hint for the host, which launches the N = 4096 kernel only
+// while recent frames asked for it (a plain store to host-mapped memory; read without any synchronisation
+// when the next call is queued, so it lags by a call or two, which is all the accuracy it needs).
+template <int N>
+__device__ __forceinline__ void lds_decline(const CompTables& t, int frame, int nraw) {
+    if (threadIdx.x != 0) return;
+    t.path[frame] = 0;
+    if (N < 4096 && t.big_hint && nraw <= 4096 && nraw <= t.cap)
+        __hip_atomic_store(t.big_hint, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <int N>
 __global__ __launch_bounds__(CC_THREADS) void cc_detect_lds_kernel(LevelBatch lb, CompTables t, int level,
                                                                    DetectOut out, int frame0) {
-    __shared__ LdsCC L;
+    using LdsCC = LdsCCT<N>;
+    constexpr int LROOTS = LdsCC::LROOTS, LSTK = LdsCC::LSTK, LEPT = LdsCC::LEPT;
+    extern __shared__ __attribute__((aligned(16))) char lds_cc_raw[];
+    LdsCC& L = *reinterpret_cast<LdsCC*>(lds_cc_raw);
     if (!(t.lds_path & 16)) __builtin_amdgcn_s_setprio(3);
     const int frame = frame0 + blockIdx.x, tid = threadIdx.x;
+    if (N > 2048 && t.path[frame]) return;  // the smaller tables took it
     const int nraw = t.hot_cnt[frame];
     FrameView v = make_view(lb, t, frame);
     if (!lds_load_and_label(L, v, nraw, t.cap)) {
-        if (tid == 0) t.path[frame] = 0;
+        lds_decline<N>(t, frame, nraw);
         return;
     }
     const int n = nraw, w = v.w, h = v.h;
@@ -789,7 +818,7 @@ __global__ __launch_bounds__(CC_THREADS) void cc_detect_lds_kernel(LevelBatch lb
     // (sum of hot-neighbour counts + 1) words, which bounds the pushes of all fills of it together
     for (int i = tid; i < n; i += CC_THREADS) {
         if (L.xy[i] == kHotDead || L.lab[i] != i) continue;
-        const int a = L.u.acc[i], cnt = a & 0xfff, need = (a >> 12) + 1;
+        const int a = L.u.acc[i], cnt = a & 0x1fff, need = (a >> 13) + 1;
         if (cnt < kBlobMinPixels) continue;
         const int r = atomicAdd(&L.nroots, 1);
         const int so = atomicAdd(&L.top, need);
@@ -797,7 +826,7 @@ __global__ __launch_bounds__(CC_THREADS) void cc_detect_lds_kernel(LevelBatch lb
     }
     __syncthreads();
     if (L.nroots > LROOTS || L.top > LSTK) {  // does not fit: nothing has been modified
-        if (tid == 0) t.path[frame] = 0;
+        lds_decline<N>(t, frame, nraw);
         return;
     }
     const int nroots = L.nroots;
@@ -890,29 +919,35 @@ __global__ __launch_bounds__(CC_THREADS) void cc_detect_lds_kernel(LevelBatch lb
     emit_detect_outputs(v, L.u.keys, nvalid, level, out, frame);
 }
 
-constexpr int LPTS = 512;                    // points per frame the LDS refine kernel takes
-constexpr int LPPT = LPTS / CC_THREADS;     // points per thread
-
+template <int N>
 __global__ __launch_bounds__(CC_THREADS) void cc_refine_lds_kernel(LevelBatch lb, CompTables t, int level,
                                                                    RefineIO io, int frame0) {
-    __shared__ LdsCC L;
+    using LdsCC = LdsCCT<N>;
+    constexpr int LN = LdsCC::LN, LSTK = LdsCC::LSTK;
+    extern __shared__ __attribute__((aligned(16))) char lds_cc_raw[];
+    LdsCC& L = *reinterpret_cast<LdsCC*>(lds_cc_raw);
     if (!(t.lds_path & 16)) __builtin_amdgcn_s_setprio(3);
     const int frame = frame0 + blockIdx.x, tid = threadIdx.x;
+    if (N > 2048 && t.path[frame]) return;  // the smaller tables took it
     const int nraw = t.hot_cnt[frame];
     const int npts = min(io.npoints[frame], io.pitch);
     FrameView v = make_view(lb, t, frame);
-    if (npts > LPTS || !lds_load_and_label(L, v, nraw, t.cap)) {
+    if (npts > LPTS) {  // no LDS variant takes that many points
         if (tid == 0) t.path[frame] = 0;
+        return;
+    }
+    if (!lds_load_and_label(L, v, nraw, t.cap)) {
+        lds_decline<N>(t, frame, nraw);
         return;
     }
     const int n = nraw, w = v.w, h = v.h;
     // LIFO demand of every super-component at its root, then the accumulators become the claim table
-    for (int i = tid; i < n; i += CC_THREADS) L.w.need16[i] = (int16_t)((L.u.acc[i] >> 12) + 1);
+    for (int i = tid; i < n; i += CC_THREADS) L.w.need16[i] = (int16_t)((L.u.acc[i] >> 13) + 1);
     __syncthreads();
     int32_t* claim = L.u.acc;
     for (int i = tid; i < n; i += CC_THREADS) claim[i] = 0x7fffffff;
     // the group leader of every point, -1 for a point that is not refinable at this level: behind
-    // need16[] in the same union (LN * 2 bytes used of 5120), npts <= LPTS entries
+    // need16[] in the same union (LN * 2 bytes used of 2.5 LN), npts <= LPTS entries
     int16_t* lead16 = L.w.need16 + LN;
     static_assert(sizeof(L.w) >= (size_t)LN * 2 + (size_t)LPTS * 2, "lead16 must fit behind need16");
 
@@ -1019,7 +1054,7 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_lds_kernel(LevelBatch lb
     }
     __syncthreads();
     if (L.total > LSTK) {  // does not fit: no point, no response has been modified
-        if (tid == 0) t.path[frame] = 0;
+        lds_decline<N>(t, frame, nraw);
         return;
     }
     if (tid == 0) t.path[frame] = 1;
@@ -1051,16 +1086,29 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_lds_kernel(LevelBatch lb
     if (tid == 0 && io.nrefined) io.nrefined[frame] = L.nref;
 }
 
+template <int N, class K, class... A>
+static void launch_lds(K kernel, int nframes, hipStream_t s, A... args) {
+    static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LdsCCT<N>)), true);
+    (void)once;
+    hipLaunchKernelGGL(kernel, dim3(nframes), dim3(CC_THREADS), sizeof(LdsCCT<N>), s, args...);
+}
+
+// Every frame is tried with the 2048-entry tables (one workgroup slot of the pixel kernel each).  The
+// 4096-entry kernel costs two slots per workgroup and has to wait for them, which costs the pixel kernels 4 %
+// when nobody needs it -- it is launched only when `use_big` (the host's view of CompTables::big_hint).
 void launch_cc_detect_lds(const LevelBatch& lb, const CompTables& t, int level, const DetectOut& out, int frame0,
                           int nframes, hipStream_t s) {
     if (!t.lds_path || nframes <= 0) return;
-    hipLaunchKernelGGL(cc_detect_lds_kernel, dim3(nframes), dim3(CC_THREADS), 0, s, lb, t, level, out, frame0);
+    launch_lds<2048>(cc_detect_lds_kernel<2048>, nframes, s, lb, t, level, out, frame0);
+    if (t.use_big) launch_lds<4096>(cc_detect_lds_kernel<4096>, nframes, s, lb, t, level, out, frame0);
 }
 
 void launch_cc_refine_lds(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io, int frame0,
                           int nframes, hipStream_t s) {
     if (!t.lds_path || nframes <= 0) return;
-    hipLaunchKernelGGL(cc_refine_lds_kernel, dim3(nframes), dim3(CC_THREADS), 0, s, lb, t, level, io, frame0);
+    launch_lds<2048>(cc_refine_lds_kernel<2048>, nframes, s, lb, t, level, io, frame0);
+    if (t.use_big) launch_lds<4096>(cc_refine_lds_kernel<4096>, nframes, s, lb, t, level, io, frame0);
 }
 
 }  // namespace mrg

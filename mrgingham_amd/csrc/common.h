@@ -61,6 +61,8 @@ struct CompTables {
     // it is left to the global-memory kernels (more hot pixels / components than the LDS tables hold).
     int32_t* path;            // [nframes]
     int lds_path;             // 0: the LDS kernels are not launched and path[] is not consulted
+    int* big_hint;            // host-mapped word of this level: set by a kernel that left a frame for larger tables
+    int use_big;              // the host's decision for this call: also launch the 4096-entry LDS kernels
 };
 
 // A component that passed the size / peak / margin tests and waits for the

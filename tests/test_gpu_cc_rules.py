@@ -173,31 +173,50 @@ def _blob_field(h, w, nblobs, size, rng):
 
 
 def test_every_fallback_reason_of_the_lds_path():
-    """Frames that fit are handled out of LDS; each reason for leaving a frame to the global-memory kernels is
+    """Frames that fit are handled out of LDS; each reason for leaving a frame to the next implementation is
     met on purpose -- hot pixels, multi-pixel components, LIFO demand, points -- in ONE batch with frames that
-    fit, and every frame equals the oracle."""
+    fit, and every frame equals the oracle.  Three settings of the launcher: only the 2048-entry tables
+    (cc_lds = 1 | 64), the 4096-entry tables always behind them (1 | 32), and the default, where the larger
+    kernel is launched once earlier calls have asked for it."""
+    rng = np.random.RandomState(3)
+    h, w = 400, 600
+    frames = {
+        "fits": _blob_field(h, w, 100, 6, rng),                    # 600 hot pixels, 100 components
+        "2049+ hot pixels": _blob_field(h, w, 300, 8, rng),          # 2400 hot
+        "513+ components": _blob_field(h, w, 600, 3, rng),           # 1800 hot, 600 components
+        "LIFO demand": np.zeros((h, w), np.int16),                   # one solid 44 x 44 block: 1936 hot, degree sum 7568
+        "fits too": _blob_field(h, w, 40, 12, rng),
+        "4097+ hot pixels": _blob_field(h, w, 520, 8, rng),          # 4160 hot: no LDS variant
+    }
+    frames["LIFO demand"][100:144, 100:144] = rng.randint(200, 300, (44, 44))
+    names = list(frames)
+    ds = [frames[n] for n in names]
+    img = cc_cases.flat_img(h, w)
+    wants = [oracle.cc_detect_on_response(d, img) for d in ds]
+
+    def run(det, expect_paths):
+        got = _detect(det, ds, [img] * len(ds), capacity=4096)
+        paths = det.debug_paths(0, len(ds))
+        if expect_paths is not None:
+            assert paths.tolist() == expect_paths, dict(zip(names, paths.tolist()))
+        for n, g, want in zip(names, got, wants):
+            assert np.array_equal(g, want), n
+        return paths.tolist()
+
+    for mode, expect in [(1 | 64, [1, 0, 0, 0, 1, 0]), (1 | 32, [1, 1, 1, 1, 1, 0])]:
+        det = mrgingham_amd.Detector(0)
+        try:
+            det.set_option("cc_lds", mode)
+            run(det, expect)
+        finally:
+            det.close()
     det = mrgingham_amd.Detector(0)
     try:
-        rng = np.random.RandomState(3)
-        h, w = 400, 600
-        frames = {
-            "fits": _blob_field(h, w, 100, 6, rng),                    # 600 hot pixels, 100 components
-            "2049+ hot pixels": _blob_field(h, w, 300, 8, rng),          # 2400 hot
-            "513+ components": _blob_field(h, w, 600, 3, rng),           # 1800 hot, 600 components
-            "LIFO demand": np.zeros((h, w), np.int16),                   # one solid 44 x 44 block: 1936 hot, degree sum 7568
-            "fits too": _blob_field(h, w, 40, 12, rng),
-        }
-        frames["LIFO demand"][100:144, 100:144] = rng.randint(200, 300, (44, 44))
-        names = list(frames)
-        ds = [frames[n] for n in names]
-        img = cc_cases.flat_img(h, w)
-        got = _detect(det, ds, [img] * len(ds), capacity=2048)
-        paths = det.debug_paths(0, len(ds))
-        assert paths.tolist() == [1, 0, 0, 0, 1], dict(zip(names, paths.tolist()))
-        for n, d, g in zip(names, ds, got):
-            want = oracle.cc_detect_on_response(d, img)
-            assert np.array_equal(g, want), n
-            assert len(want) > 0 or n == "LIFO demand"
+        first = run(det, None)                      # default: the larger kernel only after it was asked for
+        assert first in ([1, 0, 0, 0, 1, 0], [1, 1, 1, 1, 1, 0])
+        for _ in range(3):
+            last = run(det, None)
+        assert last == [1, 1, 1, 1, 1, 0]
         # refine: more than 512 points per frame goes to the global-memory kernels, 512 stay in LDS
         d = frames["fits"]
         ys, xs = np.nonzero(d > 15)
@@ -212,5 +231,19 @@ def test_every_fallback_reason_of_the_lds_path():
             assert det.debug_paths(0, 1).tolist() == [want_path], npts
             wp, wl, wn = oracle.cc_refine_on_response(pts, lv, d, img, 0)
             assert int(nref[0]) == wn and np.array_equal(tl[0].cpu().numpy(), wl) and np.array_equal(tp[0].cpu().numpy(), wp)
+        # refine of a frame that needs the larger tables
+        d = frames["2049+ hot pixels"]
+        ys, xs = np.nonzero(d > 15)
+        sel = rng.choice(len(xs), size=300, replace=False)
+        pts = np.stack([xs[sel] + rng.uniform(-1, 1, 300), ys[sel] + rng.uniform(-1, 1, 300)], axis=1)
+        lv = np.ones(300, np.int8)
+        for _ in range(2):
+            tp = torch.from_numpy(pts[None].copy()).cuda()
+            tl = torch.from_numpy(lv[None].copy()).cuda()
+            n = torch.tensor([300], dtype=torch.int32).cuda()
+            nref = det.cc_refine_on_response(torch.from_numpy(d[None]).cuda(), torch.from_numpy(img[None]).cuda(), 0, tp, tl, n)
+            wp, wl, wn = oracle.cc_refine_on_response(pts, lv, d, img, 0)
+            assert int(nref[0]) == wn and np.array_equal(tl[0].cpu().numpy(), wl) and np.array_equal(tp[0].cpu().numpy(), wp)
+        assert det.debug_paths(0, 1).tolist() == [1]
     finally:
         det.close()
