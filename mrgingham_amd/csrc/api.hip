@@ -126,9 +126,10 @@ struct mrgingham_amd_ctx {
     // launch (measured slower: 1.171 ms)
     int multi_level = 1;
     // component-chain schedule of chain_batch: 0 = every level's component kernels start as soon as
-    // that level's response is done; 1 = levels 1 and 0 wait for the level-0 response (they then run
-    // underneath the NEXT call's pyramid and small levels instead of underneath this call's level 0)
-    int cc_schedule = 0;
+    // that level's response is done; 1 (default) = levels 1 and 0 wait for the level-0 response (they then
+    // run underneath the NEXT call's pyramid and small levels instead of underneath this call's level 0:
+    // same step time, level-0 launch 668 -> 657 us); 2 = every level waits for the level-0 response
+    int cc_schedule = 1;
     // Host-mapped hint words, one per level (CompTables::big_hint): a kernel stores 1 when a frame needed the
     // 4096-entry LDS tables.  Read without synchronisation when a call is queued; cleared every 1024 calls so
     // that a stream whose frames got simpler stops paying for the larger kernel.
