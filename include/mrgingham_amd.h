@@ -49,8 +49,11 @@ void mrgingham_ChESS_response_5(int16_t* response, const uint8_t* image, int w, 
  * nothing was found or on an error (message on stderr):
  *   - image_pyramid_level outside [0,10]            (find_chessboard_corners.cc:433-441)
  *   - level 0 and stride != Ncols (non-continuous)  (find_chessboard_corners.cc:461-466)
- *   - doblobs: the blob detector (find_blobs.cc) is outside this library's
- *     path; always false, with a message. */
+ * doblobs (bridge.cc:50-55): the blob detector, find_blobs_from_image_array (find_blobs.cc:14-46: a
+ * cv::SimpleBlobDetector with minArea 20, maxArea 80000, minDistBetweenBlobs 5, dark blobs), at level 0
+ * only (any other level: false); like the reference it always "finds", i.e. add_points is called even with
+ * N = 0.  debug: the reference's /tmp/mrgingham-* dumps of the pass
+ * (find_chessboard_corners.cc:282-315, :453-459, :513-541). */
 bool find_chessboard_corners_from_image_array_C(int Nrows, int Ncols, int stride, char* imagebuffer,
                                                 int image_pyramid_level, bool doblobs, bool debug,
                                                 bool (*add_points)(int* xy, int N, double scale, void* cookie),
@@ -73,8 +76,10 @@ int refine_chessboard_corners_from_image_array_C(int Nrows, int Ncols, int strid
  * < 0 tries levels 3, 2, 1, 0 until the grid finder succeeds; the gridn x gridn corners are then
  * refined towards level 0 and handed to add_points(xy, gridn*gridn, cookie) in board order.
  * The detector and the refinement run on the GPU, the grid finder (find_grid.cc) on the host.
- * Returns false when no board is found or on an error; doblobs is not supported (false);
- * debug / debug_sequence_* are accepted and ignored. */
+ * Returns false when no board is found or on an error; doblobs (level 0 only, bridge.cc:104-113) is
+ * find_circle_grid_from_image_array: blob detector + grid finder, no refinement;
+ * debug writes the detector's / refinement's dumps (see above); debug_sequence_* (the grid finder's own dumps)
+ * are accepted and ignored. */
 bool find_chessboard_from_image_array_C(int Nrows, int Ncols, int stride, char* imagebuffer, const int gridn,
                                         int image_pyramid_level, bool doblobs, bool debug, int debug_sequence_x,
                                         int debug_sequence_y,
