@@ -326,7 +326,11 @@ def main():
         # level-0 ChESS launches per step = number of stream chunks; frames per launch follows
         launches_per_step = max(1, nlaunch // max(1, args.steps))
         frames_per_launch = batch / launches_per_step
-        alg_bytes = frames_per_launch * W * H * 3.0
+        fused, merged = det.chain_info()
+        # 3 B/px: the frame read once, the int16 response written once.  When the launch also writes the
+        # level images 1..3 (fused pyramid) those bytes are its algorithmic output too: 1/4 + 1/16 + 1/64 B/px.
+        bpp = 3.0 + (sum(0.25 ** L for L in range(1, min(start_level, 3) + 1)) if fused else 0.0)
+        alg_bytes = frames_per_launch * W * H * bpp
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         # HBM-side bytes per launch: PMC counters cannot be read from inside this process, so the
         # figure is the per-pixel traffic measured by the committed rocprofv3 --pmc passes of this
@@ -362,8 +366,11 @@ def main():
                        "frames_with_full_grid_last_step": found},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "level-0 ChESS response (+clamp +hot-pixel compaction)",
-                         "bytes_model": "3 B/px (u8 read once + int16 written once)",
+                         "kernel": "level-0 ChESS response (+clamp +hot-pixel compaction" +
+                                   (" +level images 1..3)" if fused else ")"),
+                         "bytes_model": ("%.4f B/px (u8 read once + int16 written once + u8 level images 1..3 "
+                                         "written once)" % bpp) if fused else
+                                        "3 B/px (u8 read once + int16 written once)",
                          "bytes_per_launch": alg_bytes, "avg_launch_ms": kern_ms,
                          "launches_timed": nlaunch},
         }

@@ -285,7 +285,15 @@ int mrgingham_amd_debug_paths(mrgingham_amd_ctx* ctx, int level, int nframes, in
 /* Device memory the context currently holds (level scratch of both sets, point scratch, staging). */
 long long mrgingham_amd_scratch_bytes(const mrgingham_amd_ctx* ctx);
 
+/* How the most recent mrgingham_amd_chain_batch call was launched (for benchmarks that price the level-0
+ * kernel): *fused_pyramid = 1 when the level-0 response kernel also wrote the level images 1..3 (frames of
+ * whole 16 x 8 blocks, option "fuse_pyramid"), 0 when a separate pyramid kernel did; *merged_levels = number
+ * of levels whose responses shared one launch (0 = one launch per level).  Either pointer may be NULL. */
+int mrgingham_amd_chain_info(const mrgingham_amd_ctx* ctx, int* fused_pyramid, int* merged_levels);
+
 /* Tunables outside the reference's surface.  Known names:
+ *   "fuse_pyramid"        1 (default): chain calls on frames of whole 16 x 8 blocks take the level images
+ *                         1..3 out of the level-0 response kernel; 0: separate pyramid kernel
  *   "hot_capacity_shift"  per-frame capacity of the hot-pixel / component tables is
  *                         (width*height) >> shift entries (default 3; 0 = one per pixel)
  *   "chess_v0"            1 = use the plain reference-shaped ChESS kernel (cross-check)

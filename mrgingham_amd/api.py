@@ -413,6 +413,13 @@ class Detector:
         self._check(self.L.mrgingham_amd_debug_paths(self.ctx, int(level), int(nframes), out.ctypes.data))
         return out
 
+    def chain_info(self):
+        """(fused_pyramid, merged_levels) of the most recent chain() call: whether the level-0 response kernel
+        also wrote the level images, and how many levels shared one response launch."""
+        f, m = ctypes.c_int(0), ctypes.c_int(0)
+        self._check(self.L.mrgingham_amd_chain_info(self.ctx, ctypes.byref(f), ctypes.byref(m)))
+        return bool(f.value), int(m.value)
+
     def scratch_bytes(self):
         """Device memory the context holds right now."""
         return int(self.L.mrgingham_amd_scratch_bytes(self.ctx))

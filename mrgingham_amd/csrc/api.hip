@@ -125,6 +125,8 @@ struct mrgingham_amd_ctx {
     // boundaries fewer per step, 1.129 -> 1.113 ms per 64 frames of 4096x3072); 2 = levels 0..3 in one
     // launch (measured slower: 1.171 ms)
     int multi_level = 1;
+    int last_fused = 0, last_merged = 0;  // mrgingham_amd_chain_info
+    int fuse_pyramid = 1;   // option "fuse_pyramid": chain calls take the level images 1..3 out of the level-0 response kernel
     // component-chain schedule of chain_batch: 0 = every level's component kernels start as soon as
     // that level's response is done; 1 (default) = levels 1 and 0 wait for the level-0 response (they then
     // run underneath the NEXT call's pyramid and small levels instead of underneath this call's level 0:
@@ -405,16 +407,22 @@ static void end_op(mrgingham_amd_ctx* ctx) {
 }
 
 // Level images of levels [1, max_level] of the batch into the level scratch, on the pixel stream.
-static void queue_level_images(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int max_level) {
-    const FrameBatch fb{fr->frames, fr->frame_pitch, fr->width, fr->height, fr->stride};
+static PyramidOut pyramid_out_of(mrgingham_amd_ctx* ctx, int max_level) {
     PyramidOut po{};
-    int top = max_level < 3 ? max_level : 3;
+    const int top = max_level < 3 ? max_level : 3;
     for (int L = 1; L <= top; ++L) {
         po.out[L - 1] = (uint8_t*)cur_levels(ctx)[L].img.p;
         po.w[L - 1] = cur_levels(ctx)[L].w;
         po.h[L - 1] = cur_levels(ctx)[L].h;
     }
-    if (top >= 1) launch_pyramid(fb, po, top, fr->nframes, ctx->pix);
+    return po;
+}
+// `levels_1_to_3` false: those come out of the level-0 response kernel (launch_chess_pyramid)
+static void queue_level_images(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int max_level,
+                               bool levels_1_to_3 = true) {
+    const FrameBatch fb{fr->frames, fr->frame_pitch, fr->width, fr->height, fr->stride};
+    const int top = max_level < 3 ? max_level : 3;
+    if (top >= 1 && levels_1_to_3) launch_pyramid(fb, pyramid_out_of(ctx, max_level), top, fr->nframes, ctx->pix);
     for (int L = 4; L <= max_level; ++L)
         launch_decimate(fb, L, (uint8_t*)cur_levels(ctx)[L].img.p, (long long)cur_levels(ctx)[L].w * cur_levels(ctx)[L].h,
                         cur_levels(ctx)[L].w, cur_levels(ctx)[L].h, 0, fr->nframes, ctx->pix);
@@ -565,6 +573,13 @@ int mrgingham_amd_debug_paths(mrgingham_amd_ctx* ctx, int level, int nframes, in
     return MRGINGHAM_AMD_OK;
 }
 
+int mrgingham_amd_chain_info(const mrgingham_amd_ctx* ctx, int* fused_pyramid, int* merged_levels) {
+    if (!ctx) return MRGINGHAM_AMD_ERR_ARG;
+    if (fused_pyramid) *fused_pyramid = ctx->last_fused;
+    if (merged_levels) *merged_levels = ctx->last_merged;
+    return 0;
+}
+
 long long mrgingham_amd_scratch_bytes(const mrgingham_amd_ctx* ctx) {
     if (!ctx) return 0;
     long long total = 0;
@@ -600,6 +615,7 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
     if (!strcmp(name, "chess_v0")) { ctx->use_v0 = value != 0; return 0; }
     if (!strcmp(name, "multi_level_launch")) { ctx->multi_level = value < 0 ? 0 : value > 2 ? 2 : value; return 0; }
     if (!strcmp(name, "cc_schedule")) { ctx->cc_schedule = value; return 0; }
+    if (!strcmp(name, "fuse_pyramid")) { ctx->fuse_pyramid = value != 0; return 0; }
     if (!strcmp(name, "cc_lds")) { ctx->cc_lds = value; return 0; }
     if (!strcmp(name, "chess_multi_min_blocks")) { mrg::chess_multi_min_blocks = value; return 0; }
     if (!strcmp(name, "chess_stage")) { mrg::chess_stage_override = value; return 0; }
@@ -882,12 +898,40 @@ int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames
         order_after_previous(ctx, {{(const char*)d_points, np * 16}, {(const char*)d_levels, np},
                                    {(const char*)d_npoints, (size_t)fr->nframes * 4}}, {});
     }
-    // pixel stream: every level image in one pass over the frames, then the responses top-down
-    queue_level_images(ctx, fr, start_level);
     LevelBatch lbs[kMaxLevel + 1];
+    hipEvent_t lev_ev[kMaxLevel + 1] = {};
+    auto note_pending = [&](int L) {
+        if (fr->nframes > ctx->pending_frames[ctx->cur][L]) ctx->pending_frames[ctx->cur][L] = fr->nframes;
+    };
+    // pixel stream.  Frames of whole 16 x 8 blocks (every BASELINE size): level 0 first, its kernel also
+    // writes the level images 1..3 out of the rows it holds in LDS anyway, so the batch is read from HBM
+    // once instead of twice; the small levels follow.  Other shapes: every level image in one pass over
+    // the frames (pyramid kernel), then the responses top-down.
+    lbs[0] = level_batch_of(ctx, fr, 0);
+    const bool fused = ctx->fuse_pyramid && !ctx->use_v0 && start_level >= 1 && ctx->multi_level != 2 &&
+                       chess_pyramid_ok(lbs[0], fr->nframes);
+    queue_level_images(ctx, fr, start_level, !fused);
+    if (fused) {
+        hipEvent_t e0 = nullptr;
+        if (ctx->timing) {
+            e0 = timing_event(ctx);
+            hipEventRecord(e0, ctx->pix);
+        }
+        launch_chess_pyramid(lbs[0], tables_of(ctx, 0), pyramid_out_of(ctx, start_level), fr->nframes, ctx->pix);
+        if (e0) {
+            hipEvent_t e1 = timing_event(ctx);
+            hipEventRecord(e1, ctx->pix);
+            ctx->events.emplace_back(e0, e1);
+            lev_ev[0] = e1;
+        }  // else: the event behind level 1 stands in (the component chain reaches level 0 last anyway)
+        note_pending(0);
+    }
     // levels 3 (or the top), 2, 1 -- or all of them, level 0 included -- in one launch when the shapes
-    // allow it
+    // allow it.  Every hipEventRecord on the pixel stream is a packet of its own between two kernels
+    // (~4 us each in the kernel trace), so a boundary gets ONE: the levels of a merged launch share an
+    // event, and with kernel timing on the timing marks double as the hand-over events.
     bool merged = false;
+    hipEvent_t before_l0 = nullptr;  // timing mode: an event recorded right before the level-0 launch, if there is one
     const int top = start_level < 3 ? start_level : 3;
     const int lowest = ctx->multi_level == 2 ? 0 : 1;  // lowest level inside the merged launch
     if (top - lowest >= 1 && !ctx->use_v0 && ctx->multi_level) {
@@ -900,34 +944,72 @@ int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames
         }
         // decided BEFORE anything is queued: a level must not be appended to its hot list twice
         if (chess_multi_ok(mlb, n, fr->nframes)) {
-            for (int L = start_level; L > top; --L) lbs[L] = queue_level_chess(ctx, fr, L);
-            hipEvent_t e0 = nullptr, e1 = nullptr;
+            for (int L = start_level; L > top; --L) {
+                lbs[L] = queue_level_chess(ctx, fr, L);
+                lev_ev[L] = ctx->ev_pix[L];
+            }
+            hipEvent_t e0 = nullptr;
             if (lowest == 0 && ctx->timing) {
                 e0 = timing_event(ctx);
-                e1 = timing_event(ctx);
                 hipEventRecord(e0, ctx->pix);
             }
             merged = launch_chess_multi(mlb, mt, n, fr->nframes, ctx->pix);
-            if (e0) {
-                hipEventRecord(e1, ctx->pix);
-                ctx->events.emplace_back(e0, e1);
+            if (merged) {
+                hipEvent_t em = (ctx->timing && !fused) ? timing_event(ctx) : ctx->ev_pix[top];
+                hipEventRecord(em, ctx->pix);
+                if (e0) ctx->events.emplace_back(e0, em);  // all levels in one launch: that launch is what is timed
+                else if (ctx->timing) before_l0 = em;
+                for (int L = top; L >= lowest; --L) {
+                    lbs[L] = mlb[L - lowest];
+                    lev_ev[L] = em;
+                    note_pending(L);
+                }
+            } else if (e0) {
+                ctx->event_pool.push_back(e0);
             }
         }
-        if (merged)
-            for (int L = top; L >= lowest; --L) {
-                lbs[L] = mlb[L - lowest];
-                hipEventRecord(ctx->ev_pix[L], ctx->pix);
-                if (fr->nframes > ctx->pending_frames[ctx->cur][L]) ctx->pending_frames[ctx->cur][L] = fr->nframes;
-            }
     }
-    for (int L = merged ? lowest - 1 : start_level; L >= 0; --L) lbs[L] = queue_level_chess(ctx, fr, L);
+    for (int L = merged ? lowest - 1 : start_level; L >= 1; --L) {
+        lbs[L] = queue_level_chess(ctx, fr, L);
+        lev_ev[L] = ctx->ev_pix[L];
+    }
+    if (fused) {
+        if (!lev_ev[0]) lev_ev[0] = lev_ev[1];
+    } else if (!(merged && lowest == 0)) {  // level 0 on its own
+        const CompTables t0 = tables_of(ctx, 0);
+        if (ctx->timing) {
+            hipEvent_t e0 = before_l0;
+            if (!e0) {
+                e0 = timing_event(ctx);
+                hipEventRecord(e0, ctx->pix);
+            }
+            launch_chess_any(ctx, lbs[0], t0, fr->nframes, true, true, ctx->pix, false);
+            hipEvent_t e1 = timing_event(ctx);
+            hipEventRecord(e1, ctx->pix);
+            ctx->events.emplace_back(e0, e1);
+            lev_ev[0] = e1;
+        } else {
+            launch_chess_any(ctx, lbs[0], t0, fr->nframes, true, true, ctx->pix, false);
+            hipEventRecord(ctx->ev_pix[0], ctx->pix);
+            lev_ev[0] = ctx->ev_pix[0];
+        }
+        note_pending(0);
+    }
+    ctx->last_fused = fused;
+    ctx->last_merged = merged ? top - lowest + 1 : 0;
     // component stream: detect at the top (mrgingham.cc:50), candidates -> corners
     // (find_grid.cc:353-354), then refine level by level (mrgingham.cc:87-99)
-    MRG_HIP_CHECK(hipStreamWaitEvent(cur_cc(ctx), ctx->ev_pix[ctx->cc_schedule == 2 ? 0 : start_level], 0));
+    // which pixel-stream event a level's search waits for: level 0 runs LAST on the pixel stream in the
+    // classic order (cc_schedule 1 holds levels 1 and 0 back until then, 2 holds everything back) and
+    // FIRST in the fused order (then level 1 is the last)
+    auto gate_of = [&](int L) {
+        if (fused) return lev_ev[ctx->cc_schedule == 2 ? 1 : (L > 1 ? L : 1)];
+        return lev_ev[(ctx->cc_schedule == 1 && L <= 1) || ctx->cc_schedule == 2 ? 0 : L];
+    };
+    MRG_HIP_CHECK(hipStreamWaitEvent(cur_cc(ctx), gate_of(start_level), 0));
     launch_cc_detect(lbs[start_level], tables_of(ctx, start_level), start_level, out, 0, fr->nframes, cur_cc(ctx));
     for (int L = start_level - 1; L >= 0; --L) {
-        const int gate = (ctx->cc_schedule == 1 && L <= 1) ? 0 : (ctx->cc_schedule == 2 ? 0 : L);
-        MRG_HIP_CHECK(hipStreamWaitEvent(cur_cc(ctx), ctx->ev_pix[gate], 0));
+        MRG_HIP_CHECK(hipStreamWaitEvent(cur_cc(ctx), gate_of(L), 0));
         launch_cc_refine(lbs[L], tables_of(ctx, L), L, io, 0, fr->nframes, cur_cc(ctx));
     }
     end_op(ctx);

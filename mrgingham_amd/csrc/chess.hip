@@ -360,11 +360,78 @@ __device__ __forceinline__ void flush_hot(const uint32_t* hotbuf, int* hotcnt, c
     }
 }
 
+// ---------------------------------------------------------------------------
+// Pyramid levels 1..3 out of the ring (level-0 launches of the chain; frames whose width is a multiple
+// of 16 and height a multiple of 8, i.e. whole cells only, where every level is (a+b+c+d+2)>>2 of four
+// FULL-RESOLUTION pixels -- see decimate.hip).  The 8 frame rows y..y+7 an iteration produces responses
+// for sit complete in the ring, already split into the two pair planes, and a 2x2 cell is exactly one
+// pair of two consecutive rows:
+//   level 1, pixel X of row Y: rows 2Y, 2Y+1, columns 2X, 2X+1     -> plane P0, pair  X      (4 rows x 128)
+//   level 2                  : rows 4Y+1, 4Y+2, columns 4X+1, 4X+2 -> plane P1, pair 2X      (2 rows x 64)
+//   level 3                  : rows 8Y+3, 8Y+4, columns 8X+3, 8X+4 -> plane P1, pair 4X+1    (1 row  x 32)
+// (pairs counted from the strip's first pixel).  That saves the separate pyramid kernel its read of the
+// whole batch.  Wave 3 does all of it: level 1 with eight pixels per lane, then levels 2 (lanes 0..31, four
+// pixels each) and 3 (lanes 32..63, one pixel each) in one pass: 8 ds_read_b128 and ~42 VALU per iteration.
+// It has to be that wave: it is the one that stages nothing, so (a) it has some issue slots to spare and
+// (b) it never waits on vmcnt inside the loop.  On a staging wave ANY store is poison: vmcnt retires in
+// order, the wave waits for its prefetched rows twice per iteration, and hipcc's wait-count insertion turns
+// a store in divergent control flow into vmcnt(0) at those waits -- the workgroup then sits at the barrier
+// for the latency of a store.  Measured per launch (64 frames of 4096x3072, pipeline, plain kernel 645 us):
+//   all of it on wave 3 via LDS (this code)                       743 us
+//   levels 2, 3 on wave 2 instead                                 +55 us
+//   cells built in registers on every wave with v_permlane32_swap (no LDS reads, 10-19 VALU per wave),
+//   stores from the waves that hold them                          778 us; stores moved behind the ring
+//   store 875 us; the cell arithmetic alone (nothing stored) already +72 us: the kernel is VALU-bound,
+//   so 8 pixels per lane on one wave beats 2 pixels per lane on four
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t cells4(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
+    // v = (left column sum, right column sum) of a cell as u16 halves; four cells -> four bytes
+    const uint32_t lo01 = __builtin_amdgcn_perm(v1, v0, 0x05040100u), hi01 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const uint32_t lo23 = __builtin_amdgcn_perm(v3, v2, 0x05040100u), hi23 = __builtin_amdgcn_perm(v3, v2, 0x07060302u);
+    const uint32_t s01 = (lo01 + hi01 + 0x00020002u) >> 2, s23 = (lo23 + hi23 + 0x00020002u) >> 2;
+    return __builtin_amdgcn_perm(s23, s01, 0x06040200u);
+}
+__device__ __forceinline__ void emit_pyramid_rows(const char* lds, int y, int strip_x, int w, int frame, int wvu, int lane,
+                                                  const PyramidOut& po) {
+    if (wvu != 3) return;
+    // wave-uniform parts (scalar registers): ring slot of row y, first output pixel of this strip and row group
+    const uint32_t slot0 = (uint32_t)((y + 64) & (V1_NR - 1));  // y is a multiple of 8: rows y..y+7 do not wrap
+    const int j = lane & 15, R = (lane >> 4) & 3;
+    if (po.out[0]) {
+        uint8_t* base = po.out[0] + ((long long)frame * po.h[0] + (y >> 1)) * po.w[0] + (strip_x >> 1);
+        const char* ra = lds + slot0 * V1_ROWB + 2 * V1_HL + (uint32_t)(R * (2 * V1_ROWB) + 32 * j);
+        const u32x4 a0 = lds_read_b128(ra), a1 = lds_read_b128(ra + 16);
+        const u32x4 b0 = lds_read_b128(ra + V1_ROWB), b1 = lds_read_b128(ra + V1_ROWB + 16);
+        uint2 o;
+        o.x = cells4(a0.x + b0.x, a0.y + b0.y, a0.z + b0.z, a0.w + b0.w);
+        o.y = cells4(a1.x + b1.x, a1.y + b1.y, a1.z + b1.z, a1.w + b1.w);
+        if (strip_x + 16 * j < w) *reinterpret_cast<uint2*>(base + (uint32_t)(R * po.w[0] + 8 * j)) = o;
+    }
+    if (po.out[1]) {
+        const bool l3 = lane >= 32;
+        const uint32_t loff = l3 ? 3 * V1_ROWB + 16 * (lane - 32) : (1 + 4 * (R & 1)) * V1_ROWB + 32 * j;
+        const char* ra = lds + slot0 * V1_ROWB + V1_PLANE + 2 * V1_HL + loff;
+        const u32x4 a0 = lds_read_b128(ra), a1 = lds_read_b128(ra + 16);
+        const u32x4 b0 = lds_read_b128(ra + V1_ROWB), b1 = lds_read_b128(ra + V1_ROWB + 16);
+        const uint32_t v0 = l3 ? a0.y + b0.y : a0.x + b0.x;
+        const uint32_t o = cells4(v0, a0.z + b0.z, a1.x + b1.x, a1.z + b1.z);
+        if (!l3) {
+            if (strip_x + 16 * j < w) {
+                uint8_t* base = po.out[1] + ((long long)frame * po.h[1] + (y >> 2)) * po.w[1] + (strip_x >> 2);
+                *reinterpret_cast<uint32_t*>(base + (uint32_t)((R & 1) * po.w[1] + 4 * j)) = o;
+            }
+        } else if (po.out[2] && strip_x + 8 * (lane - 32) < w) {
+            uint8_t* base = po.out[2] + ((long long)frame * po.h[2] + (y >> 3)) * po.w[2] + (strip_x >> 3);
+            base[lane - 32] = (uint8_t)o;
+        }
+    }
+}
+
 // The body of the kernel for workgroup `bid` of `nwg` of one level (the multi-level launch below runs
 // several levels in one grid).
-template <bool CLAMP, bool HOT, int STAGE>
+template <bool CLAMP, bool HOT, int STAGE, bool PYR = false>
 __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTables& t, int frame0, int seg, unsigned bid,
-                                              unsigned nwg_level, char* lds) {
+                                              unsigned nwg_level, char* lds, const PyramidOut* po = nullptr) {
     // XCD-aware work order: workgroup b is dispatched to XCD b % 8 (observed, used
     // for speed only).  Give each XCD a contiguous run of work items, strips
     // fastest, so the 32-pixel column halo and the 10-row segment halo a
@@ -573,6 +640,13 @@ __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTa
                 for (int i = 0; i < w - x0; ++i) dst[i] = (int16_t)(out[i >> 1] >> (16 * (i & 1)));
             }
         }
+        if (PYR) {
+            // after the math, when the window registers are dead: the max-ILP scheduler would otherwise
+            // hoist these LDS reads into the math block and push the kernel over 128 VGPRs (3 waves/SIMD)
+            __builtin_amdgcn_sched_barrier(0);
+            emit_pyramid_rows(lds, y, strip_x, w, frame, wvu, lane, *po);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // LDS-only workgroup barrier: the output stores stay in flight across it
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         __builtin_amdgcn_s_barrier();
@@ -585,6 +659,12 @@ template <bool CLAMP, bool HOT, int STAGE>
 __global__ __launch_bounds__(256) void chess_v1_kernel(LevelBatch lb, CompTables t, int frame0, int seg) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     chess_v1_body<CLAMP, HOT, STAGE>(lb, t, frame0, seg, blockIdx.x, gridDim.x, lds);
+}
+
+// Level 0 of the chain: response + clamp + hot list + the level images 1..3 (see emit_pyramid_rows).
+__global__ __launch_bounds__(256, 4) void chess_v1_pyr_kernel(LevelBatch lb, CompTables t, int seg, PyramidOut po) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    chess_v1_body<true, true, STAGE_PERM16, true>(lb, t, 0, seg, blockIdx.x, gridDim.x, lds, &po);
 }
 
 // Several pyramid levels of the same batch in ONE grid (clamp + hot list, widths that are multiples
@@ -660,6 +740,22 @@ void launch_chess(const LevelBatch& lb, const CompTables& t, int frame0, int nfr
     else { MRG_LAUNCH_ST(false, false) }
 #undef MRG_LAUNCH_ST
 #undef MRG_LAUNCH
+}
+
+// Level 0 with the pyramid fused in; false when the shape does not qualify (whole cells only, 16-byte rows).
+bool chess_pyramid_ok(const LevelBatch& lb, int nframes) {
+    return nframes > 0 && lb.w >= 16 && lb.w % 16 == 0 && lb.h >= 8 && lb.h % 8 == 0 && lb.img_stride % 16 == 0 &&
+           lb.img_pitch % 16 == 0 && ((uintptr_t)lb.img & 15) == 0;
+}
+bool launch_chess_pyramid(const LevelBatch& lb, const CompTables& t, const PyramidOut& po, int nframes, hipStream_t s) {
+    if (!chess_pyramid_ok(lb, nframes)) return false;
+    const int seg = pick_segment(lb.w, lb.h, nframes);  // a multiple of 8: an iteration's rows are whole cells
+    dim3 grid(((lb.w + V1_SW - 1) / V1_SW) * ((lb.h + seg - 1) / seg) * nframes);
+    const size_t lds = 2 * V1_PLANE + (V1_HOTBUF + 4) * sizeof(int);
+    PyramidOut p2 = po;
+    if (const char* e = getenv("MRG_PYR_DEBUG")) for (int k = 0; k < 3; ++k) if (atoi(e) >> k & 1) p2.out[k] = nullptr;
+    hipLaunchKernelGGL(chess_v1_pyr_kernel, grid, dim3(256), lds, s, lb, t, seg, p2);
+    return true;
 }
 
 // Levels lbs[0..n) (n <= 3, largest first) of one batch in one launch; returns false when the shapes do

@@ -7,11 +7,20 @@
 
 namespace mrg {
 
+struct PyramidOut {
+    uint8_t* out[3];  // dense level images of levels 1..3 (NULL = not wanted), frames back to back
+    int w[3], h[3];
+};
+
 // chess.hip
 void launch_chess_v0(const LevelBatch& lb, const CompTables& t, int frame0, int nframes, bool clamp, bool hot,
                      hipStream_t s);
 void launch_chess(const LevelBatch& lb, const CompTables& t, int frame0, int nframes, bool clamp, bool hot,
                   hipStream_t s);
+
+// level 0 of a chain with the level images 1..3 produced by the same kernel (out of its LDS ring)
+bool chess_pyramid_ok(const LevelBatch& lb, int nframes);
+bool launch_chess_pyramid(const LevelBatch& lb, const CompTables& t, const PyramidOut& po, int nframes, hipStream_t s);
 
 bool chess_multi_ok(const LevelBatch* lbs, int n, int nframes);
 bool launch_chess_multi(const LevelBatch* lbs, const CompTables* ts, int n, int nframes, hipStream_t s);
@@ -27,10 +36,6 @@ struct FrameBatch {
 };
 void launch_decimate(const FrameBatch& in, int level, uint8_t* out, long long out_pitch, int ow, int oh, int frame0,
                      int nframes, hipStream_t s);
-struct PyramidOut {
-    uint8_t* out[3];  // dense level images of levels 1..3 (NULL = not wanted), frames back to back
-    int w[3], h[3];
-};
 void launch_pyramid(const FrameBatch& in, const PyramidOut& po, int top, int nframes, hipStream_t s);
 void launch_box_blur(const FrameBatch& in, int radius, uint8_t* out, int frame0, int nframes, hipStream_t s);
 

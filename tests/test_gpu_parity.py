@@ -385,3 +385,30 @@ def test_multi_level_launch_option_gives_the_same_chain(mode):
         assert int(npts[0]) == len(wp) and np.array_equal(pts[0, :len(wp)].cpu().numpy(), wp)
     finally:
         d2.close()
+
+
+@pytest.mark.parametrize("fuse,multi", [(1, 1), (1, 0), (0, 1)])
+def test_fused_pyramid_option_gives_the_same_chain(fuse, multi):
+    """set_option("fuse_pyramid", 1) (the default): chain calls on frames of whole 16 x 8 blocks take the level
+    images 1..3 out of the level-0 response kernel; 0 = the separate pyramid kernel.  Same corners either way
+    (and the same as the oracle's), for every start level, strips that end inside a 256-pixel strip included."""
+    d2 = mrgingham_amd.Detector(0)
+    try:
+        d2.set_option("fuse_pyramid", fuse)
+        d2.set_option("multi_level_launch", multi)
+        for (w, h) in ((1280, 960), (1328, 984), (272, 264)):
+            frames = np.stack([synth.board_frame(w, h, 10, s).numpy() for s in (0, 3)] +
+                              [synth.noise_frame(w, h, 2, smooth=1).numpy()])
+            d = _cuda(frames)
+            for start in (3, 2, 1, 4):
+                if min(w, h) >> start < 32:
+                    continue
+                pts, lv, npts = d2.chain(d, start_level=start, max_points=4096)
+                for f in range(len(frames)):
+                    wp, wl = oracle.chain(frames[f], start)
+                    n = int(npts[f])
+                    assert n == len(wp), (w, h, start, f)
+                    assert np.array_equal(pts[f, :n].cpu().numpy(), wp), (w, h, start, f)
+                    assert np.array_equal(lv[f, :n].cpu().numpy(), wl), (w, h, start, f)
+    finally:
+        d2.close()

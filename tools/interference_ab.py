@@ -52,6 +52,12 @@ settings = [
     ("merged small levels: min blocks 512", {"OPTIONS": "chess_multi_min_blocks=512"}),
     ("merged small levels: min blocks 256", {"OPTIONS": "chess_multi_min_blocks=256"}),
     ("LDS search without s_setprio 3", {"OPTIONS": "cc_lds=17"}),
+    ("dbg fused, nothing emitted", {"MRG_PYR_DEBUG": "7"}),
+    ("dbg fused, level 1 only", {"MRG_PYR_DEBUG": "6"}),
+    ("dbg fused, levels 2+3 only", {"MRG_PYR_DEBUG": "1"}),
+    ("dbg fused, level 3 only", {"MRG_PYR_DEBUG": "3"}),
+    ("separate pyramid kernel", {"OPTIONS": "fuse_pyramid=0"}),
+    ("fused pyramid + schedule 2", {"OPTIONS": "cc_schedule=2"}),
     ("baseline again", {}),
 ]
 flt = sys.argv[1] if len(sys.argv) > 1 else ""

@@ -39,13 +39,17 @@ def grab(fn, kernel_grid, ctr):
     return float(re.search(re.escape(ctr) + r"\s+mean\s+([0-9.]+)", blk).group(1))
 
 
-kg = "chess_v1_kernel<true, true, 1>  grid=3145728"
+fused = "chess_v1_pyr_kernel" in rd("pmc_rd.txt")
+kg = "chess_v1_pyr_kernel  grid=3145728" if fused else "chess_v1_kernel<true, true, 1>  grid=3145728"
 rdb = 128 * grab("pmc_rd", kg, "TCC_EA0_RDREQ_128B") + 64 * grab("pmc_rd", kg, "TCC_EA0_RDREQ_64B") + 32 * grab("pmc_rd", kg, "TCC_EA0_RDREQ_32B")
 wr64, wrall = grab("pmc_wr", kg, "TCC_EA0_WRREQ_64B"), grab("pmc_wr", kg, "TCC_EA0_WRREQ ")
 wrb = 64 * wr64 + 32 * (wrall - wr64)
 px = 64 * 4096 * 3072
 j = json.load(open(os.path.join(P, "chess_l0_traffic.json")))
-j["kernel"] = "mrg::chess_v1_kernel<true, true, 1> (CLAMP, HOT, STAGE_PERM16)"
+j["kernel"] = ("mrg::chess_v1_pyr_kernel (CLAMP, HOT, STAGE_PERM16, + level images 1..3)" if fused else
+               "mrg::chess_v1_kernel<true, true, 1> (CLAMP, HOT, STAGE_PERM16)")
+j["algorithmic_bytes_per_pixel"] = 3.328125 if fused else 3.0
+j["_comment"] = re.sub(r"mrg::chess_v1\w*(<true,true>)?", j["kernel"].split(" ")[0], j["_comment"])
 j["source"] = f"profiles/{RND}_bench_pmc_ea_traffic.txt"
 j["_comment"] = j["_comment"].replace("round 1, profiles/r01_bench_pmc_ea_traffic.txt", f"round {RND[1:]}, profiles/{RND}_bench_pmc_ea_traffic.txt")
 j.update(read_bytes=int(rdb), write_bytes=int(wrb), fetch_size_kib_raw=grab("pmc_fetch", kg, "FETCH_SIZE"),

@@ -34,6 +34,30 @@ def main(path):
               f"{min(d) / 1e3:10.1f} {max(d) / 1e3:10.1f} {sum(d) / 1e6:9.2f} {vg:5d} {sg:5d} {lds:6d}")
     print(f"# mrg:: kernels total {tot / 1e6:.2f} ms; other kernels (synthetic-frame generator, fills, copies): "
           f"{other[0]} calls, {other[1] / 1e6:.2f} ms")
+    # idle time of the pixel stream between its kernels (pyramid -> small levels -> level 0 -> next pyramid)
+    try:
+        cols = [r[1] for r in c.execute("pragma table_info(kernels)").fetchall()]
+        if "start" in cols and "end" in cols:
+            pix = c.execute("select name, start, end from kernels where name like '%pyramid%' or name like '%chess_v1%' "
+                            "order by start").fetchall()
+            gaps = [(pix[i + 1][1] - pix[i][2]) / 1e3 for i in range(len(pix) - 1)]
+            kinds = {}
+            for i, g in enumerate(gaps):
+                if 0 <= g < 200:
+                    short = lambda n: ("chess+pyramid" if "chess_v1_pyr" in n else "pyramid" if "pyramid" in n
+                                       else "multi" if "multi" in n else "chess")
+                    kinds.setdefault(short(pix[i][0]) + " -> " + short(pix[i + 1][0]), []).append(g)
+            for k, v in sorted(kinds.items()):
+                v.sort()
+                print(f"#   {k:20s} n={len(v):4d}  median {v[len(v) // 2]:6.1f} us  mean {sum(v) / len(v):6.1f} us")
+            gaps = [g for g in gaps if 0 <= g < 200]          # drop the host-side pauses between phases of the run
+            steps = sum(1 for n, _, _ in pix if "pyramid" in n or "chess_v1_pyr" in n)
+            if gaps and steps:
+                gaps.sort()
+                print(f"# pixel stream: {len(gaps)} kernel boundaries, median gap {gaps[len(gaps) // 2]:.1f} us, mean "
+                      f"{sum(gaps) / len(gaps):.1f} us, {sum(gaps) / steps:.1f} us per step ({steps} steps)")
+    except sqlite3.Error as e:
+        print(f"# (no gap analysis: {e})")
 
 
 if __name__ == "__main__":
