@@ -1006,11 +1006,13 @@ int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames
         if (fused) return lev_ev[ctx->cc_schedule == 2 ? 1 : (L > 1 ? L : 1)];
         return lev_ev[(ctx->cc_schedule == 1 && L <= 1) || ctx->cc_schedule == 2 ? 0 : L];
     };
+    const bool no_cc = (ctx->cc_lds & 128) != 0;  // timing experiment only (tools/interference_ab.py): pixel kernels alone
     MRG_HIP_CHECK(hipStreamWaitEvent(cur_cc(ctx), gate_of(start_level), 0));
-    launch_cc_detect(lbs[start_level], tables_of(ctx, start_level), start_level, out, 0, fr->nframes, cur_cc(ctx));
+    if (!no_cc)
+        launch_cc_detect(lbs[start_level], tables_of(ctx, start_level), start_level, out, 0, fr->nframes, cur_cc(ctx));
     for (int L = start_level - 1; L >= 0; --L) {
         MRG_HIP_CHECK(hipStreamWaitEvent(cur_cc(ctx), gate_of(L), 0));
-        launch_cc_refine(lbs[L], tables_of(ctx, L), L, io, 0, fr->nframes, cur_cc(ctx));
+        if (!no_cc) launch_cc_refine(lbs[L], tables_of(ctx, L), L, io, 0, fr->nframes, cur_cc(ctx));
     }
     end_op(ctx);
     MRG_HIP_CHECK(hipGetLastError());

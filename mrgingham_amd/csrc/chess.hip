@@ -397,24 +397,25 @@ __device__ __forceinline__ void emit_pyramid_rows(const char* lds, int y, int st
     // wave-uniform parts (scalar registers): ring slot of row y, first output pixel of this strip and row group
     const uint32_t slot0 = (uint32_t)((y + 64) & (V1_NR - 1));  // y is a multiple of 8: rows y..y+7 do not wrap
     const int j = lane & 15, R = (lane >> 4) & 3;
+    // all eight reads first, then the arithmetic: one LDS latency per iteration instead of two
+    const bool l3 = lane >= 32;
+    const char* r1 = lds + slot0 * V1_ROWB + 2 * V1_HL + (uint32_t)(R * (2 * V1_ROWB) + 32 * j);
+    const uint32_t loff = l3 ? 3 * V1_ROWB + 16 * (lane - 32) : (1 + 4 * (R & 1)) * V1_ROWB + 32 * j;
+    const char* r2 = lds + slot0 * V1_ROWB + V1_PLANE + 2 * V1_HL + loff;
+    const u32x4 a0 = lds_read_b128(r1), a1 = lds_read_b128(r1 + 16);
+    const u32x4 b0 = lds_read_b128(r1 + V1_ROWB), b1 = lds_read_b128(r1 + V1_ROWB + 16);
+    const u32x4 c0 = lds_read_b128(r2), c1 = lds_read_b128(r2 + 16);
+    const u32x4 d0 = lds_read_b128(r2 + V1_ROWB), d1 = lds_read_b128(r2 + V1_ROWB + 16);
     if (po.out[0]) {
         uint8_t* base = po.out[0] + ((long long)frame * po.h[0] + (y >> 1)) * po.w[0] + (strip_x >> 1);
-        const char* ra = lds + slot0 * V1_ROWB + 2 * V1_HL + (uint32_t)(R * (2 * V1_ROWB) + 32 * j);
-        const u32x4 a0 = lds_read_b128(ra), a1 = lds_read_b128(ra + 16);
-        const u32x4 b0 = lds_read_b128(ra + V1_ROWB), b1 = lds_read_b128(ra + V1_ROWB + 16);
         uint2 o;
         o.x = cells4(a0.x + b0.x, a0.y + b0.y, a0.z + b0.z, a0.w + b0.w);
         o.y = cells4(a1.x + b1.x, a1.y + b1.y, a1.z + b1.z, a1.w + b1.w);
         if (strip_x + 16 * j < w) *reinterpret_cast<uint2*>(base + (uint32_t)(R * po.w[0] + 8 * j)) = o;
     }
     if (po.out[1]) {
-        const bool l3 = lane >= 32;
-        const uint32_t loff = l3 ? 3 * V1_ROWB + 16 * (lane - 32) : (1 + 4 * (R & 1)) * V1_ROWB + 32 * j;
-        const char* ra = lds + slot0 * V1_ROWB + V1_PLANE + 2 * V1_HL + loff;
-        const u32x4 a0 = lds_read_b128(ra), a1 = lds_read_b128(ra + 16);
-        const u32x4 b0 = lds_read_b128(ra + V1_ROWB), b1 = lds_read_b128(ra + V1_ROWB + 16);
-        const uint32_t v0 = l3 ? a0.y + b0.y : a0.x + b0.x;
-        const uint32_t o = cells4(v0, a0.z + b0.z, a1.x + b1.x, a1.z + b1.z);
+        const uint32_t v0 = l3 ? c0.y + d0.y : c0.x + d0.x;
+        const uint32_t o = cells4(v0, c0.z + d0.z, c1.x + d1.x, c1.z + d1.z);
         if (!l3) {
             if (strip_x + 16 * j < w) {
                 uint8_t* base = po.out[1] + ((long long)frame * po.h[1] + (y >> 2)) * po.w[1] + (strip_x >> 2);

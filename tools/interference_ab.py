@@ -56,6 +56,8 @@ settings = [
     ("dbg fused, level 1 only", {"MRG_PYR_DEBUG": "6"}),
     ("dbg fused, levels 2+3 only", {"MRG_PYR_DEBUG": "1"}),
     ("dbg fused, level 3 only", {"MRG_PYR_DEBUG": "3"}),
+    ("pixel kernels only (no component kernels; results meaningless)", {"OPTIONS": "cc_lds=129"}),
+    ("pixel kernels only, separate pyramid kernel", {"OPTIONS": "cc_lds=129,fuse_pyramid=0"}),
     ("separate pyramid kernel", {"OPTIONS": "fuse_pyramid=0"}),
     ("fused pyramid + schedule 2", {"OPTIONS": "cc_schedule=2"}),
     ("baseline again", {}),
