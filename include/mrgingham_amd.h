@@ -278,8 +278,10 @@ int mrgingham_amd_find_boards_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_
                                     int nthreads);
 
 /* TEST HOOK: which implementation of the component search handled each frame of the most recent call at
- * `level`: h_paths[f] = 1 out of LDS, 0 the global-memory kernels (more than 2048 hot pixels, more than 512
- * multi-pixel components / points, or more LIFO demand than the LDS tables hold).  Synchronises. */
+ * `level`: h_paths[f] = 1 out of LDS, 0 the global-memory kernels (hot pixels that cannot be cut into bands
+ * of at most 2048, more than 512 multi-pixel components per band / points, or more LIFO demand than the LDS
+ * tables hold), 2 = a refinement the LDS kernel began band by band and the global-memory kernel finished.
+ * Synchronises. */
 int mrgingham_amd_debug_paths(mrgingham_amd_ctx* ctx, int level, int nframes, int32_t* h_paths);
 
 /* Device memory the context currently holds (level scratch of both sets, point scratch, staging). */
@@ -299,8 +301,10 @@ int mrgingham_amd_chain_info(const mrgingham_amd_ctx* ctx, int* fused_pyramid, i
  *   "chess_v0"            1 = use the plain reference-shaped ChESS kernel (cross-check)
  *   "multi_level_launch"  chain_batch: 0 = one ChESS launch per pyramid level, 1 (default) = levels 3..1 in one
  *                         launch, 2 = all levels in one launch
- *   "cc_lds"              1 (default) = component search out of LDS for frames with at most 2048 hot pixels
- *                         (the global-memory kernels take the others), 0 = global-memory kernels only
+ *   "cc_lds"              1 (default) = component search out of LDS: frames with at most 2048 hot pixels in one
+ *                         pass, frames with up to 16384 in bands of rows separated by three rows without a hot
+ *                         pixel (the global-memory kernels take what is left), 0 = global-memory kernels only;
+ *                         1 | 256 = no banding (test hook)
  *   "cc_schedule", "chess_seg", "chess_stage"   experiment hooks (tools/interference_ab.py, tools/stage_ab.py) */
 int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value);
 

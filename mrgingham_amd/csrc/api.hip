@@ -132,12 +132,6 @@ struct mrgingham_amd_ctx {
     // run underneath the NEXT call's pyramid and small levels instead of underneath this call's level 0:
     // same step time, level-0 launch 668 -> 657 us); 2 = every level waits for the level-0 response
     int cc_schedule = 1;
-    // Host-mapped hint words, one per level (CompTables::big_hint): a kernel stores 1 when a frame needed the
-    // 4096-entry LDS tables.  Read without synchronisation when a call is queued; cleared every 1024 calls so
-    // that a stream whose frames got simpler stops paying for the larger kernel.
-    int* big_hint_host = nullptr;
-    int* big_hint_dev = nullptr;
-    unsigned big_hint_age = 0;
     int cc_lds = 1;  // component search out of LDS for frames with few hot pixels (option "cc_lds"; bits 1-3: timing ablations)
 
     mrg::LevelScratch lvs[2][mrg::kMaxLevel + 1];
@@ -331,10 +325,6 @@ static CompTables tables_of(mrgingham_amd_ctx* ctx, int level) {
     t.status = status_of(ctx, level);
     t.path = path_of(ctx, level);
     t.lds_path = ctx->cc_lds;
-    t.big_hint = ctx->big_hint_dev ? ctx->big_hint_dev + level : nullptr;
-    t.use_big = ctx->big_hint_host ? (*(volatile int*)(ctx->big_hint_host + level) != 0) : 0;
-    if (ctx->cc_lds & 32) t.use_big = 1;       // tuning hook: always
-    if (ctx->cc_lds & 64) t.use_big = 0;       // tuning hook: never
     return t;
 }
 
@@ -368,8 +358,6 @@ static void launch_chess_any(mrgingham_amd_ctx* ctx, const LevelBatch& lb, const
 static void begin_op(mrgingham_amd_ctx* ctx, int max_level) {
     (void)max_level;
     ctx->cur ^= 1;  // this set was last used two calls ago
-    if (ctx->big_hint_host && (++ctx->big_hint_age & 1023u) == 0)  // re-probe: kernels set the words again if still needed
-        for (int L = 0; L <= kMaxLevel; ++L) *(volatile int*)(ctx->big_hint_host + L) = 0;
     if (ctx->cc_pending[ctx->cur]) hipStreamWaitEvent(ctx->pix, ctx->ev_cc_done[ctx->cur], 0);
     // The hot-pixel counters of this set are zero here: they are zeroed at allocation and again by
     // end_op behind the component kernels that consumed them -- on the component stream, off the
@@ -519,11 +507,6 @@ mrgingham_amd_ctx* mrgingham_amd_create(int device_ordinal) {
          hipEventCreateWithFlags(&ctx->ev_cc_done[1], hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i <= kMaxLevel; ++i)
         ok = hipEventCreateWithFlags(&ctx->ev_pix[i], hipEventDisableTiming) == hipSuccess;
-    if (ok && hipHostMalloc((void**)&ctx->big_hint_host, (kMaxLevel + 1) * sizeof(int), hipHostMallocMapped) == hipSuccess) {
-        memset(ctx->big_hint_host, 0, (kMaxLevel + 1) * sizeof(int));
-        if (hipHostGetDevicePointer((void**)&ctx->big_hint_dev, ctx->big_hint_host, 0) != hipSuccess)
-            ctx->big_hint_dev = nullptr;  // no hint: the larger LDS kernels are never launched, the global ones take over
-    }
     if (!ok) {
         fprintf(stderr, "mrgingham_amd: could not create HIP streams/events\n");
         mrgingham_amd_destroy(ctx);
@@ -557,7 +540,6 @@ void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx) {
     for (hipEvent_t e : ctx->ev_cc_done)
         if (e) hipEventDestroy(e);
     if (ctx->ev_ext) hipEventDestroy(ctx->ev_ext);
-    if (ctx->big_hint_host) hipHostFree(ctx->big_hint_host);
     if (ctx->pix) hipStreamDestroy(ctx->pix);
     for (hipStream_t c : ctx->ccs)
         if (c) hipStreamDestroy(c);

@@ -130,7 +130,7 @@ constexpr int CCL_THREADS = 1024;
 // per-root pixel count, bounding box and smallest raster position.  Workgroup barriers in between.
 __global__ __launch_bounds__(CCL_THREADS) void cc_label_kernel(LevelBatch lb, CompTables t, int frame0) {
     const int frame = frame0 + blockIdx.y;
-    if (t.lds_path && t.path[frame]) return;  // done out of LDS
+    if (t.lds_path && t.path[frame] == 1) return;  // done out of LDS
     if (t.hot_cnt[frame] > t.cap) return;  // overflow is reported by the per-frame kernel
     const FrameView v = make_view(lb, t, frame);
     const int w = v.w;
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(CC_THREADS) void cc_detect_kernel(LevelBatch lb, Co
     // latency-bound and tiny next to the pixel kernels it shares CUs with: take issue priority
     __builtin_amdgcn_s_setprio(3);
     const int frame = frame0 + blockIdx.x;
-    if (t.lds_path && t.path[frame]) return;  // done out of LDS
+    if (t.lds_path && t.path[frame] == 1) return;  // done out of LDS
     if (t.hot_cnt[frame] > t.cap) {  // table overflow: report, produce nothing
         if (threadIdx.x == 0) {
             wg_or(t.status + frame, kStatusHotOverflow);
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, Co
     __shared__ unsigned long long s_arena_top;
     __builtin_amdgcn_s_setprio(3);
     const int frame = frame0 + blockIdx.x;
-    if (t.lds_path && t.path[frame]) return;  // done out of LDS
+    if (t.lds_path && t.path[frame] == 1) return;  // done out of LDS
     if (t.hot_cnt[frame] > t.cap) {
         if (threadIdx.x == 0) {
             wg_or(t.status + frame, kStatusHotOverflow);
@@ -577,7 +577,10 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, Co
     __syncthreads();
     if (threadIdx.x == 0) {
         if (s_arena_full) wg_or(v.status, kStatusCandOverflow);  // points refined so far stay refined; the call fails
-        if (io.nrefined) io.nrefined[frame] = s_arena_full ? -1 : s_nref;
+        // path 2: the LDS kernel refined the points of the bands it finished before it gave up (their count
+        // is in nrefined already); what is refined here is the rest
+        const int before = (t.lds_path && t.path[frame] == 2 && io.nrefined) ? io.nrefined[frame] : 0;
+        if (io.nrefined) io.nrefined[frame] = s_arena_full ? -1 : before + s_nref;
     }
 }
 
@@ -601,12 +604,24 @@ void launch_cc_refine(const LevelBatch& lb, const CompTables& t, int level, cons
 // hot pixel), never written.  Frames that do not fit (hot pixels, components or LIFO demand) are left
 // to the global-memory kernels through CompTables::path.
 //
-// LDS per workgroup: 39 968 B, so that a workgroup fits next to three resident ChESS workgroups
-// (163 840 - 3 * 39 952 B) as soon as a fourth one retires.
+// LDS per workgroup: 40 KB, so that a workgroup fits next to three resident ChESS workgroups
+// (163 840 - 3 * 39 952 B = 43 984 B) as soon as a fourth one retires.
+//
+// Frames with MORE hot pixels than the tables hold (a 14x14 board has ~2600 at level 0) are cut into
+// horizontal BANDS of at most LN hot pixels each, separated by three consecutive rows without a hot pixel,
+// and the same workgroup runs the search band after band on the same tables:
+//   * no 4-connected component crosses a row without hot pixels, so every component -- and with it every
+//     fill, its running maximum and its order of operations -- lies inside one band;
+//   * the 3x3 seed window of a refined point spans three rows, so it cannot hold hot pixels of two bands
+//     (they are at least four rows apart): a point is refined in the band its seeds are in, and points
+//     that share a component share the band;
+//   * the output order of detect is by seed position and is restored by the final sort.
+// A frame whose rows do not offer such separators (or with more than kMaxBands * LN hot pixels, or more
+// than kBandRows rows) goes to the global-memory kernels like before.  (Round 2 first had a second kernel
+// with 4096-entry tables = 80 KB = two ChESS workgroup slots: it waited 100-900 us for two ADJACENT slots to
+// fall free underneath the level-0 launch, and BASELINE config 3 as stated was bound by that wait.)
 // ===========================================================================
-// Table sizes for N hot-list entries.  N = 2048 is the size every frame is tried at (39 968 B); N = 4096
-// (79 904 B: TWO workgroup slots of the pixel kernel) is launched only while the stream has frames that
-// need it (a 14x14 board has ~2600 hot pixels at level 0), see launch_cc_detect_lds.
+constexpr int kMaxBands = 8;
 template <int N>
 struct LdsCCT {
     static constexpr int LN = N;              // hot-list entries
@@ -629,15 +644,25 @@ struct LdsCCT {
         struct { int16_t root[LROOTS], cnt[LROOTS], soff[LROOTS]; uint32_t first[LROOTS]; } r;
         int16_t need16[LN];       // refine: LIFO demand of the super-component, at its root
     } w;
-    int nroots, ncand, top, total, changed, nref, mtop, pad1;
+    int nroots, ncand, top, total, changed, nref, mtop, nload;
+    int nbands, best, band_y[kMaxBands + 1], shear;
+    uint32_t edge[4];
 };
 constexpr int LPTS = 512;                    // points per frame the LDS refine kernel takes
 constexpr int LPPT = LPTS / CC_THREADS;     // points per thread
-static_assert(sizeof(LdsCCT<2048>) <= 39968, "must fit beside three ChESS workgroups");
-static_assert(sizeof(LdsCCT<4096>) <= 2 * 39952, "must fit beside two ChESS workgroups");
+static_assert(sizeof(LdsCCT<2048>) <= 43984, "must fit beside three ChESS workgroups");
+static_assert(offsetof(LdsCCT<2048>, nroots) >= (8192 + CC_THREADS / 64) * 4, "the band planner's key arrays overlay the tables");
 
+// Fibonacci hashing with an independent multiplier per coordinate: the hot pixels of a calibration board sit on a
+// lattice, and ONE multiplier on the packed (y << 16 | x) lets only the low 16 bits of the constant act on y --
+// at level 1 of a 14x14 board at 4096x3072 that put the lattice in resonance with the table (11.6 probes per
+// miss, 71 at worst; the fills ran 4x longer).  Measured on 16 board / level combinations: 1.03-1.3 probes per
+// hit, 1.1-2.1 per miss (tools/hash_probe.py).
 template <class LdsCC>
-__device__ __forceinline__ uint32_t lds_hash(uint32_t e) { return ((e * 0x9E3779B1u) >> 16) & (uint32_t)(LdsCC::LHASH - 1); }
+__device__ __forceinline__ uint32_t lds_hash(uint32_t e) {
+    static_assert(LdsCC::LHASH == 4096, "the shift below takes the top 12 bits");
+    return ((e & 0xffffu) * 0x9E3779B1u + (e >> 16) * 0x85EBCA77u) >> 20;
+}
 
 template <class LdsCC>
 __device__ __forceinline__ void lds_insert(LdsCC& L, uint32_t e, int i) {
@@ -706,26 +731,224 @@ __device__ __forceinline__ int drain_lds(LdsCC& L, int w, int h, int16_t* stk, i
     return consumed;
 }
 
-// Load the frame's hot list into LDS, label the super-components (lab = smallest list index) and leave in
-// L.u.acc, at every root, (pixels of the super-component) | (sum of hot-neighbour counts << 13): the
-// latter bounds the pushes of any fill of it.  Returns false (uniformly) when the frame does not
-// fit.  All threads call it.
+// Band key of a pixel for shear k (in 1/32 pixels of y per pixel of x, |k| <= 32): k = 0 is the row.  A board
+// that is rotated in the image has its corner rows on slanted lines, and no image row between them is free of
+// hot pixels -- but a sheared "row" that follows the slant is.
+__device__ __forceinline__ int band_key(uint32_t e, int k, int w) {
+    const int x = (int)(e & 0xffffu), y = (int)(e >> 16);
+    const int ak = k < 0 ? -k : k;
+    return y + (((k >= 0 ? x : w - 1 - x) * ak) >> 5);
+}
+// Two pixels at most 2 apart in x and in y (4-neighbours; two seeds of one 3x3 window) differ in key by at most
+// this much: a band boundary with that many empty keys keeps them in one band.
+__device__ __forceinline__ int band_gap(int k) {
+    const int ak = k < 0 ? -k : k;
+    return 2 + (ak ? (2 * ak) / 32 + 1 : 0);
+}
+constexpr int kBandKeys = 8192;  // keys 0 .. h - 1 + (w - 1) * |k| / 32 must stay below this
+
+// One attempt at cutting the frame into bands of at most LN hot pixels along shear k.  Leaves L.nbands,
+// L.band_y[0 .. nbands] (key bounds) and L.shear; returns the number of bands, 0 (uniformly) when this shear
+// offers no separators.  Uses the table storage as scratch.  All threads call it.  A thread owns 32 consecutive
+// keys and keeps their counts, prefix sums and "a band may end here" bits in registers, so that a greedy step
+// costs one LDS read, one LDS atomic and two barriers (~10 us per attempt; with every test read from LDS in
+// dependent order it was 35-50).
 template <class LdsCC>
-__device__ __forceinline__ bool lds_load_and_label(LdsCC& L, const FrameView& v, int nraw, int cap) {
+__device__ __noinline__ int lds_try_bands(LdsCC& L, const FrameView& v, int nraw, int k) {
+    constexpr int LN = LdsCC::LN;
+    const int tid = threadIdx.x, w = v.w;
+    const int nkeys = v.h + (((w - 1) * (k < 0 ? -k : k)) >> 5);
+    if (nkeys > kBandKeys) return 0;
+    uint32_t* rcw = reinterpret_cast<uint32_t*>(&L);  // hot pixels per key, two 16-bit counters per word
+    uint32_t* cumw = rcw + kBandKeys / 2;             // hot pixels below the key, likewise
+    uint32_t* part = cumw + kBandKeys / 2;            // per-wave totals
+    constexpr int WPT = kBandKeys / 2 / CC_THREADS;   // words per thread = 16 (keys 32 * tid ..)
+    static_assert(WPT == 16, "the register arrays below assume 32 keys per thread");
+    {
+        uint4* z = reinterpret_cast<uint4*>(rcw + WPT * tid);
+        z[0] = z[1] = z[2] = z[3] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    for (int i = tid; i < nraw; i += CC_THREADS) {
+        const uint32_t e = v.hot_xy[i];
+        if (e == kHotDead) continue;
+        const int b = band_key(e, k, w);
+        if (b < kBandKeys) atomicAdd(&rcw[b >> 1], 1u << ((b & 1) * 16));  // (n <= 16384: a counter cannot carry)
+    }
+    __syncthreads();
+    uint32_t wv[WPT + 2];
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(rcw + WPT * tid);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 x = src[q];
+            wv[4 * q] = x.x; wv[4 * q + 1] = x.y; wv[4 * q + 2] = x.z; wv[4 * q + 3] = x.w;
+        }
+        wv[WPT] = tid + 1 < CC_THREADS ? rcw[WPT * (tid + 1)] : 0u;  // the four keys after mine (the gap test)
+        wv[WPT + 1] = tid + 1 < CC_THREADS ? rcw[WPT * (tid + 1) + 1] : 0u;
+    }
+    uint32_t mine = 0;
+    unsigned long long emptym = 0;  // bit q: key 32 * tid + q holds no pixel
+#pragma unroll
+    for (int q = 0; q < WPT + 2; ++q) {
+        const uint32_t lo = wv[q] & 0xffffu, hi = wv[q] >> 16;
+        if (q < WPT) mine += lo + hi;
+        emptym |= (unsigned long long)(lo == 0) << (2 * q) | (unsigned long long)(hi == 0) << (2 * q + 1);
+    }
+    // exclusive prefix of `mine` over the workgroup
+    uint32_t incl = mine;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if ((tid & 63) >= d) incl += o;
+    }
+    if ((tid & 63) == 63) part[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t run = incl - mine, total = 0;
+    for (int q = 0; q < CC_THREADS / 64; ++q) {
+        if (q < (tid >> 6)) run += part[q];
+        total += part[q];
+    }
+    const uint32_t start = run;  // pixels below key 32 * tid
+#pragma unroll
+    for (int q = 0; q < WPT; ++q) {
+        const uint32_t lo = run, hi = run + (wv[q] & 0xffffu);
+        cumw[WPT * tid + q] = lo | (hi << 16);  // (<= 16384: fits)
+        run = hi + (wv[q] >> 16);
+    }
+    // a band may end at key r when keys r .. r + gap - 1 hold no pixel (keys past the frame hold none)
+    const int gap = band_gap(k);
+    unsigned long long sepm = emptym;
+    for (int g = 1; g < gap; ++g) sepm &= emptym >> g;
+    const uint32_t sep = (uint32_t)sepm;
+    __syncthreads();
+    int y0 = 0, nb = 0;
+    while (true) {
+        if (tid == 0) L.best = -1;
+        __syncthreads();
+        const uint32_t base = (cumw[y0 >> 1] >> ((y0 & 1) * 16)) & 0xffffu;
+        int end = nkeys;
+        if (total - base > (uint32_t)LN) {
+            // the last key r > y0 the band [y0, r) may end at with at most LN hot pixels in it
+            uint32_t ok = 0, below = start;  // pixels below key r
+#pragma unroll
+            for (int q = 0; q < 2 * WPT; ++q) {
+                const int r = 2 * WPT * tid + q;
+                ok |= (uint32_t)(r > y0 && r < nkeys && below - base <= (uint32_t)LN) << q;
+                below += (q & 1) ? wv[q >> 1] >> 16 : wv[q >> 1] & 0xffffu;
+            }
+            ok &= sep;
+            if (ok) atomicMax(&L.best, 2 * WPT * tid + 31 - __builtin_clz(ok));
+            __syncthreads();
+            end = L.best;
+            if (end < 0) return 0;
+        }
+        if (tid == 0) L.band_y[nb] = y0;
+        ++nb;
+        y0 = end;
+        if (end >= nkeys) break;
+        if (nb == kMaxBands) return 0;
+        __syncthreads();  // everybody has read L.best
+    }
+    if (tid == 0) { L.band_y[nb] = nkeys; L.nbands = nb; L.shear = k; }
+    __syncthreads();
+    return nb;
+}
+
+// Cut the frame into bands of at most LN hot pixels (see the top of this section): rows first, then sheared
+// rows along the slopes of the upper and the lower edge of the hot pixels (a rotated board) and between them.
+// Returns the number of bands, 0 (uniformly) when the frame cannot be banded.  All threads call it.
+template <class LdsCC>
+__device__ __noinline__ int lds_plan_bands(LdsCC& L, const FrameView& v, int nraw) {
+    constexpr int LN = LdsCC::LN;
+    const int tid = threadIdx.x, w = v.w, h = v.h;
+    if (nraw <= LN) {
+        if (tid == 0) { L.nbands = 1; L.band_y[0] = 0; L.band_y[1] = h; L.shear = 0; }
+        __syncthreads();
+        return 1;
+    }
+    if (nraw > LN * kMaxBands || h > kBandKeys) return 0;
+    int nb = lds_try_bands(L, v, nraw, 0);
+    if (nb) return nb;
+    // upper / lower edge of the hot pixels in the left and in the right third of the frame
+    if (tid < 4) L.edge[tid] = (tid & 1) ? 0u : 0xffffffffu;  // [0] min left, [1] max left, [2] min right, [3] max right
+    __syncthreads();
+    {
+        uint32_t mn[2] = {0xffffffffu, 0xffffffffu}, mx[2] = {0u, 0u};
+        for (int i = tid; i < nraw; i += CC_THREADS) {
+            const uint32_t e = v.hot_xy[i];
+            if (e == kHotDead) continue;
+            const int x = (int)(e & 0xffffu);
+            const int side = 3 * x < w ? 0 : (3 * x >= 2 * w ? 1 : -1);
+            if (side < 0) continue;
+            mn[side] = min(mn[side], e);
+            mx[side] = max(mx[side], e);
+        }
+        for (int sd = 0; sd < 2; ++sd) {
+            if (mn[sd] != 0xffffffffu) atomicMin(&L.edge[2 * sd], mn[sd]);
+            if (mx[sd] != 0u) atomicMax(&L.edge[2 * sd + 1], mx[sd]);
+        }
+    }
+    __syncthreads();
+    const uint32_t e0 = L.edge[0], e1 = L.edge[1], e2 = L.edge[2], e3 = L.edge[3];
+    __syncthreads();
+    if (e0 == 0xffffffffu || e2 == 0xffffffffu) return 0;  // nothing in one of the thirds: not a board that spans the frame
+    auto slope32 = [](uint32_t a, uint32_t b) {  // shear that takes pixel a (left) and pixel b (right) to the same key
+        const int dx = (int)(b & 0xffffu) - (int)(a & 0xffffu), dy = (int)(b >> 16) - (int)(a >> 16);
+        int k = dx > 0 ? (-dy * 32 + (dy < 0 ? dx / 2 : -dx / 2)) / dx : 0;
+        return k < -32 ? -32 : (k > 32 ? 32 : k);
+    };
+    const int kt = slope32(e0, e2), kb = slope32(e1, e3), km = (kt + kb) / 2;
+    const int cand[9] = {km, kt, kb, km + 1, km - 1, kt + 1, kt - 1, kb + 1, kb - 1};
+    for (int c = 0; c < 9; ++c) {
+        const int k = cand[c];
+        if (k == 0 || k < -32 || k > 32) continue;
+        bool seen = false;
+        for (int p = 0; p < c; ++p) seen = seen || cand[p] == k;
+        if (seen) continue;
+        nb = lds_try_bands(L, v, nraw, k);
+        if (nb) return nb;
+    }
+    return 0;
+}
+
+// Load the hot pixels with band keys in [y0, y1) (`banded`; otherwise the whole list as it stands) into LDS,
+// label the super-components (lab = smallest list index) and leave in L.u.acc, at every root, (pixels of the
+// super-component) | (sum of hot-neighbour counts << 13): the latter bounds the pushes of any fill of it.
+// n = entries loaded.  Returns false (uniformly) when they do not fit.  All threads call it.
+template <class LdsCC>
+__device__ __forceinline__ bool lds_load_and_label(LdsCC& L, const FrameView& v, int nraw, int cap, bool banded, int y0,
+                                                   int y1, int& n) {
     constexpr int LN = LdsCC::LN, LHASH = LdsCC::LHASH, LEPT = LdsCC::LEPT;
     const int tid = threadIdx.x;
-    if (nraw > cap || nraw > LN) return false;
-    const int n = nraw, w = v.w;
+    n = 0;
+    if (nraw > cap || (!banded && nraw > LN)) return false;
+    const int w = v.w;
     for (int k = tid; k < LHASH / 2; k += CC_THREADS) L.hashw[k] = 0xffffffffu;
-    if (tid == 0) { L.nroots = 0; L.ncand = 0; L.top = 0; L.total = 0; L.changed = 0; L.nref = 0; L.mtop = 0; }
+    const int shear = L.shear;
+    if (tid == 0) { L.nroots = 0; L.top = 0; L.total = 0; L.changed = 0; L.mtop = 0; L.nload = 0; }
     __syncthreads();
+    if (banded) {
+        for (int i = tid; i < nraw; i += CC_THREADS) {
+            const uint32_t e = v.hot_xy[i];
+            const int y = e != kHotDead ? band_key(e, shear, w) : -1;
+            if (y >= y0 && y < y1) {
+                const int slot = atomicAdd(&L.nload, 1);
+                if (slot < LN) L.xy[slot] = e;
+            }
+        }
+        __syncthreads();
+        n = L.nload;
+        if (n > LN) return false;  // (the planner counted the same pixels: cannot happen)
+    } else {
+        n = nraw;
+    }
     uint32_t own[LEPT];
 #pragma unroll
     for (int k = 0; k < LEPT; ++k) {
         const int i = tid + CC_THREADS * k;
         own[k] = kHotDead;
         if (i < n) {
-            const uint32_t e = v.hot_xy[i];
+            const uint32_t e = banded ? L.xy[i] : v.hot_xy[i];
             own[k] = e;
             L.xy[i] = e;
             L.lab[i] = (int16_t)i;
@@ -784,20 +1007,24 @@ __device__ __forceinline__ bool lds_load_and_label(LdsCC& L, const FrameView& v,
     return true;
 }
 
-// What a declining kernel leaves behind: the frame stays with the next implementation (path 0), and -- when
-// the larger LDS tables could take it -- a hint for the host, which launches the N = 4096 kernel only
-// while recent frames asked for it (a plain store to host-mapped memory; read without any synchronisation
-// when the next call is queued, so it lags by a call or two, which is all the accuracy it needs).
-template <int N>
-__device__ __forceinline__ void lds_decline(const CompTables& t, int frame, int nraw) {
+// What a declining kernel leaves behind: the frame stays with the global-memory kernels (path 0).  A kernel
+// that declines after its first band has already appended candidates (detect: scratch the fallback
+// overwrites) or refined the points of the bands it finished (refine: their level is updated, so the
+// fallback skips them, and their components are disjoint from what is left -- same result).
+__device__ __forceinline__ void lds_decline(const CompTables& t, int frame) {
+    if (threadIdx.x == 0) t.path[frame] = 0;
+}
+// refine after the first band: path 2 = "the global-memory kernel finishes the frame and ADDS to nrefined"
+__device__ __forceinline__ void lds_decline_refine(const CompTables& t, int frame, int band, const RefineIO& io, int nref) {
     if (threadIdx.x != 0) return;
-    t.path[frame] = 0;
-    if (N < 4096 && t.big_hint && nraw <= 4096 && nraw <= t.cap)
-        __hip_atomic_store(t.big_hint, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    t.path[frame] = band > 0 ? 2 : 0;
+    if (band > 0 && io.nrefined) io.nrefined[frame] = nref;
 }
 
+// (launch bounds: at most 128 VGPRs, so that a wave of these kernels fits into what ONE retiring wave of the pixel
+// kernels frees on a SIMD -- at 129 VGPRs the refine kernel waited for two, 80 -> 270 us per launch)
 template <int N>
-__global__ __launch_bounds__(CC_THREADS) void cc_detect_lds_kernel(LevelBatch lb, CompTables t, int level,
+__global__ __launch_bounds__(CC_THREADS, 4) void cc_detect_lds_kernel(LevelBatch lb, CompTables t, int level,
                                                                    DetectOut out, int frame0) {
     using LdsCC = LdsCCT<N>;
     constexpr int LROOTS = LdsCC::LROOTS, LSTK = LdsCC::LSTK, LEPT = LdsCC::LEPT;
@@ -805,122 +1032,157 @@ __global__ __launch_bounds__(CC_THREADS) void cc_detect_lds_kernel(LevelBatch lb
     LdsCC& L = *reinterpret_cast<LdsCC*>(lds_cc_raw);
     if (!(t.lds_path & 16)) __builtin_amdgcn_s_setprio(3);
     const int frame = frame0 + blockIdx.x, tid = threadIdx.x;
-    if (N > 2048 && t.path[frame]) return;  // the smaller tables took it
     const int nraw = t.hot_cnt[frame];
     FrameView v = make_view(lb, t, frame);
-    if (!lds_load_and_label(L, v, nraw, t.cap)) {
-        lds_decline<N>(t, frame, nraw);
+    const int w = v.w, h = v.h;
+    int nbands = 0;  // cc_lds bit 256: no banding (test hook)
+    if (nraw <= t.cap && !(nraw > LdsCC::LN && (t.lds_path & 256))) nbands = lds_plan_bands(L, v, nraw);
+    if (nbands == 0) {
+        lds_decline(t, frame);
         return;
     }
-    const int n = nraw, w = v.w, h = v.h;
-    if (t.lds_path & 8) { if (tid == 0) { t.path[frame] = 1; out.counts[frame] = 0; } return; }  // ablation (timing only)
-    // roots with >= 2 pixels (a single hot pixel can only give a one-pixel blob, :205); each gets a LIFO of
-    // (sum of hot-neighbour counts + 1) words, which bounds the pushes of all fills of it together
-    for (int i = tid; i < n; i += CC_THREADS) {
-        if (L.xy[i] == kHotDead || L.lab[i] != i) continue;
-        const int a = L.u.acc[i], cnt = a & 0x1fff, need = (a >> 13) + 1;
-        if (cnt < kBlobMinPixels) continue;
-        const int r = atomicAdd(&L.nroots, 1);
-        const int so = atomicAdd(&L.top, need);
-        if (r < LROOTS) { L.w.r.root[r] = (int16_t)i; L.w.r.cnt[r] = (int16_t)cnt; L.w.r.soff[r] = (int16_t)so; }
-    }
-    __syncthreads();
-    if (L.nroots > LROOTS || L.top > LSTK) {  // does not fit: nothing has been modified
-        lds_decline<N>(t, frame, nraw);
-        return;
-    }
-    const int nroots = L.nroots;
-    // smallest raster position of every super-component: the first seed the raster scan meets
-    for (int i = tid; i < n; i += CC_THREADS) L.u.acc[i] = 0x7fffffff;
-    __syncthreads();
-    for (int i = tid; i < n; i += CC_THREADS)
-        if (L.xy[i] != kHotDead) atomicMin(&L.u.acc[L.lab[i]], (int)L.xy[i]);
-    __syncthreads();
-    for (int r = tid; r < nroots; r += CC_THREADS) L.w.r.first[r] = (uint32_t)L.u.acc[L.w.r.root[r]];
-    __syncthreads();
-    // member lists (list indices of the pixels of a super-component, unordered): what the "raster scan goes
-    // on" step below walks instead of the whole hot list.  They take over the storage of the labels.
-    int mylab[LEPT];
-#pragma unroll
-    for (int k = 0; k < LEPT; ++k) {
-        const int i = tid + CC_THREADS * k;
-        mylab[k] = (i < n && L.xy[i] != kHotDead) ? (int)L.lab[i] : -1;
-    }
-    for (int i = tid; i < n; i += CC_THREADS) L.u.acc[i] = -1;
-    __syncthreads();
-    for (int r = tid; r < nroots; r += CC_THREADS) {
-        const int mo = atomicAdd(&L.mtop, (int)L.w.r.cnt[r]);
-        L.u.acc[L.w.r.root[r]] = mo;      // running write position of this list
-        L.w.r.root[r] = (int16_t)mo;      // the root's list index is not needed any more
-    }
-    __syncthreads();
-    int16_t* members = L.lab;
-#pragma unroll
-    for (int k = 0; k < LEPT; ++k) {
-        if (mylab[k] < 0 || L.u.acc[mylab[k]] < 0) continue;  // (acc only grows: a list's slot stays >= 0)
-        members[atomicAdd(&L.u.acc[mylab[k]], 1)] = (int16_t)(tid + CC_THREADS * k);
-    }
-    __syncthreads();  // the accumulators are dead: their storage becomes the LIFOs
-    if (tid == 0) t.path[frame] = 1;
-
+    if (tid == 0) L.ncand = 0;
     // seeds live in [8, w-8) x [8, h-8) (:332-333)
     auto seedable = [&](uint32_t e) {
         const int x = (int)(e & 0xffffu), y = (int)(e >> 16);
         return x > kMargin && x < w - kMargin - 1 && y > kMargin && y < h - kMargin - 1;
     };
-    for (int r = tid; r < nroots; r += CC_THREADS) {
-        const int cnt = L.w.r.cnt[r], mo = L.w.r.root[r];
-        int left = cnt;
-        int16_t* stk = L.u.stk + L.w.r.soff[r];
-        uint32_t seed = L.w.r.first[r];
-        bool have = seedable(seed);
+    for (int band = 0; band < nbands; ++band) {
+        int n;
+        if (!lds_load_and_label(L, v, nraw, t.cap, nbands > 1, L.band_y[band], L.band_y[band + 1], n)) {
+            lds_decline(t, frame);
+            return;
+        }
+        if (t.lds_path & 8) { if (tid == 0) { t.path[frame] = 1; out.counts[frame] = 0; } return; }  // ablation (timing only)
+        // roots with >= 2 pixels (a single hot pixel can only give a one-pixel blob, :205); each gets a LIFO of
+        // (sum of hot-neighbour counts + 1) words, which bounds the pushes of all fills of it together
+        for (int i = tid; i < n; i += CC_THREADS) {
+            if (L.xy[i] == kHotDead || L.lab[i] != i) continue;
+            const int a = L.u.acc[i], cnt = a & 0x1fff, need = (a >> 13) + 1;
+            if (cnt < kBlobMinPixels) continue;
+            const int r = atomicAdd(&L.nroots, 1);
+            if (need > LSTK) L.total = 1;  // one super-component alone wants more LIFO than there is
+            if (r < LROOTS) { L.w.r.root[r] = (int16_t)i; L.w.r.cnt[r] = (int16_t)cnt; L.w.r.soff[r] = (int16_t)min(need, LSTK); }
+        }
+        __syncthreads();
+        if (L.nroots > LROOTS || L.total) {  // does not fit
+            lds_decline(t, frame);
+            return;
+        }
+        const int nroots = L.nroots;
+        // smallest raster position of every super-component: the first seed the raster scan meets
+        for (int i = tid; i < n; i += CC_THREADS) L.u.acc[i] = 0x7fffffff;
+        __syncthreads();
+        for (int i = tid; i < n; i += CC_THREADS)
+            if (L.xy[i] != kHotDead) atomicMin(&L.u.acc[L.lab[i]], (int)L.xy[i]);
+        __syncthreads();
+        for (int r = tid; r < nroots; r += CC_THREADS) L.w.r.first[r] = (uint32_t)L.u.acc[L.w.r.root[r]];
+        __syncthreads();
+        // member lists (list indices of the pixels of a super-component, unordered): what the "raster scan goes
+        // on" step below walks instead of the whole hot list.  They take over the storage of the labels.
+        int mylab[LEPT];
+#pragma unroll
+        for (int k = 0; k < LEPT; ++k) {
+            const int i = tid + CC_THREADS * k;
+            mylab[k] = (i < n && L.xy[i] != kHotDead) ? (int)L.lab[i] : -1;
+        }
+        for (int i = tid; i < n; i += CC_THREADS) L.u.acc[i] = -1;
+        __syncthreads();
+        for (int r = tid; r < nroots; r += CC_THREADS) {
+            const int mo = atomicAdd(&L.mtop, (int)L.w.r.cnt[r]);
+            L.u.acc[L.w.r.root[r]] = mo;      // running write position of this list
+            L.w.r.root[r] = (int16_t)mo;      // the root's list index is not needed any more
+        }
+        __syncthreads();
+        int16_t* members = L.lab;
+#pragma unroll
+        for (int k = 0; k < LEPT; ++k) {
+            if (mylab[k] < 0 || L.u.acc[mylab[k]] < 0) continue;  // (acc only grows: a list's slot stays >= 0)
+            members[atomicAdd(&L.u.acc[mylab[k]], 1)] = (int16_t)(tid + CC_THREADS * k);
+        }
+        __syncthreads();  // the accumulators are dead: their storage becomes the LIFOs
+
+        // The fills of a band share LSTK LIFO words.  When the super-components together want more (a 14x14 board:
+        // ~150 of them per band at ~50 words each), they run in rounds: every pending root asks for its words, the
+        // ones that still fit run, the others wait for the next round (the first to ask always fits).
+        static_assert(LROOTS <= 2 * CC_THREADS, "a thread owns at most two roots");
+        bool pending[2] = {tid < nroots, tid + CC_THREADS < nroots};
         while (true) {
-            if (!have) {
-                // the raster scan goes on: the smallest seedable position among what is left of this
-                // super-component (pixels below the running-maximum threshold are consumed but not
-                // expanded, so the fringe of a blob is often left over)
-                uint32_t best = kHotDead;
-                for (int q = 0; q < cnt; ++q) {
-                    const int i = members[mo + q];
-                    if (L.val[i] > 0 && seedable(L.xy[i])) best = min(best, L.xy[i]);
+        if (tid == 0) { L.top = 0; L.changed = 0; }
+        __syncthreads();
+        for (int rr = 0; rr < 2; ++rr) {
+            if (!pending[rr]) continue;
+            const int r = tid + CC_THREADS * rr;
+            const int need = L.w.r.soff[r];
+            const int so = atomicAdd(&L.top, need);
+            if (so + need > LSTK) { L.changed = 1; continue; }
+            pending[rr] = false;
+            const int cnt = L.w.r.cnt[r], mo = L.w.r.root[r];
+            int left = cnt;
+            int16_t* stk = L.u.stk + so;
+            uint32_t seed = L.w.r.first[r];
+            bool have = seedable(seed);
+            while (true) {
+                if (!have) {
+                    // the raster scan goes on: the smallest seedable position among what is left of this
+                    // super-component (pixels below the running-maximum threshold are consumed but not
+                    // expanded, so the fringe of a blob is often left over)
+                    uint32_t best = kHotDead;
+                    for (int q = 0; q < cnt; ++q) {
+                        const int i = members[mo + q];
+                        if (L.val[i] > 0 && seedable(L.xy[i])) best = min(best, L.xy[i]);
+                    }
+                    if (best == kHotDead) break;
+                    seed = best;
                 }
-                if (best == kHotDead) break;
-                seed = best;
-            }
-            have = false;
-            stk[0] = (int16_t)lds_find(L, seed);  // :338
-            Blob b;
-            if (t.lds_path & 4) { b.touched = true; left = 0; }  // ablation (timing only)
-            else left -= drain_lds(L, w, h, stk, 1, b);
-            if (blob_passes_cheap_tests(b) &&
-                ((t.lds_path & 2) || window_variance_high(v.img, v.img_stride, w, h, b.xpk, b.ypk))) {  // :207
-                const int c = atomicAdd(&L.ncand, 1);
-                if (c < v.cand_cap) {
-                    Cand cd;
-                    cd.sum_rx = b.srx; cd.sum_ry = b.sry; cd.sum_r = b.sr;
-                    cd.seed = (int32_t)seed;
-                    cd.x_peak = (uint16_t)b.xpk; cd.y_peak = (uint16_t)b.ypk;
-                    cd.ok = 1; cd.pad = 0;
-                    v.cand[c] = cd;
+                have = false;
+                stk[0] = (int16_t)lds_find(L, seed);  // :338
+                Blob b;
+                if (t.lds_path & 4) { b.touched = true; left = 0; }  // ablation (timing only)
+                else left -= drain_lds(L, w, h, stk, 1, b);
+                if (blob_passes_cheap_tests(b) &&
+                    ((t.lds_path & 2) || window_variance_high(v.img, v.img_stride, w, h, b.xpk, b.ypk))) {  // :207
+                    const int c = atomicAdd(&L.ncand, 1);
+                    if (c < v.cand_cap) {
+                        Cand cd;
+                        cd.sum_rx = b.srx; cd.sum_ry = b.sry; cd.sum_r = b.sr;
+                        cd.seed = (int32_t)seed;
+                        cd.x_peak = (uint16_t)b.xpk; cd.y_peak = (uint16_t)b.ypk;
+                        cd.ok = 1; cd.pad = 0;
+                        v.cand[c] = cd;
+                    }
                 }
+                if (left <= 0) break;
             }
-            if (left <= 0) break;
+        }
+        __syncthreads();
+        if (!L.changed) break;
+        __syncthreads();  // everybody has read the flag before it is reset
         }
     }
-    __syncthreads();
-    const int nvalid = L.ncand;  // <= LN / 2 <= LSTK / 4 keys, <= cand_cap (>= 1024)
-    // order by seed position = the reference's output order (:332-353), sorted in LDS
+    // order by seed position = the reference's output order (:332-353), sorted in LDS.  The tables are dead:
+    // the keys take the whole allocation (one band: at most LN / 2 candidates; several: whatever they gave)
+    const int nvalid = L.ncand;
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(lds_cc_raw);
+    constexpr int kMaxKeys = 4096;
+    static_assert(kMaxKeys * 8 <= (int)offsetof(LdsCC, nroots), "the sort keys must not reach the counters");
+    if (nvalid > kMaxKeys || nvalid > v.cand_cap) {
+        lds_decline(t, frame);
+        return;
+    }
+    __syncthreads();  // every thread has read L.ncand before the keys overwrite the tables
+    if (tid == 0) t.path[frame] = 1;
     int n_pad = 1;
     while (n_pad < nvalid) n_pad <<= 1;
     for (int c = tid; c < n_pad; c += CC_THREADS)
-        L.u.keys[c] = c < nvalid ? (((unsigned long long)(uint32_t)v.cand[c].seed << 32) | (uint32_t)c) : ~0ull;
+        keys[c] = c < nvalid ? (((unsigned long long)(uint32_t)v.cand[c].seed << 32) | (uint32_t)c) : ~0ull;
     __syncthreads();
-    bitonic_sort(L.u.keys, n_pad);
-    emit_detect_outputs(v, L.u.keys, nvalid, level, out, frame);
+    bitonic_sort(keys, n_pad);
+    emit_detect_outputs(v, keys, nvalid, level, out, frame);
 }
 
 template <int N>
-__global__ __launch_bounds__(CC_THREADS) void cc_refine_lds_kernel(LevelBatch lb, CompTables t, int level,
+__global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch lb, CompTables t, int level,
                                                                    RefineIO io, int frame0) {
     using LdsCC = LdsCCT<N>;
     constexpr int LN = LdsCC::LN, LSTK = LdsCC::LSTK;
@@ -928,162 +1190,202 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_lds_kernel(LevelBatch lb
     LdsCC& L = *reinterpret_cast<LdsCC*>(lds_cc_raw);
     if (!(t.lds_path & 16)) __builtin_amdgcn_s_setprio(3);
     const int frame = frame0 + blockIdx.x, tid = threadIdx.x;
-    if (N > 2048 && t.path[frame]) return;  // the smaller tables took it
     const int nraw = t.hot_cnt[frame];
     const int npts = min(io.npoints[frame], io.pitch);
     FrameView v = make_view(lb, t, frame);
-    if (npts > LPTS) {  // no LDS variant takes that many points
-        if (tid == 0) t.path[frame] = 0;
+    if (npts > LPTS) {  // the LDS kernel does not take that many points
+        lds_decline(t, frame);
         return;
     }
-    if (!lds_load_and_label(L, v, nraw, t.cap)) {
-        lds_decline<N>(t, frame, nraw);
+    int nbands = 0;  // cc_lds bit 256: no banding (test hook)
+    if (nraw <= t.cap && !(nraw > LN && (t.lds_path & 256))) nbands = lds_plan_bands(L, v, nraw);
+    if (nbands == 0) {
+        lds_decline(t, frame);
         return;
     }
-    const int n = nraw, w = v.w, h = v.h;
-    // LIFO demand of every super-component at its root, then the accumulators become the claim table
-    for (int i = tid; i < n; i += CC_THREADS) L.w.need16[i] = (int16_t)((L.u.acc[i] >> 13) + 1);
-    __syncthreads();
-    int32_t* claim = L.u.acc;
-    for (int i = tid; i < n; i += CC_THREADS) claim[i] = 0x7fffffff;
-    // the group leader of every point, -1 for a point that is not refinable at this level: behind
-    // need16[] in the same union (LN * 2 bytes used of 2.5 LN), npts <= LPTS entries
-    int16_t* lead16 = L.w.need16 + LN;
-    static_assert(sizeof(L.w) >= (size_t)LN * 2 + (size_t)LPTS * 2, "lead16 must fit behind need16");
-
+    if (tid == 0) L.nref = 0;
+    const int w = v.w, h = v.h;
     const long long pb = (long long)frame * io.pitch;
     double* pts = io.points + 2 * pb;
     signed char* lv = io.levels + pb;
     uint32_t* seeds = io.seeds + 9 * pb;  // here: list indices, read back by the group's leader lane
     int32_t* nseeds = io.nseeds + pb;
+    int32_t* gneed = io.need + pb;  // per leader
     const uint16_t coord_scale = (uint16_t)(1u << level);
+    // the group leader of every point, -1 for a point that is not refinable at this level: behind
+    // need16[] in the same union (LN * 2 bytes used of 2.5 LN), npts <= LPTS entries
+    int16_t* lead16 = L.w.need16 + LN;
+    static_assert(sizeof(L.w) >= (size_t)LN * 2 + (size_t)LPTS * 2, "lead16 must fit behind need16");
 
-    // R1: seeds of every refinable point (:362-382), in the reference's push order.  A thread owns points
-    // tid and tid + 256 and keeps their seed roots, seed counts and leaders in registers.
-    int ns_[LPPT], lead_[LPPT], need_[LPPT];
-    short sroot_[LPPT][9];
-#pragma unroll
-    for (int q = 0; q < LPPT; ++q) {
-        const int i = tid + CC_THREADS * q;
-        int ns = -1;  // -1: not refinable at this level (or no such point)
-        if (i < npts && lv[i] == level + 1) {
-            ns = 0;
-            const double lx = rescale_coord(pts[2 * i + 0], 1.0 / coord_scale);  // :369
-            const double ly = rescale_coord(pts[2 * i + 1], 1.0 / coord_scale);
-            const int x = (int)(lx + 0.5), y = (int)(ly + 0.5);  // :371-372
-#pragma unroll
-            for (int dx = -1; dx <= 1; ++dx)
-#pragma unroll
-                for (int dy = -1; dy <= 1; ++dy) {
-                    const int sx = (int16_t)(x + dx), sy = (int16_t)(y + dy);  // is_valid takes int16_t
-                    int j = -1;
-                    if (sx >= 0 && sx < w && sy >= 0 && sy < h)
-                        j = lds_find(L, ((uint32_t)sy << 16) | (uint32_t)sx);  // hot <=> listed (nothing consumed yet)
-                    if (j >= 0) {
-                        seeds[9 * i + ns] = (uint32_t)j;
-#pragma unroll
-                        for (int k = 0; k < 9; ++k)  // static register index
-                            if (k == ns) sroot_[q][k] = L.lab[j];
-                        ++ns;
-                    }
-                }
-            nseeds[i] = ns;
+    for (int band = 0; band < nbands; ++band) {
+        int n;
+        if (!lds_load_and_label(L, v, nraw, t.cap, nbands > 1, L.band_y[band], L.band_y[band + 1], n)) {
+            lds_decline_refine(t, frame, band, io, L.nref);
+            return;
         }
-        ns_[q] = ns;
-        lead_[q] = i;
-        need_[q] = 0;
-    }
-    __syncthreads();
+        // LIFO demand of every super-component at its root, then the accumulators become the claim table
+        for (int i = tid; i < n; i += CC_THREADS) L.w.need16[i] = (int16_t)((L.u.acc[i] >> 13) + 1);
+        __syncthreads();
+        int32_t* claim = L.u.acc;
+        for (int i = tid; i < n; i += CC_THREADS) claim[i] = 0x7fffffff;
 
-    // R2: points whose seeds share a super-component are replayed in index order by one lane:
-    // propagate the minimum point index over the bipartite graph points <-> super-components
-    while (true) {
-        bool changed = false;
+        // R1: seeds of every refinable point (:362-382), in the reference's push order.  A thread owns points
+        // tid and tid + 256 and keeps their seed roots, seed counts and leaders in registers.  (With bands: a
+        // point finds its seeds in exactly one band -- the hash only holds this band's pixels -- and is not
+        // refinable any more once a band has refined it.)
+        int ns_[LPPT], lead_[LPPT];
+        short sroot_[LPPT][9];
 #pragma unroll
         for (int q = 0; q < LPPT; ++q) {
-            if (ns_[q] <= 0) continue;
-            int m = lead_[q];
+            const int i = tid + CC_THREADS * q;
+            int ns = -1;  // -1: not refinable at this level (or no such point)
+            if (i < npts && lv[i] == level + 1) {
+                ns = 0;
+                const double lx = rescale_coord(pts[2 * i + 0], 1.0 / coord_scale);  // :369
+                const double ly = rescale_coord(pts[2 * i + 1], 1.0 / coord_scale);
+                const int x = (int)(lx + 0.5), y = (int)(ly + 0.5);  // :371-372
 #pragma unroll
-            for (int k = 0; k < 9; ++k)
-                if (k < ns_[q])
-                    m = min(m, __hip_atomic_load(&claim[sroot_[q][k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-            changed |= m < lead_[q];
+                for (int dx = -1; dx <= 1; ++dx)
 #pragma unroll
-            for (int k = 0; k < 9; ++k)
-                if (k < ns_[q] && atomicMin(&claim[sroot_[q][k]], m) > m) changed = true;
-            lead_[q] = m;
+                    for (int dy = -1; dy <= 1; ++dy) {
+                        const int sx = (int16_t)(x + dx), sy = (int16_t)(y + dy);  // is_valid takes int16_t
+                        int j = -1;
+                        if (sx >= 0 && sx < w && sy >= 0 && sy < h)
+                            j = lds_find(L, ((uint32_t)sy << 16) | (uint32_t)sx);  // hot <=> listed (nothing consumed yet)
+                        if (j >= 0) {
+                            seeds[9 * i + ns] = (uint32_t)j;
+#pragma unroll
+                            for (int k = 0; k < 9; ++k)  // static register index
+                                if (k == ns) sroot_[q][k] = L.lab[j];
+                            ++ns;
+                        }
+                    }
+                nseeds[i] = ns;
+            }
+            ns_[q] = ns;
+            lead_[q] = i;
         }
-        if (changed) L.changed = 1;
         __syncthreads();
-        const int c = L.changed;
-        __syncthreads();
-        if (!c) break;
-        if (tid == 0) L.changed = 0;
-        __syncthreads();
-    }
-#pragma unroll
-    for (int q = 0; q < LPPT; ++q) {
-        const int i = tid + CC_THREADS * q;
-        if (i < npts) lead16[i] = (int16_t)(ns_[q] < 0 ? -1 : lead_[q]);
-    }
 
-    // R3: LIFO demand of each group = sum over its super-components, each counted once; groups take
-    // their LIFOs in the order of a running counter
-    int32_t* gneed = io.need + pb;  // per leader
+        // R2: points whose seeds share a super-component are replayed in index order by one lane:
+        // propagate the minimum point index over the bipartite graph points <-> super-components
+        while (true) {
+            bool changed = false;
 #pragma unroll
-    for (int q = 0; q < LPPT; ++q) {
-        const int i = tid + CC_THREADS * q;
-        if (i < npts) gneed[i] = 0;
-    }
-    __syncthreads();
+            for (int q = 0; q < LPPT; ++q) {
+                if (ns_[q] <= 0) continue;
+                int m = lead_[q];
 #pragma unroll
-    for (int q = 0; q < LPPT; ++q) {
-        if (ns_[q] < 0) continue;
-        const int i = tid + CC_THREADS * q, ld = lead_[q];
-        int add = ld == i ? 10 : 0;
+                for (int k = 0; k < 9; ++k)
+                    if (k < ns_[q])
+                        m = min(m, __hip_atomic_load(&claim[sroot_[q][k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                changed |= m < lead_[q];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            if (k >= ns_[q]) continue;
-            const int root = sroot_[q][k];
-            if (atomicCAS(&claim[root], ld, ld | 0x40000000) == ld) add += (int)L.w.need16[root];
+                for (int k = 0; k < 9; ++k)
+                    if (k < ns_[q] && atomicMin(&claim[sroot_[q][k]], m) > m) changed = true;
+                lead_[q] = m;
+            }
+            if (changed) L.changed = 1;
+            __syncthreads();
+            const int c = L.changed;
+            __syncthreads();
+            if (!c) break;
+            if (tid == 0) L.changed = 0;
+            __syncthreads();
         }
-        if (add) {
-            wg_add(gneed + ld, add);
-            atomicAdd(&L.total, add);
+#pragma unroll
+        for (int q = 0; q < LPPT; ++q) {
+            const int i = tid + CC_THREADS * q;
+            if (i < npts) lead16[i] = (int16_t)(ns_[q] < 0 ? -1 : lead_[q]);
         }
-    }
-    __syncthreads();
-    if (L.total > LSTK) {  // does not fit: no point, no response has been modified
-        lds_decline<N>(t, frame, nraw);
-        return;
-    }
-    if (tid == 0) t.path[frame] = 1;
-    __syncthreads();  // the claim table is dead: its storage becomes the LIFOs
 
-    // R4: one lane per group, members in index order (:358); accepted points are written in place
+        // R3: LIFO demand of each group = sum over its super-components, each counted once; groups take
+        // their LIFOs in the order of a running counter
 #pragma unroll
-    for (int q = 0; q < LPPT; ++q) {
-        const int i = tid + CC_THREADS * q;
-        if (ns_[q] < 0 || lead_[q] != i) continue;
-        int16_t* stk = L.u.stk + atomicAdd(&L.top, aload(gneed + i));
-        for (int j = i; j < npts; ++j) {
-            if (lead16[j] != i) continue;
-            const int ns = j == i ? ns_[q] : aload(nseeds + j);
-            for (int k = 0; k < ns; ++k) stk[k] = (int16_t)__hip_atomic_load(&seeds[9 * j + k], MRG_WG);
-            Blob b;
-            drain_lds(L, w, h, stk, ns, b);
-            if (!blob_passes_cheap_tests(b)) continue;
-            if (!window_variance_high(v.img, v.img_stride, w, h, b.xpk, b.ypk)) continue;  // :207
-            const double cx = (double)b.srx / (double)b.sr;  // :262-263
-            const double cy = (double)b.sry / (double)b.sr;
-            pts[2 * j + 0] = rescale_coord(cx, (double)coord_scale);  // :390
-            pts[2 * j + 1] = rescale_coord(cy, (double)coord_scale);
-            lv[j] = (signed char)level;  // :393
-            atomicAdd(&L.nref, 1);
+        for (int q = 0; q < LPPT; ++q) {
+            const int i = tid + CC_THREADS * q;
+            if (i < npts) gneed[i] = 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < LPPT; ++q) {
+            if (ns_[q] <= 0) continue;  // nothing hot around the point (in this band): :383-384, no fill
+            const int i = tid + CC_THREADS * q, ld = lead_[q];
+            int add = ld == i ? 10 : 0;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                if (k >= ns_[q]) continue;
+                const int root = sroot_[q][k];
+                if (atomicCAS(&claim[root], ld, ld | 0x40000000) == ld) add += (int)L.w.need16[root];
+            }
+            if (add) wg_add(gneed + ld, add);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < LPPT; ++q) {
+            const int i = tid + CC_THREADS * q;
+            if (ns_[q] > 0 && lead_[q] == i) atomicMax(&L.total, aload(gneed + i));
+        }
+        __syncthreads();
+        if (L.total > LSTK) {  // one group alone wants more LIFO than there is
+            lds_decline_refine(t, frame, band, io, L.nref);
+            return;
+        }
+        __syncthreads();  // the claim table is dead: its storage becomes the LIFOs
+
+        // R4: one lane per group, members in index order (:358); accepted points are written in place.  The
+        // groups share LSTK LIFO words and run in rounds when together they want more (see the detect kernel).
+        bool pending[LPPT];
+#pragma unroll
+        for (int q = 0; q < LPPT; ++q) pending[q] = ns_[q] > 0 && lead_[q] == tid + CC_THREADS * q;
+        while (true) {
+        if (tid == 0) { L.top = 0; L.changed = 0; }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < LPPT; ++q) {
+            const int i = tid + CC_THREADS * q;
+            if (!pending[q]) continue;
+            const int need = aload(gneed + i);
+            const int so = atomicAdd(&L.top, need);
+            if (so + need > LSTK) { L.changed = 1; continue; }
+            pending[q] = false;
+            int16_t* stk = L.u.stk + so;
+            for (int j = i; j < npts; ++j) {
+                if (lead16[j] != i) continue;
+                const int ns = j == i ? ns_[q] : aload(nseeds + j);
+                for (int k = 0; k < ns; ++k) stk[k] = (int16_t)__hip_atomic_load(&seeds[9 * j + k], MRG_WG);
+                Blob b;
+                drain_lds(L, w, h, stk, ns, b);
+                if (!blob_passes_cheap_tests(b)) continue;
+                if (!window_variance_high(v.img, v.img_stride, w, h, b.xpk, b.ypk)) continue;  // :207
+                const double cx = (double)b.srx / (double)b.sr;  // :262-263
+                const double cy = (double)b.sry / (double)b.sr;
+                pts[2 * j + 0] = rescale_coord(cx, (double)coord_scale);  // :390
+                pts[2 * j + 1] = rescale_coord(cy, (double)coord_scale);
+                lv[j] = (signed char)level;  // :393
+                atomicAdd(&L.nref, 1);
+            }
+        }
+        __syncthreads();
+        if (!L.changed) break;
+        __syncthreads();  // everybody has read the flag before it is reset
+        }
+        __threadfence_block();
+        __syncthreads();  // the next band reads the levels this one wrote
+        // Several bands: what this band's fills consumed goes back into the dense response, like the
+        // global-memory kernel leaves it.  If a later band has to give the frame up, that kernel finishes
+        // it, and a point of THIS band that was rejected because an earlier point had consumed its
+        // component must find it consumed again.
+        if (nbands > 1) {
+            for (int i = tid; i < n; i += CC_THREADS)
+                if (L.val[i] == 0) v.d[(int)(L.xy[i] >> 16) * w + (int)(L.xy[i] & 0xffffu)] = 0;
+            __syncthreads();
         }
     }
-    __syncthreads();
-    if (tid == 0 && io.nrefined) io.nrefined[frame] = L.nref;
+    if (tid == 0) {
+        t.path[frame] = 1;
+        if (io.nrefined) io.nrefined[frame] = L.nref;
+    }
 }
 
 template <int N, class K, class... A>
@@ -1094,21 +1396,16 @@ static void launch_lds(K kernel, int nframes, hipStream_t s, A... args) {
     hipLaunchKernelGGL(kernel, dim3(nframes), dim3(CC_THREADS), sizeof(LdsCCT<N>), s, args...);
 }
 
-// Every frame is tried with the 2048-entry tables (one workgroup slot of the pixel kernel each).  The
-// 4096-entry kernel costs two slots per workgroup and has to wait for them, which costs the pixel kernels 4 %
-// when nobody needs it -- it is launched only when `use_big` (the host's view of CompTables::big_hint).
 void launch_cc_detect_lds(const LevelBatch& lb, const CompTables& t, int level, const DetectOut& out, int frame0,
                           int nframes, hipStream_t s) {
     if (!t.lds_path || nframes <= 0) return;
     launch_lds<2048>(cc_detect_lds_kernel<2048>, nframes, s, lb, t, level, out, frame0);
-    if (t.use_big) launch_lds<4096>(cc_detect_lds_kernel<4096>, nframes, s, lb, t, level, out, frame0);
 }
 
 void launch_cc_refine_lds(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io, int frame0,
                           int nframes, hipStream_t s) {
     if (!t.lds_path || nframes <= 0) return;
     launch_lds<2048>(cc_refine_lds_kernel<2048>, nframes, s, lb, t, level, io, frame0);
-    if (t.use_big) launch_lds<4096>(cc_refine_lds_kernel<4096>, nframes, s, lb, t, level, io, frame0);
 }
 
 }  // namespace mrg

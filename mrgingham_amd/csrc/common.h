@@ -58,11 +58,10 @@ struct CompTables {
     int sort_cap;             // power of two >= cand_cap
     int32_t* status;          // [nframes] bit 0: hot table overflow, bit 1: candidate overflow
     // Component search out of LDS (cc.hip, "LDS path"): path[f] = 1 when frame f was handled there, 0 when
-    // it is left to the global-memory kernels (more hot pixels / components than the LDS tables hold).
+    // it is left to the global-memory kernels (more hot pixels / components than the LDS tables hold), 2 when
+    // a banded refinement was begun there and the global-memory kernel finishes it.
     int32_t* path;            // [nframes]
     int lds_path;             // 0: the LDS kernels are not launched and path[] is not consulted
-    int* big_hint;            // host-mapped word of this level: set by a kernel that left a frame for larger tables
-    int use_big;              // the host's decision for this call: also launch the 4096-entry LDS kernels
 };
 
 // A component that passed the size / peak / margin tests and waits for the

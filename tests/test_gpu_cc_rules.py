@@ -160,90 +160,146 @@ def test_random_refine_against_oracle(det, shape, level):
 
 # ----------------------------------------------------------------------------- which implementation ran
 
-def _blob_field(h, w, nblobs, size, rng):
-    """`nblobs` separate blobs of `size` hot pixels each (a row of pixels), on a grid, all accepted-looking."""
+def _blob_field(h, w, nblobs, size, rng, row_step=3, y_first=12):
+    """`nblobs` separate blobs of `size` hot pixels each (a row of pixels), on a grid, all accepted-looking.
+    row_step 2 leaves one row without hot pixels between blob rows (the band planner needs two), 3 two, 5 four."""
     d = np.zeros((h, w), np.int16)
     per_row = (w - 40) // (size + 3)
     for k in range(nblobs):
-        y = 12 + 3 * (k // per_row)
+        y = y_first + row_step * (k // per_row)
         x = 12 + (size + 3) * (k % per_row)
         assert y < h - 12
         d[y, x:x + size] = rng.randint(130, 400, size)
     return d
 
 
+def _slanted_field(h, w, nrows, size, slope, rng, y_first=12, row_step=14):
+    """Rows of blobs like _blob_field, but every row runs along y = y_row + slope * x: between such rows no image
+    row is free of hot pixels (for |slope| * w > row_step), a sheared row is."""
+    d = np.zeros((h, w), np.int16)
+    per_row = (w - 40) // (size + 3)
+    for r in range(nrows):
+        for c in range(per_row):
+            x = 12 + (size + 3) * c
+            y = y_first + row_step * r + int(round(slope * (x if slope >= 0 else x - w)))
+            assert 12 <= y < h - 12, (r, c, y)
+            d[y, x:x + size] = rng.randint(130, 400, size)
+            d[y + 1, x:x + size // 2] = rng.randint(130, 400, size // 2)   # two rows tall: no pair of empty image rows in between
+    return d
+
+
+def _points_near_hot(d, npts, rng, replace=False):
+    ys, xs = np.nonzero(d > 15)
+    sel = rng.choice(len(xs), size=npts, replace=replace)
+    return np.stack([xs[sel] + rng.uniform(-1, 1, npts), ys[sel] + rng.uniform(-1, 1, npts)], axis=1)
+
+
 def test_every_fallback_reason_of_the_lds_path():
-    """Frames that fit are handled out of LDS; each reason for leaving a frame to the next implementation is
-    met on purpose -- hot pixels, multi-pixel components, LIFO demand, points -- in ONE batch with frames that
-    fit, and every frame equals the oracle.  Three settings of the launcher: only the 2048-entry tables
-    (cc_lds = 1 | 64), the 4096-entry tables always behind them (1 | 32), and the default, where the larger
-    kernel is launched once earlier calls have asked for it."""
+    """Frames that fit are handled out of LDS in one pass, frames with more hot pixels band by band when their
+    rows offer separators; each reason for leaving a frame to the global-memory kernels is met on purpose -- hot
+    pixels that cannot be banded, too many of them, multi-pixel components, LIFO demand (in the first band
+    and in a later one), points -- in ONE batch with frames that fit, and every frame equals the oracle."""
     rng = np.random.RandomState(3)
     h, w = 400, 600
+    late = _blob_field(h, w, 180, 8, rng, row_step=5)                   # 1440 hot in rows 12..27, then a solid block
+    late[200:244, 100:144] = rng.randint(200, 300, (44, 44))            # 1936 hot, degree sum 7568: the second band gives up
     frames = {
-        "fits": _blob_field(h, w, 100, 6, rng),                    # 600 hot pixels, 100 components
-        "2049+ hot pixels": _blob_field(h, w, 300, 8, rng),          # 2400 hot
-        "513+ components": _blob_field(h, w, 600, 3, rng),           # 1800 hot, 600 components
-        "LIFO demand": np.zeros((h, w), np.int16),                   # one solid 44 x 44 block: 1936 hot, degree sum 7568
+        "fits": _blob_field(h, w, 100, 6, rng),                          # 600 hot pixels, 100 components
+        "2400 hot pixels, bands": _blob_field(h, w, 300, 8, rng, row_step=5),
+        "2400 hot pixels, no separators": _blob_field(h, w, 300, 8, rng, row_step=2),   # one empty row between blob rows
+        "513+ components": _blob_field(h, w, 600, 3, rng),               # 1800 hot, 600 components
+        "LIFO demand": np.zeros((h, w), np.int16),                       # one solid 44 x 44 block
         "fits too": _blob_field(h, w, 40, 12, rng),
-        "4097+ hot pixels": _blob_field(h, w, 520, 8, rng),          # 4160 hot: no LDS variant
+        "9600 hot pixels, bands": _blob_field(h, w, 1200, 8, rng, row_step=5),
+        "16385+ hot pixels": _blob_field(h, w, 2100, 8, rng, row_step=5),
+        "LIFO demand in the second band": late,
+        "3600 hot pixels in slanted rows": _slanted_field(h, w, 6, 8, 0.25, rng),
+        "4800 hot pixels in rows slanted the other way": _slanted_field(h, w, 8, 8, -0.4, rng),
     }
     frames["LIFO demand"][100:144, 100:144] = rng.randint(200, 300, (44, 44))
     names = list(frames)
     ds = [frames[n] for n in names]
     img = cc_cases.flat_img(h, w)
     wants = [oracle.cc_detect_on_response(d, img) for d in ds]
+    assert len(wants[6]) == 1200 and len(wants[1]) == 300
 
     def run(det, expect_paths):
         got = _detect(det, ds, [img] * len(ds), capacity=4096)
         paths = det.debug_paths(0, len(ds))
-        if expect_paths is not None:
-            assert paths.tolist() == expect_paths, dict(zip(names, paths.tolist()))
+        assert paths.tolist() == expect_paths, dict(zip(names, paths.tolist()))
         for n, g, want in zip(names, got, wants):
             assert np.array_equal(g, want), n
-        return paths.tolist()
 
-    for mode, expect in [(1 | 64, [1, 0, 0, 0, 1, 0]), (1 | 32, [1, 1, 1, 1, 1, 0])]:
+    for mode, expect in [(1, [1, 1, 0, 0, 0, 1, 1, 0, 0, 1, 1]), (1 | 256, [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0])]:
         det = mrgingham_amd.Detector(0)
         try:
             det.set_option("cc_lds", mode)
+            det.set_option("hot_capacity_shift", 1)     # room in the global-memory tables for the 16800-pixel frame
+            run(det, expect)
             run(det, expect)
         finally:
             det.close()
+
+    def refine(det, d, pts):
+        lv = np.ones(len(pts), np.int8)
+        tp = torch.from_numpy(pts[None].copy()).cuda()
+        tl = torch.from_numpy(lv[None].copy()).cuda()
+        n = torch.tensor([len(pts)], dtype=torch.int32).cuda()
+        nref = det.cc_refine_on_response(torch.from_numpy(d[None]).cuda(), torch.from_numpy(img[None]).cuda(), 0, tp, tl, n)
+        path = det.debug_paths(0, 1).tolist()
+        wp, wl, wn = oracle.cc_refine_on_response(pts, lv, d, img, 0)
+        assert int(nref[0]) == wn, (int(nref[0]), wn, path)
+        assert np.array_equal(tl[0].cpu().numpy(), wl) and np.array_equal(tp[0].cpu().numpy(), wp), path
+        return path
+
     det = mrgingham_amd.Detector(0)
     try:
-        first = run(det, None)                      # default: the larger kernel only after it was asked for
-        assert first in ([1, 0, 0, 0, 1, 0], [1, 1, 1, 1, 1, 0])
-        for _ in range(3):
-            last = run(det, None)
-        assert last == [1, 1, 1, 1, 1, 0]
         # refine: more than 512 points per frame goes to the global-memory kernels, 512 stay in LDS
-        d = frames["fits"]
-        ys, xs = np.nonzero(d > 15)
         for npts, want_path in [(512, 1), (513, 0)]:
-            sel = rng.choice(len(xs), size=npts, replace=True)
-            pts = np.stack([xs[sel] + rng.uniform(-1, 1, npts), ys[sel] + rng.uniform(-1, 1, npts)], axis=1)
-            lv = np.ones(npts, np.int8)
-            tp = torch.from_numpy(pts[None].copy()).cuda()
-            tl = torch.from_numpy(lv[None].copy()).cuda()
-            n = torch.tensor([npts], dtype=torch.int32).cuda()
-            nref = det.cc_refine_on_response(torch.from_numpy(d[None]).cuda(), torch.from_numpy(img[None]).cuda(), 0, tp, tl, n)
-            assert det.debug_paths(0, 1).tolist() == [want_path], npts
-            wp, wl, wn = oracle.cc_refine_on_response(pts, lv, d, img, 0)
-            assert int(nref[0]) == wn and np.array_equal(tl[0].cpu().numpy(), wl) and np.array_equal(tp[0].cpu().numpy(), wp)
-        # refine of a frame that needs the larger tables
-        d = frames["2049+ hot pixels"]
-        ys, xs = np.nonzero(d > 15)
-        sel = rng.choice(len(xs), size=300, replace=False)
-        pts = np.stack([xs[sel] + rng.uniform(-1, 1, 300), ys[sel] + rng.uniform(-1, 1, 300)], axis=1)
-        lv = np.ones(300, np.int8)
-        for _ in range(2):
-            tp = torch.from_numpy(pts[None].copy()).cuda()
-            tl = torch.from_numpy(lv[None].copy()).cuda()
-            n = torch.tensor([300], dtype=torch.int32).cuda()
-            nref = det.cc_refine_on_response(torch.from_numpy(d[None]).cuda(), torch.from_numpy(img[None]).cuda(), 0, tp, tl, n)
-            wp, wl, wn = oracle.cc_refine_on_response(pts, lv, d, img, 0)
-            assert int(nref[0]) == wn and np.array_equal(tl[0].cpu().numpy(), wl) and np.array_equal(tp[0].cpu().numpy(), wp)
-        assert det.debug_paths(0, 1).tolist() == [1]
+            assert refine(det, frames["fits"], _points_near_hot(frames["fits"], npts, rng, replace=True)) == [want_path]
+        # refine band by band: points in every band, several per component (replayed in index order), and
+        # points with nothing hot around them
+        for name in ("2400 hot pixels, bands", "9600 hot pixels, bands", "3600 hot pixels in slanted rows",
+                     "4800 hot pixels in rows slanted the other way"):
+            d = frames[name]
+            pts = np.concatenate([_points_near_hot(d, 300, rng), _points_near_hot(d, 100, rng, replace=True),
+                                  [[300.0, 390.0], [5.0, 5.0]]])
+            assert refine(det, d, pts[rng.permutation(len(pts))]) == [1], name
+        assert refine(det, frames["2400 hot pixels, no separators"],
+                      _points_near_hot(frames["2400 hot pixels, no separators"], 300, rng)) == [0]
+        # the first band is refined out of LDS, the second gives up: the global-memory kernel finishes the frame.
+        # Two points on one blob of the FIRST band: the second of them finds its component consumed, there and
+        # again in the kernel that finishes the frame
+        d = frames["LIFO demand in the second band"]
+        ys, xs = np.nonzero(d[:100] > 15)
+        twin = np.array([[xs[5] + 0.2, ys[5] - 0.3], [xs[5] + 0.4, ys[5] + 0.1]])
+        pts = np.concatenate([_points_near_hot(d, 200, rng), twin, [[120.0, 220.0], [130.0, 230.0]]])
+        assert refine(det, d, pts) == [2]
+    finally:
+        det.close()
+
+
+@pytest.mark.parametrize("angle", [12.0, -27.0])
+def test_rotated_dense_board_is_searched_band_by_band(angle):
+    """A 14x14 board rotated in the image: ~2600 hot pixels at level 0, corner rows on slanted lines, so no pair
+    of image rows between them is free of hot pixels.  The band planner follows the slant (sheared rows), the
+    whole chain stays in LDS, and corners and levels equal the oracle's."""
+    from scipy import ndimage
+    from mrgingham_amd import synth
+    base = synth.board_frame(2560, 1920, 14, 4).numpy()
+    frame = ndimage.rotate(base, angle, reshape=False, order=1, mode="nearest").astype(np.uint8)
+    frames = np.stack([frame, base])
+    det = mrgingham_amd.Detector(0)
+    try:
+        pts, lv, npts = det.chain(torch.from_numpy(frames).cuda(), start_level=2, max_points=2048)
+        paths = det.debug_paths(0, 2).tolist()
+        for f in range(2):
+            wp, wl = oracle.chain(frames[f], 2)
+            n = int(npts[f])
+            assert n == len(wp) and n >= 196, (f, n, len(wp))
+            assert np.array_equal(pts[f, :n].cpu().numpy(), wp) and np.array_equal(lv[f, :n].cpu().numpy(), wl), f
+        hot0 = int((oracle.clamped_response(frame, 0)[0] > 15).sum())
+        assert hot0 > 2048, hot0                      # otherwise this test does not exercise the bands
+        assert paths == [1, 1], paths
     finally:
         det.close()

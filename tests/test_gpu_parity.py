@@ -412,3 +412,35 @@ def test_fused_pyramid_option_gives_the_same_chain(fuse, multi):
                     assert np.array_equal(lv[f, :n].cpu().numpy(), wl), (w, h, start, f)
     finally:
         d2.close()
+
+
+def test_fused_pyramid_random_shapes(det):
+    """Frames of whole 16 x 8 blocks take the fused level-0 + pyramid kernel in chain(): random sizes (strips that
+    end anywhere inside a 256-pixel strip, segments that end anywhere), random content, every start level that
+    leaves a usable image; corners and levels equal the oracle's."""
+    rng = np.random.default_rng(20260929)
+    for case in range(14):
+        w = 16 * int(rng.integers(4, 48))
+        h = 8 * int(rng.integers(6, 70))
+        kind = case % 3
+        if kind == 0:
+            frames = np.stack([synth.board_frame(w, h, 6 + case % 5, s).numpy() for s in (case, case + 1)])
+        elif kind == 1:
+            frames = np.stack([synth.noise_frame(w, h, s, smooth=case % 2).numpy() for s in (case, case + 1)])
+        else:                                   # coarse random blocks: many strong corners at every level
+            cell = int(rng.integers(5, 14))
+            blocks = rng.integers(0, 2, size=(2, h // cell + 1, w // cell + 1), dtype=np.uint8) * 200 + 20
+            frames = np.repeat(np.repeat(blocks, cell, axis=1), cell, axis=2)[:, :h, :w].copy()
+            frames += rng.integers(0, 16, size=frames.shape, dtype=np.uint8)
+        d = _cuda(frames)
+        for start in (1, 2, 3):
+            if min(w, h) >> start < 24:
+                continue
+            pts, lv, npts = det.chain(d, start_level=start, max_points=8192)
+            assert det.chain_info()[0], (w, h)
+            for f in range(2):
+                wp, wl = oracle.chain(frames[f], start)
+                n = int(npts[f])
+                assert n == len(wp), (case, w, h, start, f, n, len(wp))
+                assert np.array_equal(pts[f, :n].cpu().numpy(), wp), (case, w, h, start, f)
+                assert np.array_equal(lv[f, :n].cpu().numpy(), wl), (case, w, h, start, f)
