@@ -395,6 +395,23 @@ static void end_op(mrgingham_amd_ctx* ctx) {
 }
 
 // Level images of levels [1, max_level] of the batch into the level scratch, on the pixel stream.
+// One level image (level >= 1) of the batch into `out` (dense, frames back to back): levels 1..3 through the
+// one-pass pyramid kernel restricted to that level (16 x 8 source blocks per thread, 16-byte loads; the
+// per-pixel kernel took 425 us for level 1 of 64 frames of 4096x3072, this one reads the frames at HBM speed),
+// which falls back to the per-pixel kernels itself for ragged shapes.
+static void launch_one_level_image(const mrgingham_amd_frames* fr, int level, uint8_t* out, int w, int h, hipStream_t s) {
+    const FrameBatch fb{fr->frames, fr->frame_pitch, fr->width, fr->height, fr->stride};
+    if (level <= 3) {
+        PyramidOut po{};
+        po.out[level - 1] = out;
+        po.w[level - 1] = w;
+        po.h[level - 1] = h;
+        launch_pyramid(fb, po, level, fr->nframes, s);
+    } else {
+        launch_decimate(fb, level, out, (long long)w * h, w, h, 0, fr->nframes, s);
+    }
+}
+
 static PyramidOut pyramid_out_of(mrgingham_amd_ctx* ctx, int max_level) {
     PyramidOut po{};
     const int top = max_level < 3 ? max_level : 3;
@@ -697,8 +714,7 @@ int mrgingham_amd_chess_response_batch(mrgingham_amd_ctx* ctx, const mrgingham_a
         lb.img_stride = fr->stride;
     } else {
         if ((rc = ensure(ctx, ctx->aux_img, (size_t)fr->nframes * w * h + 16))) return rc;
-        const FrameBatch fb{fr->frames, fr->frame_pitch, fr->width, fr->height, fr->stride};
-        launch_decimate(fb, level, (uint8_t*)ctx->aux_img.p, (long long)w * h, w, h, 0, fr->nframes, s);
+        launch_one_level_image(fr, level, (uint8_t*)ctx->aux_img.p, w, h, s);
         lb.img = (const uint8_t*)ctx->aux_img.p;
         lb.img_pitch = (long long)w * h;
         lb.img_stride = w;
@@ -726,18 +742,7 @@ int mrgingham_amd_decimate_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_fra
                                            fr->stride, w, h, hipMemcpyDeviceToDevice, s));
         return 0;
     }
-    const FrameBatch fb{fr->frames, fr->frame_pitch, fr->width, fr->height, fr->stride};
-    if (level <= 3) {
-        // the one-pass pyramid kernel, restricted to the requested level (same arithmetic, tested against
-        // the single-level kernel)
-        PyramidOut po{};
-        po.out[level - 1] = d_out;
-        po.w[level - 1] = w;
-        po.h[level - 1] = h;
-        launch_pyramid(fb, po, level, fr->nframes, s);
-    } else {
-        launch_decimate(fb, level, d_out, (long long)w * h, w, h, 0, fr->nframes, s);
-    }
+    launch_one_level_image(fr, level, d_out, w, h, s);
     MRG_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -802,9 +807,7 @@ int mrgingham_amd_detect_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frame
     if ((rc = ensure_level(ctx, level, fr->nframes, fr->width, fr->height, 0))) return rc;
     begin_op(ctx, level);
     if (level > 0) {
-        const FrameBatch fb{fr->frames, fr->frame_pitch, fr->width, fr->height, fr->stride};
-        launch_decimate(fb, level, (uint8_t*)cur_levels(ctx)[level].img.p, (long long)w * h, w, h, 0, fr->nframes,
-                        ctx->pix);
+        launch_one_level_image(fr, level, (uint8_t*)cur_levels(ctx)[level].img.p, w, h, ctx->pix);
     }
     const LevelBatch lb = queue_level_chess(ctx, fr, level);
     order_after_previous(ctx, {{(const char*)d_xy, (size_t)fr->nframes * capacity_per_frame * 8},
@@ -833,9 +836,7 @@ int mrgingham_amd_refine_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frame
     if ((rc = ensure_points(ctx, fr->nframes, points_pitch))) return rc;
     begin_op(ctx, level);
     if (level > 0) {
-        const FrameBatch fb{fr->frames, fr->frame_pitch, fr->width, fr->height, fr->stride};
-        launch_decimate(fb, level, (uint8_t*)cur_levels(ctx)[level].img.p, (long long)w * h, w, h, 0, fr->nframes,
-                        ctx->pix);
+        launch_one_level_image(fr, level, (uint8_t*)cur_levels(ctx)[level].img.p, w, h, ctx->pix);
     }
     const LevelBatch lb = queue_level_chess(ctx, fr, level);
     auto& ps = ctx->pts[ctx->cur];

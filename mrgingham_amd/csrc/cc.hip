@@ -121,20 +121,22 @@ __device__ __forceinline__ FrameView make_view(const LevelBatch& lb, const CompT
     return v;
 }
 
-// P0, P1 and P2 are one kernel of their own, one 1024-thread workgroup per frame (so that
+// P0, P1 and P2 open the global-memory kernels below, which run one 512-thread workgroup per frame (so that
 // workgroup-scope atomics suffice, see above): at full resolution a noisy frame has tens of thousands
-// of hot pixels, nearly all of them isolated, which P1 flags so that P2 skips them.
-constexpr int CCL_THREADS = 1024;
+// of hot pixels, nearly all of them isolated, which P1 flags so that P2 skips them.  (They were a kernel of
+// their own until the LDS path made these kernels the rare case: one launch per level less on the component
+// stream, whose kernels mostly find their frames done and leave.)
+// 512 threads at no more than 64 VGPRs: the two waves per SIMD of such a workgroup fit into the registers ONE
+// retiring wave of the pixel kernels frees (128).  With 1024 threads the kernels -- which mostly only look at
+// the path word and leave -- waited for two: 0.98 -> 1.06 ms per step.
+constexpr int CCG_THREADS = 512;
 // P0: reset the per-entry tables (the pixel kernel only writes the hot list and the pixel -> index
 // map); P1: union-find over the hot list (left / up neighbours); P2: flatten (parent[i] = root of i),
-// per-root pixel count, bounding box and smallest raster position.  Workgroup barriers in between.
-__global__ __launch_bounds__(CCL_THREADS) void cc_label_kernel(LevelBatch lb, CompTables t, int frame0) {
-    const int frame = frame0 + blockIdx.y;
-    if (t.lds_path && t.path[frame] == 1) return;  // done out of LDS
-    if (t.hot_cnt[frame] > t.cap) return;  // overflow is reported by the per-frame kernel
-    const FrameView v = make_view(lb, t, frame);
+// per-root pixel count, bounding box and smallest raster position.  Workgroup barriers in between; all
+// threads of the workgroup call it.
+__device__ __forceinline__ void label_frame(const FrameView& v) {
     const int w = v.w;
-    for (int i = threadIdx.x; i < v.n; i += CCL_THREADS) {
+    for (int i = threadIdx.x; i < v.n; i += CCG_THREADS) {
         v.parent[i] = i;
         v.comp_cnt[i] = 0;
         v.comp_box[i] = make_int4(0x7fffffff, 0x7fffffff, -1, -1);
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(CCL_THREADS) void cc_label_kernel(LevelBatch lb, Co
         v.comp_first[i] = 0x7fffffff;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < v.n; i += CCL_THREADS) {
+    for (int i = threadIdx.x; i < v.n; i += CCG_THREADS) {
         const uint32_t e = v.hot_xy[i];
         if (e == kHotDead) continue;  // unused slot: flagged already (bit 31), P2 skips it
         const int x = (int)(e & 0xffffu), y = (int)(e >> 16);
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(CCL_THREADS) void cc_label_kernel(LevelBatch lb, Co
         if (!(l || u || r || dn)) v.hot_xy[i] = e | kHotSingleton;
     }
     __syncthreads();  // every union of the frame is done (the tables are only touched by this workgroup)
-    for (int i = threadIdx.x; i < v.n; i += CCL_THREADS) {
+    for (int i = threadIdx.x; i < v.n; i += CCG_THREADS) {
         const uint32_t e = v.hot_xy[i];
         if (e & kHotSingleton) continue;  // its own root, count 0: never a blob, never shared
         const int r = uf_root(v.parent, i);
@@ -173,18 +175,13 @@ __global__ __launch_bounds__(CCL_THREADS) void cc_label_kernel(LevelBatch lb, Co
         wg_add(v.comp_cnt + r, 1);
         wg_min(v.comp_first + r, (int)e);  // (y << 16) | x orders like the raster index
     }
+    __syncthreads();
 }
 
 void launch_cc_detect_lds(const LevelBatch& lb, const CompTables& t, int level, const DetectOut& out, int frame0,
                           int nframes, hipStream_t s);
 void launch_cc_refine_lds(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io, int frame0,
                           int nframes, hipStream_t s);
-
-void launch_cc_label(const LevelBatch& lb, const CompTables& t, int frame0, int nframes, hipStream_t s) {
-    if (nframes <= 0) return;
-    const dim3 grid(1, nframes);
-    hipLaunchKernelGGL(cc_label_kernel, grid, dim3(CCL_THREADS), 0, s, lb, t, frame0);
-}
 
 // Hot list of a CALLER-SUPPLIED response (mrgingham_amd_cc_on_response_batch, the entry point the
 // rule tests drive): copies it into the level scratch the way the component search expects it --
@@ -317,7 +314,7 @@ __device__ __forceinline__ double rescale_coord(double p, double scale) { return
 __device__ void bitonic_sort(unsigned long long* keys, int n_pad) {
     for (int k = 2; k <= n_pad; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < n_pad; i += CC_THREADS) {
+            for (int i = threadIdx.x; i < n_pad; i += (int)blockDim.x) {
                 const int ixj = i ^ j;
                 if (ixj > i) {
                     const unsigned long long a = keys[i], b = keys[ixj];
@@ -341,7 +338,7 @@ __device__ __forceinline__ void emit_detect_outputs(const FrameView& v, const un
     const int npt = out.points ? (nout < out.points_pitch ? nout : out.points_pitch) : 0;
     double* opt = out.points ? out.points + (long long)frame * out.points_pitch * 2 : nullptr;
     signed char* olv = out.points ? out.levels + (long long)frame * out.points_pitch : nullptr;
-    for (int k = threadIdx.x; k < nout; k += CC_THREADS) {
+    for (int k = threadIdx.x; k < nout; k += (int)blockDim.x) {
         const Cand& cd = v.cand[(uint32_t)(keys[k] & 0xffffffffu)];
         const double cx = (double)cd.sum_rx / (double)cd.sum_r;  // :262-263
         const double cy = (double)cd.sum_ry / (double)cd.sum_r;
@@ -364,7 +361,7 @@ __device__ __forceinline__ void emit_detect_outputs(const FrameView& v, const un
 // ---------------------------------------------------------------------------
 // Detect: process_connected_components, points_scaled_out branch (:330-355)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(CC_THREADS) void cc_detect_kernel(LevelBatch lb, CompTables t, int level,
+__global__ __launch_bounds__(CCG_THREADS, 4) void cc_detect_kernel(LevelBatch lb, CompTables t, int level,
                                                                DetectOut out, int frame0) {
     __shared__ int s_nroots, s_ncand, s_arena_full;
     __shared__ unsigned long long s_arena_top;
@@ -381,18 +378,18 @@ __global__ __launch_bounds__(CC_THREADS) void cc_detect_kernel(LevelBatch lb, Co
     }
     const FrameView v = make_view(lb, t, frame);
     if (threadIdx.x == 0) { s_nroots = 0; s_ncand = 0; s_arena_top = 0; s_arena_full = 0; }
-    __syncthreads();
+    label_frame(v);
 
     // P3a: compact the roots.  A super-component of a single hot pixel can only ever give a
     // one-pixel blob, which the size test rejects (:205), and nothing else can reach it: skipped.
-    for (int i = threadIdx.x; i < v.n; i += CC_THREADS)
+    for (int i = threadIdx.x; i < v.n; i += CCG_THREADS)
         if (v.parent[i] == i && v.comp_cnt[i] >= kBlobMinPixels) v.roots[atomicAdd(&s_nroots, 1)] = i;
     __syncthreads();
     const int nroots = s_nroots;
 
     // P3b: one lane per super-component replays the reference's sequence
     const int w = v.w, h = v.h;
-    for (int k = threadIdx.x; k < nroots; k += CC_THREADS) {
+    for (int k = threadIdx.x; k < nroots; k += CCG_THREADS) {
         const int r = v.roots[k];
         const int4 box = v.comp_box[r];
         const int cnt = v.comp_cnt[r];
@@ -442,11 +439,11 @@ __global__ __launch_bounds__(CC_THREADS) void cc_detect_kernel(LevelBatch lb, Co
     const int nvalid = s_ncand;
 
     // P5: order by seed raster index = the reference's output order (:332-353)
-    for (int c = threadIdx.x; c < nvalid; c += CC_THREADS)
+    for (int c = threadIdx.x; c < nvalid; c += CCG_THREADS)
         v.sortkeys[c] = ((unsigned long long)(uint32_t)v.cand[c].seed << 32) | (uint32_t)c;
     int n_pad = 1;
     while (n_pad < nvalid) n_pad <<= 1;
-    for (int i = nvalid + threadIdx.x; i < n_pad; i += CC_THREADS) v.sortkeys[i] = ~0ull;
+    for (int i = nvalid + threadIdx.x; i < n_pad; i += CCG_THREADS) v.sortkeys[i] = ~0ull;
     __syncthreads();
     bitonic_sort(v.sortkeys, n_pad);
     emit_detect_outputs(v, v.sortkeys, nvalid, level, out, frame);
@@ -456,14 +453,13 @@ void launch_cc_detect(const LevelBatch& lb, const CompTables& t, int level, cons
                       int nframes, hipStream_t s) {
     if (nframes <= 0) return;
     launch_cc_detect_lds(lb, t, level, out, frame0, nframes, s);
-    launch_cc_label(lb, t, frame0, nframes, s);
-    hipLaunchKernelGGL(cc_detect_kernel, dim3(nframes), dim3(CC_THREADS), 0, s, lb, t, level, out, frame0);
+    hipLaunchKernelGGL(cc_detect_kernel, dim3(nframes), dim3(CCG_THREADS), 0, s, lb, t, level, out, frame0);
 }
 
 // ---------------------------------------------------------------------------
 // Refine: process_connected_components, points_refinement branch (:356-397)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, CompTables t, int level,
+__global__ __launch_bounds__(CCG_THREADS, 4) void cc_refine_kernel(LevelBatch lb, CompTables t, int level,
                                                                RefineIO io, int frame0) {
     __shared__ int s_changed, s_nref, s_arena_full;
     __shared__ unsigned long long s_arena_top;
@@ -479,7 +475,7 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, Co
     }
     const FrameView v = make_view(lb, t, frame);
     if (threadIdx.x == 0) { s_changed = 0; s_nref = 0; s_arena_top = 0; s_arena_full = 0; }
-    __syncthreads();  // v.roots[] was preset to INT_MAX by cc_label_kernel: it is the claim table here
+    label_frame(v);  // (presets v.roots[] to INT_MAX: it is the claim table here)
 
     const int w = v.w, h = v.h;
     const int npts = min(io.npoints[frame], io.pitch);
@@ -495,7 +491,7 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, Co
 
     // R1: seeds of every refinable point (:362-382), in the reference's push order, and the
     // super-component (root) each seed belongs to
-    for (int i = threadIdx.x; i < npts; i += CC_THREADS) {
+    for (int i = threadIdx.x; i < npts; i += CCG_THREADS) {
         int ns = -1;  // -1: not refinable at this level
         if (lv[i] == level + 1) {
             ns = 0;
@@ -523,7 +519,7 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, Co
     // order by one lane; label-propagate the minimum point index over the
     // bipartite graph points <-> super-components until nothing changes.
     while (true) {
-        for (int i = threadIdx.x; i < npts; i += CC_THREADS) {
+        for (int i = threadIdx.x; i < npts; i += CCG_THREADS) {
             const int ns = nseeds[i];
             if (ns <= 0) continue;
             int m = leader[i];
@@ -543,7 +539,7 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, Co
     }
 
     // R3: stack demand of each group = 4 * (hot pixels of its super-components), counted once
-    for (int i = threadIdx.x; i < npts; i += CC_THREADS) {
+    for (int i = threadIdx.x; i < npts; i += CCG_THREADS) {
         const int ns = nseeds[i];
         for (int k = 0; k < ns; ++k) {
             const int old = wg_or(v.comp_cnt + sroot[9 * i + k], (int)0x80000000);
@@ -553,7 +549,7 @@ __global__ __launch_bounds__(CC_THREADS) void cc_refine_kernel(LevelBatch lb, Co
     __syncthreads();
 
     // R4: one lane per group, members in index order (:358); accepted points are written in place
-    for (int i = threadIdx.x; i < npts; i += CC_THREADS) {
+    for (int i = threadIdx.x; i < npts; i += CCG_THREADS) {
         if (nseeds[i] < 0 || leader[i] != i) continue;
         const unsigned long long off = atomicAdd(&s_arena_top, (unsigned long long)(need[i] + 10));
         if (off + (unsigned long long)(need[i] + 10) > (unsigned long long)v.arena_cap) { s_arena_full = 1; continue; }
@@ -588,8 +584,7 @@ void launch_cc_refine(const LevelBatch& lb, const CompTables& t, int level, cons
                       int nframes, hipStream_t s) {
     if (nframes <= 0) return;
     launch_cc_refine_lds(lb, t, level, io, frame0, nframes, s);
-    launch_cc_label(lb, t, frame0, nframes, s);
-    hipLaunchKernelGGL(cc_refine_kernel, dim3(nframes), dim3(CC_THREADS), 0, s, lb, t, level, io, frame0);
+    hipLaunchKernelGGL(cc_refine_kernel, dim3(nframes), dim3(CCG_THREADS), 0, s, lb, t, level, io, frame0);
 }
 
 
