@@ -1218,6 +1218,7 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
             lds_decline_refine(t, frame, band, io, L.nref);
             return;
         }
+        if (t.lds_path & 8) { if (tid == 0) t.path[frame] = 1; return; }  // ablation (timing only)
         // LIFO demand of every super-component at its root, then the accumulators become the claim table
         for (int i = tid; i < n; i += CC_THREADS) L.w.need16[i] = (int16_t)((L.u.acc[i] >> 13) + 1);
         __syncthreads();
@@ -1350,9 +1351,10 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
                 const int ns = j == i ? ns_[q] : aload(nseeds + j);
                 for (int k = 0; k < ns; ++k) stk[k] = (int16_t)__hip_atomic_load(&seeds[9 * j + k], MRG_WG);
                 Blob b;
+                if (t.lds_path & 4) continue;  // ablation (timing only)
                 drain_lds(L, w, h, stk, ns, b);
                 if (!blob_passes_cheap_tests(b)) continue;
-                if (!window_variance_high(v.img, v.img_stride, w, h, b.xpk, b.ypk)) continue;  // :207
+                if (!(t.lds_path & 2) && !window_variance_high(v.img, v.img_stride, w, h, b.xpk, b.ypk)) continue;  // :207
                 const double cx = (double)b.srx / (double)b.sr;  // :262-263
                 const double cy = (double)b.sry / (double)b.sr;
                 pts[2 * j + 0] = rescale_coord(cx, (double)coord_scale);  // :390
