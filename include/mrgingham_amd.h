@@ -284,6 +284,12 @@ int mrgingham_amd_find_boards_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_
  * Synchronises. */
 int mrgingham_amd_debug_paths(mrgingham_amd_ctx* ctx, int level, int nframes, int32_t* h_paths);
 
+/* TEST HOOK: with option "cc_lds" = 1 | 512 the LDS refinement kernel leaves a phase clock of the first frame of
+ * the call: h_ticks12[0..7] = 100 MHz ticks at start, bands planned, hot list loaded + labelled, seeds found,
+ * groups formed, LIFO demand known + neighbour table built, fills done (all of the first band), end;
+ * [8..11] = hot pixels, points, bands, level.  Synchronises.  (tools/cc_phases.py) */
+int mrgingham_amd_debug_refine_clock(mrgingham_amd_ctx* ctx, long long* h_ticks12);
+
 /* Device memory the context currently holds (level scratch of both sets, point scratch, staging). */
 long long mrgingham_amd_scratch_bytes(const mrgingham_amd_ctx* ctx);
 
@@ -304,7 +310,8 @@ int mrgingham_amd_chain_info(const mrgingham_amd_ctx* ctx, int* fused_pyramid, i
  *   "cc_lds"              1 (default) = component search out of LDS: frames with at most 2048 hot pixels in one
  *                         pass, frames with up to 16384 in bands of rows separated by three rows without a hot
  *                         pixel (the global-memory kernels take what is left), 0 = global-memory kernels only;
- *                         1 | 256 = no banding (test hook)
+ *                         1 | 256 = no banding (test hook); bits 2, 4, 8 timing ablations (wrong results),
+ *                         128 = no component kernels at all, 512 = phase clock (mrgingham_amd_debug_refine_clock)
  *   "cc_schedule", "chess_seg", "chess_stage"   experiment hooks (tools/interference_ab.py, tools/stage_ab.py) */
 int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value);
 

@@ -31,7 +31,7 @@ EXPORTS = [
     "mrgingham_amd_preprocess_batch", "mrgingham_amd_process_image", "mrgingham_amd_process_image_ex", "mrgingham_amd_preprocess_image16", "mrgingham_amd_preprocess_image",
     "find_chessboard_corners_from_image_file_C", "find_chessboard_from_image_file_C",
     "mrgingham_amd_detect_batch", "mrgingham_amd_refine_batch", "mrgingham_amd_chain_batch",
-    "mrgingham_amd_find_boards_batch", "mrgingham_amd_cc_on_response_batch", "mrgingham_amd_scratch_bytes", "mrgingham_amd_chain_info", "mrgingham_amd_debug_paths", "mrgingham_amd_read_image",
+    "mrgingham_amd_find_boards_batch", "mrgingham_amd_cc_on_response_batch", "mrgingham_amd_scratch_bytes", "mrgingham_amd_chain_info", "mrgingham_amd_debug_refine_clock", "mrgingham_amd_debug_paths", "mrgingham_amd_read_image",
     "mrgingham_amd_set_option", "mrgingham_amd_sync", "mrgingham_amd_stream_wait", "mrgingham_amd_after_stream", "mrgingham_amd_set_kernel_timing",
     "mrgingham_amd_chess_kernel_ms",
 ]
@@ -100,6 +100,7 @@ def lib():
                                            ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     L.mrgingham_amd_debug_paths.argtypes = [c_vp, c_int, c_int, c_vp]
     L.mrgingham_amd_chain_info.argtypes = [c_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    L.mrgingham_amd_debug_refine_clock.argtypes = [c_vp, c_vp]
     L.mrgingham_amd_scratch_bytes.argtypes = [c_vp]
     L.mrgingham_amd_scratch_bytes.restype = ctypes.c_longlong
     L.mrgingham_amd_set_option.argtypes = [c_vp, ctypes.c_char_p, c_int]

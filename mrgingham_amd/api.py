@@ -413,6 +413,12 @@ class Detector:
         self._check(self.L.mrgingham_amd_debug_paths(self.ctx, int(level), int(nframes), out.ctypes.data))
         return out
 
+    def debug_refine_clock(self):
+        """Phase clock of the most recent refinement (option cc_lds = 1 | 512): 12 int64, see the header."""
+        out = np.zeros(12, dtype=np.int64)
+        self._check(self.L.mrgingham_amd_debug_refine_clock(self.ctx, out.ctypes.data))
+        return out
+
     def chain_info(self):
         """(fused_pyramid, merged_levels) of the most recent chain() call: whether the level-0 response kernel
         also wrote the level images, and how many levels shared one response launch."""

@@ -572,6 +572,16 @@ int mrgingham_amd_debug_paths(mrgingham_amd_ctx* ctx, int level, int nframes, in
     return MRGINGHAM_AMD_OK;
 }
 
+int mrgingham_amd_debug_refine_clock(mrgingham_amd_ctx* ctx, long long* h_ticks12) {
+    if (!ctx || !h_ticks12) return MRGINGHAM_AMD_ERR_ARG;
+    MRG_HIP_CHECK(hipSetDevice(ctx->device));
+    MRG_HIP_CHECK(hipDeviceSynchronize());
+    const DevBuf& b = ctx->pts[ctx->cur].sroot;
+    if (!b.p || b.bytes < 12 * sizeof(long long)) return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "no refinement has run yet");
+    MRG_HIP_CHECK(hipMemcpy(h_ticks12, b.p, 12 * sizeof(long long), hipMemcpyDeviceToHost));
+    return MRGINGHAM_AMD_OK;
+}
+
 int mrgingham_amd_chain_info(const mrgingham_amd_ctx* ctx, int* fused_pyramid, int* merged_levels) {
     if (!ctx) return MRGINGHAM_AMD_ERR_ARG;
     if (fused_pyramid) *fused_pyramid = ctx->last_fused;

@@ -599,8 +599,8 @@ void launch_cc_refine(const LevelBatch& lb, const CompTables& t, int level, cons
 // hot pixel), never written.  Frames that do not fit (hot pixels, components or LIFO demand) are left
 // to the global-memory kernels through CompTables::path.
 //
-// LDS per workgroup: 40 KB, so that a workgroup fits next to three resident ChESS workgroups
-// (163 840 - 3 * 39 952 B = 43 984 B) as soon as a fourth one retires.
+// LDS per workgroup: 40 KB, the slot one ChESS workgroup leaves when it retires (39 952 B there, 40 960 B in
+// allocation granules: four per CU).
 //
 // Frames with MORE hot pixels than the tables hold (a 14x14 board has ~2600 at level 0) are cut into
 // horizontal BANDS of at most LN hot pixels each, separated by three consecutive rows without a hot pixel,
@@ -645,7 +645,9 @@ struct LdsCCT {
 };
 constexpr int LPTS = 512;                    // points per frame the LDS refine kernel takes
 constexpr int LPPT = LPTS / CC_THREADS;     // points per thread
-static_assert(sizeof(LdsCCT<2048>) <= 43984, "must fit beside three ChESS workgroups");
+// One workgroup slot of the pixel kernels, in LDS allocation granules (1280 B on this part: 39 952 B of a ChESS
+// workgroup occupy 40 960, four of them the whole 160 KB): anything above 40 960 B would need two.
+static_assert(sizeof(LdsCCT<2048>) <= 40960, "must fit into the LDS slot of one ChESS workgroup");
 static_assert(offsetof(LdsCCT<2048>, nroots) >= (8192 + CC_THREADS / 64) * 4, "the band planner's key arrays overlay the tables");
 
 // Fibonacci hashing with an independent multiplier per coordinate: the hot pixels of a calibration board sit on a
@@ -684,6 +686,33 @@ __device__ __forceinline__ int lds_find(const LdsCC& L, uint32_t e) {
         if (v == 0xffffu) return -1;
         if (L.xy[v] == e) return (int)v;
         s = (s + 1u) & (uint32_t)(LdsCC::LHASH - 1);
+    }
+}
+
+// The four neighbours of pixel e at once: the first probes of the four lookups are independent, so their slot
+// reads and then their position reads go out together (two dependent LDS round trips for all four in the
+// common case, 1.0-1.7 probes per lookup); whatever is not settled by then continues on its own.
+template <class LdsCC>
+__device__ __forceinline__ void lds_find4(const LdsCC& L, uint32_t e, int (&j)[4]) {
+    const uint32_t q[4] = {e + 1u, e - 1u, e + 0x10000u, e - 0x10000u};
+    uint32_t s[4], v[4], x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] = lds_hash<LdsCC>(q[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (L.hashw[s[k] >> 1] >> ((s[k] & 1u) * 16)) & 0xffffu;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = L.xy[v[k] & (uint32_t)(LdsCC::LN - 1)];  // (any slot: compared below)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (v[k] == 0xffffu) { j[k] = -1; continue; }
+        if (x[k] == q[k]) { j[k] = (int)v[k]; continue; }
+        uint32_t sk = (s[k] + 1u) & (uint32_t)(LdsCC::LHASH - 1);
+        while (true) {
+            const uint32_t vv = (L.hashw[sk >> 1] >> ((sk & 1u) * 16)) & 0xffffu;
+            if (vv == 0xffffu) { j[k] = -1; break; }
+            if (L.xy[vv] == q[k]) { j[k] = (int)vv; break; }
+            sk = (sk + 1u) & (uint32_t)(LdsCC::LHASH - 1);
+        }
     }
 }
 
@@ -906,6 +935,94 @@ __device__ __noinline__ int lds_plan_bands(LdsCC& L, const FrameView& v, int nra
     return 0;
 }
 
+// The same fill with the four neighbours of every entry looked up beforehand (lds_build_neighbours): a pop is
+// two dependent LDS round trips (entry: value, position, neighbours; then the neighbours' values) instead of
+// eleven through the hash map.  The refine kernel's fills went from 43-58 us to ... per launch with it.
+constexpr uint32_t kNoNb = 0xfffu;  // 12 bits per neighbour: a list index (< 2048) or this
+template <class LdsCC>
+__device__ __forceinline__ int drain_nb(LdsCC& L, const uint16_t* nb3, int w, int h, int16_t* stk, int sp, Blob& b) {
+    b.srx = b.sry = b.sr = 0;
+    b.npix = 0;
+    b.rmax = 0;
+    b.xpk = b.ypk = 0;
+    b.touched = false;
+    int consumed = 0;
+    while (sp > 0) {
+        const int i = stk[--sp];
+        const int v = L.val[i];
+        const uint32_t e = L.xy[i];
+        const uint16_t* q = nb3 + 3 * i;
+        const uint32_t q0 = q[0], q1 = q[1], q2 = q[2];
+        if (v <= 0) continue;  // visited already
+        const int x = (int)(e & 0xffffu), y = (int)(e >> 16);
+        const uint32_t jxp = q0 & 0xfffu, jxm = (q0 >> 12) | ((q1 & 0xffu) << 4), jyp = (q1 >> 8) | ((q2 & 0xfu) << 8), jym = q2 >> 4;
+        // the neighbours' values do not depend on v: read together
+        const int vxp = jxp != kNoNb ? (int)L.val[jxp] : 0, vxm = jxm != kNoNb ? (int)L.val[jxm] : 0;
+        const int vyp = jyp != kNoNb ? (int)L.val[jyp] : 0, vym = jym != kNoNb ? (int)L.val[jym] : 0;
+        L.val[i] = 0;  // :245 / :250
+        ++consumed;    // every listed pixel is hot
+        if (!(v > (b.rmax >> 4))) continue;                    // :159-171 with :27 (v > 15 holds)
+        if (v > b.rmax) { b.rmax = v; b.xpk = x; b.ypk = y; }  // :176-181, first maximum wins
+        b.srx += (unsigned long long)(v * x);
+        b.sry += (unsigned long long)(v * y);
+        b.sr += (unsigned long long)v;
+        b.npix++;
+        // :252-255 then :216-226; a neighbour is worth pushing only while it is hot and unvisited
+        if (x + 1 >= w - kMargin) b.touched = true;
+        else if (vxp > 0) stk[sp++] = (int16_t)jxp;
+        if (x - 1 < kMargin) b.touched = true;
+        else if (vxm > 0) stk[sp++] = (int16_t)jxm;
+        if (y + 1 >= h - kMargin) b.touched = true;
+        else if (vyp > 0) stk[sp++] = (int16_t)jyp;
+        if (y - 1 < kMargin) b.touched = true;
+        else if (vym > 0) stk[sp++] = (int16_t)jym;
+    }
+    return consumed;
+}
+
+// The neighbour table of drain_nb: 48 bits per entry (+x, -x, +y, -y at 12 bits each) = 12 KB over the labels
+// and the hash map, which must both be dead: every thread looks its entries' neighbours up in the hash first,
+// then (barrier) overwrites it.  All threads call it.
+template <class LdsCC>
+__device__ __forceinline__ uint16_t* lds_build_neighbours(LdsCC& L, int n) {
+    constexpr int LEPT = LdsCC::LEPT;
+    static_assert(offsetof(LdsCC, hashw) == offsetof(LdsCC, lab) + sizeof(L.lab), "labels and hash map must be adjacent");
+    static_assert(sizeof(L.lab) + sizeof(L.hashw) >= (size_t)LdsCC::LN * 6, "48 bits per entry");
+    static_assert(LdsCC::LN <= (int)kNoNb, "12-bit list indices");
+    const int tid = threadIdx.x;
+    uint32_t lo[LEPT];
+    uint16_t hi[LEPT];
+#pragma unroll
+    for (int k = 0; k < LEPT; ++k) {
+        const int i = tid + CC_THREADS * k;
+        lo[k] = 0;
+        hi[k] = 0;
+        if (i >= n) continue;
+        const uint32_t e = L.xy[i];
+        uint32_t j[4] = {kNoNb, kNoNb, kNoNb, kNoNb};
+        if (e != kHotDead) {
+            int f[4];
+            lds_find4(L, e, f);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) j[q] = f[q] < 0 ? kNoNb : (uint32_t)f[q];
+        }
+        lo[k] = j[0] | (j[1] << 12) | (j[2] << 24);          // bits 0 .. 31 of the 48
+        hi[k] = (uint16_t)((j[2] >> 8) | (j[3] << 4));       // bits 32 .. 47
+    }
+    __syncthreads();
+    uint16_t* nb3 = reinterpret_cast<uint16_t*>(L.lab);
+#pragma unroll
+    for (int k = 0; k < LEPT; ++k) {
+        const int i = tid + CC_THREADS * k;
+        if (i >= n) continue;
+        nb3[3 * i] = (uint16_t)lo[k];
+        nb3[3 * i + 1] = (uint16_t)(lo[k] >> 16);
+        nb3[3 * i + 2] = hi[k];
+    }
+    __syncthreads();
+    return nb3;
+}
+
 // Load the hot pixels with band keys in [y0, y1) (`banded`; otherwise the whole list as it stands) into LDS,
 // label the super-components (lab = smallest list index) and leave in L.u.acc, at every root, (pixels of the
 // super-component) | (sum of hot-neighbour counts << 13): the latter bounds the pushes of any fill of it.
@@ -957,16 +1074,24 @@ __device__ __forceinline__ bool lds_load_and_label(LdsCC& L, const FrameView& v,
         }
     }
     __syncthreads();
-    short nb[LEPT][4];
+    // the four neighbours of every entry, 12 bits each (kNoNb = none), packed like the table of drain_nb
+    uint32_t nlo[LEPT];
+    uint16_t nhi[LEPT];
 #pragma unroll
     for (int k = 0; k < LEPT; ++k) {
         const uint32_t e = own[k];
-        const bool live = e != kHotDead;
-        nb[k][0] = live ? (short)lds_find(L, e + 1u) : (short)-1;
-        nb[k][1] = live ? (short)lds_find(L, e - 1u) : (short)-1;
-        nb[k][2] = live ? (short)lds_find(L, e + 0x10000u) : (short)-1;
-        nb[k][3] = live ? (short)lds_find(L, e - 0x10000u) : (short)-1;
+        int f[4] = {-1, -1, -1, -1};
+        if (e != kHotDead) lds_find4(L, e, f);
+        uint32_t j[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) j[q] = f[q] < 0 ? kNoNb : (uint32_t)f[q];
+        nlo[k] = j[0] | (j[1] << 12) | (j[2] << 24);
+        nhi[k] = (uint16_t)((j[2] >> 8) | (j[3] << 4));
     }
+    auto nb_of = [&](int k, int q) -> uint32_t {  // q static after unrolling
+        return q == 0 ? nlo[k] & 0xfffu : q == 1 ? (nlo[k] >> 12) & 0xfffu
+             : q == 2 ? (nlo[k] >> 24) | (((uint32_t)nhi[k] & 0xfu) << 8) : (uint32_t)nhi[k] >> 4;
+    };
     // min-label propagation with shortcutting; labels only ever decrease and always name a member of
     // the same super-component, so unsynchronised reads within a round are harmless
     while (true) {
@@ -978,8 +1103,10 @@ __device__ __forceinline__ bool lds_load_and_label(LdsCC& L, const FrameView& v,
             const int cur = L.lab[i];
             int m = cur;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (nb[k][q] >= 0) m = min(m, (int)L.lab[nb[k][q]]);
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t jq = nb_of(k, q);
+                if (jq != kNoNb) m = min(m, (int)L.lab[jq]);
+            }
             m = min(m, (int)L.lab[m]);
             if (m < cur) { L.lab[i] = (int16_t)m; ch = true; }
         }
@@ -995,7 +1122,9 @@ __device__ __forceinline__ bool lds_load_and_label(LdsCC& L, const FrameView& v,
     for (int k = 0; k < LEPT; ++k) {
         if (own[k] == kHotDead) continue;
         const int i = tid + CC_THREADS * k;
-        const int deg = (nb[k][0] >= 0) + (nb[k][1] >= 0) + (nb[k][2] >= 0) + (nb[k][3] >= 0);
+        int deg = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) deg += nb_of(k, q) != kNoNb;
         atomicAdd(&L.u.acc[L.lab[i]], 1 + (deg << 13));
     }
     __syncthreads();
@@ -1185,6 +1314,12 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
     LdsCC& L = *reinterpret_cast<LdsCC*>(lds_cc_raw);
     if (!(t.lds_path & 16)) __builtin_amdgcn_s_setprio(3);
     const int frame = frame0 + blockIdx.x, tid = threadIdx.x;
+    // phase clock (cc_lds bit 512, mrgingham_amd_debug_refine_clock, tools/cc_phases.py): thread 0 of the first
+    // frame leaves 100 MHz ticks of the phase boundaries of its first band in the scratch of the global-memory kernel
+    const bool clk = (t.lds_path & 512) && blockIdx.x == 0 && tid == 0;
+    long long* tk = reinterpret_cast<long long*>(io.sroot);  // (scratch of the global-memory kernel, unused here)
+    auto tick = [&](int k) { if (clk) tk[k] = wall_clock64(); };
+    tick(0);
     const int nraw = t.hot_cnt[frame];
     const int npts = min(io.npoints[frame], io.pitch);
     FrameView v = make_view(lb, t, frame);
@@ -1199,6 +1334,7 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
         return;
     }
     if (tid == 0) L.nref = 0;
+    tick(1);
     const int w = v.w, h = v.h;
     const long long pb = (long long)frame * io.pitch;
     double* pts = io.points + 2 * pb;
@@ -1219,6 +1355,7 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
             return;
         }
         if (t.lds_path & 8) { if (tid == 0) t.path[frame] = 1; return; }  // ablation (timing only)
+        if (band == 0) tick(2);
         // LIFO demand of every super-component at its root, then the accumulators become the claim table
         for (int i = tid; i < n; i += CC_THREADS) L.w.need16[i] = (int16_t)((L.u.acc[i] >> 13) + 1);
         __syncthreads();
@@ -1262,6 +1399,7 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
             lead_[q] = i;
         }
         __syncthreads();
+        if (band == 0) tick(3);
 
         // R2: points whose seeds share a super-component are replayed in index order by one lane:
         // propagate the minimum point index over the bipartite graph points <-> super-components
@@ -1295,6 +1433,7 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
             if (i < npts) lead16[i] = (int16_t)(ns_[q] < 0 ? -1 : lead_[q]);
         }
 
+        if (band == 0) tick(4);
         // R3: LIFO demand of each group = sum over its super-components, each counted once; groups take
         // their LIFOs in the order of a running counter
 #pragma unroll
@@ -1328,7 +1467,11 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
             return;
         }
         __syncthreads();  // the claim table is dead: its storage becomes the LIFOs
+        // (here rather than behind R1, where labels and hash map die: the seed roots of R1-R3 are out of the
+        // registers by now)
+        const uint16_t* nb3 = lds_build_neighbours(L, n);
 
+        if (band == 0) tick(5);
         // R4: one lane per group, members in index order (:358); accepted points are written in place.  The
         // groups share LSTK LIFO words and run in rounds when together they want more (see the detect kernel).
         bool pending[LPPT];
@@ -1352,7 +1495,7 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
                 for (int k = 0; k < ns; ++k) stk[k] = (int16_t)__hip_atomic_load(&seeds[9 * j + k], MRG_WG);
                 Blob b;
                 if (t.lds_path & 4) continue;  // ablation (timing only)
-                drain_lds(L, w, h, stk, ns, b);
+                drain_nb(L, nb3, w, h, stk, ns, b);
                 if (!blob_passes_cheap_tests(b)) continue;
                 if (!(t.lds_path & 2) && !window_variance_high(v.img, v.img_stride, w, h, b.xpk, b.ypk)) continue;  // :207
                 const double cx = (double)b.srx / (double)b.sr;  // :262-263
@@ -1367,6 +1510,7 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
         if (!L.changed) break;
         __syncthreads();  // everybody has read the flag before it is reset
         }
+        if (band == 0) tick(6);
         __threadfence_block();
         __syncthreads();  // the next band reads the levels this one wrote
         // Several bands: what this band's fills consumed goes back into the dense response, like the
@@ -1382,6 +1526,10 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
     if (tid == 0) {
         t.path[frame] = 1;
         if (io.nrefined) io.nrefined[frame] = L.nref;
+    }
+    if (clk) {
+        tick(7);
+        tk[8] = nraw; tk[9] = npts; tk[10] = nbands; tk[11] = level;
     }
 }
 
