@@ -1535,10 +1535,13 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
 
 template <int N, class K, class... A>
 static void launch_lds(K kernel, int nframes, hipStream_t s, A... args) {
+    // MRGINGHAM_AMD_CC_LDS_PAD: extra bytes of dynamic LDS per workgroup (experiment: where does the allocation
+    // stop fitting into one slot of the pixel kernels?)
+    static const int pad = [] { const char* e = getenv("MRGINGHAM_AMD_CC_LDS_PAD"); return e ? atoi(e) : 0; }();
     static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LdsCCT<N>)), true);
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LdsCCT<N>) + pad), true);
     (void)once;
-    hipLaunchKernelGGL(kernel, dim3(nframes), dim3(CC_THREADS), sizeof(LdsCCT<N>), s, args...);
+    hipLaunchKernelGGL(kernel, dim3(nframes), dim3(CC_THREADS), sizeof(LdsCCT<N>) + pad, s, args...);
 }
 
 void launch_cc_detect_lds(const LevelBatch& lb, const CompTables& t, int level, const DetectOut& out, int frame0,
