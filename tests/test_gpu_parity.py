@@ -444,3 +444,29 @@ def test_fused_pyramid_random_shapes(det):
                 assert n == len(wp), (case, w, h, start, f, n, len(wp))
                 assert np.array_equal(pts[f, :n].cpu().numpy(), wp), (case, w, h, start, f)
                 assert np.array_equal(lv[f, :n].cpu().numpy(), wl), (case, w, h, start, f)
+
+
+def test_fused_pyramid_on_strided_frames(det):
+    """chain() on frames that are a window of a larger device buffer (row stride and frame pitch larger than
+    the frame, 16-byte aligned): still the fused level-0 + pyramid kernel, same corners as the dense copy."""
+    w, h = 1328, 984
+    frames = np.stack([synth.board_frame(w, h, 10, s).numpy() for s in (0, 5, 6)])
+    buf = torch.full((3, h + 8, w + 32), 77, dtype=torch.uint8, device="cuda")
+    view = buf[:, 4:4 + h, 16:16 + w]
+    view.copy_(torch.from_numpy(frames).cuda())
+    assert not view.is_contiguous()
+    pts, lv, npts = det.chain(view, start_level=3, max_points=2048)
+    assert det.chain_info()[0]
+    for f in range(3):
+        wp, wl = oracle.chain(frames[f], 3)
+        n = int(npts[f])
+        assert n == len(wp) and np.array_equal(pts[f, :n].cpu().numpy(), wp) and np.array_equal(lv[f, :n].cpu().numpy(), wl)
+    # a window that starts at an odd byte is not 16-byte aligned: the separate pyramid kernel takes it
+    view2 = buf[:, 4:4 + h, 3:3 + w]
+    view2.copy_(torch.from_numpy(frames).cuda())
+    pts, lv, npts = det.chain(view2, start_level=3, max_points=2048)
+    assert not det.chain_info()[0]
+    for f in range(3):
+        wp, wl = oracle.chain(frames[f], 3)
+        n = int(npts[f])
+        assert n == len(wp) and np.array_equal(pts[f, :n].cpu().numpy(), wp) and np.array_equal(lv[f, :n].cpu().numpy(), wl)
