@@ -372,6 +372,13 @@ def main():
                                          "written once)" % bpp) if fused else
                                         "3 B/px (u8 read once + int16 written once)",
                          "bytes_per_launch": alg_bytes, "avg_launch_ms": kern_ms,
+                         # the same launch on SURVEY.md 8d's two other ways of counting: its ChESS-pass model alone
+                         # (3 B/px, as if the level images were free), and what the unfused schedule moves for the same
+                         # outputs (ChESS pass 3 B/px + decimation pass 1 B/px read + the level images written)
+                         "frac_3Bpx_chess_pass_model": (frames_per_launch * W * H * 3.0 / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                                                       if kern_ms > 0 else 0.0,
+                         "frac_two_pass_equivalent": (frames_per_launch * W * H * (bpp + (1.0 if fused else 0.0)) /
+                                                      (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kern_ms > 0 else 0.0,
                          "launches_timed": nlaunch},
         }
         res["gather_checked"] = gather_ok
