@@ -209,6 +209,8 @@ def main():
                          "rocprofv3 --pmc passes, where tracing the ~37k tiny kernels of the frame generator is "
                          "the bottleneck); default: every frame distinct")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--scratch-sets", type=int, default=0,
+                    help="option scratch_sets of the library (0 = its default, 2): calls' component searches in flight")
     ap.add_argument("--force-gather", action="store_true",
                     help="with one rank: still create the (one-rank) RCCL group and issue the gather every step")
     ap.add_argument("--prime", type=int, default=30,
@@ -254,6 +256,8 @@ def main():
     else:
         frames = synth.board_batch(batch, W, H, gridn=gridn, seed0=lo, device=dev)
     det = mrgingham_amd.Detector(local_rank)
+    if args.scratch_sets:
+        det.set_option("scratch_sets", args.scratch_sets)
     P = args.max_points
     # Output ring: consecutive steps overlap on the device (step N+1's pixel kernels run while step
     # N's component kernels and gather finish), so a step must not overwrite a predecessor whose
@@ -382,6 +386,7 @@ def main():
                          "launches_timed": nlaunch},
         }
         res["gather_checked"] = gather_ok
+        res["scratch_sets"] = args.scratch_sets or 2
         res["setup_prime_steps"] = args.prime
         res["timed_region_s"] = dt
         res["notes"] = ("steps are queued back to back (streaming pipeline); the first few dozen passes of a process "

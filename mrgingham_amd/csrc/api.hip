@@ -96,25 +96,31 @@ struct HostPool {
     }
 };
 
+constexpr int kMaxSets = 3;  // scratch sets a context can rotate through (option "scratch_sets": 2 or 3)
+
 struct mrgingham_amd_ctx {
     int device = 0;
+    int nsets = 2;
     // HIP streams of a context: `pix` runs the pixel kernels (pyramid, ChESS) back to back, each
     // over the whole batch; `ccs[set]` run the latency-bound component kernels (a serial chain
     // detect -> refine -> refine ... per call) underneath them, one stream per scratch set so that
     // the chains of consecutive calls overlap each other as well.  Events order cc(L) after pix(L).
     hipStream_t pix = nullptr;
-    hipStream_t ccs[2] = {nullptr, nullptr};
+    hipStream_t ccs[kMaxSets] = {};
     // Device buffers the last call of each set wrote / read (caller-owned outputs and inputs):
     // consecutive calls run on different component streams, so a call that touches a buffer the
     // previous call wrote (or writes one it read) must wait for it explicitly.
     struct Span { const char* p; size_t n; };
-    std::vector<Span> last_w[2], last_r[2];
+    std::vector<Span> last_w[kMaxSets], last_r[kMaxSets];
     hipEvent_t ev_pix[mrg::kMaxLevel + 1] = {};
-    // Level scratch exists twice: call N+1 fills set (N+1)%2 on the pixel stream while the
-    // component stream still works through call N in the other set.
-    hipEvent_t ev_cc_done[2] = {};
+    // Level scratch exists `nsets` times (2, or 3 with option "scratch_sets"): call N+1 fills set (N+1) % nsets on
+    // the pixel stream while the component streams still work through the calls before it in the other sets.
+    // Two sets keep two component chains in flight, which hides them as long as a chain is shorter than two
+    // steps of the pixel kernels; small frames (64 x 640x480: chain 430 us, pixel kernels 62 us) and dense boards
+    // want three.
+    hipEvent_t ev_cc_done[kMaxSets] = {};
     hipEvent_t ev_ext = nullptr;  // mrgingham_amd_after_stream
-    bool cc_pending[2] = {false, false};
+    bool cc_pending[kMaxSets] = {};
     int cur = 0;  // scratch set of the call being queued
     std::string err;
     int cap_shift = 3;    // hot-pixel table capacity = level pixels >> cap_shift per frame
@@ -134,17 +140,17 @@ struct mrgingham_amd_ctx {
     int cc_schedule = 1;
     int cc_lds = 1;  // component search out of LDS for frames with few hot pixels (option "cc_lds"; bits 1-3: timing ablations)
 
-    mrg::LevelScratch lvs[2][mrg::kMaxLevel + 1];
-    mrg::DevBuf counters2[2];  // per scratch set: hot_cnt words [level][counters_nf], then status words, then path words
+    mrg::LevelScratch lvs[kMaxSets][mrg::kMaxLevel + 1];
+    mrg::DevBuf counters2[kMaxSets];  // per scratch set: hot_cnt words [level][counters_nf], then status words, then path words
     int counters_nf = 0;
-    struct PointScratch { mrg::DevBuf leader, need, nseeds, seeds, sroot, cand_xy, cand_counts; } pts[2];  // per scratch set
+    struct PointScratch { mrg::DevBuf leader, need, nseeds, seeds, sroot, cand_xy, cand_counts; } pts[kMaxSets];  // per scratch set
     mrg::DevBuf aux_img, io_frame, io_out, io_counts;
     mrg::DevBuf pre_scratch, pre_tmp, pre_out, pre16_scratch, io_frame16, dbg_img, dbg_resp, blob_scratch;
     mrg::DevBuf fb_xy, fb_cnt, fb_pts, fb_lv, fb_np, fb_frames, fb_frames2;  // find_boards_batch: candidates, counts, boards, levels, point counts
     HostPool pool;  // preprocessing: extrema + tile histograms + LUTs, CLAHE output before the blur
     int pts_nframes = 0, pts_pitch = 0;
     // levels (and frame counts) whose status words must be checked at the next sync
-    int pending_frames[2][mrg::kMaxLevel + 1] = {};
+    int pending_frames[kMaxSets][mrg::kMaxLevel + 1] = {};
 
     // dominant-kernel timing
     bool timing = false;
@@ -243,7 +249,7 @@ static int ensure_level_set(mrgingham_amd_ctx* ctx, int set, int level, int nfra
     if (nframes > ctx->counters_nf) {
         MRG_HIP_CHECK(hipDeviceSynchronize());
         const int cnf = nframes + nframes / 8 + 8;
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < kMaxSets; ++k) {
             if ((rc = ensure(ctx, ctx->counters2[k], (size_t)(kMaxLevel + 1) * 3 * cnf * 4))) return rc;
             MRG_HIP_CHECK(hipMemset(ctx->counters2[k].p, 0, ctx->counters2[k].bytes));
         }
@@ -265,8 +271,9 @@ static int ensure_level_set(mrgingham_amd_ctx* ctx, int set, int level, int nfra
 }
 
 static int ensure_level(mrgingham_amd_ctx* ctx, int level, int nframes, int W, int H, int pitch) {
-    int rc = ensure_level_set(ctx, 0, level, nframes, W, H, pitch);
-    return rc ? rc : ensure_level_set(ctx, 1, level, nframes, W, H, pitch);
+    int rc = 0;
+    for (int set = 0; !rc && set < ctx->nsets; ++set) rc = ensure_level_set(ctx, set, level, nframes, W, H, pitch);
+    return rc;
 }
 
 // Per-call point scratch shared by the levels (the component kernels of the levels of one call
@@ -357,7 +364,7 @@ static void launch_chess_any(mrgingham_amd_ctx* ctx, const LevelBatch& lb, const
 // overwrite level scratch the component stream of the previous call still reads.
 static void begin_op(mrgingham_amd_ctx* ctx, int max_level) {
     (void)max_level;
-    ctx->cur ^= 1;  // this set was last used two calls ago
+    ctx->cur = (ctx->cur + 1) % ctx->nsets;  // this set was last used nsets calls ago
     if (ctx->cc_pending[ctx->cur]) hipStreamWaitEvent(ctx->pix, ctx->ev_cc_done[ctx->cur], 0);
     // The hot-pixel counters of this set are zero here: they are zeroed at allocation and again by
     // end_op behind the component kernels that consumed them -- on the component stream, off the
@@ -370,20 +377,21 @@ static hipStream_t cur_cc(mrgingham_amd_ctx* ctx) { return ctx->ccs[ctx->cur]; }
 // they overlap anything that call wrote or read-then-we-write.  Call after begin_op.
 static void order_after_previous(mrgingham_amd_ctx* ctx, std::initializer_list<mrgingham_amd_ctx::Span> w,
                                  std::initializer_list<mrgingham_amd_ctx::Span> r) {
-    const int cur = ctx->cur, prev = cur ^ 1;
+    const int cur = ctx->cur;
     auto overlaps = [](const mrgingham_amd_ctx::Span& a, const mrgingham_amd_ctx::Span& b) {
         return a.p && b.p && a.n && b.n && a.p < b.p + b.n && b.p < a.p + a.n;
     };
-    bool dep = false;
-    if (ctx->cc_pending[prev]) {
+    for (int prev = 0; prev < kMaxSets; ++prev) {  // every call that may still be running on another component stream
+        if (prev == cur || !ctx->cc_pending[prev]) continue;
+        bool dep = false;
         for (const auto& pw : ctx->last_w[prev]) {
             for (const auto& x : w) dep |= overlaps(x, pw);
             for (const auto& x : r) dep |= overlaps(x, pw);
         }
         for (const auto& pr : ctx->last_r[prev])
             for (const auto& x : w) dep |= overlaps(x, pr);
+        if (dep) hipStreamWaitEvent(ctx->ccs[cur], ctx->ev_cc_done[prev], 0);
     }
-    if (dep) hipStreamWaitEvent(ctx->ccs[cur], ctx->ev_cc_done[prev], 0);
     ctx->last_w[cur].assign(w.begin(), w.end());
     ctx->last_r[cur].assign(r.begin(), r.end());
 }
@@ -511,17 +519,17 @@ mrgingham_amd_ctx* mrgingham_amd_create(int device_ordinal) {
         uint32_t mask[8] = {}, inv[8];
         for (int b = 0; b < 8 * cc_cus; ++b) mask[b >> 5] |= 1u << (b & 31);
         for (int i = 0; i < 8; ++i) inv[i] = ~mask[i];
-        ok = hipExtStreamCreateWithCUMask(&ctx->ccs[0], 8, mask) == hipSuccess &&
-             hipExtStreamCreateWithCUMask(&ctx->ccs[1], 8, mask) == hipSuccess &&
+        for (int k = 0; ok && k < kMaxSets; ++k) ok = hipExtStreamCreateWithCUMask(&ctx->ccs[k], 8, mask) == hipSuccess;
+        ok = ok &&
              (pix_compl ? hipExtStreamCreateWithCUMask(&ctx->pix, 8, inv)
                         : hipStreamCreateWithPriority(&ctx->pix, hipStreamNonBlocking, prio_lo)) == hipSuccess;
     } else {
-        ok = hipStreamCreateWithPriority(&ctx->pix, hipStreamNonBlocking, prio_lo) == hipSuccess &&
-             hipStreamCreateWithPriority(&ctx->ccs[0], hipStreamNonBlocking, prio_hi) == hipSuccess &&
-             hipStreamCreateWithPriority(&ctx->ccs[1], hipStreamNonBlocking, prio_hi) == hipSuccess;
+        ok = hipStreamCreateWithPriority(&ctx->pix, hipStreamNonBlocking, prio_lo) == hipSuccess;
+        for (int k = 0; ok && k < kMaxSets; ++k)
+            ok = hipStreamCreateWithPriority(&ctx->ccs[k], hipStreamNonBlocking, prio_hi) == hipSuccess;
     }
-    ok = ok && hipEventCreateWithFlags(&ctx->ev_cc_done[0], hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&ctx->ev_cc_done[1], hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; ok && k < kMaxSets; ++k)
+        ok = hipEventCreateWithFlags(&ctx->ev_cc_done[k], hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i <= kMaxLevel; ++i)
         ok = hipEventCreateWithFlags(&ctx->ev_pix[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
@@ -546,7 +554,9 @@ void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx) {
     for (auto& ps : ctx->pts)
         for (DevBuf* b : {&ps.leader, &ps.need, &ps.nseeds, &ps.seeds, &ps.sroot, &ps.cand_xy, &ps.cand_counts})
             if (b->p) hipFree(b->p);
-    DevBuf* bufs[] = {&ctx->counters2[0], &ctx->counters2[1], &ctx->io_counts, &ctx->aux_img, &ctx->io_frame, &ctx->io_out, &ctx->pre_scratch, &ctx->pre_tmp, &ctx->pre_out, &ctx->pre16_scratch, &ctx->io_frame16, &ctx->dbg_img, &ctx->dbg_resp, &ctx->blob_scratch,
+    for (DevBuf& b : ctx->counters2)
+        if (b.p) hipFree(b.p);
+    DevBuf* bufs[] = {&ctx->io_counts, &ctx->aux_img, &ctx->io_frame, &ctx->io_out, &ctx->pre_scratch, &ctx->pre_tmp, &ctx->pre_out, &ctx->pre16_scratch, &ctx->io_frame16, &ctx->dbg_img, &ctx->dbg_resp, &ctx->blob_scratch,
                       &ctx->fb_xy, &ctx->fb_cnt, &ctx->fb_pts, &ctx->fb_lv, &ctx->fb_np, &ctx->fb_frames, &ctx->fb_frames2};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
@@ -624,6 +634,13 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
     if (!strcmp(name, "chess_v0")) { ctx->use_v0 = value != 0; return 0; }
     if (!strcmp(name, "multi_level_launch")) { ctx->multi_level = value < 0 ? 0 : value > 2 ? 2 : value; return 0; }
     if (!strcmp(name, "cc_schedule")) { ctx->cc_schedule = value; return 0; }
+    if (!strcmp(name, "scratch_sets")) {
+        if (value < 2 || value > kMaxSets) return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "scratch_sets must be 2 or %d", kMaxSets);
+        const int rc = mrgingham_amd_sync(ctx);  // nothing may be in flight when the rotation changes
+        ctx->nsets = value;
+        ctx->cur = 0;
+        return rc;
+    }
     if (!strcmp(name, "fuse_pyramid")) { ctx->fuse_pyramid = value != 0; return 0; }
     if (!strcmp(name, "cc_lds")) { ctx->cc_lds = value; return 0; }
     if (!strcmp(name, "chess_multi_min_blocks")) { mrg::chess_multi_min_blocks = value; return 0; }
@@ -654,13 +671,14 @@ int mrgingham_amd_sync(mrgingham_amd_ctx* ctx) {
     if (!ctx) return MRGINGHAM_AMD_ERR_ARG;
     MRG_HIP_CHECK(hipSetDevice(ctx->device));
     MRG_HIP_CHECK(hipStreamSynchronize(ctx->pix));
-    MRG_HIP_CHECK(hipStreamSynchronize(ctx->ccs[0]));
-    MRG_HIP_CHECK(hipStreamSynchronize(ctx->ccs[1]));
-    ctx->cc_pending[0] = ctx->cc_pending[1] = false;
+    for (int set = 0; set < kMaxSets; ++set) {
+        MRG_HIP_CHECK(hipStreamSynchronize(ctx->ccs[set]));
+        ctx->cc_pending[set] = false;
+    }
     MRG_HIP_CHECK(hipGetLastError());
     int rc = MRGINGHAM_AMD_OK;
     const int saved = ctx->cur;
-    for (int set = 0; set < 2; ++set)
+    for (int set = 0; set < kMaxSets; ++set)
         for (int level = 0; level <= kMaxLevel; ++level) {
             const int nact = ctx->pending_frames[set][level];
             ctx->pending_frames[set][level] = 0;
@@ -689,7 +707,7 @@ int mrgingham_amd_sync(mrgingham_amd_ctx* ctx) {
 int mrgingham_amd_stream_wait(mrgingham_amd_ctx* ctx, void* stream) {
     if (!ctx) return MRGINGHAM_AMD_ERR_ARG;
     MRG_HIP_CHECK(hipSetDevice(ctx->device));
-    for (int set = 0; set < 2; ++set)  // consecutive calls finish on different component streams
+    for (int set = 0; set < kMaxSets; ++set)  // consecutive calls finish on different component streams
         if (ctx->cc_pending[set]) MRG_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, ctx->ev_cc_done[set], 0));
     return MRGINGHAM_AMD_OK;
 }

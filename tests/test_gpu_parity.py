@@ -470,3 +470,40 @@ def test_fused_pyramid_on_strided_frames(det):
         wp, wl = oracle.chain(frames[f], 3)
         n = int(npts[f])
         assert n == len(wp) and np.array_equal(pts[f, :n].cpu().numpy(), wp) and np.array_equal(lv[f, :n].cpu().numpy(), wl)
+
+
+def test_three_scratch_sets_pipeline():
+    """set_option("scratch_sets", 3): three calls' component searches in flight.  Calls queued back to back without
+    a host sync -- distinct outputs, then dependent calls on shared buffers -- give the same results as one at a time."""
+    d3 = mrgingham_amd.Detector(0)
+    try:
+        d3.set_option("scratch_sets", 3)
+        imgs = [np.stack([synth.board_frame(1280, 960, 10, 7 * k + s).numpy() for s in range(3)]) for k in range(4)]
+        devs = [_cuda(x) for x in imgs]
+        outs = [d3.chain(devs[k % 4], start_level=3, max_points=1024, sync=False) for k in range(9)]
+        d3.sync()
+        for k, (pts, lv, npts) in enumerate(outs):
+            for f in range(3):
+                wp, wl = oracle.chain(imgs[k % 4][f], 3)
+                n = int(npts[f])
+                assert n == len(wp), (k, f)
+                assert np.array_equal(pts[f, :n].cpu().numpy(), wp) and np.array_equal(lv[f, :n].cpu().numpy(), wl), (k, f)
+        # dependent calls on shared buffers (see test_dependent_calls_without_sync_are_ordered)
+        frames = devs[0]
+        rp, rl, rn = [t.clone() for t in d3.chain(frames, 2, 256)]
+        xy, counts = d3.detect(frames, 2, capacity=256, sync=True)
+        pts0 = (xy.to(torch.float64) / 1000.0).contiguous()
+        for rep in range(3):
+            p, l = pts0.clone(), torch.full((3, 256), 2, dtype=torch.int8, device="cuda")
+            torch.cuda.synchronize()
+            d3.refine(frames, 1, p, l, counts, sync=False)
+            d3.chain(devs[1], 3, 256, sync=False)                 # an unrelated call in between
+            d3.refine(frames, 0, p, l, counts, sync=False)        # reads what the call two before wrote
+            d3.sync()
+            for f in range(3):
+                k = int(rn[f])
+                assert torch.equal(p[f, :k], rp[f, :k]) and torch.equal(l[f, :k], rl[f, :k]), (rep, f)
+        with pytest.raises(ValueError):
+            d3.set_option("scratch_sets", 4)
+    finally:
+        d3.close()

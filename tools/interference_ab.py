@@ -61,6 +61,7 @@ settings = [
     ("cc LDS +896 B (40928: still one slot of 1280-B granules)", {"MRGINGHAM_AMD_CC_LDS_PAD": "896"}),
     ("cc LDS +1024 B (41056: 33 granules)", {"MRGINGHAM_AMD_CC_LDS_PAD": "1024"}),
     ("cc LDS +3900 B (43932: below 163840 - 3 * 39952)", {"MRGINGHAM_AMD_CC_LDS_PAD": "3900"}),
+    ("three scratch sets", {"OPTIONS": "scratch_sets=3"}),
     ("separate pyramid kernel", {"OPTIONS": "fuse_pyramid=0"}),
     ("fused pyramid + schedule 2", {"OPTIONS": "cc_schedule=2"}),
     ("baseline again", {}),
