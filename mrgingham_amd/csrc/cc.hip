@@ -1453,13 +1453,14 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
                 const int root = sroot_[q][k];
                 if (atomicCAS(&claim[root], ld, ld | 0x40000000) == ld) add += (int)L.w.need16[root];
             }
-            if (add) wg_add(gneed + ld, add);
+            // bits 20..: members of the group (so that its lane knows when it has seen the last one)
+            wg_add(gneed + ld, add + (1 << 20));
         }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < LPPT; ++q) {
             const int i = tid + CC_THREADS * q;
-            if (ns_[q] > 0 && lead_[q] == i) atomicMax(&L.total, aload(gneed + i));
+            if (ns_[q] > 0 && lead_[q] == i) atomicMax(&L.total, aload(gneed + i) & 0xfffff);
         }
         __syncthreads();
         if (L.total > LSTK) {  // one group alone wants more LIFO than there is
@@ -1484,13 +1485,15 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
         for (int q = 0; q < LPPT; ++q) {
             const int i = tid + CC_THREADS * q;
             if (!pending[q]) continue;
-            const int need = aload(gneed + i);
+            const int gn = aload(gneed + i), need = gn & 0xfffff;
             const int so = atomicAdd(&L.top, need);
             if (so + need > LSTK) { L.changed = 1; continue; }
             pending[q] = false;
             int16_t* stk = L.u.stk + so;
-            for (int j = i; j < npts; ++j) {
+            int left = gn >> 20;  // members not met yet: most groups are one point, and the walk ends at once
+            for (int j = i; left > 0; ++j) {
                 if (lead16[j] != i) continue;
+                --left;
                 const int ns = j == i ? ns_[q] : aload(nseeds + j);
                 for (int k = 0; k < ns; ++k) stk[k] = (int16_t)__hip_atomic_load(&seeds[9 * j + k], MRG_WG);
                 Blob b;
