@@ -15,16 +15,16 @@
 //      reference's sequence (raster order of seeds, push order +x,-x,+y,-y,
 //      first-maximum-wins) be replayed, and that is done by a single lane.
 //
-// P1 and P2 are grid-wide kernels (kernel boundaries order them); from P3 on one
-// 1024-thread workgroup owns one frame, so every later hand-off is a workgroup
-// barrier (no cross-XCD traffic, no grid sync):
-//   P1 union-find over the hot list (left/up neighbours)        -> forest
-//   P2 flatten; per-root pixel count and bounding box
-//   P3 one lane per root: scan its box in raster order, replay the fills
-//      (detect)  |  group the points that share super-components, one lane per
-//      group replays them in index order (refine)
-//   P4 one wave per surviving component: 21x21 variance test (:50-88)
-//   P5 order by seed raster index (detect: bitonic sort) and emit coordinates.
+// Two implementations of that, tried in this order per frame (CompTables::path says which one took it):
+//   * out of LDS (second half of this file): the hot list, the values of the listed pixels, a hash map and
+//     the LIFOs of a frame -- or of a band of it -- in 40 KB; the common case;
+//   * in global memory (first half): one 512-thread workgroup per frame, every hand-off a workgroup barrier
+//     (no cross-XCD traffic, no grid sync):
+//       P0-P2 union-find over the hot list (left/up neighbours), flatten, per-root count / box / first pixel
+//       P3    one lane per root: scan its box in raster order, replay the fills (detect)  |  group the points
+//             that share super-components, one lane per group replays them in index order (refine)
+//       P4    21x21 variance test of every surviving component (:50-88), same lane
+//       P5    order by seed raster index (detect: bitonic sort) and emit coordinates.
 //
 // Floating point: centroid, level rescaling and the *1000 rounding are the
 // reference's exact double expressions (:262-263, :278-279, :350-351); the file
@@ -37,8 +37,8 @@ namespace mrg {
 
 constexpr int CC_THREADS = 256;
 
-// Every table of a frame is only ever touched by ONE workgroup per kernel (the labelling kernels
-// and the detect / refine kernels all run one workgroup per frame), so the atomics on them are
+// Every table of a frame is only ever touched by ONE workgroup per kernel (the detect / refine kernels
+// run one workgroup per frame), so the atomics on them are
 // WORKGROUP scope: they execute in the XCD's L2.  Agent-scope atomics on this multi-XCD part go to
 // the memory side instead; a few hundred thousand of them per level were slowing the HBM-streaming
 // pixel kernels they run underneath by ~6 % (measured by replacing the labelling kernels with empty
