@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py"                              # defaults: 200 steps, 20 warmup
-TRACEB="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline"   # short run under the tracer
+TRACEB="python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline"   # short run under the tracer
 PMCB="python $R/bench.py --distinct 4 --steps 3 --warmup 1 --no-cpu-baseline"
 # 1. the bench line itself
 timeout 600 $BENCH > $OUT/bench.json 2> $OUT/bench.err

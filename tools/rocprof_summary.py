@@ -34,6 +34,18 @@ def main(path):
               f"{min(d) / 1e3:10.1f} {max(d) / 1e3:10.1f} {sum(d) / 1e6:9.2f} {vg:5d} {sg:5d} {lds:6d}")
     print(f"# mrg:: kernels total {tot / 1e6:.2f} ms; other kernels (synthetic-frame generator, fills, copies): "
           f"{other[0]} calls, {other[1] / 1e6:.2f} ms")
+    # the dominant kernel: median and quartiles next to the average above.  The first dozens of launches of a
+    # process run slower (clock ramp, first touch of the scratch) and bench.py's host-fed leg at the end runs
+    # its launches beside the uploads, so the average over ALL calls is not what the timed region sees.
+    try:
+        if groups:
+            top = max(groups.items(), key=lambda kv: sum(kv[1]))
+            d = sorted(top[1])
+            if len(d) >= 8:
+                q = lambda f: d[int(f * (len(d) - 1))] / 1e3
+                print(f"# {top[0][0]}: {len(d)} launches, quartiles {q(0.25):.1f} / {q(0.5):.1f} / {q(0.75):.1f} us")
+    except (ValueError, IndexError) as e:
+        print(f"# (no quartile line: {e})")
     # idle time of the pixel stream between its kernels (pyramid -> small levels -> level 0 -> next pyramid)
     try:
         cols = [r[1] for r in c.execute("pragma table_info(kernels)").fetchall()]
