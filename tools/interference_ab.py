@@ -66,6 +66,9 @@ settings = [
     ("fused pyramid + schedule 2", {"OPTIONS": "cc_schedule=2"}),
     ("baseline again", {}),
 ]
+import glob
+for so in sorted(glob.glob(os.path.join(ROOT, "scratch", "lib_*.so"))):     # tools/build_variant.sh outputs
+    settings.append(("variant: " + os.path.basename(so), {"MRGINGHAM_AMD_LIB": so}))
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
 for label, env in settings:
     if flt and flt not in label:
