@@ -635,15 +635,15 @@ struct LdsCCT {
     } u;
     union {
         // detect, per super-component with >= 2 pixels: list index of its root (later: offset of its member
-        // list), pixel count, offset of its LIFO, smallest raster position
-        struct { int16_t root[LROOTS], cnt[LROOTS], soff[LROOTS]; uint32_t first[LROOTS]; } r;
-        int16_t need16[LN];       // refine: LIFO demand of the super-component, at its root
+        // list), pixel count, LIFO demand, list index of its pixel with the smallest raster position
+        struct { int16_t root[LROOTS], cnt[LROOTS], soff[LROOTS], fidx[LROOTS]; } r;
+        int16_t need16[LN + 512]; // refine: LIFO demand of the super-component, at its root; behind them lead16[LPTS]
     } w;
     int nroots, ncand, top, total, changed, nref, mtop, nload;
     int nbands, best, band_y[kMaxBands + 1], shear;
     uint32_t edge[4];
 };
-constexpr int LPTS = 512;                    // points per frame the LDS refine kernel takes
+constexpr int LPTS = 512;                    // points per frame the LDS refine kernel takes (LdsCCT::w.need16 has room for it)
 constexpr int LPPT = LPTS / CC_THREADS;     // points per thread
 // One workgroup slot of the pixel kernels, in LDS allocation granules (1280 B on this part: 39 952 B of a ChESS
 // workgroup occupy 40 960, four of them the whole 160 KB): anything above 40 960 B would need two.
@@ -716,231 +716,14 @@ __device__ __forceinline__ void lds_find4(const LdsCC& L, uint32_t e, int (&j)[4
     }
 }
 
-// follow_connected_component (:236-256) on the LDS tables; the LIFO holds list indices.
-template <class LdsCC>
-__device__ __forceinline__ int drain_lds(LdsCC& L, int w, int h, int16_t* stk, int sp, Blob& b) {
-    b.srx = b.sry = b.sr = 0;
-    b.npix = 0;
-    b.rmax = 0;
-    b.xpk = b.ypk = 0;
-    b.touched = false;
-    int consumed = 0;
-    while (sp > 0) {
-        const int i = stk[--sp];
-        const int v = L.val[i];
-        if (v <= 0) continue;  // visited already
-        const uint32_t e = L.xy[i];
-        const int x = (int)(e & 0xffffu), y = (int)(e >> 16);
-        // the four lookups do not depend on v: issued together
-        const int jxp = lds_find(L, e + 1u), jxm = lds_find(L, e - 1u);
-        const int jyp = lds_find(L, e + 0x10000u), jym = lds_find(L, e - 0x10000u);
-        L.val[i] = 0;  // :245 / :250
-        ++consumed;    // every listed pixel is hot
-        if (!(v > (b.rmax >> 4))) continue;                    // :159-171 with :27 (v > 15 holds)
-        if (v > b.rmax) { b.rmax = v; b.xpk = x; b.ypk = y; }  // :176-181, first maximum wins
-        b.srx += (unsigned long long)(v * x);
-        b.sry += (unsigned long long)(v * y);
-        b.sr += (unsigned long long)v;
-        b.npix++;
-        // :252-255 then :216-226; a neighbour is worth pushing only while it is hot and unvisited
-        if (x + 1 >= w - kMargin) b.touched = true;
-        else if (jxp >= 0 && L.val[jxp] > 0) stk[sp++] = (int16_t)jxp;
-        if (x - 1 < kMargin) b.touched = true;
-        else if (jxm >= 0 && L.val[jxm] > 0) stk[sp++] = (int16_t)jxm;
-        if (y + 1 >= h - kMargin) b.touched = true;
-        else if (jyp >= 0 && L.val[jyp] > 0) stk[sp++] = (int16_t)jyp;
-        if (y - 1 < kMargin) b.touched = true;
-        else if (jym >= 0 && L.val[jym] > 0) stk[sp++] = (int16_t)jym;
-    }
-    return consumed;
-}
-
-// Band key of a pixel for shear k (in 1/32 pixels of y per pixel of x, |k| <= 32): k = 0 is the row.  A board
-// that is rotated in the image has its corner rows on slanted lines, and no image row between them is free of
-// hot pixels -- but a sheared "row" that follows the slant is.
-__device__ __forceinline__ int band_key(uint32_t e, int k, int w) {
-    const int x = (int)(e & 0xffffu), y = (int)(e >> 16);
-    const int ak = k < 0 ? -k : k;
-    return y + (((k >= 0 ? x : w - 1 - x) * ak) >> 5);
-}
-// Two pixels at most 2 apart in x and in y (4-neighbours; two seeds of one 3x3 window) differ in key by at most
-// this much: a band boundary with that many empty keys keeps them in one band.
-__device__ __forceinline__ int band_gap(int k) {
-    const int ak = k < 0 ? -k : k;
-    return 2 + (ak ? (2 * ak) / 32 + 1 : 0);
-}
-constexpr int kBandKeys = 8192;  // keys 0 .. h - 1 + (w - 1) * |k| / 32 must stay below this
-
-// One attempt at cutting the frame into bands of at most LN hot pixels along shear k.  Leaves L.nbands,
-// L.band_y[0 .. nbands] (key bounds) and L.shear; returns the number of bands, 0 (uniformly) when this shear
-// offers no separators.  Uses the table storage as scratch.  All threads call it.  A thread owns 32 consecutive
-// keys and keeps their counts, prefix sums and "a band may end here" bits in registers, so that a greedy step
-// costs one LDS read, one LDS atomic and two barriers (~10 us per attempt; with every test read from LDS in
-// dependent order it was 35-50).
-template <class LdsCC>
-__device__ __noinline__ int lds_try_bands(LdsCC& L, const FrameView& v, int nraw, int k) {
-    constexpr int LN = LdsCC::LN;
-    const int tid = threadIdx.x, w = v.w;
-    const int nkeys = v.h + (((w - 1) * (k < 0 ? -k : k)) >> 5);
-    if (nkeys > kBandKeys) return 0;
-    uint32_t* rcw = reinterpret_cast<uint32_t*>(&L);  // hot pixels per key, two 16-bit counters per word
-    uint32_t* cumw = rcw + kBandKeys / 2;             // hot pixels below the key, likewise
-    uint32_t* part = cumw + kBandKeys / 2;            // per-wave totals
-    constexpr int WPT = kBandKeys / 2 / CC_THREADS;   // words per thread = 16 (keys 32 * tid ..)
-    static_assert(WPT == 16, "the register arrays below assume 32 keys per thread");
-    {
-        uint4* z = reinterpret_cast<uint4*>(rcw + WPT * tid);
-        z[0] = z[1] = z[2] = z[3] = make_uint4(0, 0, 0, 0);
-    }
-    __syncthreads();
-    for (int i = tid; i < nraw; i += CC_THREADS) {
-        const uint32_t e = v.hot_xy[i];
-        if (e == kHotDead) continue;
-        const int b = band_key(e, k, w);
-        if (b < kBandKeys) atomicAdd(&rcw[b >> 1], 1u << ((b & 1) * 16));  // (n <= 16384: a counter cannot carry)
-    }
-    __syncthreads();
-    uint32_t wv[WPT + 2];
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(rcw + WPT * tid);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint4 x = src[q];
-            wv[4 * q] = x.x; wv[4 * q + 1] = x.y; wv[4 * q + 2] = x.z; wv[4 * q + 3] = x.w;
-        }
-        wv[WPT] = tid + 1 < CC_THREADS ? rcw[WPT * (tid + 1)] : 0u;  // the four keys after mine (the gap test)
-        wv[WPT + 1] = tid + 1 < CC_THREADS ? rcw[WPT * (tid + 1) + 1] : 0u;
-    }
-    uint32_t mine = 0;
-    unsigned long long emptym = 0;  // bit q: key 32 * tid + q holds no pixel
-#pragma unroll
-    for (int q = 0; q < WPT + 2; ++q) {
-        const uint32_t lo = wv[q] & 0xffffu, hi = wv[q] >> 16;
-        if (q < WPT) mine += lo + hi;
-        emptym |= (unsigned long long)(lo == 0) << (2 * q) | (unsigned long long)(hi == 0) << (2 * q + 1);
-    }
-    // exclusive prefix of `mine` over the workgroup
-    uint32_t incl = mine;
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(incl, d);
-        if ((tid & 63) >= d) incl += o;
-    }
-    if ((tid & 63) == 63) part[tid >> 6] = incl;
-    __syncthreads();
-    uint32_t run = incl - mine, total = 0;
-    for (int q = 0; q < CC_THREADS / 64; ++q) {
-        if (q < (tid >> 6)) run += part[q];
-        total += part[q];
-    }
-    const uint32_t start = run;  // pixels below key 32 * tid
-#pragma unroll
-    for (int q = 0; q < WPT; ++q) {
-        const uint32_t lo = run, hi = run + (wv[q] & 0xffffu);
-        cumw[WPT * tid + q] = lo | (hi << 16);  // (<= 16384: fits)
-        run = hi + (wv[q] >> 16);
-    }
-    // a band may end at key r when keys r .. r + gap - 1 hold no pixel (keys past the frame hold none)
-    const int gap = band_gap(k);
-    unsigned long long sepm = emptym;
-    for (int g = 1; g < gap; ++g) sepm &= emptym >> g;
-    const uint32_t sep = (uint32_t)sepm;
-    __syncthreads();
-    int y0 = 0, nb = 0;
-    while (true) {
-        if (tid == 0) L.best = -1;
-        __syncthreads();
-        const uint32_t base = (cumw[y0 >> 1] >> ((y0 & 1) * 16)) & 0xffffu;
-        int end = nkeys;
-        if (total - base > (uint32_t)LN) {
-            // the last key r > y0 the band [y0, r) may end at with at most LN hot pixels in it
-            uint32_t ok = 0, below = start;  // pixels below key r
-#pragma unroll
-            for (int q = 0; q < 2 * WPT; ++q) {
-                const int r = 2 * WPT * tid + q;
-                ok |= (uint32_t)(r > y0 && r < nkeys && below - base <= (uint32_t)LN) << q;
-                below += (q & 1) ? wv[q >> 1] >> 16 : wv[q >> 1] & 0xffffu;
-            }
-            ok &= sep;
-            if (ok) atomicMax(&L.best, 2 * WPT * tid + 31 - __builtin_clz(ok));
-            __syncthreads();
-            end = L.best;
-            if (end < 0) return 0;
-        }
-        if (tid == 0) L.band_y[nb] = y0;
-        ++nb;
-        y0 = end;
-        if (end >= nkeys) break;
-        if (nb == kMaxBands) return 0;
-        __syncthreads();  // everybody has read L.best
-    }
-    if (tid == 0) { L.band_y[nb] = nkeys; L.nbands = nb; L.shear = k; }
-    __syncthreads();
-    return nb;
-}
-
-// Cut the frame into bands of at most LN hot pixels (see the top of this section): rows first, then sheared
-// rows along the slopes of the upper and the lower edge of the hot pixels (a rotated board) and between them.
-// Returns the number of bands, 0 (uniformly) when the frame cannot be banded.  All threads call it.
-template <class LdsCC>
-__device__ __noinline__ int lds_plan_bands(LdsCC& L, const FrameView& v, int nraw) {
-    constexpr int LN = LdsCC::LN;
-    const int tid = threadIdx.x, w = v.w, h = v.h;
-    if (nraw <= LN) {
-        if (tid == 0) { L.nbands = 1; L.band_y[0] = 0; L.band_y[1] = h; L.shear = 0; }
-        __syncthreads();
-        return 1;
-    }
-    if (nraw > LN * kMaxBands || h > kBandKeys) return 0;
-    int nb = lds_try_bands(L, v, nraw, 0);
-    if (nb) return nb;
-    // upper / lower edge of the hot pixels in the left and in the right third of the frame
-    if (tid < 4) L.edge[tid] = (tid & 1) ? 0u : 0xffffffffu;  // [0] min left, [1] max left, [2] min right, [3] max right
-    __syncthreads();
-    {
-        uint32_t mn[2] = {0xffffffffu, 0xffffffffu}, mx[2] = {0u, 0u};
-        for (int i = tid; i < nraw; i += CC_THREADS) {
-            const uint32_t e = v.hot_xy[i];
-            if (e == kHotDead) continue;
-            const int x = (int)(e & 0xffffu);
-            const int side = 3 * x < w ? 0 : (3 * x >= 2 * w ? 1 : -1);
-            if (side < 0) continue;
-            mn[side] = min(mn[side], e);
-            mx[side] = max(mx[side], e);
-        }
-        for (int sd = 0; sd < 2; ++sd) {
-            if (mn[sd] != 0xffffffffu) atomicMin(&L.edge[2 * sd], mn[sd]);
-            if (mx[sd] != 0u) atomicMax(&L.edge[2 * sd + 1], mx[sd]);
-        }
-    }
-    __syncthreads();
-    const uint32_t e0 = L.edge[0], e1 = L.edge[1], e2 = L.edge[2], e3 = L.edge[3];
-    __syncthreads();
-    if (e0 == 0xffffffffu || e2 == 0xffffffffu) return 0;  // nothing in one of the thirds: not a board that spans the frame
-    auto slope32 = [](uint32_t a, uint32_t b) {  // shear that takes pixel a (left) and pixel b (right) to the same key
-        const int dx = (int)(b & 0xffffu) - (int)(a & 0xffffu), dy = (int)(b >> 16) - (int)(a >> 16);
-        int k = dx > 0 ? (-dy * 32 + (dy < 0 ? dx / 2 : -dx / 2)) / dx : 0;
-        return k < -32 ? -32 : (k > 32 ? 32 : k);
-    };
-    const int kt = slope32(e0, e2), kb = slope32(e1, e3), km = (kt + kb) / 2;
-    const int cand[9] = {km, kt, kb, km + 1, km - 1, kt + 1, kt - 1, kb + 1, kb - 1};
-    for (int c = 0; c < 9; ++c) {
-        const int k = cand[c];
-        if (k == 0 || k < -32 || k > 32) continue;
-        bool seen = false;
-        for (int p = 0; p < c; ++p) seen = seen || cand[p] == k;
-        if (seen) continue;
-        nb = lds_try_bands(L, v, nraw, k);
-        if (nb) return nb;
-    }
-    return 0;
-}
-
-// The same fill with the four neighbours of every entry looked up beforehand (lds_build_neighbours): a pop is
-// two dependent LDS round trips (entry: value, position, neighbours; then the neighbours' values) instead of
-// eleven through the hash map.  The refine kernel's fills went from 43-58 us to ... per launch with it.
+// follow_connected_component (:236-256) on the LDS tables; the LIFO holds list indices.  The four neighbours of
+// every entry have been looked up beforehand (lds_build_neighbours): a pop is two dependent LDS round trips
+// (entry: value, position, neighbours; then the neighbours' values) instead of eleven through the hash map; the
+// refine kernel's fills went from 58 to 36 us per launch with it (level 0 of the bench frames).
 constexpr uint32_t kNoNb = 0xfffu;  // 12 bits per neighbour: a list index (< 2048) or this
 template <class LdsCC>
-__device__ __forceinline__ int drain_nb(LdsCC& L, const uint16_t* nb3, int w, int h, int16_t* stk, int sp, Blob& b) {
+__device__ __forceinline__ int drain_nb(LdsCC& L, const uint32_t* nlo, const uint16_t* nhi, int w, int h, int16_t* stk, int sp,
+                                        Blob& b) {
     b.srx = b.sry = b.sr = 0;
     b.npix = 0;
     b.rmax = 0;
@@ -951,11 +734,10 @@ __device__ __forceinline__ int drain_nb(LdsCC& L, const uint16_t* nb3, int w, in
         const int i = stk[--sp];
         const int v = L.val[i];
         const uint32_t e = L.xy[i];
-        const uint16_t* q = nb3 + 3 * i;
-        const uint32_t q0 = q[0], q1 = q[1], q2 = q[2];
+        const uint32_t lo = nlo[i], hi = nhi[i];
         if (v <= 0) continue;  // visited already
         const int x = (int)(e & 0xffffu), y = (int)(e >> 16);
-        const uint32_t jxp = q0 & 0xfffu, jxm = (q0 >> 12) | ((q1 & 0xffu) << 4), jyp = (q1 >> 8) | ((q2 & 0xfu) << 8), jym = q2 >> 4;
+        const uint32_t jxp = lo & 0xfffu, jxm = (lo >> 12) & 0xfffu, jyp = (lo >> 24) | ((hi & 0xfu) << 8), jym = hi >> 4;
         // the neighbours' values do not depend on v: read together
         const int vxp = jxp != kNoNb ? (int)L.val[jxp] : 0, vxm = jxm != kNoNb ? (int)L.val[jxm] : 0;
         const int vyp = jyp != kNoNb ? (int)L.val[jyp] : 0, vym = jym != kNoNb ? (int)L.val[jym] : 0;
@@ -980,14 +762,14 @@ __device__ __forceinline__ int drain_nb(LdsCC& L, const uint16_t* nb3, int w, in
     return consumed;
 }
 
-// The neighbour table of drain_nb: 48 bits per entry (+x, -x, +y, -y at 12 bits each) = 12 KB over the labels
-// and the hash map, which must both be dead: every thread looks its entries' neighbours up in the hash first,
-// then (barrier) overwrites it.  All threads call it.
+// The neighbour table of drain_nb: 48 bits per entry (+x, -x, +y, -y at 12 bits each), the low 32 over the hash
+// map (which must be dead: every thread looks its entries' neighbours up in it first, then -- barrier -- overwrites
+// it), the high 16 wherever the caller has 2 bytes per entry to spare (refine: the labels; detect: the front of
+// the LIFO space).  All threads call it.
 template <class LdsCC>
-__device__ __forceinline__ uint16_t* lds_build_neighbours(LdsCC& L, int n) {
+__device__ __forceinline__ void lds_build_neighbours(LdsCC& L, int n, uint16_t* nhi) {
     constexpr int LEPT = LdsCC::LEPT;
-    static_assert(offsetof(LdsCC, hashw) == offsetof(LdsCC, lab) + sizeof(L.lab), "labels and hash map must be adjacent");
-    static_assert(sizeof(L.lab) + sizeof(L.hashw) >= (size_t)LdsCC::LN * 6, "48 bits per entry");
+    static_assert(sizeof(L.hashw) >= (size_t)LdsCC::LN * 4, "32 bits per entry over the hash map");
     static_assert(LdsCC::LN <= (int)kNoNb, "12-bit list indices");
     const int tid = threadIdx.x;
     uint32_t lo[LEPT];
@@ -1010,17 +792,15 @@ __device__ __forceinline__ uint16_t* lds_build_neighbours(LdsCC& L, int n) {
         hi[k] = (uint16_t)((j[2] >> 8) | (j[3] << 4));       // bits 32 .. 47
     }
     __syncthreads();
-    uint16_t* nb3 = reinterpret_cast<uint16_t*>(L.lab);
+    uint32_t* nlo = L.hashw;
 #pragma unroll
     for (int k = 0; k < LEPT; ++k) {
         const int i = tid + CC_THREADS * k;
         if (i >= n) continue;
-        nb3[3 * i] = (uint16_t)lo[k];
-        nb3[3 * i + 1] = (uint16_t)(lo[k] >> 16);
-        nb3[3 * i + 2] = hi[k];
+        nlo[i] = lo[k];
+        nhi[i] = hi[k];
     }
     __syncthreads();
-    return nb3;
 }
 
 // Load the hot pixels with band keys in [y0, y1) (`banded`; otherwise the whole list as it stands) into LDS,
@@ -1151,7 +931,8 @@ template <int N>
 __global__ __launch_bounds__(CC_THREADS, 4) void cc_detect_lds_kernel(LevelBatch lb, CompTables t, int level,
                                                                    DetectOut out, int frame0) {
     using LdsCC = LdsCCT<N>;
-    constexpr int LROOTS = LdsCC::LROOTS, LSTK = LdsCC::LSTK, LEPT = LdsCC::LEPT;
+    constexpr int LROOTS = LdsCC::LROOTS, LEPT = LdsCC::LEPT;
+    constexpr int LSTKD = LdsCC::LSTK - LdsCC::LN;  // LIFO words of the fills: the neighbour table takes the first LN
     extern __shared__ __attribute__((aligned(16))) char lds_cc_raw[];
     LdsCC& L = *reinterpret_cast<LdsCC*>(lds_cc_raw);
     if (!(t.lds_path & 16)) __builtin_amdgcn_s_setprio(3);
@@ -1185,8 +966,8 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_detect_lds_kernel(LevelBatch
             const int a = L.u.acc[i], cnt = a & 0x1fff, need = (a >> 13) + 1;
             if (cnt < kBlobMinPixels) continue;
             const int r = atomicAdd(&L.nroots, 1);
-            if (need > LSTK) L.total = 1;  // one super-component alone wants more LIFO than there is
-            if (r < LROOTS) { L.w.r.root[r] = (int16_t)i; L.w.r.cnt[r] = (int16_t)cnt; L.w.r.soff[r] = (int16_t)min(need, LSTK); }
+            if (need > LSTKD) L.total = 1;  // one super-component alone wants more LIFO than there is
+            if (r < LROOTS) { L.w.r.root[r] = (int16_t)i; L.w.r.cnt[r] = (int16_t)cnt; L.w.r.soff[r] = (int16_t)min(need, LSTKD); }
         }
         __syncthreads();
         if (L.nroots > LROOTS || L.total) {  // does not fit
@@ -1200,7 +981,9 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_detect_lds_kernel(LevelBatch
         for (int i = tid; i < n; i += CC_THREADS)
             if (L.xy[i] != kHotDead) atomicMin(&L.u.acc[L.lab[i]], (int)L.xy[i]);
         __syncthreads();
-        for (int r = tid; r < nroots; r += CC_THREADS) L.w.r.first[r] = (uint32_t)L.u.acc[L.w.r.root[r]];
+        // ... as a list index: the fills below have no hash map any more
+        for (int r = tid; r < nroots; r += CC_THREADS)
+            L.w.r.fidx[r] = (int16_t)lds_find(L, (uint32_t)L.u.acc[L.w.r.root[r]]);
         __syncthreads();
         // member lists (list indices of the pixels of a super-component, unordered): what the "raster scan goes
         // on" step below walks instead of the whole hot list.  They take over the storage of the labels.
@@ -1225,8 +1008,13 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_detect_lds_kernel(LevelBatch
             members[atomicAdd(&L.u.acc[mylab[k]], 1)] = (int16_t)(tid + CC_THREADS * k);
         }
         __syncthreads();  // the accumulators are dead: their storage becomes the LIFOs
+        // neighbour table of the fills (drain_nb): low words over the hash map, high halves in the first LN words of
+        // the LIFO space, the LIFOs behind them
+        uint16_t* nhi = reinterpret_cast<uint16_t*>(L.u.stk);
+        lds_build_neighbours(L, n, nhi);
+        int16_t* lifo = L.u.stk + LdsCC::LN;
 
-        // The fills of a band share LSTK LIFO words.  When the super-components together want more (a 14x14 board:
+        // The fills of a band share LSTKD LIFO words.  When the super-components together want more (a 14x14 board:
         // ~150 of them per band at ~50 words each), they run in rounds: every pending root asks for its words, the
         // ones that still fit run, the others wait for the next round (the first to ask always fits).
         static_assert(LROOTS <= 2 * CC_THREADS, "a thread owns at most two roots");
@@ -1239,12 +1027,13 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_detect_lds_kernel(LevelBatch
             const int r = tid + CC_THREADS * rr;
             const int need = L.w.r.soff[r];
             const int so = atomicAdd(&L.top, need);
-            if (so + need > LSTK) { L.changed = 1; continue; }
+            if (so + need > LSTKD) { L.changed = 1; continue; }
             pending[rr] = false;
             const int cnt = L.w.r.cnt[r], mo = L.w.r.root[r];
             int left = cnt;
-            int16_t* stk = L.u.stk + so;
-            uint32_t seed = L.w.r.first[r];
+            int16_t* stk = lifo + so;
+            int si = L.w.r.fidx[r];
+            uint32_t seed = L.xy[si];
             bool have = seedable(seed);
             while (true) {
                 if (!have) {
@@ -1254,16 +1043,17 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_detect_lds_kernel(LevelBatch
                     uint32_t best = kHotDead;
                     for (int q = 0; q < cnt; ++q) {
                         const int i = members[mo + q];
-                        if (L.val[i] > 0 && seedable(L.xy[i])) best = min(best, L.xy[i]);
+                        const uint32_t e = L.xy[i];
+                        if (L.val[i] > 0 && seedable(e) && e < best) { best = e; si = i; }
                     }
                     if (best == kHotDead) break;
                     seed = best;
                 }
                 have = false;
-                stk[0] = (int16_t)lds_find(L, seed);  // :338
+                stk[0] = (int16_t)si;  // :338
                 Blob b;
                 if (t.lds_path & 4) { b.touched = true; left = 0; }  // ablation (timing only)
-                else left -= drain_lds(L, w, h, stk, 1, b);
+                else left -= drain_nb(L, L.hashw, nhi, w, h, stk, 1, b);
                 if (blob_passes_cheap_tests(b) &&
                     ((t.lds_path & 2) || window_variance_high(v.img, v.img_stride, w, h, b.xpk, b.ypk))) {  // :207
                     const int c = atomicAdd(&L.ncand, 1);
@@ -1470,7 +1260,8 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
         __syncthreads();  // the claim table is dead: its storage becomes the LIFOs
         // (here rather than behind R1, where labels and hash map die: the seed roots of R1-R3 are out of the
         // registers by now)
-        const uint16_t* nb3 = lds_build_neighbours(L, n);
+        uint16_t* nhi = reinterpret_cast<uint16_t*>(L.lab);  // (the labels are dead as well)
+        lds_build_neighbours(L, n, nhi);
 
         if (band == 0) tick(5);
         // R4: one lane per group, members in index order (:358); accepted points are written in place.  The
@@ -1498,7 +1289,7 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
                 for (int k = 0; k < ns; ++k) stk[k] = (int16_t)__hip_atomic_load(&seeds[9 * j + k], MRG_WG);
                 Blob b;
                 if (t.lds_path & 4) continue;  // ablation (timing only)
-                drain_nb(L, nb3, w, h, stk, ns, b);
+                drain_nb(L, L.hashw, nhi, w, h, stk, ns, b);
                 if (!blob_passes_cheap_tests(b)) continue;
                 if (!(t.lds_path & 2) && !window_variance_high(v.img, v.img_stride, w, h, b.xpk, b.ypk)) continue;  // :207
                 const double cx = (double)b.srx / (double)b.sr;  // :262-263
