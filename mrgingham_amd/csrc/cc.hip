@@ -716,6 +716,186 @@ __device__ __forceinline__ void lds_find4(const LdsCC& L, uint32_t e, int (&j)[4
     }
 }
 
+// Band key of a pixel for shear k (in 1/32 pixels of y per pixel of x, |k| <= 32): k = 0 is the row.  A board
+// that is rotated in the image has its corner rows on slanted lines, and no image row between them is free of
+// hot pixels -- but a sheared "row" that follows the slant is.
+__device__ __forceinline__ int band_key(uint32_t e, int k, int w) {
+    const int x = (int)(e & 0xffffu), y = (int)(e >> 16);
+    const int ak = k < 0 ? -k : k;
+    return y + (((k >= 0 ? x : w - 1 - x) * ak) >> 5);
+}
+// Two pixels at most 2 apart in x and in y (4-neighbours; two seeds of one 3x3 window) differ in key by at most
+// this much: a band boundary with that many empty keys keeps them in one band.
+__device__ __forceinline__ int band_gap(int k) {
+    const int ak = k < 0 ? -k : k;
+    return 2 + (ak ? (2 * ak) / 32 + 1 : 0);
+}
+constexpr int kBandKeys = 8192;  // keys 0 .. h - 1 + (w - 1) * |k| / 32 must stay below this
+
+// One attempt at cutting the frame into bands of at most LN hot pixels along shear k.  Leaves L.nbands,
+// L.band_y[0 .. nbands] (key bounds) and L.shear; returns the number of bands, 0 (uniformly) when this shear
+// offers no separators.  Uses the table storage as scratch.  All threads call it.  A thread owns 32 consecutive
+// keys and keeps their counts, prefix sums and "a band may end here" bits in registers, so that a greedy step
+// costs one LDS read, one LDS atomic and two barriers (~10 us per attempt; with every test read from LDS in
+// dependent order it was 35-50).
+template <class LdsCC>
+__device__ __noinline__ int lds_try_bands(LdsCC& L, const FrameView& v, int nraw, int k) {
+    constexpr int LN = LdsCC::LN;
+    const int tid = threadIdx.x, w = v.w;
+    const int nkeys = v.h + (((w - 1) * (k < 0 ? -k : k)) >> 5);
+    if (nkeys > kBandKeys) return 0;
+    uint32_t* rcw = reinterpret_cast<uint32_t*>(&L);  // hot pixels per key, two 16-bit counters per word
+    uint32_t* cumw = rcw + kBandKeys / 2;             // hot pixels below the key, likewise
+    uint32_t* part = cumw + kBandKeys / 2;            // per-wave totals
+    constexpr int WPT = kBandKeys / 2 / CC_THREADS;   // words per thread = 16 (keys 32 * tid ..)
+    static_assert(WPT == 16, "the register arrays below assume 32 keys per thread");
+    {
+        uint4* z = reinterpret_cast<uint4*>(rcw + WPT * tid);
+        z[0] = z[1] = z[2] = z[3] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    for (int i = tid; i < nraw; i += CC_THREADS) {
+        const uint32_t e = v.hot_xy[i];
+        if (e == kHotDead) continue;
+        const int b = band_key(e, k, w);
+        if (b < kBandKeys) atomicAdd(&rcw[b >> 1], 1u << ((b & 1) * 16));  // (n <= 16384: a counter cannot carry)
+    }
+    __syncthreads();
+    uint32_t wv[WPT + 2];
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(rcw + WPT * tid);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 x = src[q];
+            wv[4 * q] = x.x; wv[4 * q + 1] = x.y; wv[4 * q + 2] = x.z; wv[4 * q + 3] = x.w;
+        }
+        wv[WPT] = tid + 1 < CC_THREADS ? rcw[WPT * (tid + 1)] : 0u;  // the four keys after mine (the gap test)
+        wv[WPT + 1] = tid + 1 < CC_THREADS ? rcw[WPT * (tid + 1) + 1] : 0u;
+    }
+    uint32_t mine = 0;
+    unsigned long long emptym = 0;  // bit q: key 32 * tid + q holds no pixel
+#pragma unroll
+    for (int q = 0; q < WPT + 2; ++q) {
+        const uint32_t lo = wv[q] & 0xffffu, hi = wv[q] >> 16;
+        if (q < WPT) mine += lo + hi;
+        emptym |= (unsigned long long)(lo == 0) << (2 * q) | (unsigned long long)(hi == 0) << (2 * q + 1);
+    }
+    // exclusive prefix of `mine` over the workgroup
+    uint32_t incl = mine;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if ((tid & 63) >= d) incl += o;
+    }
+    if ((tid & 63) == 63) part[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t run = incl - mine, total = 0;
+    for (int q = 0; q < CC_THREADS / 64; ++q) {
+        if (q < (tid >> 6)) run += part[q];
+        total += part[q];
+    }
+    const uint32_t start = run;  // pixels below key 32 * tid
+#pragma unroll
+    for (int q = 0; q < WPT; ++q) {
+        const uint32_t lo = run, hi = run + (wv[q] & 0xffffu);
+        cumw[WPT * tid + q] = lo | (hi << 16);  // (<= 16384: fits)
+        run = hi + (wv[q] >> 16);
+    }
+    // a band may end at key r when keys r .. r + gap - 1 hold no pixel (keys past the frame hold none)
+    const int gap = band_gap(k);
+    unsigned long long sepm = emptym;
+    for (int g = 1; g < gap; ++g) sepm &= emptym >> g;
+    const uint32_t sep = (uint32_t)sepm;
+    __syncthreads();
+    int y0 = 0, nb = 0;
+    while (true) {
+        if (tid == 0) L.best = -1;
+        __syncthreads();
+        const uint32_t base = (cumw[y0 >> 1] >> ((y0 & 1) * 16)) & 0xffffu;
+        int end = nkeys;
+        if (total - base > (uint32_t)LN) {
+            // the last key r > y0 the band [y0, r) may end at with at most LN hot pixels in it
+            uint32_t ok = 0, below = start;  // pixels below key r
+#pragma unroll
+            for (int q = 0; q < 2 * WPT; ++q) {
+                const int r = 2 * WPT * tid + q;
+                ok |= (uint32_t)(r > y0 && r < nkeys && below - base <= (uint32_t)LN) << q;
+                below += (q & 1) ? wv[q >> 1] >> 16 : wv[q >> 1] & 0xffffu;
+            }
+            ok &= sep;
+            if (ok) atomicMax(&L.best, 2 * WPT * tid + 31 - __builtin_clz(ok));
+            __syncthreads();
+            end = L.best;
+            if (end < 0) return 0;
+        }
+        if (tid == 0) L.band_y[nb] = y0;
+        ++nb;
+        y0 = end;
+        if (end >= nkeys) break;
+        if (nb == kMaxBands) return 0;
+        __syncthreads();  // everybody has read L.best
+    }
+    if (tid == 0) { L.band_y[nb] = nkeys; L.nbands = nb; L.shear = k; }
+    __syncthreads();
+    return nb;
+}
+
+// Cut the frame into bands of at most LN hot pixels (see the top of this section): rows first, then sheared
+// rows along the slopes of the upper and the lower edge of the hot pixels (a rotated board) and between them.
+// Returns the number of bands, 0 (uniformly) when the frame cannot be banded.  All threads call it.
+template <class LdsCC>
+__device__ __noinline__ int lds_plan_bands(LdsCC& L, const FrameView& v, int nraw) {
+    constexpr int LN = LdsCC::LN;
+    const int tid = threadIdx.x, w = v.w, h = v.h;
+    if (nraw <= LN) {
+        if (tid == 0) { L.nbands = 1; L.band_y[0] = 0; L.band_y[1] = h; L.shear = 0; }
+        __syncthreads();
+        return 1;
+    }
+    if (nraw > LN * kMaxBands || h > kBandKeys) return 0;
+    int nb = lds_try_bands(L, v, nraw, 0);
+    if (nb) return nb;
+    // upper / lower edge of the hot pixels in the left and in the right third of the frame
+    if (tid < 4) L.edge[tid] = (tid & 1) ? 0u : 0xffffffffu;  // [0] min left, [1] max left, [2] min right, [3] max right
+    __syncthreads();
+    {
+        uint32_t mn[2] = {0xffffffffu, 0xffffffffu}, mx[2] = {0u, 0u};
+        for (int i = tid; i < nraw; i += CC_THREADS) {
+            const uint32_t e = v.hot_xy[i];
+            if (e == kHotDead) continue;
+            const int x = (int)(e & 0xffffu);
+            const int side = 3 * x < w ? 0 : (3 * x >= 2 * w ? 1 : -1);
+            if (side < 0) continue;
+            mn[side] = min(mn[side], e);
+            mx[side] = max(mx[side], e);
+        }
+        for (int sd = 0; sd < 2; ++sd) {
+            if (mn[sd] != 0xffffffffu) atomicMin(&L.edge[2 * sd], mn[sd]);
+            if (mx[sd] != 0u) atomicMax(&L.edge[2 * sd + 1], mx[sd]);
+        }
+    }
+    __syncthreads();
+    const uint32_t e0 = L.edge[0], e1 = L.edge[1], e2 = L.edge[2], e3 = L.edge[3];
+    __syncthreads();
+    if (e0 == 0xffffffffu || e2 == 0xffffffffu) return 0;  // nothing in one of the thirds: not a board that spans the frame
+    auto slope32 = [](uint32_t a, uint32_t b) {  // shear that takes pixel a (left) and pixel b (right) to the same key
+        const int dx = (int)(b & 0xffffu) - (int)(a & 0xffffu), dy = (int)(b >> 16) - (int)(a >> 16);
+        int k = dx > 0 ? (-dy * 32 + (dy < 0 ? dx / 2 : -dx / 2)) / dx : 0;
+        return k < -32 ? -32 : (k > 32 ? 32 : k);
+    };
+    const int kt = slope32(e0, e2), kb = slope32(e1, e3), km = (kt + kb) / 2;
+    const int cand[9] = {km, kt, kb, km + 1, km - 1, kt + 1, kt - 1, kb + 1, kb - 1};
+    for (int c = 0; c < 9; ++c) {
+        const int k = cand[c];
+        if (k == 0 || k < -32 || k > 32) continue;
+        bool seen = false;
+        for (int p = 0; p < c; ++p) seen = seen || cand[p] == k;
+        if (seen) continue;
+        nb = lds_try_bands(L, v, nraw, k);
+        if (nb) return nb;
+    }
+    return 0;
+}
+
 // follow_connected_component (:236-256) on the LDS tables; the LIFO holds list indices.  The four neighbours of
 // every entry have been looked up beforehand (lds_build_neighbours): a pop is two dependent LDS round trips
 // (entry: value, position, neighbours; then the neighbours' values) instead of eleven through the hash map; the
