@@ -943,42 +943,35 @@ __device__ __forceinline__ int drain_nb(LdsCC& L, const uint32_t* nlo, const uin
 }
 
 // The neighbour table of drain_nb: 48 bits per entry (+x, -x, +y, -y at 12 bits each), the low 32 over the hash
-// map (which must be dead: every thread looks its entries' neighbours up in it first, then -- barrier -- overwrites
-// it), the high 16 wherever the caller has 2 bytes per entry to spare (refine: the labels; detect: the front of
-// the LIFO space).  All threads call it.
+// map (which must be dead, and a barrier behind its last reader), the high 16 wherever the caller has 2 bytes per
+// entry to spare (refine: the labels; detect: the front of the LIFO space).  The loader has looked the neighbours up
+// for the labelling already and parked them in global scratch; every thread fetches its own entries back (one
+// coalesced round trip: 2-3 us where looking them up a second time took 9-25).  All threads call it.
 template <class LdsCC>
-__device__ __forceinline__ void lds_build_neighbours(LdsCC& L, int n, uint16_t* nhi) {
+__device__ __forceinline__ void lds_build_neighbours(LdsCC& L, const FrameView& v, int n, uint16_t* nhi) {
     constexpr int LEPT = LdsCC::LEPT;
     static_assert(sizeof(L.hashw) >= (size_t)LdsCC::LN * 4, "32 bits per entry over the hash map");
     static_assert(LdsCC::LN <= (int)kNoNb, "12-bit list indices");
     const int tid = threadIdx.x;
-    uint32_t lo[LEPT];
-    uint16_t hi[LEPT];
-#pragma unroll
-    for (int k = 0; k < LEPT; ++k) {
-        const int i = tid + CC_THREADS * k;
-        lo[k] = 0;
-        hi[k] = 0;
-        if (i >= n) continue;
-        const uint32_t e = L.xy[i];
-        uint32_t j[4] = {kNoNb, kNoNb, kNoNb, kNoNb};
-        if (e != kHotDead) {
-            int f[4];
-            lds_find4(L, e, f);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) j[q] = f[q] < 0 ? kNoNb : (uint32_t)f[q];
-        }
-        lo[k] = j[0] | (j[1] << 12) | (j[2] << 24);          // bits 0 .. 31 of the 48
-        hi[k] = (uint16_t)((j[2] >> 8) | (j[3] << 4));       // bits 32 .. 47
-    }
-    __syncthreads();
+    const uint2* parked = reinterpret_cast<const uint2*>(v.arena);
     uint32_t* nlo = L.hashw;
+    static_assert(LEPT % 4 == 0, "four entries at a time");
 #pragma unroll
-    for (int k = 0; k < LEPT; ++k) {
-        const int i = tid + CC_THREADS * k;
-        if (i >= n) continue;
-        nlo[i] = lo[k];
-        nhi[i] = hi[k];
+    for (int k0 = 0; k0 < LEPT; k0 += 4) {
+        uint2 p[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = tid + CC_THREADS * (k0 + k);
+            p[k] = i < n ? parked[i] : make_uint2(0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = tid + CC_THREADS * (k0 + k);
+            if (i < n) {
+                nlo[i] = p[k].x;
+                nhi[i] = (uint16_t)p[k].y;
+            }
+        }
     }
     __syncthreads();
 }
@@ -1047,6 +1040,10 @@ __device__ __forceinline__ bool lds_load_and_label(LdsCC& L, const FrameView& v,
         for (int q = 0; q < 4; ++q) j[q] = f[q] < 0 ? kNoNb : (uint32_t)f[q];
         nlo[k] = j[0] | (j[1] << 12) | (j[2] << 24);
         nhi[k] = (uint16_t)((j[2] >> 8) | (j[3] << 4));
+        // parked for lds_build_neighbours (same thread, same entries) in the LIFO arena of the global-memory
+        // kernels, which nothing uses while a frame is searched out of LDS: 2 words per entry of >= 16384
+        const int i = tid + CC_THREADS * k;
+        if (i < n) reinterpret_cast<uint2*>(v.arena)[i] = make_uint2(nlo[k], nhi[k]);
     }
     auto nb_of = [&](int k, int q) -> uint32_t {  // q static after unrolling
         return q == 0 ? nlo[k] & 0xfffu : q == 1 ? (nlo[k] >> 12) & 0xfffu
@@ -1191,7 +1188,7 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_detect_lds_kernel(LevelBatch
         // neighbour table of the fills (drain_nb): low words over the hash map, high halves in the first LN words of
         // the LIFO space, the LIFOs behind them
         uint16_t* nhi = reinterpret_cast<uint16_t*>(L.u.stk);
-        lds_build_neighbours(L, n, nhi);
+        lds_build_neighbours(L, v, n, nhi);
         int16_t* lifo = L.u.stk + LdsCC::LN;
 
         // The fills of a band share LSTKD LIFO words.  When the super-components together want more (a 14x14 board:
@@ -1441,7 +1438,7 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
         // (here rather than behind R1, where labels and hash map die: the seed roots of R1-R3 are out of the
         // registers by now)
         uint16_t* nhi = reinterpret_cast<uint16_t*>(L.lab);  // (the labels are dead as well)
-        lds_build_neighbours(L, n, nhi);
+        lds_build_neighbours(L, v, n, nhi);
 
         if (band == 0) tick(5);
         // R4: one lane per group, members in index order (:358); accepted points are written in place.  The
