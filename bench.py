@@ -210,7 +210,8 @@ def main():
                          "the bottleneck); default: every frame distinct")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--scratch-sets", type=int, default=0,
-                    help="option scratch_sets of the library (0 = its default, 2): calls' component searches in flight")
+                    help="option scratch_sets of the library (0 = its default: chosen from the batch shape): calls' component "
+                         "searches in flight")
     ap.add_argument("--force-gather", action="store_true",
                     help="with one rank: still create the (one-rank) RCCL group and issue the gather every step")
     ap.add_argument("--prime", type=int, default=30,
@@ -386,7 +387,7 @@ def main():
                          "launches_timed": nlaunch},
         }
         res["gather_checked"] = gather_ok
-        res["scratch_sets"] = args.scratch_sets or 2
+        res["scratch_sets"] = args.scratch_sets or "auto"
         res["setup_prime_steps"] = args.prime
         res["timed_region_s"] = dt
         res["notes"] = ("steps are queued back to back (streaming pipeline); the first few dozen passes of a process "

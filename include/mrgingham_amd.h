@@ -302,9 +302,10 @@ int mrgingham_amd_chain_info(const mrgingham_amd_ctx* ctx, int* fused_pyramid, i
 /* Tunables outside the reference's surface.  Known names:
  *   "fuse_pyramid"        1 (default): chain calls on frames of whole 16 x 8 blocks take the level images
  *                         1..3 out of the level-0 response kernel; 0: separate pyramid kernel
- *   "scratch_sets"        2 (default) or 3: how many calls' component searches may be in flight while the pixel
- *                         kernels of the next call run (each set is a full copy of the level scratch); 3 pays for small frames and dense boards, whose search chain is longer
- *                         than two steps of the pixel kernels.  Synchronises.
+ *   "scratch_sets"        how many calls' component searches may be in flight while the pixel kernels of the next call
+ *                         run (each set is a full copy of the level scratch): 0 (default) = chosen per batch shape --
+ *                         three while three sets stay below 8 GB (small frames, whose search chain is longer than two
+ *                         steps of the pixel kernels), two otherwise --, 2 or 3 = fixed.  Synchronises.
  *   "hot_capacity_shift"  per-frame capacity of the hot-pixel / component tables is
  *                         (width*height) >> shift entries (default 3; 0 = one per pixel)
  *   "chess_v0"            1 = use the plain reference-shaped ChESS kernel (cross-check)

@@ -101,6 +101,7 @@ constexpr int kMaxSets = 3;  // scratch sets a context can rotate through (optio
 struct mrgingham_amd_ctx {
     int device = 0;
     int nsets = 2;
+    bool nsets_fixed = false;  // option "scratch_sets" given: no automatic choice
     // HIP streams of a context: `pix` runs the pixel kernels (pyramid, ChESS) back to back, each
     // over the whole batch; `ccs[set]` run the latency-bound component kernels (a serial chain
     // detect -> refine -> refine ... per call) underneath them, one stream per scratch set so that
@@ -268,6 +269,22 @@ static int ensure_level_set(mrgingham_amd_ctx* ctx, int set, int level, int nfra
     L.cap = (int)cap; L.cand_cap = (int)cand_cap; L.sort_cap = (int)sort_cap; L.arena_cap = arena_cap;
     L.shift = ctx->cap_shift;
     return 0;
+}
+
+// How many scratch sets (= calls whose component searches may be in flight) this batch shape gets, unless the
+// option "scratch_sets" fixed it: three while three sets of the whole chain's scratch stay below 8 GB (small
+// frames, whose search chain is much longer than their pixel kernels: 64 x 640x480 chains 280 k -> 399 k
+// frames/s), two otherwise (64 x 4096x3072: no gain from a third, 9.9 GiB each).  A change of the rotation waits
+// for everything in flight first.
+static int choose_sets(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr) {
+    if (ctx->nsets_fixed) return 0;
+    const double per_set = 12.5 * (double)fr->nframes * fr->width * fr->height;  // bytes; measured 12.2 per frame pixel
+    const int want = 3.0 * per_set <= 8e9 ? 3 : 2;
+    if (want == ctx->nsets) return 0;
+    const int rc = mrgingham_amd_sync(ctx);
+    ctx->nsets = want;
+    ctx->cur = 0;
+    return rc;
 }
 
 static int ensure_level(mrgingham_amd_ctx* ctx, int level, int nframes, int W, int H, int pitch) {
@@ -635,9 +652,11 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
     if (!strcmp(name, "multi_level_launch")) { ctx->multi_level = value < 0 ? 0 : value > 2 ? 2 : value; return 0; }
     if (!strcmp(name, "cc_schedule")) { ctx->cc_schedule = value; return 0; }
     if (!strcmp(name, "scratch_sets")) {
-        if (value < 2 || value > kMaxSets) return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "scratch_sets must be 2 or %d", kMaxSets);
+        if (value != 0 && (value < 2 || value > kMaxSets))
+            return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "scratch_sets must be 0 (automatic), 2 or %d", kMaxSets);
         const int rc = mrgingham_amd_sync(ctx);  // nothing may be in flight when the rotation changes
-        ctx->nsets = value;
+        ctx->nsets_fixed = value != 0;
+        if (value) ctx->nsets = value;
         ctx->cur = 0;
         return rc;
     }
@@ -832,6 +851,7 @@ int mrgingham_amd_detect_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frame
     if (fr->nframes == 0) return 0;
     if (!d_xy || !d_counts || capacity_per_frame < 0) return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "NULL outputs");
     MRG_HIP_CHECK(hipSetDevice(ctx->device));
+    if ((rc = choose_sets(ctx, fr))) return rc;
     if ((rc = ensure_level(ctx, level, fr->nframes, fr->width, fr->height, 0))) return rc;
     begin_op(ctx, level);
     if (level > 0) {
@@ -860,6 +880,7 @@ int mrgingham_amd_refine_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frame
     if (!d_points || !d_levels || !d_npoints || points_pitch <= 0)
         return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "NULL point buffers");
     MRG_HIP_CHECK(hipSetDevice(ctx->device));
+    if ((rc = choose_sets(ctx, fr))) return rc;
     if ((rc = ensure_level(ctx, level, fr->nframes, fr->width, fr->height, points_pitch))) return rc;
     if ((rc = ensure_points(ctx, fr->nframes, points_pitch))) return rc;
     begin_op(ctx, level);
@@ -892,6 +913,7 @@ int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames
     if (!d_points || !d_levels || !d_npoints || points_pitch <= 0)
         return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "NULL point buffers");
     MRG_HIP_CHECK(hipSetDevice(ctx->device));
+    if ((rc = choose_sets(ctx, fr))) return rc;
     for (int L = 0; L <= start_level; ++L)
         if ((rc = ensure_level(ctx, L, fr->nframes, fr->width, fr->height, points_pitch))) return rc;
     if ((rc = ensure_points(ctx, fr->nframes, points_pitch))) return rc;
