@@ -102,6 +102,7 @@ struct mrgingham_amd_ctx {
     int device = 0;
     int nsets = 2;
     bool nsets_fixed = false;  // option "scratch_sets" given: no automatic choice
+    double max_set_bytes = 0;
     // HIP streams of a context: `pix` runs the pixel kernels (pyramid, ChESS) back to back, each
     // over the whole batch; `ccs[set]` run the latency-bound component kernels (a serial chain
     // detect -> refine -> refine ... per call) underneath them, one stream per scratch set so that
@@ -279,7 +280,8 @@ static int ensure_level_set(mrgingham_amd_ctx* ctx, int set, int level, int nfra
 static int choose_sets(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr) {
     if (ctx->nsets_fixed) return 0;
     const double per_set = 12.5 * (double)fr->nframes * fr->width * fr->height;  // bytes; measured 12.2 per frame pixel
-    const int want = 3.0 * per_set <= 8e9 ? 3 : 2;
+    if (per_set > ctx->max_set_bytes) ctx->max_set_bytes = per_set;  // the largest batch so far decides (scratch only grows)
+    const int want = 3.0 * ctx->max_set_bytes <= 8e9 ? 3 : 2;
     if (want == ctx->nsets) return 0;
     const int rc = mrgingham_amd_sync(ctx);
     ctx->nsets = want;
