@@ -698,16 +698,34 @@ int chess_seg_override = 0;  // tuning hook (mrgingham_amd_set_option "chess_seg
 int chess_multi_min_blocks = 2048;  // tuning hook "chess_multi_min_blocks": per-level block target inside a merged launch
 int chess_stage_override = 0;  // tuning hook "chess_stage": 0 = automatic, 2 / 3 = typed staging, -1 = generic
 
-static int pick_segment(int w, int h, int nframes, int min_blocks = 2048) {
+// Rows per workgroup.  Tall segments amortise the three-group prologue (24 rows staged before the first response
+// row: worth ~13 rows of the steady state), short ones leave a smaller tail when the launch drains (the chip runs
+// 1024 workgroups at a time) and fill it when the batch is small.  Cost model fitted to measured launches
+// (tools/seg_ab.py; 64 frames): time ~ strips * frames * (h + segments * 13) / 1024 + 1.18 * (segment + 13) / 2.
+//   1920x1080: 256 -> 128 rows, 147 -> 137 us; 1280x960: 128 (89 us; 256: 99); 4096x3072 and 2560x1920: 256.
+// `min_blocks` > 0: the older rule for the levels inside a merged launch (tallest segment that still gives that
+// many workgroups), where the largest level fills the chip and the others only pack its tail.
+static int pick_segment(int w, int h, int nframes, int min_blocks = 0) {
     if (chess_seg_override > 0) return (chess_seg_override + 7) / 8 * 8;
-    // tall segments amortise the 10-row halo and the three-group prologue; short ones fill the 256 CUs
-    // when the batch is small
     const long long strips = (w + V1_SW - 1) / V1_SW;
-    for (int seg : {256, 128, 64, 32}) {
-        const long long blocks = strips * ((h + seg - 1) / seg) * nframes;
-        if (blocks >= min_blocks || seg == 32) return seg;
+    if (min_blocks > 0) {
+        for (int seg : {256, 128, 64, 32}) {
+            const long long blocks = strips * ((h + seg - 1) / seg) * nframes;
+            if (blocks >= min_blocks || seg == 32) return seg;
+        }
+        return 32;
     }
-    return 32;
+    int best = 256;
+    double best_cost = 0;
+    for (int seg : {256, 128, 64, 32}) {
+        const int nsegs = (h + seg - 1) / seg;
+        const double cost = (double)strips * nframes * (h + 13.0 * nsegs) / 1024.0 + 1.18 * ((seg < h ? seg : h) + 13.0) / 2.0;
+        if (seg == 256 || cost < 0.98 * best_cost) {  // a taller segment keeps the choice unless a shorter one gains 2 %
+            best = seg;
+            best_cost = cost;
+        }
+    }
+    return best;
 }
 
 // Production entry point.
