@@ -507,3 +507,26 @@ def test_three_scratch_sets_pipeline():
             d3.set_option("scratch_sets", 4)
     finally:
         d3.close()
+
+
+@pytest.mark.parametrize("seg", [32, 64, 128, 256])
+def test_segment_height_does_not_change_results(seg):
+    """The segment height of the ChESS kernels (a cost model picks it per batch shape; option "chess_seg" fixes it)
+    only changes how the frame is cut into workgroups: responses, hot lists and so the chain are the same."""
+    d2 = mrgingham_amd.Detector(0)
+    try:
+        d2.set_option("chess_seg", seg)
+        for (w, h) in ((1328, 984), (1000, 760)):
+            frames = np.stack([synth.board_frame(w, h, 10, s).numpy() for s in (1, 4)])
+            d = _cuda(frames)
+            r = d2.chess_response(d, 0, clamp=True).cpu().numpy()
+            for f in range(2):
+                assert np.array_equal(r[f], oracle.clamped_response(frames[f], 0)[0]), (seg, w, h, f)
+            pts, lv, npts = d2.chain(d, start_level=3, max_points=2048)
+            for f in range(2):
+                wp, wl = oracle.chain(frames[f], 3)
+                n = int(npts[f])
+                assert n == len(wp) and np.array_equal(pts[f, :n].cpu().numpy(), wp) and np.array_equal(lv[f, :n].cpu().numpy(), wl)
+    finally:
+        d2.set_option("chess_seg", 0)
+        d2.close()

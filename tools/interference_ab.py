@@ -52,10 +52,10 @@ settings = [
     ("merged small levels: min blocks 512", {"OPTIONS": "chess_multi_min_blocks=512"}),
     ("merged small levels: min blocks 256", {"OPTIONS": "chess_multi_min_blocks=256"}),
     ("LDS search without s_setprio 3", {"OPTIONS": "cc_lds=17"}),
-    ("dbg fused, nothing emitted", {"MRG_PYR_DEBUG": "7"}),
-    ("dbg fused, level 1 only", {"MRG_PYR_DEBUG": "6"}),
-    ("dbg fused, levels 2+3 only", {"MRG_PYR_DEBUG": "1"}),
-    ("dbg fused, level 3 only", {"MRG_PYR_DEBUG": "3"}),
+    ("dbg fused, nothing emitted", {"MRGINGHAM_AMD_PYR_SKIP": "7"}),
+    ("dbg fused, level 1 only", {"MRGINGHAM_AMD_PYR_SKIP": "6"}),
+    ("dbg fused, levels 2+3 only", {"MRGINGHAM_AMD_PYR_SKIP": "1"}),
+    ("dbg fused, level 3 only", {"MRGINGHAM_AMD_PYR_SKIP": "3"}),
     ("pixel kernels only (no component kernels; results meaningless)", {"OPTIONS": "cc_lds=129"}),
     ("pixel kernels only, separate pyramid kernel", {"OPTIONS": "cc_lds=129,fuse_pyramid=0"}),
     ("cc LDS +896 B (40928: still one slot of 1280-B granules)", {"MRGINGHAM_AMD_CC_LDS_PAD": "896"}),
