@@ -655,63 +655,82 @@ static_assert(offsetof(LdsCCT<2048>, nroots) >= (8192 + CC_THREADS / 64) * 4, "t
 // at level 1 of a 14x14 board at 4096x3072 that put the lattice in resonance with the table (11.6 probes per
 // miss, 71 at worst; the fills ran 4x longer).  Measured on 16 board / level combinations: 1.03-1.3 probes per
 // hit, 1.1-2.1 per miss (tools/hash_probe.py).
+// The map is bucketed: a 32-bit word is a bucket of two 16-bit list indices (0xffff = empty), probing goes bucket
+// by bucket, and an element sits in the first bucket of its probe sequence that had an empty half when it came.
+// A wave pays for the LONGEST probe sequence among its 64 lanes; with two candidates per probe that maximum is
+// ~40 % shorter than with one (bench frames, level 0: 2.95 -> 1.73 probes, 14x14 level 1: 6.2 -> 3.4), at the
+// same two dependent LDS round trips per probe (the word, then both positions).
 template <class LdsCC>
 __device__ __forceinline__ uint32_t lds_hash(uint32_t e) {
-    static_assert(LdsCC::LHASH == 4096, "the shift below takes the top 12 bits");
-    return ((e & 0xffffu) * 0x9E3779B1u + (e >> 16) * 0x85EBCA77u) >> 20;
+    static_assert(LdsCC::LHASH == 4096, "the shift below takes the top 11 bits: LHASH / 2 buckets");
+    return ((e & 0xffffu) * 0x9E3779B1u + (e >> 16) * 0x85EBCA77u) >> 21;
 }
+template <class LdsCC>
+__device__ __forceinline__ uint32_t lds_next_bucket(uint32_t b) { return (b + 1u) & (uint32_t)(LdsCC::LHASH / 2 - 1); }
 
 template <class LdsCC>
 __device__ __forceinline__ void lds_insert(LdsCC& L, uint32_t e, int i) {
-    uint32_t s = lds_hash<LdsCC>(e);
+    uint32_t b = lds_hash<LdsCC>(e);
     while (true) {
-        uint32_t* wp = &L.hashw[s >> 1];
-        const int sh = (int)(s & 1u) * 16;
+        uint32_t* wp = &L.hashw[b];
         const uint32_t old = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (((old >> sh) & 0xffffu) == 0xffffu) {
-            const uint32_t nw = (old & ~(0xffffu << sh)) | ((uint32_t)i << sh);
-            if (atomicCAS(wp, old, nw) == old) return;  // else: the word changed under us, look again
-        } else {
-            s = (s + 1u) & (uint32_t)(LdsCC::LHASH - 1);
-        }
+        uint32_t nw;
+        if ((old & 0xffffu) == 0xffffu) nw = (old & 0xffff0000u) | (uint32_t)i;
+        else if ((old >> 16) == 0xffffu) nw = (old & 0xffffu) | ((uint32_t)i << 16);
+        else { b = lds_next_bucket<LdsCC>(b); continue; }
+        if (atomicCAS(wp, old, nw) == old) return;  // else: the word changed under us, look again
     }
+}
+
+// One probe: the bucket's two candidates against pixel q.  Returns true when the lookup is settled (j = list
+// index, or -1: a bucket with an empty half ends every probe sequence that reaches it).
+template <class LdsCC>
+__device__ __forceinline__ bool lds_probe(uint32_t wv, uint32_t xlo, uint32_t xhi, uint32_t q, int& j) {
+    const uint32_t lo = wv & 0xffffu, hi = wv >> 16;
+    if (lo != 0xffffu && xlo == q) { j = (int)lo; return true; }
+    if (hi != 0xffffu && xhi == q) { j = (int)hi; return true; }
+    if (lo == 0xffffu || hi == 0xffffu) { j = -1; return true; }
+    return false;
 }
 
 // list index of pixel e, or -1 when it is not hot
 template <class LdsCC>
 __device__ __forceinline__ int lds_find(const LdsCC& L, uint32_t e) {
-    uint32_t s = lds_hash<LdsCC>(e);
+    uint32_t b = lds_hash<LdsCC>(e);
     while (true) {
-        const uint32_t v = (L.hashw[s >> 1] >> ((s & 1u) * 16)) & 0xffffu;
-        if (v == 0xffffu) return -1;
-        if (L.xy[v] == e) return (int)v;
-        s = (s + 1u) & (uint32_t)(LdsCC::LHASH - 1);
+        const uint32_t wv = L.hashw[b];
+        const uint32_t xlo = L.xy[wv & (uint32_t)(LdsCC::LN - 1)], xhi = L.xy[(wv >> 16) & (uint32_t)(LdsCC::LN - 1)];
+        int j;
+        if (lds_probe<LdsCC>(wv, xlo, xhi, e, j)) return j;
+        b = lds_next_bucket<LdsCC>(b);
     }
 }
 
-// The four neighbours of pixel e at once: the first probes of the four lookups are independent, so their slot
+// The four neighbours of pixel e at once: the first probes of the four lookups are independent, so their bucket
 // reads and then their position reads go out together (two dependent LDS round trips for all four in the
-// common case, 1.0-1.7 probes per lookup); whatever is not settled by then continues on its own.
+// common case); whatever is not settled by then continues on its own.
 template <class LdsCC>
 __device__ __forceinline__ void lds_find4(const LdsCC& L, uint32_t e, int (&j)[4]) {
     const uint32_t q[4] = {e + 1u, e - 1u, e + 0x10000u, e - 0x10000u};
-    uint32_t s[4], v[4], x[4];
+    uint32_t b[4], wv[4], xlo[4], xhi[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) s[k] = lds_hash<LdsCC>(q[k]);
+    for (int k = 0; k < 4; ++k) b[k] = lds_hash<LdsCC>(q[k]);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = (L.hashw[s[k] >> 1] >> ((s[k] & 1u) * 16)) & 0xffffu;
+    for (int k = 0; k < 4; ++k) wv[k] = L.hashw[b[k]];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) x[k] = L.xy[v[k] & (uint32_t)(LdsCC::LN - 1)];  // (any slot: compared below)
+    for (int k = 0; k < 4; ++k) {  // (any slot: compared in lds_probe)
+        xlo[k] = L.xy[wv[k] & (uint32_t)(LdsCC::LN - 1)];
+        xhi[k] = L.xy[(wv[k] >> 16) & (uint32_t)(LdsCC::LN - 1)];
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (v[k] == 0xffffu) { j[k] = -1; continue; }
-        if (x[k] == q[k]) { j[k] = (int)v[k]; continue; }
-        uint32_t sk = (s[k] + 1u) & (uint32_t)(LdsCC::LHASH - 1);
+        if (lds_probe<LdsCC>(wv[k], xlo[k], xhi[k], q[k], j[k])) continue;
+        uint32_t bk = lds_next_bucket<LdsCC>(b[k]);
         while (true) {
-            const uint32_t vv = (L.hashw[sk >> 1] >> ((sk & 1u) * 16)) & 0xffffu;
-            if (vv == 0xffffu) { j[k] = -1; break; }
-            if (L.xy[vv] == q[k]) { j[k] = (int)vv; break; }
-            sk = (sk + 1u) & (uint32_t)(LdsCC::LHASH - 1);
+            const uint32_t w2 = L.hashw[bk];
+            const uint32_t y0 = L.xy[w2 & (uint32_t)(LdsCC::LN - 1)], y1 = L.xy[(w2 >> 16) & (uint32_t)(LdsCC::LN - 1)];
+            if (lds_probe<LdsCC>(w2, y0, y1, q[k], j[k])) break;
+            bk = lds_next_bucket<LdsCC>(bk);
         }
     }
 }
