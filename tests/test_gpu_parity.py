@@ -530,3 +530,40 @@ def test_segment_height_does_not_change_results(seg):
     finally:
         d2.set_option("chess_seg", 0)
         d2.close()
+
+
+@pytest.mark.parametrize("sets", [2, 3])
+def test_pipelined_chain_soak(sets):
+    """400 chain calls queued back to back without a host sync, on three alternating batches and four rotating output
+    buffers; every step's corner lists are compared ON THE DEVICE (torch's stream, ordered behind the step with
+    stream_wait) with what the same batch gives one call at a time.  A race between the pixel stream, the component
+    streams and the scratch-set rotation would show as a mismatching step (tools/soak.py is the long form)."""
+    B, P, W, H = 16, 512, 1280, 960
+    det = mrgingham_amd.Detector(0)
+    try:
+        det.set_option("scratch_sets", sets)
+        batches = [synth.board_batch(8, W, H, 10, 8 * k, device="cuda").repeat(B // 8, 1, 1).contiguous() for k in range(3)]
+        refs = []
+        for k, fr in enumerate(batches):
+            p, l, n = det.chain(fr, 3, P)
+            refs.append((p.clone(), l.clone(), n.clone()))
+            host = fr[0].cpu().numpy()
+            wp, wl = oracle.chain(host, 3)
+            assert int(n[0]) == len(wp) and np.array_equal(p[0, :len(wp)].cpu().numpy(), wp)
+        outs = [(torch.empty((B, P, 2), dtype=torch.float64, device="cuda"), torch.empty((B, P), dtype=torch.int8, device="cuda"),
+                 torch.empty((B,), dtype=torch.int32, device="cuda")) for _ in range(4)]
+        bad = torch.zeros(1, dtype=torch.int32, device="cuda")
+        idx = torch.arange(P, device="cuda")[None, :]
+        for s in range(400):
+            k, o = s % 3, outs[s % 4]
+            det.after_stream()                       # the comparison of four steps ago has read this buffer
+            det.chain(batches[k], 3, P, out=o, sync=False)
+            det.stream_wait()
+            rp, rl, rn = refs[k]
+            live = idx < rn[:, None]
+            bad += (o[2] != rn).any().int() + ((o[0] != rp).any(-1) & live).any().int() + ((o[1] != rl) & live).any().int()
+        det.sync()
+        torch.cuda.synchronize()
+        assert int(bad.item()) == 0
+    finally:
+        det.close()
