@@ -35,6 +35,14 @@
 
 namespace mrg {
 
+// Timing ablations and phase clocks (they change results or write debug data) exist only in builds made with
+// -DMRG_EXPERIMENT (tools/build_variant.sh); the shipped library ignores those bits of CompTables::lds_path.
+#ifdef MRG_EXPERIMENT
+#define MRG_EXP(bits) ((bits) != 0)
+#else
+#define MRG_EXP(bits) false
+#endif
+
 constexpr int CC_THREADS = 256;
 
 // Every table of a frame is only ever touched by ONE workgroup per kernel (the detect / refine kernels
@@ -1131,7 +1139,7 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_detect_lds_kernel(LevelBatch
     constexpr int LSTKD = LdsCC::LSTK - LdsCC::LN;  // LIFO words of the fills: the neighbour table takes the first LN
     extern __shared__ __attribute__((aligned(16))) char lds_cc_raw[];
     LdsCC& L = *reinterpret_cast<LdsCC*>(lds_cc_raw);
-    if (!(t.lds_path & 16)) __builtin_amdgcn_s_setprio(3);
+    if (!MRG_EXP(t.lds_path & 16)) __builtin_amdgcn_s_setprio(3);
     const int frame = frame0 + blockIdx.x, tid = threadIdx.x;
     const int nraw = t.hot_cnt[frame];
     FrameView v = make_view(lb, t, frame);
@@ -1154,7 +1162,7 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_detect_lds_kernel(LevelBatch
             lds_decline(t, frame);
             return;
         }
-        if (t.lds_path & 8) { if (tid == 0) { t.path[frame] = 1; out.counts[frame] = 0; } return; }  // ablation (timing only)
+        if (MRG_EXP(t.lds_path & 8)) { if (tid == 0) { t.path[frame] = 1; out.counts[frame] = 0; } return; }  // ablation (timing only)
         // roots with >= 2 pixels (a single hot pixel can only give a one-pixel blob, :205); each gets a LIFO of
         // (sum of hot-neighbour counts + 1) words, which bounds the pushes of all fills of it together
         for (int i = tid; i < n; i += CC_THREADS) {
@@ -1248,10 +1256,10 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_detect_lds_kernel(LevelBatch
                 have = false;
                 stk[0] = (int16_t)si;  // :338
                 Blob b;
-                if (t.lds_path & 4) { b.touched = true; left = 0; }  // ablation (timing only)
+                if (MRG_EXP(t.lds_path & 4)) { b.touched = true; left = 0; }  // ablation (timing only)
                 else left -= drain_nb(L, L.hashw, nhi, w, h, stk, 1, b);
                 if (blob_passes_cheap_tests(b) &&
-                    ((t.lds_path & 2) || window_variance_high(v.img, v.img_stride, w, h, b.xpk, b.ypk))) {  // :207
+                    (MRG_EXP(t.lds_path & 2) || window_variance_high(v.img, v.img_stride, w, h, b.xpk, b.ypk))) {  // :207
                     const int c = atomicAdd(&L.ncand, 1);
                     if (c < v.cand_cap) {
                         Cand cd;
@@ -1298,11 +1306,11 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
     constexpr int LN = LdsCC::LN, LSTK = LdsCC::LSTK;
     extern __shared__ __attribute__((aligned(16))) char lds_cc_raw[];
     LdsCC& L = *reinterpret_cast<LdsCC*>(lds_cc_raw);
-    if (!(t.lds_path & 16)) __builtin_amdgcn_s_setprio(3);
+    if (!MRG_EXP(t.lds_path & 16)) __builtin_amdgcn_s_setprio(3);
     const int frame = frame0 + blockIdx.x, tid = threadIdx.x;
     // phase clock (cc_lds bit 512, mrgingham_amd_debug_refine_clock, tools/cc_phases.py): thread 0 of the first
     // frame leaves 100 MHz ticks of the phase boundaries of its first band in the scratch of the global-memory kernel
-    const bool clk = (t.lds_path & 512) && blockIdx.x == 0 && tid == 0;
+    const bool clk = MRG_EXP(t.lds_path & 512) && blockIdx.x == 0 && tid == 0;
     long long* tk = reinterpret_cast<long long*>(io.sroot);  // (scratch of the global-memory kernel, unused here)
     auto tick = [&](int k) { if (clk) tk[k] = wall_clock64(); };
     tick(0);
@@ -1340,7 +1348,7 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
             lds_decline_refine(t, frame, band, io, L.nref);
             return;
         }
-        if (t.lds_path & 8) { if (tid == 0) t.path[frame] = 1; return; }  // ablation (timing only)
+        if (MRG_EXP(t.lds_path & 8)) { if (tid == 0) t.path[frame] = 1; return; }  // ablation (timing only)
         if (band == 0) tick(2);
         // LIFO demand of every super-component at its root, then the accumulators become the claim table
         for (int i = tid; i < n; i += CC_THREADS) L.w.need16[i] = (int16_t)((L.u.acc[i] >> 13) + 1);
@@ -1484,10 +1492,10 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
                 const int ns = j == i ? ns_[q] : aload(nseeds + j);
                 for (int k = 0; k < ns; ++k) stk[k] = (int16_t)__hip_atomic_load(&seeds[9 * j + k], MRG_WG);
                 Blob b;
-                if (t.lds_path & 4) continue;  // ablation (timing only)
+                if (MRG_EXP(t.lds_path & 4)) continue;  // ablation (timing only)
                 drain_nb(L, L.hashw, nhi, w, h, stk, ns, b);
                 if (!blob_passes_cheap_tests(b)) continue;
-                if (!(t.lds_path & 2) && !window_variance_high(v.img, v.img_stride, w, h, b.xpk, b.ypk)) continue;  // :207
+                if (!MRG_EXP(t.lds_path & 2) && !window_variance_high(v.img, v.img_stride, w, h, b.xpk, b.ypk)) continue;  // :207
                 const double cx = (double)b.srx / (double)b.sr;  // :262-263
                 const double cy = (double)b.sry / (double)b.sr;
                 pts[2 * j + 0] = rescale_coord(cx, (double)coord_scale);  // :390
@@ -1527,7 +1535,11 @@ template <int N, class K, class... A>
 static void launch_lds(K kernel, int nframes, hipStream_t s, A... args) {
     // MRGINGHAM_AMD_CC_LDS_PAD: extra bytes of dynamic LDS per workgroup (experiment: where does the allocation
     // stop fitting into one slot of the pixel kernels?)
+#ifdef MRG_EXPERIMENT
     static const int pad = [] { const char* e = getenv("MRGINGHAM_AMD_CC_LDS_PAD"); return e ? atoi(e) : 0; }();
+#else
+    constexpr int pad = 0;
+#endif
     static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LdsCCT<N>) + pad), true);
     (void)once;

@@ -238,11 +238,32 @@ __device__ __forceinline__ void stage_store(char* lds, int slot, int ch, const S
 // ---------------------------------------------------------------------------
 enum : int { STAGE_GENERIC = 0, STAGE_PERM16 = 1, STAGE_TYPED2 = 2, STAGE_TYPED1 = 3 };
 using i32x4 = int __attribute__((ext_vector_type(4)));
+using u32x4v = uint32_t __attribute__((ext_vector_type(4)));
 using u16x4 = unsigned short __attribute__((ext_vector_type(4)));
 __device__ u16x4 buffer_load_u8x4_as_u16x4(i32x4 rsrc, int voffset, int soffset, int aux)
     __asm("llvm.amdgcn.raw.buffer.load.format.v4i16");
 __device__ unsigned char buffer_load_u8(i32x4 rsrc, int voffset, int soffset, int aux)
     __asm("llvm.amdgcn.raw.buffer.load.i8");
+
+// Untyped buffer accesses: address = resource base (scalar registers) + VGPR offset (32 bits, bounds-checked
+// against the resource's size: an access beyond it reads 0 / is dropped) + SGPR offset (not bounds-checked).
+// Used where the lane's part of an address is a constant and the rest is wave-uniform: no 64-bit vector
+// arithmetic per access (hipcc otherwise spends a v_mad_i64_i32 + v_lshl_add_u64 per lane and iteration).
+using u32x2 = uint32_t __attribute__((ext_vector_type(2)));
+__device__ u32x4v raw_buffer_load_b128(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4i32");
+__device__ void raw_buffer_store_b128(u32x4v data, i32x4 rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.buffer.store.v4i32");
+__device__ void raw_buffer_store_b64(u32x2 data, i32x4 rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.buffer.store.v2i32");
+__device__ void raw_buffer_store_b32(uint32_t data, i32x4 rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.buffer.store.i32");
+__device__ void raw_buffer_store_b8(unsigned char data, i32x4 rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.buffer.store.i8");
+constexpr int kAuxNT = 2;  // non-temporal (gfx94x/gfx950 cache-policy bit "nt")
+__device__ __forceinline__ i32x4 raw_rsrc(const void* base, uint32_t bytes) {
+    const uint64_t a = (uint64_t)base;
+    return i32x4{(int)(uint32_t)a, (int)(uint32_t)(a >> 32), (int)bytes, 0x00020000};  // data_format 32, stride 0
+}
 
 __device__ __forceinline__ i32x4 typed_rsrc(const uint8_t* base, uint32_t bytes) {
     // word 3: dst_sel x,y,z,w = R,G,B,A (4,5,6,7); num_format UINT (4) << 12; data_format 8_8_8_8 (10) << 15
@@ -406,24 +427,27 @@ __device__ __forceinline__ void emit_pyramid_rows(const char* lds, int y, int st
     const u32x4 b0 = lds_read_b128(r1 + V1_ROWB), b1 = lds_read_b128(r1 + V1_ROWB + 16);
     const u32x4 c0 = lds_read_b128(r2), c1 = lds_read_b128(r2 + 16);
     const u32x4 d0 = lds_read_b128(r2 + V1_ROWB), d1 = lds_read_b128(r2 + V1_ROWB + 16);
+    // stores: the level image of the frame as a buffer resource, the lane's offset within the iteration's rows a
+    // constant, the rows' offset uniform (SGPR)
     if (po.out[0]) {
-        uint8_t* base = po.out[0] + ((long long)frame * po.h[0] + (y >> 1)) * po.w[0] + (strip_x >> 1);
-        uint2 o;
+        const i32x4 rs = raw_rsrc(po.out[0] + (long long)frame * po.h[0] * po.w[0], (uint32_t)(po.h[0] * po.w[0]));
+        u32x2 o;
         o.x = cells4(a0.x + b0.x, a0.y + b0.y, a0.z + b0.z, a0.w + b0.w);
         o.y = cells4(a1.x + b1.x, a1.y + b1.y, a1.z + b1.z, a1.w + b1.w);
-        if (strip_x + 16 * j < w) *reinterpret_cast<uint2*>(base + (uint32_t)(R * po.w[0] + 8 * j)) = o;
+        if (strip_x + 16 * j < w)
+            raw_buffer_store_b64(o, rs, R * po.w[0] + 8 * j + (strip_x >> 1), (y >> 1) * po.w[0], 0);
     }
     if (po.out[1]) {
         const uint32_t v0 = l3 ? c0.y + d0.y : c0.x + d0.x;
         const uint32_t o = cells4(v0, c0.z + d0.z, c1.x + d1.x, c1.z + d1.z);
         if (!l3) {
             if (strip_x + 16 * j < w) {
-                uint8_t* base = po.out[1] + ((long long)frame * po.h[1] + (y >> 2)) * po.w[1] + (strip_x >> 2);
-                *reinterpret_cast<uint32_t*>(base + (uint32_t)((R & 1) * po.w[1] + 4 * j)) = o;
+                const i32x4 rs = raw_rsrc(po.out[1] + (long long)frame * po.h[1] * po.w[1], (uint32_t)(po.h[1] * po.w[1]));
+                raw_buffer_store_b32(o, rs, (R & 1) * po.w[1] + 4 * j + (strip_x >> 2), (y >> 2) * po.w[1], 0);
             }
         } else if (po.out[2] && strip_x + 8 * (lane - 32) < w) {
-            uint8_t* base = po.out[2] + ((long long)frame * po.h[2] + (y >> 3)) * po.w[2] + (strip_x >> 3);
-            base[lane - 32] = (uint8_t)o;
+            const i32x4 rs = raw_rsrc(po.out[2] + (long long)frame * po.h[2] * po.w[2], (uint32_t)(po.h[2] * po.w[2]));
+            raw_buffer_store_b8((unsigned char)o, rs, lane - 32 + (strip_x >> 3), (y >> 3) * po.w[2], 0);
         }
     }
 }
@@ -468,6 +492,11 @@ __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTa
     const int st_gx = strip_x - V1_HL + 16 * st_ch;
     const int st_gx_c = min(max(st_gx, 0), max(w - 16, 0));  // W16: clamped chunk start / following pixel
     const int st_nx_c = min(max(st_gx + 16, 0), w - 1);
+    // W16, inside the loop: the frame as a buffer resource; a lane's chunk of row group g is at byte offset
+    // (st_row * stride + st_gx_c) + g's first row * stride -- one 32-bit add per load, and a row below the frame is
+    // out of range and reads 0 (it only feeds outputs the interior mask zeroes), so no clamp either
+    const i32x4 img_rsrc = raw_rsrc(img, (uint32_t)min((long long)(h - 1) * stride + w, 0xffffffffLL));
+    const int st_voff_g = st_row * stride + st_gx_c, st_voff_n = st_row * stride + st_nx_c;
     // staging role (typed paths): 8 rows x 36 octs = 288 tasks; thread tid takes task tid, and wave 0
     // also takes tasks 256..287 (both of its half-waves do the same 32, so the branch is wave-uniform)
     constexpr int NOCT = V1_WIN / 8;  // 36
@@ -528,6 +557,10 @@ __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTa
     const uint32_t lane_off_h = lane_off + (half ? V1_ROWB : 0u);  // + the half-wave's row
     const uint32_t halfmask = half ? 0xffffffffu : 0u;
     const bool seg_interior = ys >= kMargin && ye <= h - kMargin;  // workgroup-uniform
+    // response rows as a buffer resource: the lane's byte offset within the wave's two rows is a constant, the
+    // rows' offset is wave-uniform (SGPR offset of the store)
+    const i32x4 resp_rsrc = raw_rsrc(resp, (uint32_t)min((long long)w * h * 2, 0xffffffffLL));
+    const int st_resp_voff = (half * w + x0) * 2;
 
     int grp = 3;
     for (int y = ys; y < ye; y += V1_RB, ++grp) {
@@ -540,8 +573,13 @@ __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTa
             opre0 = oct_load<STAGE>(rsrc, oc_v0 + pr0 * stride);
             if (wvu == 0) opre1 = oct_load<STAGE>(rsrc, oc_v1 + pr0 * stride);
         } else if (stager) {
-            pre = W16 ? stage_load_fast(img, stride, h, pr, st_gx_c, st_nx_c)
-                      : stage_load(img, stride, w, h, pr, st_gx);
+            if (W16) {
+                const int rowoff = pr0 * stride;  // uniform; pr0 >= 0 inside the loop
+                pre.g = __builtin_bit_cast(uint4, raw_buffer_load_b128(img_rsrc, st_voff_g + rowoff, 0, 0));
+                pre.next = buffer_load_u8(img_rsrc, st_voff_n + rowoff, 0, 0);
+            } else {
+                pre = stage_load(img, stride, w, h, pr, st_gx);
+            }
         }
 
         const int s0 = y + 2 * wvu + 64;  // uniform, even
@@ -632,12 +670,12 @@ __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTa
             __builtin_amdgcn_s_setprio(0);
         }
         if (yy < ye && x0 < w) {
-            int16_t* dst = resp + (long long)yy * w + x0;
             if (x0 + 8 <= w) {
                 // streamed out: the dense response is only ever re-read around the few hot pixels
                 const u32x4 v = {out[0], out[1], out[2], out[3]};
-                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst));
+                raw_buffer_store_b128(v, resp_rsrc, st_resp_voff, (int)((uint32_t)(s0 - 64) * (uint32_t)w * 2u), kAuxNT);
             } else {
+                int16_t* dst = resp + (long long)yy * w + x0;
                 for (int i = 0; i < w - x0; ++i) dst[i] = (int16_t)(out[i >> 1] >> (16 * (i & 1)));
             }
         }
@@ -734,7 +772,7 @@ void launch_chess(const LevelBatch& lb, const CompTables& t, int frame0, int nfr
     const int seg = pick_segment(lb.w, lb.h, nframes);
     dim3 grid(((lb.w + V1_SW - 1) / V1_SW) * ((lb.h + seg - 1) / seg) * nframes);
     const size_t lds = 2 * V1_PLANE + (hot ? (V1_HOTBUF + 4) * sizeof(int) : 0);
-    const bool w16 = lb.w >= 16 && lb.w % 16 == 0;
+    const bool w16 = lb.w >= 16 && lb.w % 16 == 0 && (long long)(lb.h + V1_RB) * lb.img_stride < 0x7fffffffLL;
     // staging path: chess_stage_override (tuning hook "chess_stage") 0 = automatic
     // widths that are a multiple of 16 take the v_perm staging (fastest there: 624 vs 637-644 us per 64 frames of
     // 4096x3072); every other width takes the typed staging, which needs no edge handling at all (4090x3070:
@@ -764,7 +802,8 @@ void launch_chess(const LevelBatch& lb, const CompTables& t, int frame0, int nfr
 // Level 0 with the pyramid fused in; false when the shape does not qualify (whole cells only, 16-byte rows).
 bool chess_pyramid_ok(const LevelBatch& lb, int nframes) {
     return nframes > 0 && lb.w >= 16 && lb.w % 16 == 0 && lb.h >= 8 && lb.h % 8 == 0 && lb.img_stride % 16 == 0 &&
-           lb.img_pitch % 16 == 0 && ((uintptr_t)lb.img & 15) == 0;
+           lb.img_pitch % 16 == 0 && ((uintptr_t)lb.img & 15) == 0 &&
+           (long long)(lb.h + V1_RB) * lb.img_stride < 0x7fffffffLL;  // buffer offsets of the staging loads fit 31 bits
 }
 bool launch_chess_pyramid(const LevelBatch& lb, const CompTables& t, const PyramidOut& po, int nframes, hipStream_t s) {
     if (!chess_pyramid_ok(lb, nframes)) return false;
@@ -785,7 +824,8 @@ bool launch_chess_pyramid(const LevelBatch& lb, const CompTables& t, const Pyram
 bool chess_multi_ok(const LevelBatch* lbs, int n, int nframes) {
     if (n < 2 || n > kMultiMax || nframes <= 0) return false;
     for (int k = 0; k < n; ++k)
-        if (lbs[k].w < 16 || lbs[k].w % 16 != 0 || lbs[k].h <= 0) return false;
+        if (lbs[k].w < 16 || lbs[k].w % 16 != 0 || lbs[k].h <= 0 ||
+            (long long)(lbs[k].h + V1_RB) * lbs[k].img_stride >= 0x7fffffffLL) return false;
     return true;
 }
 

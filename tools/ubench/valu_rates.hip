@@ -62,6 +62,16 @@ DEF(k_mulf32, "v_mul_f32 %0, %0, %1")
 DEF(k_subf32, "v_sub_f32 %0, %0, %1")
 DEF(k_maxi16, "v_max_i16 %0, %0, %1")
 DEF(k_addu16, "v_add_u16 %0, %0, %1")
+DEF(k_movdpp, "v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf")
+DEF(k_adddpp, "v_add_u32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf")
+DEF(k_movdppw, "v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf")
+DEF(k_pksubclamp, "v_pk_sub_u16 %0, %0, %1 clamp")
+DEF(k_pkmaxi16, "v_pk_max_i16 %0, %0, %1")
+DEF(k_sub_sdwa, "v_sub_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_2")
+DEF(k_maxi16_sdwa, "v_max_i16_sdwa %0, %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1")
+DEF(k_bitop3, "v_bitop3_b32 %0, %0, %1, %2 bitop3:0xc8")
+DEF(k_lshl2, "v_lshlrev_b32 %0, %1, %0")
+DEF(k_maxu16, "v_max_u16 %0, %0, %1")
 
 template <typename K> void run(const char* name, K kern) {
     uint32_t* d; hipMalloc(&d, 256 * 4096 * 4);
@@ -81,6 +91,7 @@ int main() {
     R(k_add3); R(k_add); R(k_and); R(k_maxu32); R(k_pkmax); R(k_pkadd); R(k_pksub); R(k_pkmad); R(k_perm); R(k_mul24); R(k_mad24);
     R(k_sadu8); R(k_sadu16); R(k_sadu32); R(k_dot4); R(k_maxf32); R(k_addf32); R(k_fmaf32); R(k_pkmaxf16); R(k_pkaddf16); R(k_max3u32);
     R(k_or); R(k_xor); R(k_sub); R(k_lshl); R(k_lshr); R(k_ashr); R(k_cndmask); R(k_andor); R(k_bfi); R(k_or3); R(k_addlshl); R(k_lshladd); R(k_minu16pk); R(k_mulf32); R(k_subf32); R(k_maxi16); R(k_addu16);
+    R(k_movdpp); R(k_adddpp); R(k_movdppw); R(k_pksubclamp); R(k_pkmaxi16); R(k_sub_sdwa); R(k_maxi16_sdwa); R(k_bitop3); R(k_lshl2); R(k_maxu16);
     R(k_alignbit); R(k_bfe); R(k_lshlor); R(k_mov);
     return 0;
 }
