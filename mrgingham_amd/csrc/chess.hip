@@ -155,6 +155,9 @@ __device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b) {
 __device__ __forceinline__ uint32_t pk_add_i16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, (i16x2)(__builtin_bit_cast(i16x2, a) + __builtin_bit_cast(i16x2, b)));
 }
+__device__ __forceinline__ uint32_t pk_sub_sat_u16(uint32_t a, uint32_t b) {  // v_pk_sub_u16 ... clamp
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
 __device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, a),
                                                                   __builtin_bit_cast(i16x2, b)));
@@ -539,15 +542,16 @@ __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTa
 
     // per-lane constants
     const int x0 = strip_x + 8 * lx;
-    // CLAMP: results are carried with a +8192 bias per half (see below); the interior mask also
-    // strips that bias, so the frame mask, the un-bias and the clamp cost one AND
+    // Results are carried with a +8192 bias per half (see below).  CLAMP: ONE saturating subtraction strips the
+    // bias, clamps at 0 and zeroes the 7-pixel frame columns -- its per-lane constant is 8192 for a pixel inside
+    // the frame columns and 0xffff (more than any biased response: saturates to 0) for one outside.
     uint32_t xmask[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int xa = x0 + 2 * k, xb = xa + 1;
-        const uint32_t keep = CLAMP ? 0x1fffu : 0xffffu;
-        xmask[k] = ((xa >= kMargin && xa < w - kMargin) ? keep : 0u) |
-                   ((xb >= kMargin && xb < w - kMargin) ? keep << 16 : 0u);
+        const bool ina = xa >= kMargin && xa < w - kMargin, inb = xb >= kMargin && xb < w - kMargin;
+        if (CLAMP) xmask[k] = (ina ? 0x2000u : 0xffffu) | (inb ? 0x20000000u : 0xffff0000u);
+        else xmask[k] = (ina ? 0xffffu : 0u) | (inb ? 0xffff0000u : 0u);
     }
     // Row addressing: wave index and loop row are wave-uniform (SALU); the lane-dependent part is a
     // constant.  A wave covers rows yy = y + 2*wv + half; for even dy the slot of half 1 is the
@@ -632,7 +636,7 @@ __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTa
             const uint32_t dev = pk_max_u16(M, LM) - pk_min_u16(M, LM);  // |M - LM| per half
             const uint32_t d1x = Yb - X;
             const uint32_t P = (d1x + d1x) - dev;  // halves = response + 8192, in [2072, 10232]  (ChESS.c:104)
-            if (CLAMP) out[k] = pk_max_u16(P, 0x20002000u) & xmask[k];  // max(r,0): bit 13 is the bias, masked off
+            if (CLAMP) out[k] = pk_sub_sat_u16(P, xmask[k]);  // max(r, 0), 0 in the frame columns
             else out[k] = pk_sub_i16(P, 0x20002000u) & xmask[k];
         }
         if (!seg_interior) {
