@@ -49,12 +49,53 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 WORKLOADS = {
-    # name: (W, H, gridn, start_level, batch)
-    "c3_4096x3072_chain": (4096, 3072, 10, 3, 64),          # the size and board BASELINE.json's metric names
-    "c3_4096x3072_14x14_chain": (4096, 3072, 14, 3, 64),    # configs[2] as stated: 14x14 board
-    "c2_1920x1080_level0": (1920, 1080, 10, 0, 64),
-    "c1_640x480_chain": (640, 480, 10, 3, 64),
+    # name: (W, H, gridn, start_level, batch, background)
+    "c3_4096x3072_chain": (4096, 3072, 10, 3, 64, "flat"),          # the size and board BASELINE.json's metric names
+    "c3_4096x3072_14x14_chain": (4096, 3072, 14, 3, 64, "flat"),    # configs[2] as stated: 14x14 board
+    # configs[3]: 2048 frames sharded 256 per GPU at N = 8, one gather of the corner lists (weak scaling: every
+    # rank owns 256 frames whatever N is; `--gpus 1` is one GPU's shard of the job)
+    "c4_4096x3072_shard256": (4096, 3072, 10, 3, 256, "flat"),
+    # the board over a textured background (synth.cluttered_board_frame): ~7e4 hot pixels per frame at level 0,
+    # ~1e4 at level 1 -- the component search cannot run out of its LDS tables there
+    "c3_cluttered": (4096, 3072, 10, 3, 64, "clutter"),
+    "c2_1920x1080_level0": (1920, 1080, 10, 0, 64, "flat"),
+    "c1_640x480_chain": (640, 480, 10, 3, 64, "flat"),
 }
+
+
+def gpu_numa_cpus(local_rank):
+    """(numa node, cpu list) of the host CPUs next to HIP device `local_rank`, from sysfs; (None, None) if the
+    topology cannot be read.  Must not initialise HIP in the parent of a launcher: uses rocm-smi's sysfs tree."""
+    try:
+        bus = torch.cuda.get_device_properties(local_rank)
+        bdf = "%04x:%02x:%02x.0" % (getattr(bus, "pci_domain_id", 0), bus.pci_bus_id, bus.pci_device_id)
+        base = "/sys/bus/pci/devices/" + bdf
+        node = int(open(base + "/numa_node").read())
+        cpus = open(base + "/local_cpulist").read().strip()
+        out = []
+        for part in cpus.split(","):
+            a, _, b = part.partition("-")
+            out += list(range(int(a), int(b or a) + 1))
+        return node, out
+    except Exception:
+        return None, None
+
+
+def bind_rank_to_gpu_numa(local_rank):
+    """One rank per GPU: keep the rank's host threads (H2D staging, launches, RCCL proxy) on the cores of the
+    GPU's NUMA node -- on a two-socket 8-GPU node a rank that runs on the far socket feeds its GPU over the
+    socket interconnect (the reference's worker model has no such notion: mrgingham-from-image.cc:374-379)."""
+    node, cpus = gpu_numa_cpus(local_rank)
+    if not cpus:
+        return {"numa_node": node, "cpus": None}
+    try:
+        allowed = os.sched_getaffinity(0)
+        want = set(cpus) & allowed
+        if want:
+            os.sched_setaffinity(0, want)
+        return {"numa_node": node, "cpus": len(want)}
+    except (AttributeError, OSError):
+        return {"numa_node": node, "cpus": None}
 
 
 def physical_cores():
@@ -86,41 +127,49 @@ def physical_cores():
     return min(n, logical), logical, model
 
 
-def cpu_baseline(frames_host, start_level, cpu_seconds=15.0):
-    """Oracle (kind "port") on the host cores, frame-parallel like the reference CLI's --jobs
-    (mrgingham-from-image.cc:50, :374-379): T = 1 and T = all PHYSICAL cores, each over a bounded
-    sample of the batch (about cpu_seconds of CPU work for the parallel leg)."""
-    from concurrent.futures import ThreadPoolExecutor
+def cpu_baseline(frames_host, start_level, leg_seconds=5.0):
+    """Oracle (kind "port") on the host cores through oracle/cpu_bench.c: a pthread harness with the reference
+    CLI's worker model (mrgingham-from-image.cc:50, :374-379: T threads, one frame per thread at a time, the
+    per-call allocations of the reference kept), every leg at least `leg_seconds` long, no Python in the timed
+    region.  Legs: T = 1; T = all physical cores under glibc's default allocator policy (what the reference
+    binary gets: every 25 MB level buffer is an mmap / munmap + page faults); the same with freed blocks kept on
+    the heap.  `value` = the better of the two all-core legs.  The upstream ChESS.c built as shipped
+    (oracle/_ref, level-0 response only) runs in the same harness for scale."""
+    import numpy as np
     from oracle import oracle
     oracle.lib()
     ncores, nlogical, model = physical_cores()
+    frames_host = np.ascontiguousarray(frames_host)
     n = len(frames_host)
-    oracle.chain(frames_host[0], start_level)               # warm (page in the library, the frame)
-    t0 = time.perf_counter()
-    n1 = 0
-    while n1 < 3 or (time.perf_counter() - t0 < 2.0 and n1 < 64):   # T = 1: a few frames, ~2 s
-        oracle.chain(frames_host[n1 % n], start_level)
-        n1 += 1
-    t1 = (time.perf_counter() - t0) / n1
-    nsample = int(min(max(2 * ncores, cpu_seconds / max(t1, 1e-4)), 50 * ncores))
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=ncores) as ex:      # ctypes releases the GIL
-        list(ex.map(lambda i: oracle.chain(frames_host[i % n], start_level), range(nsample)))
-    dt = time.perf_counter() - t0
-    out = {"value": nsample / dt, "unit": "frames/s", "cores": ncores, "kind": "port",
+    oracle.bench_chain(frames_host[:1], start_level, 1, 0.0)                       # warm
+    p1, e1, _ = oracle.bench_chain(frames_host, start_level, 1, leg_seconds)
+    pa, ea, pts_a = oracle.bench_chain(frames_host, start_level, ncores, leg_seconds)
+    oracle.bench_heap_reuse(True)
+    oracle.bench_chain(frames_host, start_level, ncores, 1.0)                      # warm the heap
+    ph, eh, _ = oracle.bench_chain(frames_host, start_level, ncores, leg_seconds)
+    p1h, e1h, _ = oracle.bench_chain(frames_host, start_level, 1, min(leg_seconds, 3.0))
+    oracle.bench_heap_reuse(False)
+    t1, tall, tall_h, t1h = p1 / e1, pa / ea, ph / eh, p1h / e1h
+    best = max(tall, tall_h)
+    out = {"value": best, "unit": "frames/s", "cores": ncores, "kind": "port",
            "physical_cores": ncores, "logical_cpus": nlogical, "cpu_model": model,
-           "t1_frames_s": 1.0 / t1, "tall_frames_s": nsample / dt, "threads_all": ncores,
-           "sample": f"T=1: {n1} frames back to back on one thread ({t1 * 1e3:.0f} ms per frame); T={ncores} "
-                     f"(one thread per physical core, one frame per thread at a time): {nsample} frame passes over "
-                     f"{n} distinct frames of the batch in {dt:.1f} s; every pass is the full "
-                     f"detect(L{start_level})+refine chain of the C oracle (a port, gcc -O3)",
-           "what": "`value` = tall_frames_s = the stated CPU baseline: the oracle port, whole chain, all physical "
-                   "cores.  The upstream ChESS.c built as shipped (oracle/_ref) is timed beside it for scale only."}
+           "t1_frames_s": t1, "tall_frames_s": tall, "tall_frames_s_heap_reuse": tall_h, "t1_frames_s_heap_reuse": t1h,
+           "threads_all": ncores,
+           "parallel_efficiency": tall / (t1 * ncores), "parallel_efficiency_heap_reuse": tall_h / (t1h * ncores),
+           "candidates_per_frame": pts_a / max(pa, 1),
+           "sample": f"oracle/cpu_bench.c (pthreads, one frame per thread at a time, per-call allocations kept): "
+                     f"T=1 {p1} frame passes in {e1:.1f} s; T={ncores} {pa} passes in {ea:.1f} s (glibc default "
+                     f"allocator policy), {ph} passes in {eh:.1f} s (freed blocks kept on the heap); {n} distinct "
+                     f"frames; every pass is the full detect(L{start_level})+refine chain of the C oracle (gcc -O3)",
+           "what": "`value` = the better all-core leg of the oracle port (whole chain).  parallel_efficiency = "
+                   "tall / (t1 * cores).  The upstream ChESS.c built as shipped (oracle/_ref) is timed beside it "
+                   "(level-0 response only) for scale."}
     if oracle.have_reference_build():                       # the upstream ChESS.c itself, level 0 only
-        oracle.ref_chess_response_5(frames_host[0])
-        t0 = time.perf_counter()
-        oracle.ref_chess_response_5(frames_host[0])
-        out["upstream_chess_level0_ms_per_frame_t1"] = (time.perf_counter() - t0) * 1e3
+        pr1, er1 = oracle.bench_ref_chess(frames_host, 1, 2.0)
+        pra, era = oracle.bench_ref_chess(frames_host, ncores, 3.0)
+        out["upstream_chess_level0_ms_per_frame_t1"] = er1 / max(pr1, 1) * 1e3
+        out["upstream_chess_level0_frames_s_t1"] = pr1 / er1
+        out["upstream_chess_level0_frames_s_tall"] = pra / era
     return out
 
 
@@ -214,6 +263,8 @@ def main():
                          "searches in flight")
     ap.add_argument("--force-gather", action="store_true",
                     help="with one rank: still create the (one-rank) RCCL group and issue the gather every step")
+    ap.add_argument("--bind-numa", action="store_true",
+                    help="bind this process to the cores of its GPU's NUMA node (always done for --gpus > 1)")
     ap.add_argument("--prime", type=int, default=30,
                     help="untimed set-up passes before the W warm-up steps (scratch allocation, clock ramp); reported")
     args = ap.parse_args()
@@ -229,6 +280,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: mrgingham_amd has no CPU path")
     torch.cuda.set_device(local_rank)
+    binding = bind_rank_to_gpu_numa(local_rank) if (world > 1 or args.bind_numa) else None
     collective = world > 1 or args.force_gather
     if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -244,18 +296,19 @@ def main():
     import mrgingham_amd
     from mrgingham_amd import parallel, synth
 
-    W, H, gridn, start_level, batch = WORKLOADS[args.workload]
+    W, H, gridn, start_level, batch, background = WORKLOADS[args.workload]
+    render = synth.cluttered_board_batch if background == "clutter" else synth.board_batch
     if args.batch > 0:
         batch = args.batch
     dev = torch.device("cuda", local_rank)
     # every rank renders its own shard of the global batch (seed = global frame index)
     lo, _ = parallel.shard_range(world * batch, rank, world)
     if args.distinct and args.distinct < batch:
-        base = synth.board_batch(args.distinct, W, H, gridn=gridn, seed0=lo, device=dev)
+        base = render(args.distinct, W, H, gridn=gridn, seed0=lo, device=dev)
         frames = base.repeat((batch + args.distinct - 1) // args.distinct, 1, 1)[:batch].contiguous()
         del base
     else:
-        frames = synth.board_batch(batch, W, H, gridn=gridn, seed0=lo, device=dev)
+        frames = render(batch, W, H, gridn=gridn, seed0=lo, device=dev)
     det = mrgingham_amd.Detector(local_rank)
     if args.scratch_sets:
         det.set_option("scratch_sets", args.scratch_sets)
@@ -320,6 +373,26 @@ def main():
         dt = float(tmax.item())
 
     found = int((npts >= gridn * gridn).sum().item())
+    # the host-fed leg on EVERY rank (each rank feeds its own GPU from its own pinned buffer, all at once: what
+    # the node's PCIe / memory topology gives when all GPUs are fed together); rank 0 reports min / max over ranks
+    e2e = None
+    if not args.no_end_to_end:
+        if collective:
+            dist.barrier()
+        e2e = end_to_end(det, frames, start_level, P)
+        if collective:
+            mine = torch.tensor([e2e["h2d_GBs"], e2e["value"]], dtype=torch.float64, device=dev)
+            allr = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            h2d = [float(t[0]) for t in allr]
+            e2e = dict(e2e, ranks=world, h2d_GBs_min=min(h2d), h2d_GBs_max=max(h2d), h2d_GBs_per_rank=h2d,
+                       value=float(sum(float(t[1]) for t in allr)),
+                       what=e2e["what"] + "; all ranks at once, `value` = sum over ranks")
+    bindings = None
+    if collective and binding is not None:
+        objs = [None] * world
+        dist.all_gather_object(objs, binding)
+        bindings = objs
     gather_ok = None
     if collective and rank == 0:                             # what rank 0 received equals what the ranks produced
         last = (nstep[0] - 1) % NBUF
@@ -366,7 +439,7 @@ def main():
             "config": {"workload": f"{args.workload}: {batch} frames/GPU of {W}x{H} u8, {gridn}x{gridn} board, "
                                    f"detect at level {start_level} + refine to level 0, corner lists "
                                    f"{'gathered to rank 0' if collective else 'left on the device'}",
-                       "frames_per_gpu": batch, "width": W, "height": H, "gridn": gridn,
+                       "frames_per_gpu": batch, "width": W, "height": H, "gridn": gridn, "background": background,
                        "start_level": start_level, "parallelism": f"frames sharded x{world}",
                        "frames_with_full_grid_last_step": found},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -395,8 +468,10 @@ def main():
                         "set-up passes precede the W warm-up steps; a timed region shorter than ~0.1 s still "
                         "under-reads the steady state slightly")
         res["scratch_GiB"] = det.scratch_bytes() / 2**30
-        if world == 1 and not args.no_end_to_end:
-            res["end_to_end"] = end_to_end(det, frames, start_level, P)
+        if e2e is not None:
+            res["end_to_end"] = e2e
+        if bindings is not None or binding is not None:
+            res["cpu_binding"] = bindings if bindings is not None else [binding]
         if world == 1 and not args.no_cpu_baseline:
             nhost = min(batch, 64)
             res["cpu_baseline"] = cpu_baseline(frames[:nhost].cpu().numpy(), start_level)

@@ -149,6 +149,10 @@ struct mrgingham_amd_ctx {
     mrg::DevBuf aux_img, io_frame, io_out, io_counts;
     mrg::DevBuf pre_scratch, pre_tmp, pre_out, pre16_scratch, io_frame16, dbg_img, dbg_resp, blob_scratch;
     mrg::DevBuf fb_xy, fb_cnt, fb_pts, fb_lv, fb_np, fb_frames, fb_frames2;  // find_boards_batch: candidates, counts, boards, levels, point counts
+    // find_boards_batch's frame-by-frame retries (full-capacity detect, 1-by-1 refine) run on a single-frame
+    // context of THIS context's device, created on first use -- not on the calling thread's default context, which
+    // lives on MRGINGHAM_AMD_DEVICE / device 0 and cannot touch another GPU's frames
+    mrgingham_amd_ctx* one = nullptr;
     HostPool pool;  // preprocessing: extrema + tile histograms + LUTs, CLAHE output before the blur
     int pts_nframes = 0, pts_pitch = 0;
     // levels (and frame counts) whose status words must be checked at the next sync
@@ -561,6 +565,7 @@ mrgingham_amd_ctx* mrgingham_amd_create(int device_ordinal) {
 
 void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx) {
     if (!ctx) return;
+    if (ctx->one) mrgingham_amd_destroy(ctx->one);
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
     for (auto& set : ctx->lvs)
@@ -1115,6 +1120,16 @@ int mrgingham_amd_cc_on_response_batch(mrgingham_amd_ctx* ctx, const int16_t* d_
 /* ------------------------------------------------------------------------ */
 /* Reference symbols: host buffers in, host results out                      */
 /* ------------------------------------------------------------------------ */
+
+// Single-frame context on the same device as `ctx` (see mrgingham_amd_ctx::one).
+static mrgingham_amd_ctx* same_device_ctx(mrgingham_amd_ctx* ctx) {
+    if (!ctx->one) {
+        ctx->one = mrgingham_amd_create(ctx->device);
+        if (ctx->one) ctx->one->cap_shift = ctx->cap_shift;
+        hipSetDevice(ctx->device);
+    }
+    return ctx->one;
+}
 
 static mrgingham_amd_ctx* thread_ctx() {
     // One context per calling thread: the reference is called from N worker
@@ -1769,7 +1784,7 @@ int mrgingham_amd_find_boards_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_
         std::vector<std::vector<int32_t>> big(nb);
         for (int k = 0; k < nb && !rc; ++k) {
             if (h_found_level[cur_idx[k]] >= 0 || (h_cnt[k] >= 0 && h_cnt[k] <= cap)) continue;
-            mrgingham_amd_ctx* one = thread_ctx();
+            mrgingham_amd_ctx* one = same_device_ctx(ctx);
             if (!one) { rc = fail(ctx, MRGINGHAM_AMD_ERR_DEVICE, "no single-frame context"); break; }
             const mrgingham_amd_frames f1{cur.frames + (size_t)k * cur.frame_pitch, cur.frame_pitch, 1, cur.width,
                                           cur.height, cur.stride};
@@ -1849,7 +1864,7 @@ int mrgingham_amd_find_boards_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_
             // a frame of the refine batch overflowed the default tables at some level: refine the boards
             // found at this level one frame at a time (that path retries with one entry per pixel)
             rc = 0;
-            mrgingham_amd_ctx* one = thread_ctx();
+            mrgingham_amd_ctx* one = same_device_ctx(ctx);
             if (!one) { rc = fail(ctx, MRGINGHAM_AMD_ERR_DEVICE, "no single-frame context"); break; }
             for (int k = 0; k < nr; ++k) {
                 if (!h_np[k]) continue;

@@ -647,7 +647,7 @@ struct LdsCCT {
         struct { int16_t root[LROOTS], cnt[LROOTS], soff[LROOTS], fidx[LROOTS]; } r;
         int16_t need16[LN + 512]; // refine: LIFO demand of the super-component, at its root; behind them lead16[LPTS]
     } w;
-    int nroots, ncand, top, total, changed, nref, mtop, nload;
+    int nroots, ncand, top, total, changed, nref, mtop, nload, leak;
     int nbands, best, band_y[kMaxBands + 1], shear;
     uint32_t edge[4];
 };
@@ -1007,30 +1007,55 @@ __device__ __forceinline__ void lds_build_neighbours(LdsCC& L, const FrameView& 
 // label the super-components (lab = smallest list index) and leave in L.u.acc, at every root, (pixels of the
 // super-component) | (sum of hot-neighbour counts << 13): the latter bounds the pushes of any fill of it.
 // n = entries loaded.  Returns false (uniformly) when they do not fit.  All threads call it.
+// Window mode of the loader (refinement of frames with far more hot pixels than the tables hold -- a textured
+// scene): only the hot pixels in the CELLS around the points to refine are loaded.  `WinSel` is a bitmap over cells
+// of 2^cs x 2^cs pixels (cw cells per row); the cell of every refinable point and its eight neighbours are marked, so
+// a point's 3x3 seeds are at least 2^cs pixels away from the edge of what is loaded.  A super-component that
+// reaches that edge -- a member with a hot 4-neighbour in an unmarked cell -- is flagged "open" at its root
+// (`openbits`); the caller declines the frame if a seed falls into an open one (its fill could leave the loaded
+// set).  Everything else about the search only ever looks at the super-components of the seeds, so leaving the
+// rest of the frame's hot pixels out changes nothing.
+struct WinSel {
+    const uint32_t* bits;  // LDS
+    uint32_t* openbits;    // LDS, LN bits
+    int cs, cw;
+    __device__ __forceinline__ bool marked(int x, int y) const {
+        const int c = (y >> cs) * cw + (x >> cs);
+        return (bits[c >> 5] >> (c & 31)) & 1u;
+    }
+};
+
 template <class LdsCC>
 __device__ __forceinline__ bool lds_load_and_label(LdsCC& L, const FrameView& v, int nraw, int cap, bool banded, int y0,
-                                                   int y1, int& n) {
+                                                   int y1, int& n, const WinSel* win = nullptr) {
     constexpr int LN = LdsCC::LN, LHASH = LdsCC::LHASH, LEPT = LdsCC::LEPT;
     const int tid = threadIdx.x;
     n = 0;
+    if (win) banded = true;  // a selection out of the frame's list, like a band
     if (nraw > cap || (!banded && nraw > LN)) return false;
     const int w = v.w;
     for (int k = tid; k < LHASH / 2; k += CC_THREADS) L.hashw[k] = 0xffffffffu;
     const int shear = L.shear;
-    if (tid == 0) { L.nroots = 0; L.top = 0; L.total = 0; L.changed = 0; L.mtop = 0; L.nload = 0; }
+    if (tid == 0) { L.nroots = 0; L.top = 0; L.total = 0; L.changed = 0; L.mtop = 0; L.nload = 0; L.leak = 0; }
     __syncthreads();
     if (banded) {
         for (int i = tid; i < nraw; i += CC_THREADS) {
             const uint32_t e = v.hot_xy[i];
-            const int y = e != kHotDead ? band_key(e, shear, w) : -1;
-            if (y >= y0 && y < y1) {
+            bool take;
+            if (win) {
+                take = e != kHotDead && win->marked((int)(e & 0xffffu), (int)(e >> 16));
+            } else {
+                const int y = e != kHotDead ? band_key(e, shear, w) : -1;
+                take = y >= y0 && y < y1;
+            }
+            if (take) {
                 const int slot = atomicAdd(&L.nload, 1);
                 if (slot < LN) L.xy[slot] = e;
             }
         }
         __syncthreads();
         n = L.nload;
-        if (n > LN) return false;  // (the planner counted the same pixels: cannot happen)
+        if (n > LN) return false;  // bands: the planner counted the same pixels, cannot happen; windows: too many
     } else {
         n = nraw;
     }
@@ -1112,7 +1137,75 @@ __device__ __forceinline__ bool lds_load_and_label(LdsCC& L, const FrameView& v,
         atomicAdd(&L.u.acc[L.lab[i]], 1 + (deg << 13));
     }
     __syncthreads();
+    if (win) {
+        // open super-components (a pass of its own, rolled: the unrolled loops above hold eight entries' state in
+        // registers).  A neighbour that is not in the list is either not hot (its cell is loaded) or was not loaded;
+        // the neighbours come back from where the loop above parked them.
+        const uint2* parked = reinterpret_cast<const uint2*>(v.arena);
+#pragma unroll 1
+        for (int i = tid; i < n; i += CC_THREADS) {
+            const uint32_t e = L.xy[i];
+            if (e == kHotDead) continue;
+            const uint2 pk = parked[i];
+            const uint32_t nb[4] = {pk.x & 0xfffu, (pk.x >> 12) & 0xfffu, (pk.x >> 24) | ((pk.y & 0xfu) << 8), (pk.y >> 4) & 0xfffu};
+            const int x = (int)(e & 0xffffu), y = (int)(e >> 16);
+            bool open = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nx = x + (q == 0) - (q == 1), ny = y + (q == 2) - (q == 3);
+                if (nb[q] == kNoNb && nx >= 0 && nx < w && ny >= 0 && ny < v.h && !win->marked(nx, ny) &&
+                    v.d[ny * w + nx] > kRespMin)
+                    open = true;
+            }
+            if (open) {
+                const int r = L.lab[i];
+                atomicOr(&win->openbits[r >> 5], 1u << (r & 31));
+            }
+        }
+        __syncthreads();
+    }
     return true;
+}
+
+// Marks the cells around the refinable points of a frame (see WinSel).  `bits` must hold (cw * ch + 31) / 32 words.
+// All threads call it; returns the selection (cs = -1: the frame has too many cells for the bitmap).
+template <class LdsCC>
+__device__ __forceinline__ WinSel lds_plan_windows(LdsCC& L, const FrameView& v, const double* pts, const signed char* lv,
+                                                   int npts, int level, uint32_t* bits, int max_words, uint32_t* openbits) {
+    WinSel ws;
+    ws.bits = bits;
+    ws.openbits = openbits;
+    ws.cs = 5;
+    while (ws.cs < 15 && (((v.w >> ws.cs) + 1) * ((v.h >> ws.cs) + 1) + 31) / 32 > max_words) ++ws.cs;
+    ws.cw = (v.w >> ws.cs) + 1;
+    const int chh = (v.h >> ws.cs) + 1, nw = (ws.cw * chh + 31) / 32;
+    if (nw > max_words) { ws.cs = -1; return ws; }
+    for (int k = threadIdx.x; k < nw; k += CC_THREADS) bits[k] = 0;
+    for (int k = threadIdx.x; k < LdsCC::LN / 32; k += CC_THREADS) openbits[k] = 0;
+    __syncthreads();
+    const uint16_t coord_scale = (uint16_t)(1u << level);
+    for (int i = threadIdx.x; i < npts; i += CC_THREADS) {
+        if (lv[i] != level + 1) continue;
+        const double lx = rescale_coord(pts[2 * i + 0], 1.0 / coord_scale);
+        const double ly = rescale_coord(pts[2 * i + 1], 1.0 / coord_scale);
+        const int x = (int)(lx + 0.5), y = (int)(ly + 0.5);
+        // the nine seed positions exactly as the seeding loop forms them (int16 conversions of is_valid included)
+        for (int sdx = -1; sdx <= 1; ++sdx)
+            for (int sdy = -1; sdy <= 1; ++sdy) {
+                const int sx = (int16_t)(x + sdx), sy = (int16_t)(y + sdy);
+                if (sx < 0 || sx >= v.w || sy < 0 || sy >= v.h) continue;
+                const int cx = sx >> ws.cs, cy = sy >> ws.cs;
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int ax = cx + dx, ay = cy + dy;
+                        if (ax < 0 || ax >= ws.cw || ay < 0 || ay >= chh) continue;
+                        const int c = ay * ws.cw + ax;
+                        if (!((bits[c >> 5] >> (c & 31)) & 1u)) atomicOr(&bits[c >> 5], 1u << (c & 31));
+                    }
+            }
+    }
+    __syncthreads();
+    return ws;
 }
 
 // What a declining kernel leaves behind: the frame stays with the global-memory kernels (path 0).  A kernel
@@ -1321,18 +1414,53 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
         lds_decline(t, frame);
         return;
     }
-    int nbands = 0;  // cc_lds bit 256: no banding (test hook)
-    if (nraw <= t.cap && !(nraw > LN && (t.lds_path & 256))) nbands = lds_plan_bands(L, v, nraw);
+    const int w = v.w, h = v.h;
+    const long long pb = (long long)frame * io.pitch;
+    double* pts = io.points + 2 * pb;
+    signed char* lv = io.levels + pb;
+    int nbands = 0;  // cc_lds bit 256: no banding, no windows (test hook)
+    const bool may_select = nraw <= t.cap && !(nraw > LN && (t.lds_path & 256));
+    // More hot pixels than the tables hold: first try to load only the cells around the points (one pass over the
+    // list; a textured scene has 10^4 - 10^5 hot pixels of which the refinement needs ~10^3), then bands.
+    // The cell bitmap lives in L.w (dead until the LIFO demands are written), the open flags behind the
+    // accumulators in L.u (dead until the fills).
+    WinSel ws;
+    ws.cs = -1;
+    bool windowed = false;
+    if (may_select && nraw > LN) {
+        uint32_t* wbits = reinterpret_cast<uint32_t*>(&L.w);
+        uint32_t* obits = reinterpret_cast<uint32_t*>(L.u.stk) + LN;
+        static_assert(sizeof(L.u) >= (size_t)LN * 4 + (size_t)LN / 8, "open flags behind the accumulators");
+        ws = lds_plan_windows(L, v, pts, lv, npts, level, wbits, (int)(sizeof(L.w) / 4), obits);
+        if (ws.cs >= 0) {
+            // do the marked cells hold few enough hot pixels?  (one more pass over the list; a frame whose hot pixels
+            // are all around its points -- a large board on a flat background -- is cut into bands instead)
+            if (tid == 0) L.nload = 0;
+            __syncthreads();
+            int cnt = 0;
+            for (int i = tid; i < nraw; i += CC_THREADS) {
+                const uint32_t e = v.hot_xy[i];
+                cnt += e != kHotDead && ws.marked((int)(e & 0xffffu), (int)(e >> 16));
+            }
+            if (cnt) atomicAdd(&L.nload, cnt);
+            __syncthreads();
+            windowed = L.nload <= LN;
+            __syncthreads();
+        }
+    }
+    if (windowed) {
+        if (tid == 0) { L.band_y[0] = 0; L.band_y[1] = 0; L.shear = 0; }
+        nbands = 1;
+        __syncthreads();
+    } else if (may_select) {
+        nbands = lds_plan_bands(L, v, nraw);
+    }
     if (nbands == 0) {
         lds_decline(t, frame);
         return;
     }
     if (tid == 0) L.nref = 0;
     tick(1);
-    const int w = v.w, h = v.h;
-    const long long pb = (long long)frame * io.pitch;
-    double* pts = io.points + 2 * pb;
-    signed char* lv = io.levels + pb;
     uint32_t* seeds = io.seeds + 9 * pb;  // here: list indices, read back by the group's leader lane
     int32_t* nseeds = io.nseeds + pb;
     int32_t* gneed = io.need + pb;  // per leader
@@ -1344,7 +1472,8 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
 
     for (int band = 0; band < nbands; ++band) {
         int n;
-        if (!lds_load_and_label(L, v, nraw, t.cap, nbands > 1, L.band_y[band], L.band_y[band + 1], n)) {
+        if (!lds_load_and_label(L, v, nraw, t.cap, nbands > 1, L.band_y[band], L.band_y[band + 1], n, windowed ? &ws : nullptr)) {
+            // (window mode: the cells around the points hold more hot pixels than the tables do -- band 0, plain decline)
             lds_decline_refine(t, frame, band, io, L.nref);
             return;
         }
@@ -1381,10 +1510,13 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
                             j = lds_find(L, ((uint32_t)sy << 16) | (uint32_t)sx);  // hot <=> listed (nothing consumed yet)
                         if (j >= 0) {
                             seeds[9 * i + ns] = (uint32_t)j;
+                            const int r = L.lab[j];
 #pragma unroll
                             for (int k = 0; k < 9; ++k)  // static register index
-                                if (k == ns) sroot_[q][k] = L.lab[j];
+                                if (k == ns) sroot_[q][k] = (short)r;
                             ++ns;
+                            // window mode: a seed in a super-component that reaches the edge of what was loaded
+                            if (windowed && ((ws.openbits[r >> 5] >> (r & 31)) & 1u)) L.leak = 1;
                         }
                     }
                 nseeds[i] = ns;
@@ -1393,6 +1525,10 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
             lead_[q] = i;
         }
         __syncthreads();
+        if (windowed && L.leak) {  // (uniform) nothing has been refined yet: the global-memory kernel takes the frame
+            lds_decline(t, frame);
+            return;
+        }
         if (band == 0) tick(3);
 
         // R2: points whose seeds share a super-component are replayed in index order by one lane:

@@ -93,6 +93,32 @@ def noise_frame(W, H, seed=0, smooth=0, device="cpu"):
     return img.to(torch.uint8)
 
 
+def cluttered_board_frame(W, H, gridn=10, seed=0, smooth=2, amp=128, device="cpu"):
+    """board_frame over a textured background: smoothed pseudo-noise (box-blurred `smooth` times, contrast `amp` of
+    255 around mid-grey) everywhere except a rectangle around the board (its bounding box + 40 px).  The texture
+    gives the detector what a real calibration scene gives it -- tens of thousands of pixels with a ChESS
+    response above 15 that belong to no corner (4096x3072, smooth 2, amp 128: ~8e4 at level 0, ~1e4 at level 1,
+    against ~1.3e3 on the flat background) -- so the component search cannot run out of its LDS tables."""
+    clean = board_frame(W, H, gridn, seed, device=device).to(torch.int64)
+    bg = noise_frame(W, H, seed + 1000, smooth=smooth, device=device).to(torch.int64)
+    bg = torch.div((bg - 128) * amp, 255, rounding_mode="floor") + 128
+    lat = board_lattice(W, H, gridn, seed)                       # corner positions -> the board's extent
+    pitch = float(((lat[0, 1] - lat[0, 0]) ** 2).sum() ** 0.5)
+    pad = int(2.5 * pitch) + 40                                  # the outer ring of double cells + margin
+    x0 = max(int(lat[..., 0].min()) - pad, 0); x1 = min(int(lat[..., 0].max()) + pad, W)
+    y0 = max(int(lat[..., 1].min()) - pad, 0); y1 = min(int(lat[..., 1].max()) + pad, H)
+    img = bg.clone()
+    img[y0:y1, x0:x1] = clean[y0:y1, x0:x1]
+    return img.clamp(0, 255).to(torch.uint8)
+
+
+def cluttered_board_batch(B, W, H, gridn=10, seed0=0, device="cpu", **kw):
+    out = torch.empty((B, H, W), dtype=torch.uint8, device=device)
+    for b in range(B):
+        out[b] = cluttered_board_frame(W, H, gridn, seed0 + b, device=device, **kw)
+    return out
+
+
 def board_lattice(W, H, gridn=10, seed=0):
     """Analytic positions of the gridn x gridn interior X-corners of board_frame(W, H, gridn, seed), from the
     renderer's own geometry (no detector involved): float64 numpy [gridn, gridn, 2] of (x, y) in the

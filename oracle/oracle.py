@@ -24,7 +24,7 @@ _i8p = ctypes.POINTER(ctypes.c_int8)
 def build(force=False):
     """Compile the restatement (and oracle/_ref when /root/reference exists)."""
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(
-            os.path.getmtime(os.path.join(_HERE, f)) for f in ("mrgingham_oracle.c", "blobs_oracle.c")):
+            os.path.getmtime(os.path.join(_HERE, f)) for f in ("mrgingham_oracle.c", "blobs_oracle.c", "cpu_bench.c")):
         subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
     elif not os.path.exists(_REF) and os.path.exists("/root/reference/ChESS.c"):
         subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
@@ -248,3 +248,38 @@ def chain(image, start_level=3):
         if n <= 0:
             break
     return pts, lv
+
+
+def bench_chain(frames, start_level=3, nthreads=1, min_seconds=5.0):
+    """pthread harness (cpu_bench.c): `nthreads` workers, one frame per worker at a time, whole chain per frame,
+    for at least `min_seconds`.  frames: uint8 [n, H, W] contiguous.  -> (passes, elapsed_s, candidates_seen)."""
+    frames = np.ascontiguousarray(frames, dtype=np.uint8)
+    n, H, W = frames.shape
+    L = lib()
+    L.oracle_bench_chain.argtypes = [_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]
+    L.oracle_bench_chain.restype = ctypes.c_long
+    el, pts = ctypes.c_double(0), ctypes.c_long(0)
+    passes = L.oracle_bench_chain(frames.ctypes.data_as(_u8p), n, H, W, start_level, nthreads, float(min_seconds),
+                                  ctypes.byref(el), ctypes.byref(pts))
+    return int(passes), float(el.value), int(pts.value)
+
+
+def bench_ref_chess(frames, nthreads=1, min_seconds=5.0):
+    """The REAL upstream ChESS.c (oracle/_ref), level-0 response only, in the same harness.
+    -> (passes, elapsed_s)."""
+    frames = np.ascontiguousarray(frames, dtype=np.uint8)
+    n, H, W = frames.shape
+    L = lib()
+    L.oracle_bench_fn.argtypes = [ctypes.c_void_p, _u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                  ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
+    L.oracle_bench_fn.restype = ctypes.c_long
+    fn = ctypes.cast(ref_lib().mrgingham_ChESS_response_5, ctypes.c_void_p)
+    el = ctypes.c_double(0)
+    passes = L.oracle_bench_fn(fn, frames.ctypes.data_as(_u8p), n, H, W, nthreads, float(min_seconds), ctypes.byref(el))
+    return int(passes), float(el.value)
+
+
+def bench_heap_reuse(on):
+    """Allocator policy for the bench harness: see oracle_bench_heap_reuse in cpu_bench.c."""
+    lib().oracle_bench_heap_reuse(1 if on else 0)

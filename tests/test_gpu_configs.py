@@ -97,3 +97,31 @@ def test_scratch_for_64_frames():
         assert gib < 20, gib
     finally:
         d.close()
+
+
+def test_c3_cluttered_frames_match_the_oracle_on_both_search_paths(det):
+    """The board over a textured background (bench workload c3_cluttered): tens of thousands of hot pixels per
+    frame at level 0 -- more than the LDS tables hold and no empty rows to cut bands at -- so the frames go
+    through the global-memory kernels at the fine levels and through LDS at the coarse ones; the lists equal
+    the oracle's bit for bit either way."""
+    B = 3
+    frames = synth.cluttered_board_batch(B, W, H, gridn=10, seed0=7, device="cuda")
+    host = frames.cpu().numpy()
+    pts, lv, npts = det.chain(frames, start_level=3, max_points=512)
+    paths = {L: det.debug_paths(L, B).tolist() for L in range(4)}
+    pts, lv, npts = pts.cpu().numpy(), lv.cpu().numpy(), npts.cpu().numpy()
+    for f in range(B):
+        _check_against_oracle(host[f], pts[f], lv[f], int(npts[f]))
+        assert int((lv[f, :int(npts[f])] == 0).sum()) >= 100, f
+    # refinement at level 0 (~7e4 hot pixels per frame): out of LDS all the same, on the hot pixels in the cells
+    # around the points only (cc.hip, WinSel); level 3 (~1.6e3) fits as it is
+    assert paths[0] == [1] * B and paths[3] == [1] * B, paths
+    hot0 = int((oracle.clamped_response(host[0], 0)[0] > 15).sum())
+    assert 2e4 < hot0 < 2e5, hot0
+    for level in (0, 1, 2, 3):                                 # every level on its own as well (detect)
+        xy, counts = det.detect(frames, level, capacity=1024)
+        if level == 0:
+            assert det.debug_paths(0, B).tolist() == [0] * B   # detect needs every component: global memory
+        for f in range(B):
+            want = oracle.find_corners(host[f], level)
+            assert int(counts[f]) == len(want) and np.array_equal(xy[f, :len(want)].cpu().numpy(), want), (level, f)

@@ -124,3 +124,34 @@ def test_c5_mixed_stream_at_baseline_resolutions_one_rank_of_eight():
         assert nfound >= 4
     finally:
         det.close()
+
+
+def test_bench_c4_shard_of_256_frames_with_the_gather():
+    """BASELINE config 4 as a bench workload: 256 frames per GPU (2048 at N = 8), the step ends in the ONE gather
+    of the corner lists (a one-rank RCCL group here), the host-fed leg runs on the rank with the collective up,
+    and the rank binds itself to its GPU's NUMA node."""
+    res = _bench("--gpus", "1", "--workload", "c4_4096x3072_shard256", "--force-gather", "--bind-numa", "--steps", "3",
+                 "--warmup", "1", "--prime", "2", "--no-cpu-baseline")
+    assert res["config"]["frames_per_gpu"] == 256 and res["scaling"] == "weak"
+    assert res["gather_checked"] is True and res["config"]["frames_with_full_grid_last_step"] == 256
+    e = res["end_to_end"]
+    assert e["ranks"] == 1 and e["h2d_GBs_min"] > 0 and e["h2d_GBs_min"] <= e["h2d_GBs_max"]
+    assert e["frames_with_points_last_step"] == 256
+    assert isinstance(res["cpu_binding"], list) and len(res["cpu_binding"]) == 1
+    assert res["scratch_GiB"] <= 32.0
+
+
+def test_bench_cluttered_workload_small_run():
+    res = _bench("--gpus", "1", "--workload", "c3_cluttered", "--batch", "8", "--steps", "3", "--warmup", "1",
+                 "--prime", "2", "--no-cpu-baseline", "--no-end-to-end")
+    assert res["config"]["background"] == "clutter" and res["config"]["frames_with_full_grid_last_step"] == 8
+
+
+def test_cpu_baseline_harness_reports_efficiency():
+    import bench
+    fr = synth.board_batch(4, 640, 480, 10, 0).numpy()
+    b = bench.cpu_baseline(fr, 3, leg_seconds=0.3)
+    assert b["kind"] == "port" and b["value"] >= b["tall_frames_s"] > 0
+    assert 0 < b["parallel_efficiency"] <= 1.5 and 99 <= b["candidates_per_frame"] <= 101
+    if oracle.have_reference_build():
+        assert b["upstream_chess_level0_frames_s_tall"] > 0
