@@ -306,24 +306,39 @@ int mrgingham_amd_chain_info(const mrgingham_amd_ctx* ctx, int* fused_pyramid, i
  *                         run (each set is a full copy of the level scratch): 0 (default) = chosen per batch shape --
  *                         three while three sets stay below 8 GB (small frames, whose search chain is longer than two
  *                         steps of the pixel kernels), two otherwise --, 2 or 3 = fixed.  Synchronises.
- *   "hot_capacity_shift"  per-frame capacity of the hot-pixel / component tables is
- *                         (width*height) >> shift entries (default 3; 0 = one per pixel)
+ *   "hot_capacity_shift"  per-frame capacity of the hot-pixel / component tables of a pyramid level is
+ *                         (level width * height) >> shift entries, at least 4096 (default 7: 0.35 bytes of tables per
+ *                         pixel; 0 = one entry per pixel).  Derived limits at shift > 0: candidates per frame
+ *                         capacity / 16 + 1024, LIFO words 1.25 * capacity + 16384.  A frame that exceeds one of
+ *                         them makes the call fail with MRGINGHAM_AMD_ERR_CAPACITY at the next mrgingham_amd_sync --
+ *                         nothing is written for that frame (detect: count -1; refine: its points keep their values
+ *                         and levels, except on a LIFO overflow in the middle of a frame, where the points refined so
+ *                         far stay refined) -- and the tables of that level GROW to what the frame asked for, so
+ *                         the same call succeeds when it is made again (refinement is idempotent: points already at
+ *                         the level are skipped).  Setting the option resets what has grown.
  *   "chess_v0"            1 = use the plain reference-shaped ChESS kernel (cross-check)
  *   "multi_level_launch"  chain_batch: 0 = one ChESS launch per pyramid level, 1 (default) = levels 3..1 in one
  *                         launch, 2 = all levels in one launch
  *   "cc_lds"              1 (default) = component search out of LDS: frames with at most 2048 hot pixels in one
  *                         pass, frames with up to 16384 in bands of rows separated by three rows without a hot
- *                         pixel (the global-memory kernels take what is left), 0 = global-memory kernels only;
- *                         1 | 256 = no banding (test hook); bits 2, 4, 8 timing ablations (wrong results),
- *                         128 = no component kernels at all, 512 = phase clock (mrgingham_amd_debug_refine_clock)
- *   "cc_schedule", "chess_seg", "chess_stage"   experiment hooks (tools/interference_ab.py, tools/stage_ab.py) */
+ *                         pixel, refinement of frames with more than that on the hot pixels in the cells around
+ *                         the points (the global-memory kernels take what is left), 0 = global-memory kernels only;
+ *                         1 | 256 = neither bands nor cells (test hook; results are the same).  Any other value is
+ *                         refused.
+ *   "chess_seg"           rows per workgroup of the ChESS kernels (0 = cost model); results do not depend on it
+ * Builds made with -DMRG_EXPERIMENT (make -C mrgingham_amd/csrc EXPERIMENT=1 -> libmrgingham_amd_experiment.so)
+ * additionally accept the timing ablations and phase clocks of tools/ ("cc_lds" bits 2, 4, 8, 16, 128, 512,
+ * "cc_schedule", "chess_stage", "chess_multi_min_blocks", the MRGINGHAM_AMD_PYR_SKIP / _CC_LDS_PAD / _CC_CUS /
+ * _PIX_COMPLEMENT / _CHESS_V0 environment variables): some of them produce wrong results on purpose, which is why the
+ * shipped library has none of them and reads no environment variable except MRGINGHAM_AMD_DEVICE. */
 int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value);
 
 /* Wait for everything queued on the context's streams; returns the first
  * asynchronous error.  MRGINGHAM_AMD_ERR_CAPACITY here means a frame had more
- * hot pixels than the component tables hold (adversarial texture): lower
- * "hot_capacity_shift" and re-run the batch.  The reference-symbol wrappers in
- * section (1) do that retry themselves. */
+ * hot pixels (or candidates) than the component tables of its level hold (dense
+ * texture): the tables have grown by the time this returns, make the same call
+ * again (see "hot_capacity_shift").  The reference-symbol wrappers in section (1)
+ * and mrgingham_amd_find_boards_batch do that themselves. */
 int mrgingham_amd_sync(mrgingham_amd_ctx* ctx);
 
 /* Device-side alternative to mrgingham_amd_sync for pipelines: makes `stream` (a hipStream_t,

@@ -249,7 +249,27 @@ class Detector:
 
     def _check(self, rc):
         if rc != 0:
-            raise RuntimeError(f"mrgingham_amd error {rc}: {self.L.mrgingham_amd_last_error(self.ctx).decode()}")
+            e = RuntimeError(f"mrgingham_amd error {rc}: {self.L.mrgingham_amd_last_error(self.ctx).decode()}")
+            e.code = rc
+            raise e
+
+    ERR_CAPACITY = -3
+
+    def _sync_retrying(self, issue, retry, restore=None):
+        """issue() + sync(); a frame that overflowed the component tables of its level makes the sync fail with
+        ERR_CAPACITY *after the tables have grown to what it asked for* (include/mrgingham_amd.h,
+        "hot_capacity_shift"), so the same call is simply made again -- like the reference-symbol wrappers of the
+        library do it.  `restore` puts in/out arguments back first."""
+        for attempt in range(4):
+            issue()
+            try:
+                self.sync()
+                return
+            except RuntimeError as e:
+                if not retry or getattr(e, "code", 0) != self.ERR_CAPACITY or attempt == 3:
+                    raise
+                if restore:
+                    restore()
 
     def _frames(self, frames):
         t = self.torch
@@ -315,34 +335,48 @@ class Detector:
                                                           int(blur_radius), out.data_ptr(), stream))
         return out
 
-    def detect(self, frames, level, capacity=4096, sync=True):
-        """-> (xy int32 [B,capacity,2], counts int32 [B]) on the device."""
+    def detect(self, frames, level, capacity=4096, sync=True, retry=True):
+        """-> (xy int32 [B,capacity,2], counts int32 [B]) on the device.  sync=True waits for the result and, with
+        retry, repeats the call when a frame overflowed the (self-growing) component tables."""
         t = self.torch
         fr, B, H, W = self._frames(frames)
         xy = t.empty((B, capacity, 2), dtype=t.int32, device=frames.device)
         counts = t.empty((B,), dtype=t.int32, device=frames.device)
         t.cuda.current_stream(frames.device).synchronize()  # inputs/outputs ready before the ctx streams run
-        self._check(self.L.mrgingham_amd_detect_batch(self.ctx, ctypes.byref(fr), level, xy.data_ptr(), capacity,
-                                                      counts.data_ptr()))
+
+        def issue():
+            self._check(self.L.mrgingham_amd_detect_batch(self.ctx, ctypes.byref(fr), level, xy.data_ptr(), capacity,
+                                                          counts.data_ptr()))
         if sync:
-            self.sync()
+            self._sync_retrying(issue, retry)
+        else:
+            issue()
         return xy, counts
 
-    def refine(self, frames, level, points, levels, npoints, sync=True):
+    def refine(self, frames, level, points, levels, npoints, sync=True, retry=True):
         """In-place refine of points f64 [B,P,2], levels int8 [B,P], npoints int32 [B]; -> nrefined int32 [B]."""
         t = self.torch
         fr, B, H, W = self._frames(frames)
         assert points.dtype == t.float64 and points.is_contiguous() and levels.dtype == t.int8
         P = points.shape[1]
         nref = t.empty((B,), dtype=t.int32, device=frames.device)
+        keep = (points.clone(), levels.clone()) if (sync and retry) else None
         t.cuda.current_stream(frames.device).synchronize()
-        self._check(self.L.mrgingham_amd_refine_batch(self.ctx, ctypes.byref(fr), level, points.data_ptr(),
-                                                      levels.data_ptr(), npoints.data_ptr(), P, nref.data_ptr()))
+
+        def issue():
+            self._check(self.L.mrgingham_amd_refine_batch(self.ctx, ctypes.byref(fr), level, points.data_ptr(),
+                                                          levels.data_ptr(), npoints.data_ptr(), P, nref.data_ptr()))
+
+        def restore():
+            points.copy_(keep[0]); levels.copy_(keep[1])
+            t.cuda.current_stream(frames.device).synchronize()
         if sync:
-            self.sync()
+            self._sync_retrying(issue, retry, restore)
+        else:
+            issue()
         return nref
 
-    def chain(self, frames, start_level=3, max_points=1024, out=None, sync=True):
+    def chain(self, frames, start_level=3, max_points=1024, out=None, sync=True, retry=True):
         """detect at start_level, refine down to 0 -> (points f64 [B,P,2], levels int8 [B,P], npoints int32 [B])."""
         t = self.torch
         fr, B, H, W = self._frames(frames)
@@ -352,13 +386,17 @@ class Detector:
                    t.empty((B,), dtype=t.int32, device=frames.device))
             t.cuda.current_stream(frames.device).synchronize()
         pts, lv, npts = out
-        self._check(self.L.mrgingham_amd_chain_batch(self.ctx, ctypes.byref(fr), start_level, pts.data_ptr(),
-                                                     lv.data_ptr(), npts.data_ptr(), pts.shape[1]))
+
+        def issue():
+            self._check(self.L.mrgingham_amd_chain_batch(self.ctx, ctypes.byref(fr), start_level, pts.data_ptr(),
+                                                         lv.data_ptr(), npts.data_ptr(), pts.shape[1]))
         if sync:
-            self.sync()
+            self._sync_retrying(issue, retry)    # (the chain writes all of its outputs: nothing to restore)
+        else:
+            issue()
         return pts, lv, npts
 
-    def cc_detect_on_response(self, resp, level_images, level=0, capacity=4096, sync=True):
+    def cc_detect_on_response(self, resp, level_images, level=0, capacity=4096, sync=True, retry=True):
         """The component search alone on caller-built responses (int16 [B,h,w], device) and level
         images (uint8 [B,h,w]): -> (xy int32 [B,capacity,2], counts int32 [B]).  For the rule tests."""
         t = self.torch
@@ -368,11 +406,15 @@ class Detector:
         xy = t.empty((B, capacity, 2), dtype=t.int32, device=resp.device)
         counts = t.empty((B,), dtype=t.int32, device=resp.device)
         t.cuda.current_stream(resp.device).synchronize()
-        self._check(self.L.mrgingham_amd_cc_on_response_batch(self.ctx, resp.data_ptr(), level_images.data_ptr(), B, w,
-                                                              h, level, xy.data_ptr(), capacity, counts.data_ptr(),
-                                                              None, None, None, 0, None))
+
+        def issue():
+            self._check(self.L.mrgingham_amd_cc_on_response_batch(self.ctx, resp.data_ptr(), level_images.data_ptr(), B,
+                                                                  w, h, level, xy.data_ptr(), capacity,
+                                                                  counts.data_ptr(), None, None, None, 0, None))
         if sync:
-            self.sync()
+            self._sync_retrying(issue, retry)
+        else:
+            issue()
         return xy, counts
 
     def cc_refine_on_response(self, resp, level_images, level, points, levels, npoints, sync=True):
@@ -384,13 +426,22 @@ class Detector:
         assert points.dtype == t.float64 and points.is_contiguous() and levels.dtype == t.int8
         B, h, w = resp.shape
         nref = t.empty((B,), dtype=t.int32, device=resp.device)
+        keep = (points.clone(), levels.clone()) if sync else None
         t.cuda.current_stream(resp.device).synchronize()
-        self._check(self.L.mrgingham_amd_cc_on_response_batch(self.ctx, resp.data_ptr(), level_images.data_ptr(), B, w,
-                                                              h, level, None, 0, None, points.data_ptr(),
-                                                              levels.data_ptr(), npoints.data_ptr(), points.shape[1],
-                                                              nref.data_ptr()))
+
+        def issue():
+            self._check(self.L.mrgingham_amd_cc_on_response_batch(self.ctx, resp.data_ptr(), level_images.data_ptr(), B,
+                                                                  w, h, level, None, 0, None, points.data_ptr(),
+                                                                  levels.data_ptr(), npoints.data_ptr(),
+                                                                  points.shape[1], nref.data_ptr()))
+
+        def restore():
+            points.copy_(keep[0]); levels.copy_(keep[1])
+            t.cuda.current_stream(resp.device).synchronize()
         if sync:
-            self.sync()
+            self._sync_retrying(issue, True, restore)
+        else:
+            issue()
         return nref
 
     def find_boards(self, frames, gridn=10, image_pyramid_level=-1, nthreads=0):

@@ -125,7 +125,13 @@ struct mrgingham_amd_ctx {
     bool cc_pending[kMaxSets] = {};
     int cur = 0;  // scratch set of the call being queued
     std::string err;
-    int cap_shift = 3;    // hot-pixel table capacity = level pixels >> cap_shift per frame
+    // hot-pixel / component table capacity = level pixels >> shift entries per frame, shift = min(cap_shift,
+    // grown_shift[level]).  The default (1/128: 98 304 hot pixels for a 4096x3072 frame, whose bench frames have
+    // ~1.3e3 and whose textured ones ~7e4) keeps the tables at 0.35 B per pixel; a frame that needs more is
+    // reported (MRGINGHAM_AMD_ERR_CAPACITY at the sync) and the tables of its level GROW to what it asked for, so
+    // the same call succeeds when it is made again.
+    int cap_shift = 7;
+    int grown_shift[mrg::kMaxLevel + 1];
     bool use_v0 = false;  // reference-shaped ChESS kernel instead of the tuned one
     // levels 3..1 of a chain in one launch (set_option "multi_level_launch"): +1.5 % chain rate, but the
     // component chains then start later and overlap the level-0 launch more (+5 % on that launch): off
@@ -192,7 +198,9 @@ static int ensure(mrgingham_amd_ctx* ctx, DevBuf& b, size_t bytes) {
         b.p = nullptr;
         b.bytes = 0;
     }
-    const size_t want = bytes + bytes / 8 + 256;
+    // growth headroom for the small buffers only: the per-level tables of a large batch are gigabytes, and 1/8 on top
+    // of them was 1 GiB of the 64-frame bench's scratch
+    const size_t want = bytes + (bytes < (64u << 20) ? bytes / 8 : 0) + 256;
     MRG_HIP_CHECK(hipMalloc(&b.p, want));
     b.bytes = want;
     return 0;
@@ -227,26 +235,27 @@ static int ensure_level_set(mrgingham_amd_ctx* ctx, int set, int level, int nfra
     LevelScratch& L = ctx->lvs[set][level];
     int w, h;
     level_dims(W, H, level, &w, &h);
-    if (nframes <= L.nframes && w == L.w && h == L.h && pitch <= L.pitch && L.shift == ctx->cap_shift) return 0;
+    const int shift = ctx->cap_shift < ctx->grown_shift[level] ? ctx->cap_shift : ctx->grown_shift[level];
+    if (nframes <= L.nframes && w == L.w && h == L.h && pitch <= L.pitch && L.shift == shift) return 0;
     if (w == L.w && h == L.h) {
         nframes = nframes > L.nframes ? nframes : L.nframes;
         pitch = pitch > L.pitch ? pitch : L.pitch;
     }
     const long long px = (long long)w * h;
-    long long cap = px >> ctx->cap_shift;
+    long long cap = px >> shift;
     if (cap < 4096) cap = 4096;
     if (cap > px) cap = px > 0 ? px : 1;
     if (cap > 0x3fffffff) return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "frame too large");
     // Components that pass the size / peak / margin tests: at most cap / 2 (two pixels each).  Tables of
     // that size are only allocated at shift 0 (the "one entry per pixel" retry of the reference-symbol
     // wrappers); otherwise a fraction, with overflow reported like a hot-list overflow.
-    long long cand_cap = ctx->cap_shift == 0 ? cap / 2 + 1 : cap / 16 + 1024;
+    long long cand_cap = shift == 0 ? cap / 2 + 1 : cap / 16 + 1024;
     if (cand_cap < pitch) cand_cap = pitch;
     long long sort_cap = 1;
     while (sort_cap < cand_cap) sort_cap <<= 1;
     // LIFO arena: a super-component of n hot pixels gets 4n + 1 words (every pixel is pushed at most
     // once per neighbour), so 5 * cap bounds a frame.  Same policy as the candidate table.
-    const long long arena_cap = (ctx->cap_shift == 0 ? 5 * cap : cap + cap / 4) + 16LL * (pitch > 1024 ? pitch : 1024);
+    const long long arena_cap = (shift == 0 ? 5 * cap : cap + cap / 4) + 16LL * (pitch > 1024 ? pitch : 1024);
     const size_t nf = (size_t)nframes;
     int rc = 0;
     if (level > 0 && (rc = ensure(ctx, L.img, nf * (size_t)px + 16))) return rc;
@@ -272,8 +281,33 @@ static int ensure_level_set(mrgingham_amd_ctx* ctx, int set, int level, int nfra
     if ((rc = ensure(ctx, L.sortkeys, nf * (size_t)sort_cap * 8))) return rc;
     L.w = w; L.h = h; L.nframes = nframes; L.pitch = pitch;
     L.cap = (int)cap; L.cand_cap = (int)cand_cap; L.sort_cap = (int)sort_cap; L.arena_cap = arena_cap;
-    L.shift = ctx->cap_shift;
+    L.shift = shift;
     return 0;
+}
+
+// Every device buffer a context owns (one list for destroy and for mrgingham_amd_scratch_bytes).
+static std::vector<DevBuf*> level_set_buffers(mrgingham_amd_ctx* ctx, int set, bool with_points) {
+    std::vector<DevBuf*> v;
+    for (LevelScratch& L : ctx->lvs[set])
+        for (DevBuf* b : {&L.img, &L.resp, &L.gidx, &L.hot_xy, &L.parent, &L.comp_cnt, &L.roots, &L.comp_first, &L.comp_box,
+                          &L.arena, &L.cand, &L.sortkeys})
+            v.push_back(b);
+    if (!with_points) return v;
+    auto& ps = ctx->pts[set];
+    for (DevBuf* b : {&ps.leader, &ps.need, &ps.nseeds, &ps.seeds, &ps.sroot, &ps.cand_xy, &ps.cand_counts}) v.push_back(b);
+    return v;
+}
+static std::vector<DevBuf*> all_buffers(mrgingham_amd_ctx* ctx) {
+    std::vector<DevBuf*> v;
+    for (int set = 0; set < kMaxSets; ++set) {
+        for (DevBuf* b : level_set_buffers(ctx, set, true)) v.push_back(b);
+        v.push_back(&ctx->counters2[set]);
+    }
+    for (DevBuf* b : {&ctx->io_counts, &ctx->aux_img, &ctx->io_frame, &ctx->io_out, &ctx->pre_scratch, &ctx->pre_tmp,
+                      &ctx->pre_out, &ctx->pre16_scratch, &ctx->io_frame16, &ctx->dbg_img, &ctx->dbg_resp, &ctx->blob_scratch,
+                      &ctx->fb_xy, &ctx->fb_cnt, &ctx->fb_pts, &ctx->fb_lv, &ctx->fb_np, &ctx->fb_frames, &ctx->fb_frames2})
+        v.push_back(b);
+    return v;
 }
 
 // How many scratch sets (= calls whose component searches may be in flight) this batch shape gets, unless the
@@ -283,11 +317,17 @@ static int ensure_level_set(mrgingham_amd_ctx* ctx, int set, int level, int nfra
 // for everything in flight first.
 static int choose_sets(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr) {
     if (ctx->nsets_fixed) return 0;
-    const double per_set = 12.5 * (double)fr->nframes * fr->width * fr->height;  // bytes; measured 12.2 per frame pixel
+    const double per_set = 5.0 * (double)fr->nframes * fr->width * fr->height;  // bytes; measured 4.9 per frame pixel at the default table size
     if (per_set > ctx->max_set_bytes) ctx->max_set_bytes = per_set;  // the largest batch so far decides (scratch only grows)
     const int want = 3.0 * ctx->max_set_bytes <= 8e9 ? 3 : 2;
     if (want == ctx->nsets) return 0;
     const int rc = mrgingham_amd_sync(ctx);
+    if (want < ctx->nsets)  // the sets that leave the rotation give their scratch back (a larger batch has arrived)
+        for (int set = want; set < ctx->nsets; ++set) {
+            for (DevBuf* b : level_set_buffers(ctx, set, false))  // (the small per-point scratch stays: it is sized for all sets)
+                if (b->p) { hipFree(b->p); *b = DevBuf(); }
+            for (LevelScratch& L : ctx->lvs[set]) { L.nframes = 0; L.w = L.h = 0; L.pitch = 0; }
+        }
     ctx->nsets = want;
     ctx->cur = 0;
     return rc;
@@ -526,17 +566,26 @@ mrgingham_amd_ctx* mrgingham_amd_create(int device_ordinal) {
     if (hipSetDevice(device_ordinal) != hipSuccess) return nullptr;
     mrgingham_amd_ctx* ctx = new mrgingham_amd_ctx();
     ctx->device = device_ordinal;
+    for (int& g : ctx->grown_shift) g = 31;
+#ifdef MRG_EXPERIMENT
     const char* v0 = getenv("MRGINGHAM_AMD_CHESS_V0");
     ctx->use_v0 = v0 && atoi(v0) != 0;
+#endif
     int prio_lo = 0, prio_hi = 0;  // the component stream gets the highest dispatch priority
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     // Experiment hooks (tools/interference_ab.py): MRGINGHAM_AMD_CC_CUS = k confines the component
     // streams to k CUs per XCD (CU-mask bit i is XCD i % 8, CU i / 8: probed with
     // tools/ubench/cu_mask.hip); MRGINGHAM_AMD_PIX_COMPLEMENT = 1 keeps the pixel stream off them.
+    // (only in -DMRG_EXPERIMENT builds: the shipped library reads no environment variable but MRGINGHAM_AMD_DEVICE)
+#ifdef MRG_EXPERIMENT
     const char* ecc = getenv("MRGINGHAM_AMD_CC_CUS");
     const int cc_cus = ecc ? atoi(ecc) : 0;
     const char* epx = getenv("MRGINGHAM_AMD_PIX_COMPLEMENT");
     const bool pix_compl = epx && atoi(epx) != 0;
+#else
+    const int cc_cus = 0;
+    const bool pix_compl = false;
+#endif
     bool ok = true;
     if (cc_cus > 0 && cc_cus < 32) {
         uint32_t mask[8] = {}, inv[8];
@@ -568,21 +617,7 @@ void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx) {
     if (ctx->one) mrgingham_amd_destroy(ctx->one);
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
-    for (auto& set : ctx->lvs)
-    for (LevelScratch& L : set) {
-        DevBuf* bufs[] = {&L.img, &L.resp, &L.gidx, &L.hot_xy, &L.parent,
-                          &L.comp_cnt, &L.roots, &L.comp_first, &L.comp_box, &L.arena, &L.cand, &L.sortkeys};
-        for (DevBuf* b : bufs)
-            if (b->p) hipFree(b->p);
-    }
-    for (auto& ps : ctx->pts)
-        for (DevBuf* b : {&ps.leader, &ps.need, &ps.nseeds, &ps.seeds, &ps.sroot, &ps.cand_xy, &ps.cand_counts})
-            if (b->p) hipFree(b->p);
-    for (DevBuf& b : ctx->counters2)
-        if (b.p) hipFree(b.p);
-    DevBuf* bufs[] = {&ctx->io_counts, &ctx->aux_img, &ctx->io_frame, &ctx->io_out, &ctx->pre_scratch, &ctx->pre_tmp, &ctx->pre_out, &ctx->pre16_scratch, &ctx->io_frame16, &ctx->dbg_img, &ctx->dbg_resp, &ctx->blob_scratch,
-                      &ctx->fb_xy, &ctx->fb_cnt, &ctx->fb_pts, &ctx->fb_lv, &ctx->fb_np, &ctx->fb_frames, &ctx->fb_frames2};
-    for (DevBuf* b : bufs)
+    for (DevBuf* b : all_buffers(ctx))
         if (b->p) hipFree(b->p);
     for (auto& pr : ctx->events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : ctx->event_pool) hipEventDestroy(e);
@@ -626,18 +661,8 @@ int mrgingham_amd_chain_info(const mrgingham_amd_ctx* ctx, int* fused_pyramid, i
 long long mrgingham_amd_scratch_bytes(const mrgingham_amd_ctx* ctx) {
     if (!ctx) return 0;
     long long total = 0;
-    for (const auto& set : ctx->lvs)
-        for (const LevelScratch& L : set)
-            for (const DevBuf* b : {&L.img, &L.resp, &L.gidx, &L.hot_xy, &L.parent, &L.comp_cnt, &L.roots, &L.comp_first,
-                                    &L.comp_box, &L.arena, &L.cand, &L.sortkeys})
-                total += (long long)b->bytes;
-    for (const auto& ps : ctx->pts)
-        for (const DevBuf* b : {&ps.leader, &ps.need, &ps.nseeds, &ps.seeds, &ps.sroot, &ps.cand_xy, &ps.cand_counts})
-            total += (long long)b->bytes;
-    for (const DevBuf* b : {&ctx->counters2[0], &ctx->counters2[1], &ctx->io_counts, &ctx->aux_img, &ctx->io_frame,
-                            &ctx->io_out, &ctx->pre_scratch, &ctx->pre_tmp, &ctx->pre_out, &ctx->fb_xy, &ctx->fb_cnt,
-                            &ctx->fb_pts, &ctx->fb_lv, &ctx->fb_np, &ctx->fb_frames, &ctx->fb_frames2})
-        total += (long long)b->bytes;
+    for (const DevBuf* b : all_buffers(const_cast<mrgingham_amd_ctx*>(ctx))) total += (long long)b->bytes;
+    if (ctx->one) total += mrgingham_amd_scratch_bytes(ctx->one);
     return total;
 }
 
@@ -651,13 +676,18 @@ void mrgingham_amd_set_kernel_timing(mrgingham_amd_ctx* ctx, int enable) {
 int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value) {
     if (!ctx || !name) return MRGINGHAM_AMD_ERR_ARG;
     if (!strcmp(name, "hot_capacity_shift")) {
-        if (value < 0 || value > 8) return MRGINGHAM_AMD_ERR_ARG;
+        if (value < 0 || value > 10) return MRGINGHAM_AMD_ERR_ARG;
         ctx->cap_shift = value;
+        for (int& g : ctx->grown_shift) g = 31;  // an explicit choice starts over
         return 0;
     }
     if (!strcmp(name, "chess_v0")) { ctx->use_v0 = value != 0; return 0; }
     if (!strcmp(name, "multi_level_launch")) { ctx->multi_level = value < 0 ? 0 : value > 2 ? 2 : value; return 0; }
+#ifdef MRG_EXPERIMENT
     if (!strcmp(name, "cc_schedule")) { ctx->cc_schedule = value; return 0; }
+    if (!strcmp(name, "chess_multi_min_blocks")) { mrg::chess_multi_min_blocks = value; return 0; }
+    if (!strcmp(name, "chess_stage")) { mrg::chess_stage_override = value; return 0; }
+#endif
     if (!strcmp(name, "scratch_sets")) {
         if (value != 0 && (value < 2 || value > kMaxSets))
             return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "scratch_sets must be 0 (automatic), 2 or %d", kMaxSets);
@@ -668,9 +698,15 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
         return rc;
     }
     if (!strcmp(name, "fuse_pyramid")) { ctx->fuse_pyramid = value != 0; return 0; }
-    if (!strcmp(name, "cc_lds")) { ctx->cc_lds = value; return 0; }
-    if (!strcmp(name, "chess_multi_min_blocks")) { mrg::chess_multi_min_blocks = value; return 0; }
-    if (!strcmp(name, "chess_stage")) { mrg::chess_stage_override = value; return 0; }
+    if (!strcmp(name, "cc_lds")) {
+        // 0 / 1 and the test hook 256 (no banding, no windows: every result is still exact); the timing ablations
+        // (bits 2, 4, 8, 16, 128) and the phase clock (512) exist in -DMRG_EXPERIMENT builds only
+#ifndef MRG_EXPERIMENT
+        if (value & ~(1 | 256)) return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "cc_lds: only 0, 1 and 1 | 256 in this build");
+#endif
+        ctx->cc_lds = value;
+        return 0;
+    }
     if (!strcmp(name, "chess_seg")) { mrg::chess_seg_override = value > 0 ? value : 0; return 0; }
     return MRGINGHAM_AMD_ERR_ARG;
 }
@@ -715,16 +751,34 @@ int mrgingham_amd_sync(mrgingham_amd_ctx* ctx) {
                                     hipMemcpyDeviceToHost));
             // every pending status block is inspected and cleared; only the first error is reported
             bool dirty = false;
+            int flags = 0, first = -1;
+            long long need = 0;  // hot pixels the fullest frame asked for (status words carry it in units of 64)
             for (int f = 0; f < nact; ++f) {
-                if (!ctx->host_status[f]) continue;
+                const int st = ctx->host_status[f];
+                if (!st) continue;
                 dirty = true;
+                if (first < 0) first = f;
+                flags |= st & 0xff;
+                const long long n = (long long)((uint32_t)st >> 8) * 64;
+                if (n > need) need = n;
+            }
+            if (dirty) {
+                // grow the tables of this level to what was asked for (+25 %); candidate / LIFO overflow: four times
+                const LevelScratch& LS = ctx->lvs[set][level];
+                const long long px = (long long)LS.w * LS.h;
+                int sh = LS.shift;
+                if (flags & kStatusHotOverflow)
+                    while (sh > 0 && (px >> sh) < need + need / 4) --sh;
+                if (flags & kStatusCandOverflow) sh = sh >= 2 ? (sh - 2 < LS.shift - 2 ? sh - 2 : LS.shift - 2) : 0;
+                if (sh < 0) sh = 0;
+                if (sh < ctx->grown_shift[level]) ctx->grown_shift[level] = sh;
                 if (rc == MRGINGHAM_AMD_OK)
                     rc = fail(ctx, MRGINGHAM_AMD_ERR_CAPACITY,
-                              "frame %d, level %d: component tables overflowed (status %d); lower "
-                              "\"hot_capacity_shift\" (now %d) with mrgingham_amd_set_option and re-run",
-                              f, level, ctx->host_status[f], ctx->cap_shift);
+                              "frame %d, level %d: component tables overflowed (status %d, %lld hot pixels asked for); "
+                              "the tables of this level grow from 1/%d to 1/%d of its pixels: make the call again",
+                              first, level, flags, need, 1 << LS.shift, 1 << sh);
+                MRG_HIP_CHECK(hipMemset(status_of(ctx, level), 0, sizeof(int32_t) * nact));
             }
-            if (dirty) MRG_HIP_CHECK(hipMemset(status_of(ctx, level), 0, sizeof(int32_t) * nact));
         }
     ctx->cur = saved;
     return rc;
@@ -1230,14 +1284,16 @@ static bool detect_one_frame_all(mrgingham_amd_ctx* ctx, const mrgingham_amd_fra
     const int saved_shift = ctx->cap_shift;
     bool ok = false;
     int32_t count = 0;
-    for (int attempt = 0; attempt < 2 && !ok; ++attempt) {
+    for (int attempt = 0; attempt < 4 && !ok; ++attempt) {
         if (ensure_level(ctx, level, 1, fr1->width, fr1->height, 0) || ensure_points(ctx, 1, 1)) break;
         const int cap = ctx->lvs[0][level].cand_cap;
         if (ensure(ctx, ctx->io_out, (size_t)cap * 8 + 64) || ensure(ctx, ctx->io_counts, 64)) break;
         if (mrgingham_amd_detect_batch(ctx, fr1, level, (int32_t*)ctx->io_out.p, cap, (int32_t*)ctx->io_counts.p)) break;
         const int rc = mrgingham_amd_sync(ctx);
-        if (rc == MRGINGHAM_AMD_ERR_CAPACITY && attempt == 0) {
-            ctx->cap_shift = 0;  // adversarial texture: retry with a table entry for every pixel
+        if (rc == MRGINGHAM_AMD_ERR_CAPACITY && attempt < 3) {
+            // the tables have grown to what the frame asked for (mrgingham_amd_sync); the last retry takes a
+            // table entry for every pixel (adversarial texture)
+            if (attempt == 2) ctx->cap_shift = 0;
             continue;
         }
         if (rc) break;
@@ -1347,7 +1403,7 @@ static int refine_on_device(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* 
     const int saved_shift = ctx->cap_shift;
     int32_t nrefined = 0;
     bool ok = false;
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    for (int attempt = 0; attempt < 4; ++attempt) {
         // layout of io_out: points | levels | npoints | nrefined
         const size_t o_lv = (size_t)Npoints * 16, o_np = o_lv + (((size_t)Npoints + 7) & ~(size_t)7), o_nr = o_np + 8;
         if (ensure(ctx, ctx->io_out, o_nr + 8)) break;
@@ -1362,7 +1418,10 @@ static int refine_on_device(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* 
                                        (const int32_t*)(base + o_np), Npoints, (int32_t*)(base + o_nr)))
             break;
         const int rc = mrgingham_amd_sync(ctx);
-        if (rc == MRGINGHAM_AMD_ERR_CAPACITY && attempt == 0) { ctx->cap_shift = 0; continue; }
+        if (rc == MRGINGHAM_AMD_ERR_CAPACITY && attempt < 3) {  // (the upload above restores the points)
+            if (attempt == 2) ctx->cap_shift = 0;
+            continue;
+        }
         if (rc) break;
         if (hipMemcpy(&nrefined, base + o_nr, 4, hipMemcpyDeviceToHost) != hipSuccess) break;
         if (hipMemcpy(points_xy, base, (size_t)Npoints * 16, hipMemcpyDeviceToHost) != hipSuccess) break;
@@ -1751,7 +1810,11 @@ int mrgingham_amd_find_boards_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_
         return 0;
     };
 
+#ifdef MRG_EXPERIMENT
     static const bool dbg_t = getenv("MRG_DBG_FB") != nullptr;
+#else
+    constexpr bool dbg_t = false;
+#endif
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_prev = now();
     auto lap = [&](const char* what, int L, int n) { if (dbg_t) { const double t = now(); fprintf(stderr, "  [fb] L%d %-14s %3d frames %7.3f ms\n", L, what, n, t - t_prev); t_prev = t; } };

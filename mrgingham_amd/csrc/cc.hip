@@ -57,6 +57,12 @@ __device__ __forceinline__ int wg_min(int32_t* p, int v) { return __hip_atomic_f
 __device__ __forceinline__ int wg_max(int32_t* p, int v) { return __hip_atomic_fetch_max(p, v, MRG_WG); }
 __device__ __forceinline__ int wg_add(int32_t* p, int v) { return __hip_atomic_fetch_add(p, v, MRG_WG); }
 __device__ __forceinline__ int wg_or(int32_t* p, int v) { return __hip_atomic_fetch_or(p, v, MRG_WG); }
+// status word of a hot-list overflow: the flag + the number of hot pixels the frame has, in units of 64, above bit 8
+// (the host grows the tables to that, api.hip mrgingham_amd_sync)
+__device__ __forceinline__ int hot_overflow_status(int hot_cnt) {
+    const uint32_t units = ((uint32_t)hot_cnt + 63u) >> 6;
+    return (int)((uint32_t)kStatusHotOverflow | ((units > 0x7fffffu ? 0x7fffffu : units) << 8));
+}
 
 __device__ __forceinline__ int uf_root(const int32_t* parent, int i) {
     int p = aload(parent + i);
@@ -377,9 +383,9 @@ __global__ __launch_bounds__(CCG_THREADS, 4) void cc_detect_kernel(LevelBatch lb
     __builtin_amdgcn_s_setprio(3);
     const int frame = frame0 + blockIdx.x;
     if (t.lds_path && t.path[frame] == 1) return;  // done out of LDS
-    if (t.hot_cnt[frame] > t.cap) {  // table overflow: report, produce nothing
+    if (t.hot_cnt[frame] > t.cap) {  // table overflow: report (with what the frame asked for), produce nothing
         if (threadIdx.x == 0) {
-            wg_or(t.status + frame, kStatusHotOverflow);
+            wg_or(t.status + frame, hot_overflow_status(t.hot_cnt[frame]));
             out.counts[frame] = -1;
         }
         return;
@@ -476,7 +482,7 @@ __global__ __launch_bounds__(CCG_THREADS, 4) void cc_refine_kernel(LevelBatch lb
     if (t.lds_path && t.path[frame] == 1) return;  // done out of LDS
     if (t.hot_cnt[frame] > t.cap) {
         if (threadIdx.x == 0) {
-            wg_or(t.status + frame, kStatusHotOverflow);
+            wg_or(t.status + frame, hot_overflow_status(t.hot_cnt[frame]));
             if (io.nrefined) io.nrefined[frame] = -1;
         }
         return;

@@ -815,10 +815,12 @@ bool launch_chess_pyramid(const LevelBatch& lb, const CompTables& t, const Pyram
     dim3 grid(((lb.w + V1_SW - 1) / V1_SW) * ((lb.h + seg - 1) / seg) * nframes);
     const size_t lds = 2 * V1_PLANE + (V1_HOTBUF + 4) * sizeof(int);
     PyramidOut p2 = po;
+#ifdef MRG_EXPERIMENT
     // MRGINGHAM_AMD_PYR_SKIP (timing ablation, tools/interference_ab.py "dbg fused"): bit k = level k + 1 is not written
     static const int skip = [] { const char* e = getenv("MRGINGHAM_AMD_PYR_SKIP"); return e ? atoi(e) : 0; }();
     for (int k = 0; k < 3; ++k)
         if (skip >> k & 1) p2.out[k] = nullptr;
+#endif
     hipLaunchKernelGGL(chess_v1_pyr_kernel, grid, dim3(256), lds, s, lb, t, seg, p2);
     return true;
 }

@@ -100,3 +100,32 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 for pat in ("import oracle", "from oracle", "liboracle", "mrgingham_oracle", "oracle/", "oracle."):
                     assert pat not in text, f"{f} references the oracle ({pat})"
+
+
+def test_shipped_library_has_no_experiment_hooks():
+    """The timing ablations / placement experiments of tools/ exist in -DMRG_EXPERIMENT builds only: the shipped
+    library must not even contain the names of their environment variables (a stray variable cannot change what
+    it computes), and its source gates every one of them."""
+    import os
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    blob = open(os.path.join(here, "mrgingham_amd", "libmrgingham_amd.so"), "rb").read()
+    for name in (b"MRGINGHAM_AMD_PYR_SKIP", b"MRGINGHAM_AMD_CC_LDS_PAD", b"MRGINGHAM_AMD_CC_CUS",
+                 b"MRGINGHAM_AMD_PIX_COMPLEMENT", b"MRGINGHAM_AMD_CHESS_V0", b"MRG_DBG_FB"):
+        assert name not in blob, name
+    assert b"MRGINGHAM_AMD_DEVICE" in blob                  # the one variable it does read
+    for src in ("api.hip", "chess.hip", "cc.hip"):
+        text = open(os.path.join(here, "mrgingham_amd", "csrc", src)).read()
+        lines = text.split("\n")
+        depth = 0
+        for ln in lines:                                    # every getenv outside MRGINGHAM_AMD_DEVICE sits in #ifdef MRG_EXPERIMENT
+            st = ln.strip()
+            if st.startswith("#ifdef MRG_EXPERIMENT"):
+                depth += 1
+            elif st.startswith("#if") and depth:
+                depth += 1
+            elif st.startswith("#else") and depth == 1:
+                depth = -1                                   # the release branch of an experiment block
+            elif st.startswith("#endif") and depth:
+                depth = 0 if depth in (1, -1) else depth - 1
+            if "getenv(" in ln and "MRGINGHAM_AMD_DEVICE" not in ln:
+                assert depth > 0, (src, ln)

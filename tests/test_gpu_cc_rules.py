@@ -97,15 +97,22 @@ def test_dense_texture_response(det):
     try:
         got = _detect(det, [d], [img])[0]
     finally:
-        det.set_option("hot_capacity_shift", 3)
+        det.set_option("hot_capacity_shift", 7)
     assert np.array_equal(got, oracle.cc_detect_on_response(d, img))
 
 
 def test_capacity_overflow_is_reported(det):
     h, w = 64, 96
     d = np.full((h, w), 100, np.int16)
-    with pytest.raises(RuntimeError, match="overflowed"):
-        _detect(det, [d], [cc_cases.flat_img(h, w)])
+    img = cc_cases.flat_img(h, w)
+    d2 = mrgingham_amd.Detector(0)          # a fresh context: tables at their default size
+    try:
+        with pytest.raises(RuntimeError, match="overflowed"):
+            d2.cc_detect_on_response(torch.from_numpy(d[None]).cuda(), torch.from_numpy(img[None]).cuda(), retry=False)
+        # the tables grew: asked again (the Python method does that itself), the frame goes through
+        assert np.array_equal(_detect(d2, [d], [img])[0], oracle.cc_detect_on_response(d, img))
+    finally:
+        d2.close()
     # and the context recovers
     name, d, img, expected = cc_cases.detect_cases()[1]
     assert _detect(det, [d], [img])[0].tolist() == expected

@@ -81,7 +81,7 @@ def test_c4_shard_256_frames_in_one_call(det):
     # both scratch sets of the 256-frame shard are resident, and well below what a dense
     # int32-per-pixel index alone used to take for them (4 B/px * 1.33 * 256 frames * 2 sets = 34 GB)
     gib = det.scratch_bytes() / 2**30
-    assert gib < 120, gib
+    assert gib <= 32, gib                                      # (round 2: 78.9 GiB)
     print(f"scratch for 256 frames of {W}x{H}, both sets: {gib:.1f} GiB")
 
 
@@ -94,7 +94,7 @@ def test_scratch_for_64_frames():
         print(f"scratch for 64 frames of {W}x{H}, both sets: {gib:.2f} GiB")
         # round 1 held 4 B/px of dense index per level and set: 64 * 12.58 MB * 4 * 1.33 * 2 = 8.6 GB for
         # that table alone, ~31 GiB in total; the bound below fails if anything of that size comes back
-        assert gib < 20, gib
+        assert gib <= 8, gib                                   # (round 2: 19.7 GiB)
     finally:
         d.close()
 

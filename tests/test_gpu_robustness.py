@@ -67,16 +67,49 @@ def test_table_overflow_is_reported_and_recoverable(det):
     yy, xx = np.arange(240).reshape(-1, 1), np.arange(320).reshape(1, -1)
     dense = (((yy // 3 + xx // 3) & 1) * 255).astype(np.uint8)          # 42 % hot pixels
     frames = _cuda(np.stack([synth.board_frame(320, 240, 10, 0).numpy(), dense]))
-    with pytest.raises(RuntimeError, match="overflow"):
-        det.detect(frames, 0, capacity=65536)
-    det.set_option("hot_capacity_shift", 0)
-    try:
-        xy, counts = det.detect(frames, 0, capacity=65536)
-        for f, img in enumerate([synth.board_frame(320, 240, 10, 0).numpy(), dense]):
+    imgs = [synth.board_frame(320, 240, 10, 0).numpy(), dense]
+
+    def check(xy, counts):
+        for f, img in enumerate(imgs):
             want = oracle.find_corners(img, 0)
             assert int(counts[f]) == len(want) and np.array_equal(xy[f, :len(want)].cpu().numpy(), want)
+
+    d2 = mrgingham_amd.Detector(0)
+    try:
+        # default tables (1/128 of the pixels, at least 4096 entries): the dense frame does not fit and says so ...
+        with pytest.raises(RuntimeError, match="overflow") as ei:
+            d2.detect(frames, 0, capacity=65536, retry=False)
+        assert "make the call again" in str(ei.value)
+        # ... the tables of that level have grown meanwhile: the same call, made again, succeeds (a second overflow
+        # of another table -- candidates, LIFO words -- may take one more round)
+        for attempt in range(3):
+            try:
+                xy, counts = d2.detect(frames, 0, capacity=65536, retry=False)
+                break
+            except RuntimeError as e:
+                assert "overflow" in str(e) and attempt < 2
+        check(xy, counts)
+        gib = d2.scratch_bytes() / 2**30
+        assert gib < 0.5                                       # grown for 320x240 frames, not for the world
+        # the Python methods make that second call themselves
+        d3 = mrgingham_amd.Detector(0)
+        try:
+            check(*d3.detect(frames, 0, capacity=65536))
+            pts, lv, npts = d3.chain(frames, start_level=1, max_points=8192)
+            for f, img in enumerate(imgs):
+                wp, wl = oracle.chain(img, 1)
+                n = int(npts[f])
+                assert n == len(wp) and np.array_equal(pts[f, :n].cpu().numpy(), wp) and np.array_equal(lv[f, :n].cpu().numpy(), wl)
+        finally:
+            d3.close()
     finally:
-        det.set_option("hot_capacity_shift", 3)
+        d2.close()
+    # an explicit capacity still works (one entry per pixel), and resets what has grown
+    det.set_option("hot_capacity_shift", 0)
+    try:
+        check(*det.detect(frames, 0, capacity=65536, retry=False))
+    finally:
+        det.set_option("hot_capacity_shift", 7)
     # and the context keeps working at the default setting afterwards
     xy, counts = det.detect(frames[:1], 0, capacity=1024)
     assert int(counts[0]) == len(oracle.find_corners(synth.board_frame(320, 240, 10, 0).numpy(), 0))

@@ -7,7 +7,7 @@ B=$R/mrgingham_amd/csrc/build
 make -s -C $R/mrgingham_amd/csrc -j4 all >/dev/null
 cp $SRC $R/mrgingham_amd/csrc/_variant_$NAME.hip
 EXTRA=""; [ "$NAME" = chess ] && EXTRA="-mllvm -amdgpu-sched-strategy=max-ilp"
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -Wno-unused-value $EXTRA "$@" -c $R/mrgingham_amd/csrc/_variant_$NAME.hip -o /tmp/_variant_$NAME.o
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -Wno-unused-value -DMRG_EXPERIMENT $EXTRA "$@" -c $R/mrgingham_amd/csrc/_variant_$NAME.hip -o /tmp/_variant_$NAME.o
 rm -f $R/mrgingham_amd/csrc/_variant_$NAME.hip
 OBJS=""
 for n in chess decimate preprocess preprocess16 cc blobs api; do if [ $n = $NAME ]; then OBJS="$OBJS /tmp/_variant_$NAME.o"; else OBJS="$OBJS $B/$n.o"; fi; done
