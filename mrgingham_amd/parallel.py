@@ -87,6 +87,10 @@ def gather_packed(pack, dst=0, group=None, out=None, force=False):
     return out if rank == dst else None
 
 
+def _global_rank(group, group_rank):
+    return group_rank if group is None else dist.get_global_rank(group, group_rank)
+
+
 def gather_exact(points, levels, npoints, dst=0, group=None):
     """Exact-size form of the exchange (counts first, then grouped send / recv -- there is
     no gatherv): every rank compacts its live corners into records (frame, x, y, level), the record
@@ -114,12 +118,14 @@ def gather_exact(points, levels, npoints, dst=0, group=None):
     if rank == dst:
         bufs = [rec if r == dst else torch.empty((counts[r], 4), dtype=torch.float64, device=rec.device)
                 for r in range(world)]
-        ops = [dist.P2POp(dist.irecv, bufs[r], r, group) for r in range(world) if r != dst and counts[r] > 0]
+        # (P2POp's peer is a GLOBAL rank: translate the group-local ones for a sub-group)
+        ops = [dist.P2POp(dist.irecv, bufs[r], _global_rank(group, r), group) for r in range(world)
+               if r != dst and counts[r] > 0]
         for w in (dist.batch_isend_irecv(ops) if ops else []):
             w.wait()
         return [unpack(b) for b in bufs]
     if counts[rank] > 0:
-        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, rec, dst, group)]):
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, rec, _global_rank(group, dst), group)]):
             w.wait()
     return None
 
@@ -157,3 +163,59 @@ def plan_mixed_stream(sizes, world, rank, start_level=3):
     for i in sorted(plan):
         groups.setdefault(tuple(sizes[i]), []).append(i)
     return groups
+
+
+# ---------------------------------------------------------------------------
+# Dynamic balance: a shared work counter (SURVEY.md 8e's alternative to the static plan)
+# ---------------------------------------------------------------------------
+
+def stream_units(sizes, unit_frames=16, start_level=3):
+    """The work units of a mixed-resolution stream: frames of one resolution in sub-batches of at most
+    `unit_frames` (the batch API takes equally-sized frames), heaviest unit first by the cost MODEL
+    1.328*W*H per frame.  Deterministic, so every rank builds the same list without communicating.
+    -> list of ((width, height), [frame indices])."""
+    by_size = {}
+    for i, wh in enumerate(sizes):
+        by_size.setdefault(tuple(wh), []).append(i)
+    units = []
+    for wh, idx in sorted(by_size.items()):
+        for lo in range(0, len(idx), unit_frames):
+            units.append((wh, idx[lo:lo + unit_frames]))
+    units.sort(key=lambda u: (-frame_cost(*u[0], start_level) * len(u[1]), u[1][0]))
+    return units
+
+
+class WorkQueue:
+    """Ranks pull work units off one shared counter until it runs out: the rank that finishes a unit early takes
+    the next one, whatever the units really cost.  That matters here because the cost of a frame is NOT known in
+    advance -- the reference's level search stops at the first pyramid level where a grid is found
+    (mrgingham.cc:127-138), so a frame costs anything between the level-3 pass alone (1/64 of its pixels) and all
+    four levels -- and a static plan on the model 1.328*W*H (lpt_assign) is wrong by up to that factor.
+
+    The counter lives in the process group's key-value store (`store.add` is an atomic fetch-and-add served by
+    rank 0's TCPStore: one small round trip per UNIT, not per frame), so it needs no GPU, no collective and no
+    symmetric participation: a rank that never gets a unit never blocks the others."""
+
+    def __init__(self, nunits, name="mrgingham_amd/wq", store=None):
+        self.n = int(nunits)
+        self.key = name
+        if store is None and dist.is_available() and dist.is_initialized():
+            store = dist.distributed_c10d._get_default_store()
+        self.store = store
+        self._local = 0                      # single process: a plain counter
+
+    def next(self):
+        """Index of the next unit, or None when the queue is empty."""
+        if self.store is None:
+            i = self._local
+            self._local += 1
+        else:
+            i = self.store.add(self.key, 1) - 1
+        return i if i < self.n else None
+
+    def __iter__(self):
+        while True:
+            i = self.next()
+            if i is None:
+                return
+            yield i

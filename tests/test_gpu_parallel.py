@@ -157,3 +157,17 @@ def test_cpu_baseline_harness_reports_efficiency():
     assert 0 < b["parallel_efficiency"] <= 1.5 and abs(b["candidates_per_frame"] - want) < 1.0
     if oracle.have_reference_build():
         assert b["upstream_chess_level0_frames_s_tall"] > 0
+
+
+def test_mixed_stream_bench_pulls_units_off_the_shared_counter():
+    """tools/mixed_stream_bench.py with the dynamic balance (the default): every frame of the stream is processed
+    exactly once and every board found, with the counter in a (one-rank) process group's store."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    for balance in ("queue", "lpt"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mixed_stream_bench.py"), "--frames", "24",
+                            "--repeat", "1", "--unit", "4", "--balance", balance], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert res["balance"] == balance and res["records_on_rank0"] == 24 and res["not_found"] == 0, res
+        assert sum(res["found_at_level"]) == 24

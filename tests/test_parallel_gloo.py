@@ -117,3 +117,86 @@ def test_lpt_plan_for_mixed_resolution_stream():
                 assert all(tuple(sizes[i]) == sz for i in idx) and idx == sorted(idx)
                 seen += idx
         assert sorted(seen) == list(range(200))
+
+
+def _queue_worker(rank, world, port, ret):
+    """A stream whose true cost is off the model by up to 4x: the static LPT plan (computed on the model) leaves
+    one rank idle for a large part of the run, the shared work counter does not."""
+    import time
+    sys.path.insert(0, ROOT)
+    from mrgingham_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import random
+    rnd = random.Random(11)
+    RES = [(1280, 800), (1920, 1080), (2560, 1440), (4096, 2160), (4096, 3072)]
+    sizes = [RES[rnd.randrange(len(RES))] for _ in range(96)]
+    units = parallel.stream_units(sizes, unit_frames=4)
+    model = [parallel.frame_cost(*wh) * len(idx) for wh, idx in units]
+    # the static plan on the model, and then a truth that is deliberately wrong by 4x where it hurts that plan
+    # most: the frames rank 0 was given happen to be the ones whose board is found at the first level tried (a
+    # quarter of the modelled cost), rank 1's run all levels.  (Which frames stop early is a property of the
+    # images, mrgingham.cc:127-138: no plan made before looking at them can know.)
+    plan = parallel.lpt_assign(model, world)
+    cheap = set(plan[0])
+    true = [m * (0.25 if u in cheap else 1.0) for u, m in enumerate(model)]
+    scale = 1.2 / sum(true)                                   # the whole stream is 1.2 s of "work"
+
+    def run(my_units):
+        t0 = time.perf_counter()
+        done = []
+        for u in my_units:
+            time.sleep(true[u] * scale)
+            done.append(u)
+        return time.perf_counter() - t0, done
+
+    dist.barrier()
+    t_lpt, _ = run(plan[rank])
+    # shared counter
+    dist.barrier()
+    q = parallel.WorkQueue(len(units), name="test/wq1")
+    t_q, mine = run(iter(q))
+    tt = torch.tensor([t_lpt, t_q], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    got = [None] * world
+    dist.all_gather_object(got, mine)
+    if rank == 0:
+        ideal = 1.2 / world
+        every = sorted(u for g in got for u in g)
+        ret.put({"lpt": float(tt[0]) / ideal, "queue": float(tt[1]) / ideal, "complete": every == list(range(len(units))),
+                 "both_worked": all(len(g) > 0 for g in got)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_work_queue_balances_where_the_static_plan_cannot():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_queue_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = ret.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res["complete"] and res["both_worked"], res       # every unit done exactly once
+    assert res["queue"] <= 1.15, res                          # within 15 % of the ideal makespan
+    assert res["lpt"] >= 1.3, res                             # the static plan on the wrong model is not
+    print(res)
+
+
+def test_stream_units_and_single_process_queue():
+    sys.path.insert(0, ROOT)
+    from mrgingham_amd import parallel
+    sizes = [(640, 480)] * 5 + [(1920, 1080)] * 3 + [(640, 480)] * 2
+    units = parallel.stream_units(sizes, unit_frames=4)
+    assert sorted(i for _, idx in units for i in idx) == list(range(10))
+    assert all(len(idx) <= 4 and len({sizes[i] for i in idx}) == 1 for _, idx in units)
+    assert units[0][0] == (1920, 1080)                        # heaviest unit first
+    q = parallel.WorkQueue(len(units))                        # no process group: a local counter
+    assert list(q) == list(range(len(units))) and q.next() is None

@@ -24,6 +24,10 @@ def main():
     ap.add_argument("--frames", type=int, default=200)
     ap.add_argument("--gridn", type=int, default=10)
     ap.add_argument("--repeat", type=int, default=3)
+    ap.add_argument("--balance", choices=["queue", "lpt"], default="queue",
+                    help="queue: ranks pull per-resolution sub-batches off a shared counter (parallel.WorkQueue); "
+                         "lpt: the static plan on the cost model 1.328*W*H")
+    ap.add_argument("--unit", type=int, default=32, help="frames per work unit (queue)")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -36,22 +40,44 @@ def main():
     from mrgingham_amd import parallel, synth
     rnd = random.Random(5)
     sizes = [RES[rnd.randrange(len(RES))] for _ in range(args.frames)]
-    mine = parallel.plan_mixed_stream(sizes, world, rank)                  # {(w, h): [frame indices]}
     det = mrgingham_amd.Detector(local)
     N = args.gridn * args.gridn
-    batches = {}
-    for (w, h), idx in mine.items():
-        batches[(w, h)] = (idx, torch.stack([synth.board_frame(w, h, args.gridn, seed=i, device=dev) for i in idx]))
-    torch.cuda.synchronize()
+    passes = [0]
+    if args.balance == "lpt":
+        mine = parallel.plan_mixed_stream(sizes, world, rank)              # {(w, h): [frame indices]}
+        batches = {}
+        for (w, h), idx in mine.items():
+            batches[(w, h)] = (idx, torch.stack([synth.board_frame(w, h, args.gridn, seed=i, device=dev) for i in idx]))
 
-    def run_once():
-        recs = []
-        for (w, h), (idx, frames) in batches.items():
-            for lo in range(0, len(idx), 64):                              # sub-batches of at most 64 frames
-                boards, found = det.find_boards(frames[lo:lo + 64], gridn=args.gridn)
-                for k, f in enumerate(idx[lo:lo + 64]):
+        def run_once():
+            recs = []
+            for (w, h), (idx, frames) in batches.items():
+                for lo in range(0, len(idx), 64):                          # sub-batches of at most 64 frames
+                    boards, found = det.find_boards(frames[lo:lo + 64], gridn=args.gridn)
+                    for k, f in enumerate(idx[lo:lo + 64]):
+                        recs.append((f, int(found[k]), boards[k]))
+            return recs
+    else:
+        # Dynamic balance: every rank can reach every frame (here: has rendered it; in a deployment: reads it from
+        # the host / the shared store when it pulls the unit) and pulls per-resolution sub-batches off ONE shared
+        # counter, heaviest first.  The cost of a frame is only known once its grid has been found
+        # (mrgingham.cc:127-138), so whoever is free takes the next unit.
+        units = parallel.stream_units(sizes, unit_frames=args.unit)
+        frames_of = {}
+        for wh, idx in units:
+            frames_of[idx[0]] = torch.stack([synth.board_frame(wh[0], wh[1], args.gridn, seed=i, device=dev) for i in idx])
+
+        def run_once():
+            recs = []
+            q = parallel.WorkQueue(len(units), name=f"mixed_stream/{passes[0]}")
+            passes[0] += 1
+            for u in q:
+                wh, idx = units[u]
+                boards, found = det.find_boards(frames_of[idx[0]], gridn=args.gridn)
+                for k, f in enumerate(idx):
                     recs.append((f, int(found[k]), boards[k]))
-        return recs
+            return recs
+    torch.cuda.synchronize()
 
     run_once()                                                             # warm-up (allocations)
     if world > 1:
@@ -88,7 +114,8 @@ def main():
         print(json.dumps({"metric": "frames/sec, mixed-resolution stream, full detector with adaptive pyramid depth", "value": args.frames / dt,
                           "unit": "frames/s", "n_gpus": world, "frames": args.frames, "megapixels": mpx, "seconds_per_pass": dt,
                           "records_on_rank0": int(len(allrec)), "found_at_level": np.bincount(levels[levels >= 0], minlength=4).tolist(),
-                          "not_found": int((levels < 0).sum()), "lpt_imbalance": max(loads) / (sum(loads) / world)}))
+                          "not_found": int((levels < 0).sum()), "balance": args.balance,
+                          "lpt_model_imbalance": max(loads) / (sum(loads) / world)}))
     if world > 1:
         dist.destroy_process_group()
 
