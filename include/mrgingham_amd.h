@@ -78,8 +78,10 @@ int refine_chessboard_corners_from_image_array_C(int Nrows, int Ncols, int strid
  * The detector and the refinement run on the GPU, the grid finder (find_grid.cc) on the host.
  * Returns false when no board is found or on an error; doblobs (level 0 only, bridge.cc:104-113) is
  * find_circle_grid_from_image_array: blob detector + grid finder, no refinement;
- * debug writes the detector's / refinement's dumps (see above); debug_sequence_* (the grid finder's own dumps)
- * are accepted and ignored. */
+ * debug writes the detector's / refinement's dumps (see above); debug_sequence_x, _y both >= 0 (bridge.cc:97-104)
+ * make the grid finder trace, on stderr, the sequences it tries from the candidate nearest to that pixel
+ * (find_grid.cc:247-306, :515-553: "Looking at sequences from", "Considering connection ...", "rejecting" /
+ * "accepting"). */
 bool find_chessboard_from_image_array_C(int Nrows, int Ncols, int stride, char* imagebuffer, const int gridn,
                                         int image_pyramid_level, bool doblobs, bool debug, int debug_sequence_x,
                                         int debug_sequence_y,
@@ -89,6 +91,12 @@ bool find_chessboard_from_image_array_C(int Nrows, int Ncols, int stride, char* 
  * only: npoints interleaved (x,y)*1000 candidates in, gridn*gridn interleaved (x,y) corners out
  * (rows top to bottom, each left to right).  false when no grid is found. */
 bool mrgingham_amd_find_grid_from_points(const int* xy_scaled, int npoints, int gridn, double* xy_out);
+
+/* The same with the reference's --debug-sequence trace (mrgingham::find_grid_from_points(..., debug_sequence),
+ * mrgingham.hh:83-87): debug_sequence_x, _y >= 0 name a pixel; the sequences tried from the candidate nearest to
+ * it are reported on stderr (find_grid.cc:247-306, :515-553). */
+bool mrgingham_amd_find_grid_from_points_traced(const int* xy_scaled, int npoints, int gridn, double* xy_out,
+                                                int debug_sequence_x, int debug_sequence_y);
 
 /* TEST HOOK: the same with the parts of the visiting order that cannot be checked against the
  * reference's boost::polygon graph perturbed -- ring_seed != 0 starts every site's neighbour ring at a
@@ -259,7 +267,7 @@ int mrgingham_amd_process_image(const uint8_t* image, int width, int height, int
  * (find_chessboard_corners.cc:282-315, :453-459, :513-541) -- same names, same messages on stderr. */
 typedef struct mrgingham_amd_cli_options {
     int do_clahe, blur_radius, gridn, image_pyramid_level, do_refine, do_blobs, debug;
-    int debug_sequence_x, debug_sequence_y; /* accepted; the grid finder's own dumps are not produced */
+    int debug_sequence_x, debug_sequence_y; /* both >= 0: the grid finder's sequence trace on stderr (--debug-sequence) */
     const char* filename;                   /* names the debug dumps only; may be NULL */
 } mrgingham_amd_cli_options;
 int mrgingham_amd_process_image_ex(const void* image, int bits, int width, int height, int stride,

@@ -133,6 +133,16 @@ def find_grid_from_points(points_scaled, gridn=10):
     return out if ok else None
 
 
+def find_grid_from_points_traced(points_scaled, gridn=10, debug_sequence=(0, 0)):
+    """find_grid_from_points with the reference's --debug-sequence trace on stderr for the candidate nearest to
+    pixel debug_sequence = (x, y)."""
+    pts = np.ascontiguousarray(points_scaled, dtype=np.int32).reshape(-1, 2)
+    out = np.empty((gridn * gridn, 2), dtype=np.float64)
+    ok = _lib.lib().mrgingham_amd_find_grid_from_points_traced(pts.ctypes.data, len(pts), int(gridn), out.ctypes.data,
+                                                              int(debug_sequence[0]), int(debug_sequence[1]))
+    return out if ok else None
+
+
 def find_grid_from_points_perturbed(points_scaled, gridn=10, ring_seed=0, last_match=False):
     """Test hook: find_grid_from_points with the neighbour-ring start of every site randomised (ring_seed != 0)
     and / or the last instead of the first matching neighbour taken along a sequence."""

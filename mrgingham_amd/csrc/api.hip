@@ -1465,6 +1465,14 @@ bool mrgingham_amd_find_grid_from_points(const int* xy_scaled, int npoints, int 
     return true;
 }
 
+bool mrgingham_amd_find_grid_from_points_traced(const int* xy_scaled, int npoints, int gridn, double* xy_out,
+                                                int debug_sequence_x, int debug_sequence_y) {
+    mrg::g_grid_debug_sequence = {debug_sequence_x >= 0 && debug_sequence_y >= 0, debug_sequence_x, debug_sequence_y};
+    const bool ok = mrgingham_amd_find_grid_from_points(xy_scaled, npoints, gridn, xy_out);
+    mrg::g_grid_debug_sequence = {false, 0, 0};
+    return ok;
+}
+
 /* Test hook: the same with the visiting order perturbed (grid.h, GridPerturbation). */
 bool mrgingham_amd_find_grid_from_points_perturbed(const int* xy_scaled, int npoints, int gridn, double* xy_out,
                                                    unsigned ring_seed, int last_match) {
@@ -1517,7 +1525,11 @@ bool find_chessboard_from_image_array_C(int Nrows, int Ncols, int stride, char* 
                                         int image_pyramid_level, bool doblobs, bool debug, int debug_sequence_x,
                                         int debug_sequence_y,
                                         bool (*add_points)(double* xy, int N, void* cookie), void* cookie) {
-    (void)debug_sequence_x; (void)debug_sequence_y;  // the grid finder's own dumps are not produced
+    // bridge.cc:97-104: both coordinates >= 0 switch the grid finder's sequence trace on (stderr)
+    struct TraceScope {
+        TraceScope(int x, int y) { mrg::g_grid_debug_sequence = {x >= 0 && y >= 0, x, y}; }
+        ~TraceScope() { mrg::g_grid_debug_sequence = {false, 0, 0}; }
+    } trace_scope(debug_sequence_x, debug_sequence_y);
     if (Nrows < 0 || Ncols < 0 || stride < Ncols || !imagebuffer || !add_points || gridn < 2) return false;
     if (doblobs) {  // bridge.cc:104-113: find_circle_grid_from_image_array = blobs + grid finder, no refinement
         if (image_pyramid_level != 0) return false;
@@ -1678,6 +1690,10 @@ int mrgingham_amd_process_image_ex(const void* image, int bits, int width, int h
                 o->image_pyramid_level);
         return -2;
     }
+    struct TraceScope {  // --debug-sequence X,Y of the command-line tool (mrgingham-from-image.cc:262-276)
+        TraceScope(int x, int y) { mrg::g_grid_debug_sequence = {x >= 0 && y >= 0, x, y}; }
+        ~TraceScope() { mrg::g_grid_debug_sequence = {false, 0, 0}; }
+    } trace_scope(o->debug_sequence_x, o->debug_sequence_y);
     mrgingham_amd_ctx* ctx = thread_ctx();
     if (!ctx) return -2;
     hipSetDevice(ctx->device);

@@ -36,6 +36,7 @@ namespace mrg {
 // pseudo-random position (boost's incident_edge() start is an implementation detail); last_match takes the
 // LAST neighbour that continues a sequence instead of the first (find_grid.cc:216-222).  The tests assert
 // that neither changes any result.
+thread_local GridDebugSequence g_grid_debug_sequence = {false, 0, 0};
 thread_local GridPerturbation g_grid_perturbation{0u, false};
 
 namespace {
@@ -333,6 +334,7 @@ bool for_each_adjacent(const SiteGraph& g, const std::vector<PointI>& pts, int c
 }
 
 // thresholds, find_grid.cc:204-207
+constexpr int kScale = 1000;  // FIND_GRID_SCALE, mrgingham-internal.h:3
 constexpr double kSpacingCos = 0.984;
 constexpr double kLenRatioMin = 0.7, kLenRatioMax = 1.4, kLenRatioDev = 0.35;
 
@@ -363,21 +365,43 @@ struct SeqStats {  // HypothesisStatistics, :166-172
 };
 
 // get_adjacent_cell_along_sequence, :209-312: the first neighbour continuing the sequence, or -1
-int next_along_sequence(const AdjLists& adj, int c, SeqStats& st) {
+// `trace` != nullptr: the candidates, for the --debug-sequence messages of :247-306 (coordinates in whole pixels)
+int next_along_sequence(const AdjLists& adj, int c, SeqStats& st, const std::vector<PointI>* trace = nullptr) {
     const Adj* chosen = nullptr;
     double chosen_ratio = 0.0;
+    const int S = kScale;
     for (const Adj& a : adj[c]) {
+        if (trace)
+            fprintf(stderr, "Considering connection in sequence from (%d,%d) -> (%d,%d); delta (%d,%d) ..... \n",
+                    (*trace)[c].x / S, (*trace)[c].y / S, (*trace)[a.site].x / S, (*trace)[a.site].y / S, a.delta.x / S,
+                    a.delta.y / S);
         const double cos_err = ((double)st.delta_last.x * (double)a.delta.x + (double)st.delta_last.y * (double)a.delta.y) /
                                (st.last_len * a.len);
-        if (cos_err < kSpacingCos) continue;
+        if (cos_err < kSpacingCos) {
+            if (trace)
+                fprintf(stderr, "..... rejecting. Angle is wrong. I wanted cos_err>=threshold, but saw %f<%f\n", cos_err,
+                        kSpacingCos);
+            continue;
+        }
         const double ratio = a.len / st.last_len;
-        if (ratio < kLenRatioMin || ratio > kLenRatioMax) continue;
+        if (ratio < kLenRatioMin || ratio > kLenRatioMax) {
+            if (trace)
+                fprintf(stderr, "..... rejecting. Lengths are wrong. I wanted abs(length_ratio)<=threshold, but saw %f<%f or %f>%f\n",
+                        ratio, kLenRatioMin, ratio, kLenRatioMax);
+            continue;
+        }
         if (st.ratio_n > 2) {
             const double dev = ratio - st.ratio_sum / (double)st.ratio_n;
-            if (dev < -kLenRatioDev || dev > kLenRatioDev) continue;
+            if (dev < -kLenRatioDev || dev > kLenRatioDev) {
+                if (trace)
+                    fprintf(stderr, "..... rejecting. Lengths are wrong. I wanted abs(length_ratio_deviation)<=threshold, but saw %f>%f\n",
+                            std::fabs(dev), kLenRatioDev);
+                continue;
+            }
         }
         chosen = &a;
         chosen_ratio = ratio;
+        if (trace) fprintf(stderr, "..... accepting!\n\n");
         if (!g_grid_perturbation.last_match) break;  // the reference: the first match (:216-222)
     }
     if (!chosen) return -1;
@@ -394,12 +418,13 @@ struct Sequence {  // CandidateSequence, :148-162
 };
 
 // walks n_remaining steps from c along delta; fills `path` (if given) with the sites visited
-int walk_sequence(const AdjLists& adj, PointI delta, int c, int n_remaining, PointD* delta_mean, std::vector<int>* path) {
+int walk_sequence(const AdjLists& adj, PointI delta, int c, int n_remaining, PointD* delta_mean, std::vector<int>* path,
+                  const std::vector<PointI>* trace = nullptr) {
     SeqStats st{delta, std::hypot((double)delta.x, (double)delta.y), 0.0, 0};
     double sx = delta.x, sy = delta.y;
     int last = -1;
     for (int i = 0; i < n_remaining; ++i) {
-        const int nx = next_along_sequence(adj, c, st);
+        const int nx = next_along_sequence(adj, c, st, trace);
         if (nx < 0) return -1;
         sx += st.delta_last.x;
         sy += st.delta_last.y;
@@ -482,10 +507,27 @@ bool find_grid_from_points(std::vector<PointD>& out, const std::vector<PointI>& 
     // get_sequence_candidates, :502-569
     const AdjLists adj = build_adjacency(g, pts);
     std::vector<Sequence> seq;
+    // --debug-sequence (:515-539): the candidate nearest to the given pixel is traced
+    int tracing = -1;
+    if (g_grid_debug_sequence.on) {
+        unsigned long long best = ~0ull;
+        for (int c : g.order) {
+            const long long dx = (long long)pts[c].x - (long long)kScale * g_grid_debug_sequence.x;
+            const long long dy = (long long)pts[c].y - (long long)kScale * g_grid_debug_sequence.y;
+            const unsigned long long d2 = (unsigned long long)(dx * dx + dy * dy);
+            if (d2 < best) { best = d2; tracing = c; }
+        }
+        if (tracing >= 0)
+            fprintf(stderr, "============== Looking at sequences from (%d,%d)\n", pts[tracing].x / kScale,
+                    pts[tracing].y / kScale);
+    }
     for (int c : g.order)
         for (const Adj& a : adj[c]) {
+            if (c == tracing)
+                fprintf(stderr, "\n\n====== Looking at adjacent point (%d,%d)\n", pts[a.site].x / kScale,
+                        pts[a.site].y / kScale);
             PointD mean;
-            const int clast = walk_sequence(adj, a.delta, a.site, gridn - 2, &mean, nullptr);
+            const int clast = walk_sequence(adj, a.delta, a.site, gridn - 2, &mean, nullptr, c == tracing ? &pts : nullptr);
             if (clast >= 0) seq.push_back(Sequence{c, a.site, clast, mean});
         }
 

@@ -11,6 +11,12 @@ struct PointD { double x, y; };     // corner, pixel coordinates (point.hh:11-15
 // gridn*gridn corners in board order (rows top to bottom, each left to right) to `out`.
 bool find_grid_from_points(std::vector<PointD>& out, const std::vector<PointI>& pts, int gridn);
 
+// The reference's --debug-sequence trace (find_grid.cc:216, :247-306, :515-553): with `on`, find_grid_from_points
+// reports on stderr, for the candidate nearest to (x, y) pixels, every neighbour it starts a sequence towards and
+// every connection it considers / rejects / accepts along that sequence.  Thread-local: set around the call.
+struct GridDebugSequence { bool on; int x, y; };
+extern thread_local GridDebugSequence g_grid_debug_sequence;
+
 // visiting-order perturbations for the insensitivity tests (see grid.cpp); thread-local, default off
 struct GridPerturbation { unsigned ring_seed; bool last_match; };
 extern thread_local GridPerturbation g_grid_perturbation;

@@ -129,3 +129,14 @@ def test_shipped_library_has_no_experiment_hooks():
                 depth = 0 if depth in (1, -1) else depth - 1
             if "getenv(" in ln and "MRGINGHAM_AMD_DEVICE" not in ln:
                 assert depth > 0, (src, ln)
+
+
+def test_reference_module_name_is_importable():
+    """`import mrgingham` gives the reference's five names (mrgingham_pywrap.c:357-368)."""
+    import mrgingham
+    import mrgingham_amd
+    assert sorted(mrgingham.__all__) == ["ChESS_response_5", "find_board", "find_chessboard", "find_chessboard_corners",
+                                         "find_points"]
+    for name in mrgingham.__all__:
+        assert getattr(mrgingham, name) is getattr(mrgingham_amd, name)
+    assert mrgingham.find_chessboard is mrgingham.find_board and mrgingham.find_chessboard_corners is mrgingham.find_points

@@ -125,3 +125,29 @@ def test_c3_cluttered_frames_match_the_oracle_on_both_search_paths(det):
         for f in range(B):
             want = oracle.find_corners(host[f], level)
             assert int(counts[f]) == len(want) and np.array_equal(xy[f, :len(want)].cpu().numpy(), want), (level, f)
+
+
+def test_c2_as_stated_64_frames_1920x1080_level0_detect(det):
+    """BASELINE config 2 as stated: one batch of 64 frames of 1920x1080 with a 10x10 board through the ChESS path
+    at level 0 (detect).  Three frames bit-exact against the oracle (lists in the reference's order), the dense
+    response of one frame against the oracle, properties on all 64."""
+    B, w, h = 64, 1920, 1080
+    frames = synth.board_batch(B, w, h, gridn=10, seed0=300, device="cuda")
+    xy, counts = det.detect(frames, 0, capacity=1024)
+    xy, counts = xy.cpu().numpy(), counts.cpu().numpy()
+    for f in (0, 31, 63):
+        want = oracle.find_corners(frames[f].cpu().numpy(), 0)
+        assert int(counts[f]) == len(want) and np.array_equal(xy[f, :len(want)], want), f
+    resp = det.chess_response(frames[5:6], 0, clamp=True)[0].cpu().numpy()
+    assert np.array_equal(resp, oracle.clamped_response(frames[5].cpu().numpy(), 0)[0])
+    for f in range(B):
+        n = int(counts[f])
+        assert 100 <= n <= 1024, (f, n)
+        lat = synth.board_lattice(w, h, 10, 300 + f).reshape(-1, 2)
+        c = xy[f, :n].astype(np.float64) / 1000.0
+        d = np.sqrt(((c[None, :, :] - lat[:, None, :]) ** 2).sum(-1)).min(1)   # every rendered corner has a candidate
+        assert d.max() < 1.0, (f, d.max())                                      # within a pixel of where it was drawn
+    # batch-size independence: the same frames one at a time
+    for f in (7, 40):
+        x1, c1 = det.detect(frames[f:f + 1], 0, capacity=1024)
+        assert int(c1[0]) == int(counts[f]) and np.array_equal(x1[0, :int(c1[0])].cpu().numpy(), xy[f, :int(counts[f])])

@@ -268,3 +268,31 @@ def test_baseline_size_candidate_sets(golden_dir):
     per_point = [int((((cand - p) ** 2).sum(1) <= (0.4 * pitch) ** 2).sum()) for p in lat]
     assert min(per_point) >= 1 and max(per_point) == 2 and 1 <= sum(n == 2 for n in per_point) <= 10
     assert mrgingham_amd.find_grid_from_points(z["cand_L3_board10_4096x3072_s11"], 10) is None
+
+
+def test_debug_sequence_trace_follows_the_board(capfd):
+    """--debug-sequence X,Y (find_grid.cc:247-306, :515-553): the sequences tried from the candidate nearest to the
+    pixel are reported on stderr -- the point itself, every neighbour a sequence is started towards, and every
+    connection considered with its verdict; the result is the same as without the trace."""
+    from mrgingham_amd import api
+    pts, truth = _board(10, _rot(5), jitter=0.1, seed=3)
+    want = mrgingham_amd.find_grid_from_points(pts, 10)
+    corner = truth[0] // 1000                                   # the board's first corner, whole pixels
+    capfd.readouterr()
+    got = api.find_grid_from_points_traced(pts, 10, (int(corner[0]) + 2, int(corner[1]) - 1))
+    err = capfd.readouterr().err
+    assert want is not None and np.array_equal(got, want)
+    lines = err.splitlines()
+    assert lines[0] == "============== Looking at sequences from (%d,%d)" % (truth[0][0] // 1000, truth[0][1] // 1000)
+    assert sum(ln.startswith("====== Looking at adjacent point (") for ln in lines) >= 2
+    considered = [ln for ln in lines if ln.startswith("Considering connection in sequence from (")]
+    accepted = sum(ln == "..... accepting!" for ln in lines)
+    rejected = sum(ln.startswith("..... rejecting. ") for ln in lines)
+    assert len(considered) == accepted + rejected and accepted >= 2 * 8      # two full sequences of gridn - 2 steps leave a corner
+    assert any("Angle is wrong. I wanted cos_err>=threshold" in ln for ln in lines)
+    # along the board's first row the trace walks corner to corner
+    row = [(int(p[0]) // 1000, int(p[1]) // 1000) for p in truth[:10]]
+    assert any(ln.startswith("Considering connection in sequence from (%d,%d) -> (%d,%d)" % (*row[1], *row[2])) for ln in considered)
+    # off: silent
+    api.find_grid_from_points_traced(pts, 10, (-1, -1))
+    assert capfd.readouterr().err == ""
