@@ -303,14 +303,14 @@ bool contour_to_center(const BlobContour& c, const uint32_t* pts, const uint8_t*
     } else {
         ratio = 1;
     }
-    if (ratio < 0.1 || ratio >= FLT_MAX) return false;
+    if (ratio < (double)0.1f || ratio >= FLT_MAX) return false;  // Params::minInertiaRatio is a float: 0.100000001490...
     std::vector<IPt> p((size_t)c.n);
     for (int i = 0; i < c.n; ++i) p[i] = IPt{(int)(pts[i] & 0xffffu), (int)(pts[i] >> 16)};
     {  // filterByConvexity, minConvexity 0.95
         const double carea = polygon_area(p.data(), c.n), harea = hull_area(p);
         if (std::fabs(harea) < DBL_EPSILON) return false;
         const double conv = carea / harea;
-        if (conv < 0.95 || conv >= FLT_MAX) return false;
+        if (conv < (double)0.95f || conv >= FLT_MAX) return false;  // Params::minConvexity is a float: 0.949999988079...
     }
     if (m00 == 0.0) return false;
     out->x = m10 / m00;

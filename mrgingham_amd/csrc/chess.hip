@@ -155,6 +155,9 @@ __device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b) {
 __device__ __forceinline__ uint32_t pk_add_i16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, (i16x2)(__builtin_bit_cast(i16x2, a) + __builtin_bit_cast(i16x2, b)));
 }
+__device__ __forceinline__ uint32_t dot2_u32_u16(uint32_t a, uint32_t b, uint32_t c) {  // a.lo * b.lo + a.hi * b.hi + c
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), c, false);
+}
 __device__ __forceinline__ uint32_t pk_sub_sat_u16(uint32_t a, uint32_t b) {  // v_pk_sub_u16 ... clamp
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
 }
@@ -331,57 +334,100 @@ __device__ __forceinline__ void load12(uint32_t (&R)[12], const char* p) {
     R[8] = c.x; R[9] = c.y; R[10] = c.z; R[11] = c.w;
 }
 
-// Hot pixels of a workgroup are collected in LDS and appended to the frame's
-// list with ONE global atomic per workgroup: per-pixel (even per-wave) returning
-// atomics on the frame counter serialise and were costing more than the response
-// itself on the small pyramid levels.  Entries are (y << 16) | x.
-constexpr int V1_HOTBUF = 768;  // entries; what does not fit is appended directly (one atomic per lane)
+// Hot pixels of a workgroup are collected in LDS and appended to the frame's list with ONE global atomic per
+// workgroup: per-pixel (even per-wave) returning atomics on the frame counter serialise and were costing more than
+// the response itself on the small pyramid levels.  What a lane collects is a RECORD per aligned 8-pixel group with
+// a hot pixel -- (y << 16 | x0, 8-bit mask) -- in a segment of the buffer that belongs to its wave, at a position
+// that is the wave's own running count (a scalar register) plus the lane's rank among the lanes that have one
+// (one ballot): no atomic and no round trip in the loop.  (Round 2 expanded the pixels at once, with four ballots
+// for the prefix of the per-lane counts and a returning LDS atomic per wave and iteration: +20 % on the level-0
+// launch for a textured frame, where nearly every wave-iteration has a hot pixel.)  The flush expands the
+// records into list entries (y << 16) | x -- a group's pixels consecutive, in ascending x -- and writes the
+// pixel -> index record of every group.
+constexpr int V1_HOTBUF = 768;            // words = records: mask | group column << 8 | row within the segment << 13
+constexpr int V1_HOTSEG = V1_HOTBUF / 4;  // records per wave (192)
 
-// All lanes of the wave call this; `bits` has bit i set when pixel xy0 + i of the lane is hot.
-__device__ __forceinline__ void collect_hot(uint32_t bits, uint32_t xy0, uint32_t* hotbuf, int* hotcnt,
-                                            const CompTables& t, int frame) {
-    const int cnt = __popc(bits);  // 0..8
-    int prefix, total;
-    wave_prefix_0to8(cnt, prefix, total);
-    int base = 0;
-    if (__lane_id() == 0) base = atomicAdd(hotcnt, total);  // LDS atomic
-    base = __builtin_amdgcn_readfirstlane(base);
-    if (cnt == 0) return;
-    int k = base + prefix;
-    if (k + cnt <= V1_HOTBUF) {
-        while (bits) {
-            const int i = __ffs(bits) - 1;
-            bits &= bits - 1;
-            hotbuf[k++] = xy0 + (uint32_t)i;
+struct HotSink {          // where a workgroup's records go
+    uint32_t* seg;        // this wave's segment of the buffer (LDS)
+    int ys, strip_x;      // origin of the record coordinates: first row of the segment, first column of the strip
+    int count;            // records in the segment (wave-uniform: a scalar register)
+};
+
+// Expands records [0, nrec) of a wave's segment into list entries starting at list index `base`, and writes the
+// pixel -> index entry of every group.  All lanes of the wave call it.
+__device__ __forceinline__ void expand_records(const HotSink& hs, int nrec, int base, const CompTables& t, int frame) {
+    const int lane = threadIdx.x & 63;
+    uint32_t* hot = t.hot_xy + (long long)frame * t.cap;
+    for (int i0 = 0; i0 < nrec; i0 += 64) {
+        const int i = i0 + lane;
+        const uint32_t r = i < nrec ? hs.seg[i] : 0u;
+        const uint32_t mask = r & 0xffu;
+        const int c = __popc(mask);
+        int incl = c;  // inclusive prefix over the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
         }
-    } else {
-        // rare: the buffer is full.  The lane's group goes straight to the list (its entries must stay
-        // consecutive); the buffer slots it had reserved are flushed as unused list slots.
-        for (int j = k; j < k + cnt && j < V1_HOTBUF; ++j) hotbuf[j] = kHotDead;
-        write_group_direct(t, frame, atomicAdd(t.hot_cnt + frame, cnt), bits, xy0);
+        const int chunk = __shfl(incl, 63);
+        if (c) {
+            int k = base + incl - c;
+            const int y = hs.ys + (int)(r >> 13), x0 = hs.strip_x + 8 * (int)((r >> 8) & 31u);
+            t.gidx[(long long)frame * t.gidx_pitch + (long long)y * t.gw + (x0 >> 3)] = make_uint2((uint32_t)k, mask);
+            const uint32_t xy0 = ((uint32_t)y << 16) | (uint32_t)x0;
+            uint32_t b = mask;
+            while (b) {
+                const int j = __ffs(b) - 1;
+                b &= b - 1;
+                if (k < t.cap) hot[k] = xy0 + (uint32_t)j;
+                ++k;
+            }
+        }
+        base += chunk;
     }
 }
 
-// Flush of the workgroup's buffer: one global atomic, coalesced list writes; the first entry of every
-// 8-pixel group also writes the group's pixel -> index record.  Called by all 256 threads.
-__device__ __forceinline__ void flush_hot(const uint32_t* hotbuf, int* hotcnt, const CompTables& t, int frame) {
-    __syncthreads();
-    const int n = min(*hotcnt, V1_HOTBUF);
-    if (n <= 0) return;
-    __syncthreads();
-    if (threadIdx.x == 0) *hotcnt = atomicAdd(t.hot_cnt + frame, n);
-    __syncthreads();
-    const int gbase = *hotcnt;
-    uint32_t* hot = t.hot_xy + (long long)frame * t.cap;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const uint32_t e = hotbuf[i];
-        if (gbase + i < t.cap) hot[gbase + i] = e;
-        if (e == kHotDead || (i > 0 && (hotbuf[i - 1] >> 3) == (e >> 3))) continue;
-        uint32_t mask = 0;
-        for (int j = i; j < n && (hotbuf[j] >> 3) == (e >> 3); ++j) mask |= 1u << (hotbuf[j] & 7u);
-        t.gidx[(long long)frame * t.gidx_pitch + (long long)(e >> 16) * t.gw + ((e & 0xffffu) >> 3)] =
-            make_uint2((uint32_t)(gbase + i), mask);
+// hot pixels in records [0, nrec) of the wave's segment (wave-uniform result)
+__device__ __forceinline__ int count_record_pixels(const HotSink& hs, int nrec) {
+    const int lane = threadIdx.x & 63;
+    int mine = 0;
+    for (int i = lane; i < nrec; i += 64) mine += __popc(hs.seg[i] & 0xffu);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+    return mine;
+}
+
+// All lanes of the wave call this; `bits` has bit i set when pixel i of the lane's group (row y, columns
+// x0 .. x0 + 7, x0 a multiple of 8 inside the strip) is hot.
+__device__ __forceinline__ void collect_hot(uint32_t bits, int y, int x0, HotSink& hs, const CompTables& t, int frame) {
+    const unsigned long long m = __ballot(bits != 0);
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+    const int k = hs.count + rank;
+    hs.count += __popcll(m);
+    if (bits == 0) return;
+    if (k < V1_HOTSEG) {
+        hs.seg[k] = bits | ((uint32_t)((x0 - hs.strip_x) >> 3) << 8) | ((uint32_t)(y - hs.ys) << 13);
+    } else {
+        // rare (a wave's strip rows hold more than 192 groups with a hot pixel: dense texture): the group goes
+        // straight to the list, one returning global atomic per lane
+        write_group_direct(t, frame, atomicAdd(t.hot_cnt + frame, __popc(bits)), bits, ((uint32_t)y << 16) | (uint32_t)x0);
     }
+}
+
+// Flush at the end of the workgroup: one global atomic for the four waves' records.  Called by all 256 threads.
+__device__ __forceinline__ void flush_hot(const HotSink& hs, int* hotcnt, int wave, const CompTables& t, int frame) {
+    const int nrec = min(hs.count, V1_HOTSEG);  // (what did not fit went to the list directly)
+    const int px = count_record_pixels(hs, nrec);
+    __syncthreads();  // hotcnt is free
+    if ((threadIdx.x & 63) == 0) hotcnt[wave] = px;
+    __syncthreads();
+    const int total = hotcnt[0] + hotcnt[1] + hotcnt[2] + hotcnt[3];
+    if (total == 0) return;  // uniform
+    if (threadIdx.x == 0) hotcnt[4] = atomicAdd(t.hot_cnt + frame, total);
+    __syncthreads();
+    int base = hotcnt[4];
+    for (int w = 0; w < wave; ++w) base += hotcnt[w];
+    expand_records(hs, nrec, base, t, frame);
 }
 
 // ---------------------------------------------------------------------------
@@ -485,7 +531,7 @@ __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTa
     const int lane = tid & 63, wv = tid >> 6, half = lane >> 5, lx = lane & 31;
     uint32_t* hotbuf = reinterpret_cast<uint32_t*>(lds + 2 * V1_PLANE);
     int* hotcnt = reinterpret_cast<int*>(hotbuf + V1_HOTBUF);
-    if (HOT && tid == 0) *hotcnt = 0;
+    HotSink hsink{hotbuf + (tid >> 6) * V1_HOTSEG, ys, strip_x, 0};
     constexpr bool W16 = STAGE == STAGE_PERM16;
     constexpr bool TYPED = STAGE == STAGE_TYPED2 || STAGE == STAGE_TYPED1;
     const int wvu = __builtin_amdgcn_readfirstlane(wv);
@@ -650,13 +696,16 @@ __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTa
             const bool live = yy < ye;
             const uint32_t any = (out[0] | out[1] | out[2] | out[3]) & 0xfff0fff0u;
             if (__ballot(any != 0 && live) != 0ull) {
+                // bit i = pixel i of the lane is hot: per register, both halves to 0 / 1 (v_pk_min_u16), then the
+                // two flags go to their bit positions and into the mask in one v_dot2_u32_u16 (lo * 2^2k + hi * 2^(2k+1))
                 uint32_t bits = 0;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int v = (int)((out[i >> 1] >> (16 * (i & 1))) & 0xffffu);
-                    bits |= (uint32_t)(v > kRespMin && live) << i;
+                for (int k = 3; k >= 0; --k) {
+                    const uint32_t m = pk_min_u16(out[k] & 0xfff0fff0u, 0x00010001u);
+                    bits = dot2_u32_u16(m, (1u << (2 * k)) | (2u << (2 * k + 16)), bits);
                 }
-                collect_hot(bits, ((uint32_t)yy << 16) | (uint32_t)x0, hotbuf, hotcnt, t, frame);
+                if (!live) bits = 0;
+                collect_hot(bits, yy, x0, hsink, t, frame);
             }
         }
 
@@ -695,7 +744,7 @@ __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTa
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     }
-    if (HOT) flush_hot(hotbuf, hotcnt, t, frame);
+    if (HOT) flush_hot(hsink, hotcnt, wvu, t, frame);
 }
 
 template <bool CLAMP, bool HOT, int STAGE>
@@ -775,7 +824,7 @@ void launch_chess(const LevelBatch& lb, const CompTables& t, int frame0, int nfr
                   hipStream_t s) {
     const int seg = pick_segment(lb.w, lb.h, nframes);
     dim3 grid(((lb.w + V1_SW - 1) / V1_SW) * ((lb.h + seg - 1) / seg) * nframes);
-    const size_t lds = 2 * V1_PLANE + (hot ? (V1_HOTBUF + 4) * sizeof(int) : 0);
+    const size_t lds = 2 * V1_PLANE + (hot ? (V1_HOTBUF + 12) * sizeof(int) : 0);
     const bool w16 = lb.w >= 16 && lb.w % 16 == 0 && (long long)(lb.h + V1_RB) * lb.img_stride < 0x7fffffffLL;
     // staging path: chess_stage_override (tuning hook "chess_stage") 0 = automatic
     // widths that are a multiple of 16 take the v_perm staging (fastest there: 624 vs 637-644 us per 64 frames of
@@ -813,7 +862,7 @@ bool launch_chess_pyramid(const LevelBatch& lb, const CompTables& t, const Pyram
     if (!chess_pyramid_ok(lb, nframes)) return false;
     const int seg = pick_segment(lb.w, lb.h, nframes);  // a multiple of 8: an iteration's rows are whole cells
     dim3 grid(((lb.w + V1_SW - 1) / V1_SW) * ((lb.h + seg - 1) / seg) * nframes);
-    const size_t lds = 2 * V1_PLANE + (V1_HOTBUF + 4) * sizeof(int);
+    const size_t lds = 2 * V1_PLANE + (V1_HOTBUF + 12) * sizeof(int);
     PyramidOut p2 = po;
 #ifdef MRG_EXPERIMENT
     // MRGINGHAM_AMD_PYR_SKIP (timing ablation, tools/interference_ab.py "dbg fused"): bit k = level k + 1 is not written
@@ -851,7 +900,7 @@ bool launch_chess_multi(const LevelBatch* lbs, const CompTables* ts, int n, int 
         a.nwg[k] = k < n ? ((lbs[j].w + V1_SW - 1) / V1_SW) * ((lbs[j].h + a.seg[k] - 1) / a.seg[k]) * nframes : 0;
         total += (a.nwg[k] + 7) / 8 * 8;
     }
-    const size_t lds = 2 * V1_PLANE + (V1_HOTBUF + 4) * sizeof(int);
+    const size_t lds = 2 * V1_PLANE + (V1_HOTBUF + 12) * sizeof(int);
     hipLaunchKernelGGL(chess_v1_multi_kernel, dim3(total), dim3(256), lds, s, a);
     return true;
 }

@@ -221,13 +221,13 @@ static int contour_to_center(const ptvec_t* c, const uint8_t* image, int w, int 
         } else {
             ratio = 1;
         }
-        if (ratio < 0.1 || ratio >= FLT_MAX) return 0;    /* maxInertiaRatio = numeric_limits<float>::max() */
+        if (ratio < (double)0.1f || ratio >= FLT_MAX) return 0; /* float Params promoted to double; maxInertiaRatio = numeric_limits<float>::max() */
     }
     {                                                      /* filterByConvexity: minConvexity 0.95 */
         const double carea = polygon_area(c->p, c->n), harea = hull_area(c);
         if (fabs(harea) < DBL_EPSILON) return 0;
         const double conv = carea / harea;
-        if (conv < 0.95 || conv >= FLT_MAX) return 0;
+        if (conv < (double)0.95f || conv >= FLT_MAX) return 0; /* (float)0.95 = 0.949999988... */
     }
     if (m[0] == 0.0) return 0;
     out->x = m[1] / m[0];
