@@ -786,7 +786,7 @@ __global__ __launch_bounds__(256, 4) void chess_v1_multi_kernel(ChessMulti a) {
 
 
 int chess_seg_override = 0;  // tuning hook (mrgingham_amd_set_option "chess_seg"): 0 = automatic
-int chess_multi_min_blocks = 2048;  // tuning hook "chess_multi_min_blocks": per-level block target inside a merged launch
+int chess_multi_min_blocks = 768;  // tuning hook "chess_multi_min_blocks": per-level block target inside a merged launch
 int chess_stage_override = 0;  // tuning hook "chess_stage": 0 = automatic, 2 / 3 = typed staging, -1 = generic
 
 // Rows per workgroup.  Tall segments amortise the three-group prologue (24 rows staged before the first response
