@@ -701,7 +701,8 @@ __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTa
                 uint32_t bits = 0;
 #pragma unroll
                 for (int k = 3; k >= 0; --k) {
-                    const uint32_t m = pk_min_u16(out[k] & 0xfff0fff0u, 0x00010001u);
+                    uint32_t m;  // (as an instruction: hipcc turns min(x, 1) on the halves into two compares, two selects and a v_perm)
+                    asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(out[k] & 0xfff0fff0u), "v"(0x00010001u));
                     bits = dot2_u32_u16(m, (1u << (2 * k)) | (2u << (2 * k + 16)), bits);
                 }
                 if (!live) bits = 0;
