@@ -127,6 +127,23 @@ def physical_cores():
     return min(n, logical), logical, model
 
 
+def cpu_quota_cores():
+    """CPU time this container may use, in cores (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited.
+    The GPU boxes of this pool expose all 256 logical CPUs of the host but cap the container at 16 cores' worth
+    of CPU time: more runnable threads than that only get throttled."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(frames_host, start_level, leg_seconds=5.0):
     """Oracle (kind "port") on the host cores through oracle/cpu_bench.c: a pthread harness with the reference
     CLI's worker model (mrgingham-from-image.cc:50, :374-379: T threads, one frame per thread at a time, the
@@ -138,7 +155,10 @@ def cpu_baseline(frames_host, start_level, leg_seconds=5.0):
     import numpy as np
     from oracle import oracle
     oracle.lib()
-    ncores, nlogical, model = physical_cores()
+    nphys, nlogical, model = physical_cores()
+    quota = cpu_quota_cores()
+    # threads of the all-core legs: one per physical core the container can actually keep busy
+    ncores = nphys if quota is None else max(1, min(nphys, int(quota + 0.5)))
     frames_host = np.ascontiguousarray(frames_host)
     n = len(frames_host)
     oracle.bench_chain(frames_host[:1], start_level, 1, 0.0)                       # warm
@@ -152,16 +172,19 @@ def cpu_baseline(frames_host, start_level, leg_seconds=5.0):
     t1, tall, tall_h, t1h = p1 / e1, pa / ea, ph / eh, p1h / e1h
     best = max(tall, tall_h)
     out = {"value": best, "unit": "frames/s", "cores": ncores, "kind": "port",
-           "physical_cores": ncores, "logical_cpus": nlogical, "cpu_model": model,
+           "physical_cores": nphys, "logical_cpus": nlogical, "cpu_model": model,
+           "cpu_quota_cores": quota,
            "t1_frames_s": t1, "tall_frames_s": tall, "tall_frames_s_heap_reuse": tall_h, "t1_frames_s_heap_reuse": t1h,
            "threads_all": ncores,
            "parallel_efficiency": tall / (t1 * ncores), "parallel_efficiency_heap_reuse": tall_h / (t1h * ncores),
            "candidates_per_frame": pts_a / max(pa, 1),
            "sample": f"oracle/cpu_bench.c (pthreads, one frame per thread at a time, per-call allocations kept): "
-                     f"T=1 {p1} frame passes in {e1:.1f} s; T={ncores} {pa} passes in {ea:.1f} s (glibc default "
+                     f"T=1 {p1} frame passes in {e1:.1f} s; T={ncores} "
+                     f"({nphys} physical cores, CPU quota {'none' if quota is None else '%.1f cores' % quota}) {pa} passes in {ea:.1f} s (glibc default "
                      f"allocator policy), {ph} passes in {eh:.1f} s (freed blocks kept on the heap); {n} distinct "
                      f"frames; every pass is the full detect(L{start_level})+refine chain of the C oracle (gcc -O3)",
-           "what": "`value` = the better all-core leg of the oracle port (whole chain).  parallel_efficiency = "
+           "what": "`value` = the better all-core leg of the oracle port (whole chain).  `cores` = threads of the "
+                   "all-core legs = min(physical cores, the container's CPU quota).  parallel_efficiency = "
                    "tall / (t1 * cores).  The upstream ChESS.c built as shipped (oracle/_ref) is timed beside it "
                    "(level-0 response only) for scale."}
     if oracle.have_reference_build():                       # the upstream ChESS.c itself, level 0 only
@@ -273,6 +296,11 @@ def main():
         if torch.cuda.device_count() < args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} HIP device(s) here")
         sys.exit(launch_ranks(args.gpus))                    # no launcher: start the ranks ourselves
+    # stdout carries ONE line, the JSON: keep a private handle to it and point file descriptor 1 at stderr for
+    # everything else in the process (RCCL prints a version banner to stdout, `make` of the oracle talks, ...)
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -421,6 +449,17 @@ def main():
                 traffic_src = tj["source"]
         except (OSError, KeyError, ValueError):
             pass
+        # What binds the kernel (it moves its bytes once and is not waiting for them): the issue slots of the SIMDs.
+        # From the committed SQ counter passes of this same command (profiles/chess_l0_valu.json); null if absent.
+        valu = None
+        try:
+            vj = json.load(open(os.path.join(ROOT, "profiles", "chess_l0_valu.json")))
+            if (vj["width"], vj["height"]) == (W, H):
+                valu = {"bound": "valu_issue", "frac": vj["valu_issue_frac"], "unit": "fraction of SIMD quad-cycle issue slots "
+                        "carrying a VALU instruction (4 waves per SIMD)", "valu_insts_per_512px": vj["valu_insts_per_wave_iteration"],
+                        "wave_parked_frac": vj["wait_any_frac"], "source": vj["source"]}
+        except (OSError, KeyError, ValueError):
+            pass
         res = {
             "metric": "frames/sec, 4096x3072 10x10 board, corner-candidate path (ChESS + level decimation + "
                       "connected components), frames resident in HBM",
@@ -457,7 +496,7 @@ def main():
                                                        if kern_ms > 0 else 0.0,
                          "frac_two_pass_equivalent": (frames_per_launch * W * H * (bpp + (1.0 if fused else 0.0)) /
                                                       (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kern_ms > 0 else 0.0,
-                         "launches_timed": nlaunch},
+                         "launches_timed": nlaunch, "binding": valu},
         }
         res["gather_checked"] = gather_ok
         res["scratch_sets"] = args.scratch_sets or "auto"
@@ -475,7 +514,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             nhost = min(batch, 64)
             res["cpu_baseline"] = cpu_baseline(frames[:nhost].cpu().numpy(), start_level)
-        print(json.dumps(res), flush=True)
+        json_out.write(json.dumps(res) + "\n")
+        json_out.flush()
     if collective:
         dist.barrier()
         dist.destroy_process_group()

@@ -6,6 +6,7 @@ raises -- there is no CPU implementation to fall back to.
 import ctypes
 import os
 import subprocess
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MRGINGHAM_AMD_LIB") or os.path.join(_HERE, "libmrgingham_amd.so")  # override: A/B builds
@@ -41,8 +42,8 @@ def build(force=False):
     """hipcc --offload-arch=gfx950 build of the shared library, in-tree."""
     src = os.path.join(_HERE, "csrc")
     if force:
-        subprocess.check_call(["make", "-s", "-C", src, "clean"])
-    subprocess.check_call(["make", "-s", "-C", src, "-j4", "all"])
+        subprocess.check_call(["make", "-s", "-C", src, "clean"], stdout=sys.stderr)
+    subprocess.check_call(["make", "-s", "-C", src, "-j4", "all"], stdout=sys.stderr)
     return LIB_PATH
 
 

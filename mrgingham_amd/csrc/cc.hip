@@ -763,6 +763,25 @@ __device__ __forceinline__ int band_gap(int k) {
     const int ak = k < 0 ? -k : k;
     return 2 + (ak ? (2 * ak) / 32 + 1 : 0);
 }
+// One pass of the workgroup over a frame's hot list (entries that hold a pixel): eight independent loads per thread
+// in flight at a time.  As `for (i = tid; i < n; i += CC_THREADS) f(hot[i])` the pass is one global round trip per
+// iteration -- 2-3 us each underneath the pixel kernels, i.e. 0.5 ms for the 66 000 entries of a textured frame.
+template <class F>
+__device__ __forceinline__ void scan_hot_list(const uint32_t* hot, int n, F&& f) {
+    constexpr int U = 8;
+    for (int i0 = threadIdx.x; i0 < n; i0 += CC_THREADS * U) {
+        uint32_t e[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * CC_THREADS;
+            e[u] = i < n ? hot[i] : kHotDead;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (e[u] != kHotDead) f(e[u]);
+    }
+}
+
 constexpr int kBandKeys = 8192;  // keys 0 .. h - 1 + (w - 1) * |k| / 32 must stay below this
 
 // One attempt at cutting the frame into bands of at most LN hot pixels along shear k.  Leaves L.nbands,
@@ -787,12 +806,10 @@ __device__ __noinline__ int lds_try_bands(LdsCC& L, const FrameView& v, int nraw
         z[0] = z[1] = z[2] = z[3] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
-    for (int i = tid; i < nraw; i += CC_THREADS) {
-        const uint32_t e = v.hot_xy[i];
-        if (e == kHotDead) continue;
+    scan_hot_list(v.hot_xy, nraw, [&](uint32_t e) {
         const int b = band_key(e, k, w);
         if (b < kBandKeys) atomicAdd(&rcw[b >> 1], 1u << ((b & 1) * 16));  // (n <= 16384: a counter cannot carry)
-    }
+    });
     __syncthreads();
     uint32_t wv[WPT + 2];
     {
@@ -892,15 +909,14 @@ __device__ __noinline__ int lds_plan_bands(LdsCC& L, const FrameView& v, int nra
     __syncthreads();
     {
         uint32_t mn[2] = {0xffffffffu, 0xffffffffu}, mx[2] = {0u, 0u};
-        for (int i = tid; i < nraw; i += CC_THREADS) {
-            const uint32_t e = v.hot_xy[i];
-            if (e == kHotDead) continue;
+        scan_hot_list(v.hot_xy, nraw, [&](uint32_t e) {
             const int x = (int)(e & 0xffffu);
             const int side = 3 * x < w ? 0 : (3 * x >= 2 * w ? 1 : -1);
-            if (side < 0) continue;
-            mn[side] = min(mn[side], e);
-            mx[side] = max(mx[side], e);
-        }
+            if (side >= 0) {
+                mn[side] = min(mn[side], e);
+                mx[side] = max(mx[side], e);
+            }
+        });
         for (int sd = 0; sd < 2; ++sd) {
             if (mn[sd] != 0xffffffffu) atomicMin(&L.edge[2 * sd], mn[sd]);
             if (mx[sd] != 0u) atomicMax(&L.edge[2 * sd + 1], mx[sd]);
@@ -1045,20 +1061,19 @@ __device__ __forceinline__ bool lds_load_and_label(LdsCC& L, const FrameView& v,
     if (tid == 0) { L.nroots = 0; L.top = 0; L.total = 0; L.changed = 0; L.mtop = 0; L.nload = 0; L.leak = 0; }
     __syncthreads();
     if (banded) {
-        for (int i = tid; i < nraw; i += CC_THREADS) {
-            const uint32_t e = v.hot_xy[i];
+        scan_hot_list(v.hot_xy, nraw, [&](uint32_t e) {
             bool take;
             if (win) {
-                take = e != kHotDead && win->marked((int)(e & 0xffffu), (int)(e >> 16));
+                take = win->marked((int)(e & 0xffffu), (int)(e >> 16));
             } else {
-                const int y = e != kHotDead ? band_key(e, shear, w) : -1;
+                const int y = band_key(e, shear, w);
                 take = y >= y0 && y < y1;
             }
             if (take) {
                 const int slot = atomicAdd(&L.nload, 1);
                 if (slot < LN) L.xy[slot] = e;
             }
-        }
+        });
         __syncthreads();
         n = L.nload;
         if (n > LN) return false;  // bands: the planner counted the same pixels, cannot happen; windows: too many
@@ -1444,10 +1459,7 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
             if (tid == 0) L.nload = 0;
             __syncthreads();
             int cnt = 0;
-            for (int i = tid; i < nraw; i += CC_THREADS) {
-                const uint32_t e = v.hot_xy[i];
-                cnt += e != kHotDead && ws.marked((int)(e & 0xffffu), (int)(e >> 16));
-            }
+            scan_hot_list(v.hot_xy, nraw, [&](uint32_t e) { cnt += ws.marked((int)(e & 0xffffu), (int)(e >> 16)); });
             if (cnt) atomicAdd(&L.nload, cnt);
             __syncthreads();
             windowed = L.nload <= LN;

@@ -7,6 +7,7 @@ reference citations and the parity-pin status of each function.
 import ctypes
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -25,9 +26,9 @@ def build(force=False):
     """Compile the restatement (and oracle/_ref when /root/reference exists)."""
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(
             os.path.getmtime(os.path.join(_HERE, f)) for f in ("mrgingham_oracle.c", "blobs_oracle.c", "cpu_bench.c")):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+        subprocess.check_call(["make", "-s", "-C", _HERE, "all"], stdout=sys.stderr)
     elif not os.path.exists(_REF) and os.path.exists("/root/reference/ChESS.c"):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"], stdout=sys.stderr)
 
 
 _lib = None

@@ -27,8 +27,8 @@ def _bench(*args, env_extra=None):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]              # ONE json line, from rank 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]   # stdout is ONE json line (rank 0), nothing else
     return json.loads(lines[0])
 
 

@@ -24,13 +24,24 @@ timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OU
 # 4. issue / wait / LDS counters of the level-0 response kernel alone
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_sq1 -o p -- python $R/tools/chess_l0_alone.py > /dev/null 2> $OUT/pmc_sq1.err
 timeout 600 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2 -o p -- python $R/tools/chess_l0_alone.py > /dev/null 2> $OUT/pmc_sq2.err
+# 4b. the same counters on the kernels exactly as bench.py launches them (chess_v1_pyr_kernel: 64 frames, hot list +
+#     level images; chess_v1_multi_kernel), separate passes of the bench command
+PMCQ="python $R/bench.py --distinct 4 --steps 3 --warmup 1 --prime 2 --no-cpu-baseline --no-end-to-end"
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_sqp1 -o p -- $PMCQ > /dev/null 2> $OUT/pmc_sqp1.err
+timeout 600 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $OUT/pmc_sqp2 -o p -- $PMCQ > /dev/null 2> $OUT/pmc_sqp2.err
+# 4c. kernel trace of the textured-background workload
+timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace_clut -o t -- python $R/bench.py --workload c3_cluttered --steps 40 --warmup 5 --no-cpu-baseline --no-end-to-end > $OUT/trace_clutter_bench.json 2> $OUT/trace_clut.err
+timeout 600 python $R/bench.py --workload c3_cluttered --no-cpu-baseline --no-end-to-end > $OUT/bench_cluttered.json 2> $OUT/bench_cluttered.err
+timeout 900 python $R/bench.py --workload c4_4096x3072_shard256 --force-gather --bind-numa --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_c4.json 2> $OUT/bench_c4.err
+timeout 600 python $R/bench.py --workload c3_4096x3072_14x14_chain --no-cpu-baseline --no-end-to-end > $OUT/bench_14x14.json 2> $OUT/bench_14x14.err
 # 5. preprocessing kernels (row (f)-2)
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/pre -o t -- python $R/tools/preprocess_bench.py > $OUT/prebench.txt 2> $OUT/pre.err
 # summaries on the box (the raw rocprofv3 output is too big to travel back), then drop the raw files
 python $R/tools/rocprof_summary.py $OUT/trace/t_results.db > $OUT/bench_kernel_trace.txt 2>> $OUT/trace.err
 python $R/tools/rocprof_summary.py $OUT/pre/t_results.db > $OUT/preprocess_kernel_trace.txt 2>> $OUT/pre.err
-for d in pmc_rd pmc_wr pmc_fetch pmc_write pmc_sq1 pmc_sq2; do
+python $R/tools/rocprof_summary.py $OUT/trace_clut/t_results.db > $OUT/cluttered_kernel_trace.txt 2>> $OUT/trace_clut.err
+for d in pmc_rd pmc_wr pmc_fetch pmc_write pmc_sq1 pmc_sq2 pmc_sqp1 pmc_sqp2; do
     python $R/tools/pmc_summary.py $OUT/$d/p_counter_collection.csv > $OUT/$d.txt 2>> $OUT/$d.err
 done
-rm -rf $OUT/trace $OUT/pre $OUT/pmc_rd $OUT/pmc_wr $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq1 $OUT/pmc_sq2
+rm -rf $OUT/trace $OUT/pre $OUT/trace_clut $OUT/pmc_rd $OUT/pmc_wr $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sqp1 $OUT/pmc_sqp2
 ls -la $OUT

@@ -67,3 +67,33 @@ open(os.path.join(P, f"{RND}_chess_l0_sq_counters.txt"), "w").write(
 open(os.path.join(P, f"{RND}_preprocess_kernel_trace.txt"), "w").write(
     "# rocprofv3 --kernel-trace --stats -- python tools/preprocess_bench.py   (64 frames 4096x3072; clahe+blur, clahe only, blur only; row (f)-2)\n"
     + strip(rd("preprocess_kernel_trace.txt")) + "\n" + rd("prebench.txt"))
+
+# 5. the same SQ counters on the kernels as bench.py launches them (production level-0 kernel), and the VALU issue figure
+#    bench.py quotes next to the HBM roofline
+if os.path.exists(os.path.join(R, "pmc_sqp1.txt")):
+    open(os.path.join(P, f"{RND}_bench_sq_counters.txt"), "w").write(
+        "# rocprofv3 --pmc <SQ counters> --kernel-trace --output-format csv -- python bench.py --distinct 4 --steps 3 --warmup 1 --prime 2 --no-cpu-baseline --no-end-to-end   (two passes)\n"
+        "# the kernels exactly as the bench launches them: chess_v1_pyr_kernel = 64 frames of 4096x3072, clamp + hot list + level images 1..3\n"
+        "# per wave-iteration (512 px): divide by pixels / 512 = 1 572 864 for the level-0 launch; SQ_* cycle counters are in quad-cycles\n"
+        + rd("pmc_sqp1.txt") + rd("pmc_sqp2.txt"))
+    kgq = "chess_v1_pyr_kernel  grid=3145728"
+    wi = 64 * 4096 * 3072 / 512
+    insts, wavecyc = grab("pmc_sqp1", kgq, "SQ_INSTS_VALU"), grab("pmc_sqp1", kgq, "SQ_WAVE_CYCLES")
+    waves = grab("pmc_sqp1", kgq, "SQ_WAVES")
+    json.dump({
+        "_comment": "VALU issue of ONE launch of the dominant kernel (mrg::chess_v1_pyr_kernel, 64 frames of 4096x3072) from the rocprofv3 --pmc "
+                    f"passes of the bench command (profiles/{RND}_bench_sq_counters.txt).  A SIMD issues at most one VALU instruction per quad-cycle "
+                    "from one wave; with 4 waves resident per SIMD the wall quad-cycles per wave-iteration are SQ_WAVE_CYCLES / 4 / wave-iterations, "
+                    "and valu_issue_frac = SQ_INSTS_VALU / (SQ_WAVE_CYCLES / 4): the fraction of the SIMDs' quad-cycle issue slots that carry a VALU instruction.",
+        "kernel": "mrg::chess_v1_pyr_kernel", "frames": 64, "width": 4096, "height": 3072,
+        "valu_insts_per_wave_iteration": insts / wi, "wave_quad_cycles_per_wave_iteration": wavecyc / wi,
+        "waves_per_simd": 4, "valu_issue_frac": insts / (wavecyc / 4.0),
+        "wait_any_frac": grab("pmc_sqp1", kgq, "SQ_WAIT_ANY") / wavecyc, "wait_inst_any_frac": grab("pmc_sqp1", kgq, "SQ_WAIT_INST_ANY") / wavecyc,
+        "lds_insts_per_wave_iteration": grab("pmc_sqp2", kgq, "SQ_INSTS_LDS") / wi, "waves": waves,
+        "source": f"profiles/{RND}_bench_sq_counters.txt"}, open(os.path.join(P, "chess_l0_valu.json"), "w"), indent=1)
+for n, out in [("cluttered_kernel_trace.txt", f"{RND}_cluttered_kernel_trace.txt")]:
+    if os.path.exists(os.path.join(R, n)):
+        open(os.path.join(P, out), "w").write("# rocprofv3 --kernel-trace --stats -- python bench.py --workload c3_cluttered --steps 40 --warmup 5 --no-cpu-baseline --no-end-to-end\n" + strip(rd(n)))
+for n in ("bench_cluttered.json", "bench_c4.json", "bench_14x14.json"):
+    if os.path.exists(os.path.join(R, n)) and rd(n).strip():
+        open(os.path.join(P, f"{RND}_{n}"), "w").write(rd(n))
