@@ -92,11 +92,14 @@ bool find_chessboard_from_image_array_C(int Nrows, int Ncols, int stride, char* 
  * (rows top to bottom, each left to right).  false when no grid is found. */
 bool mrgingham_amd_find_grid_from_points(const int* xy_scaled, int npoints, int gridn, double* xy_out);
 
-/* The same with the reference's --debug-sequence trace (mrgingham::find_grid_from_points(..., debug_sequence),
- * mrgingham.hh:83-87): debug_sequence_x, _y >= 0 name a pixel; the sequences tried from the candidate nearest to
- * it are reported on stderr (find_grid.cc:247-306, :515-553). */
+/* The same with the reference's debug arguments (mrgingham::find_grid_from_points(..., debug, debug_sequence),
+ * mrgingham.hh:83-87).  debug != 0: the finder writes its self-plotting vnlog dumps /tmp/mrgingham-2-voronoi.vnl,
+ * -3-candidates(.vnl, -detailed.vnl), -4-outer-edges(.vnl, -detailed.vnl), -5-outer-edge-cycles,
+ * -6-identified-outer-edge-cycle and says on stderr what it found or why it gave up (find_grid.cc:385-779, :1229-1442).
+ * debug_sequence_x, _y >= 0 name a pixel; the sequences tried from the candidate nearest to it are reported on
+ * stderr (find_grid.cc:247-306, :515-553). */
 bool mrgingham_amd_find_grid_from_points_traced(const int* xy_scaled, int npoints, int gridn, double* xy_out,
-                                                int debug_sequence_x, int debug_sequence_y);
+                                                int debug, int debug_sequence_x, int debug_sequence_y);
 
 /* TEST HOOK: the same with the parts of the visiting order that cannot be checked against the
  * reference's boost::polygon graph perturbed -- ring_seed != 0 starts every site's neighbour ring at a

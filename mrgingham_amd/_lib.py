@@ -76,7 +76,7 @@ def lib():
     L.find_chessboard_from_image_array_C.restype = c_bool
     L.mrgingham_amd_find_grid_from_points.argtypes = [c_vp, c_int, c_int, c_vp]
     L.mrgingham_amd_find_grid_from_points.restype = c_bool
-    L.mrgingham_amd_find_grid_from_points_traced.argtypes = [c_vp, c_int, c_int, c_vp, c_int, c_int]
+    L.mrgingham_amd_find_grid_from_points_traced.argtypes = [c_vp, c_int, c_int, c_vp, c_int, c_int, c_int]
     L.mrgingham_amd_find_grid_from_points_traced.restype = c_bool
     L.mrgingham_amd_find_grid_from_points_perturbed.argtypes = [c_vp, c_int, c_int, c_vp, ctypes.c_uint, c_int]
     L.mrgingham_amd_find_grid_from_points_perturbed.restype = c_bool

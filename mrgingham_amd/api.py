@@ -133,13 +133,15 @@ def find_grid_from_points(points_scaled, gridn=10):
     return out if ok else None
 
 
-def find_grid_from_points_traced(points_scaled, gridn=10, debug_sequence=(0, 0)):
-    """find_grid_from_points with the reference's --debug-sequence trace on stderr for the candidate nearest to
-    pixel debug_sequence = (x, y)."""
+def find_grid_from_points_traced(points_scaled, gridn=10, debug_sequence=(-1, -1), debug=False):
+    """find_grid_from_points with the reference's debug arguments: `debug` writes the /tmp/mrgingham-[2-6]-* vnlog
+    dumps and reports progress on stderr; debug_sequence = (x, y) >= 0 traces the sequences from the candidate
+    nearest to that pixel on stderr."""
     pts = np.ascontiguousarray(points_scaled, dtype=np.int32).reshape(-1, 2)
     out = np.empty((gridn * gridn, 2), dtype=np.float64)
     ok = _lib.lib().mrgingham_amd_find_grid_from_points_traced(pts.ctypes.data, len(pts), int(gridn), out.ctypes.data,
-                                                              int(debug_sequence[0]), int(debug_sequence[1]))
+                                                              int(bool(debug)), int(debug_sequence[0]),
+                                                              int(debug_sequence[1]))
     return out if ok else None
 
 

@@ -1466,10 +1466,12 @@ bool mrgingham_amd_find_grid_from_points(const int* xy_scaled, int npoints, int 
 }
 
 bool mrgingham_amd_find_grid_from_points_traced(const int* xy_scaled, int npoints, int gridn, double* xy_out,
-                                                int debug_sequence_x, int debug_sequence_y) {
+                                                int debug, int debug_sequence_x, int debug_sequence_y) {
+    mrg::g_grid_debug = debug != 0;
     mrg::g_grid_debug_sequence = {debug_sequence_x >= 0 && debug_sequence_y >= 0, debug_sequence_x, debug_sequence_y};
     const bool ok = mrgingham_amd_find_grid_from_points(xy_scaled, npoints, gridn, xy_out);
     mrg::g_grid_debug_sequence = {false, 0, 0};
+    mrg::g_grid_debug = false;
     return ok;
 }
 
@@ -1506,7 +1508,9 @@ static int find_board_on_device(mrgingham_amd_ctx* ctx, const char* who, const m
         std::vector<PointI> cand((size_t)count);
         for (int i = 0; i < count; ++i) cand[i] = PointI{xy[2 * i], xy[2 * i + 1]};
         board.clear();
+        mrg::g_grid_debug = debug;  // the reference hands its debug flag to the grid finder as well (mrgingham.cc:50-52)
         found = find_grid_from_points(board, cand, gridn) && (int)board.size() == N;  // mrgingham.cc:51
+        mrg::g_grid_debug = false;
         if (found) break;
     }
     if (!found) return -1;

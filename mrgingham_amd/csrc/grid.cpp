@@ -25,7 +25,10 @@
 #include <cstdio>
 #include <map>
 #include <set>
+#include <string>
 #include <vector>
+
+#include <sys/stat.h>
 
 #include "grid.h"
 
@@ -37,6 +40,7 @@ namespace mrg {
 // LAST neighbour that continues a sequence instead of the first (find_grid.cc:216-222).  The tests assert
 // that neither changes any result.
 thread_local GridDebugSequence g_grid_debug_sequence = {false, 0, 0};
+thread_local bool g_grid_debug = false;
 thread_local GridPerturbation g_grid_perturbation{0u, false};
 
 namespace {
@@ -499,13 +503,79 @@ struct CycleSearch {
 
 }  // namespace
 
+namespace {
+// ---- the reference's debug dumps (find_grid.cc:385-421, :423-475, :609-779): same file names, header lines,
+// columns and stderr messages, so that the plots and scripts written for them keep working
+void make_executable(const char* f) { chmod(f, S_IRUSR | S_IRGRP | S_IROTH | S_IWUSR | S_IWGRP | S_IXUSR | S_IXGRP | S_IXOTH); }
+
+void dump_graph(const AdjLists& adj, const std::vector<int>& order, const std::vector<PointI>& p) {
+    const char* fn = "/tmp/mrgingham-2-voronoi.vnl";
+    FILE* fp = fopen(fn, "w");
+    if (!fp) return;
+    fprintf(fp, "#!/usr/bin/feedgnuplot --domain --dataid --with 'lines linecolor 0' --square --maxcurves 100000 --set 'yrange [:] rev'\n");
+    fprintf(fp, "# x id_edge y\n");
+    int e = 0;
+    for (int c : order)
+        for (const Adj& a : adj[c]) {
+            fprintf(fp, "%f %d %f\n", p[c].x / (double)kScale, e, p[c].y / (double)kScale);
+            fprintf(fp, "%f %d %f\n", p[a.site].x / (double)kScale, e, p[a.site].y / (double)kScale);
+            ++e;
+        }
+    fclose(fp);
+    make_executable(fn);
+    fprintf(stderr, "Wrote self-plotting voronoi diagram to %s\n", fn);
+}
+
+void dump_interval(FILE* fp, int icand, int ipt, int c0, int c1, const std::vector<PointI>& p) {
+    if (c1 < 0) {
+        fprintf(fp, "%d %d %f %f - - - - - -\n", icand, ipt, (double)p[c0].x / (double)kScale, (double)p[c0].y / (double)kScale);
+        return;
+    }
+    const double dx = (double)(p[c1].x - p[c0].x) / (double)kScale, dy = (double)(p[c1].y - p[c0].y) / (double)kScale;
+    fprintf(fp, "%d %d %f %f %f %f %f %f %f %f\n", icand, ipt, (double)p[c0].x / (double)kScale, (double)p[c0].y / (double)kScale,
+            (double)p[c1].x / (double)kScale, (double)p[c1].y / (double)kScale, dx, dy, std::hypot(dx, dy),
+            std::atan2(dy, dx) * 180.0 / M_PI);
+}
+
+// `which` == nullptr: every sequence candidate; otherwise the candidates with these indices (the outer edges)
+void dump_sequences(const char* base, const std::vector<Sequence>& seq, const std::vector<int>* which, const AdjLists& adj,
+                    const std::vector<PointI>& p, int gridn) {
+    const std::string sparse = std::string(base) + ".vnl", dense = std::string(base) + "-detailed.vnl";
+    const int n = which ? (int)which->size() : (int)seq.size();
+    auto at = [&](int i) -> const Sequence& { return seq[which ? (*which)[i] : i]; };
+    if (FILE* fp = fopen(sparse.c_str(), "w")) {
+        fprintf(fp, "#!/usr/bin/feedgnuplot --dom --aut --square --rangesizea 3 --w 'vec size screen 0.01,20 fixed fill' --set 'yr [:] rev'\n");
+        fprintf(fp, "# fromx fromy deltax deltay\n");
+        for (int i = 0; i < n; ++i)
+            fprintf(fp, "%f %f %f %f\n", (double)p[at(i).c0].x / (double)kScale, (double)p[at(i).c0].y / (double)kScale,
+                    at(i).delta_mean.x / (double)kScale, at(i).delta_mean.y / (double)kScale);
+        fclose(fp);
+        make_executable(sparse.c_str());
+        fprintf(stderr, "Wrote self-plotting sequence-candidate dump to %s\n", sparse.c_str());
+    }
+    if (FILE* fp = fopen(dense.c_str(), "w")) {
+        fprintf(fp, "# candidateid pointid fromx fromy tox toy deltax deltay len angle\n");
+        for (int i = 0; i < n; ++i) {
+            const std::vector<int> sp = sequence_points(adj, p, at(i), gridn);
+            for (int k = 0; k < (int)sp.size(); ++k)
+                dump_interval(fp, i, k, sp[k], k + 1 < (int)sp.size() ? sp[k + 1] : -1, p);
+        }
+        fclose(fp);
+        fprintf(stderr, "Wrote detailed sequence-candidate dump to %s\n", dense.c_str());
+    }
+}
+
+}  // namespace
+
 bool find_grid_from_points(std::vector<PointD>& out, const std::vector<PointI>& pts, int gridn) {
+    const bool debug = g_grid_debug;
     if (gridn < 2 || (int)pts.size() < gridn * gridn) return false;
     SiteGraph g;
     if (!build_site_graph(pts, g)) return false;
 
     // get_sequence_candidates, :502-569
     const AdjLists adj = build_adjacency(g, pts);
+    if (debug) dump_graph(adj, g.order, pts);
     std::vector<Sequence> seq;
     // --debug-sequence (:515-539): the candidate nearest to the given pixel is traced
     int tracing = -1;
@@ -531,13 +601,22 @@ bool find_grid_from_points(std::vector<PointD>& out, const std::vector<PointI>& 
             if (clast >= 0) seq.push_back(Sequence{c, a.site, clast, mean});
         }
 
+    if (debug) {
+        dump_sequences("/tmp/mrgingham-3-candidates", seq, nullptr, adj, pts, gridn);
+        fprintf(stderr, "got %zd points\n", pts.size());
+        fprintf(stderr, "got %zd sequence candidates\n", seq.size());
+    }
     // outer-edge candidates: sequences whose start site starts at least two sequences (:1246-1262)
     std::map<int, int> started;
     for (const Sequence& s : seq) started[s.c0]++;
     std::vector<int> outer;
     for (int i = 0; i < (int)seq.size(); ++i)
         if (started[seq[i].c0] >= 2) outer.push_back(i);
-    if (outer.size() < 8) return false;
+    if (outer.size() < 8) {
+        if (debug) fprintf(stderr, "Too few candidates for an outer edge of the grid. Needed at least 8, got %d\n", (int)outer.size());
+        return false;
+    }
+    if (debug) dump_sequences("/tmp/mrgingham-4-outer-edges", seq, &outer, adj, pts, gridn);
     std::map<int, std::vector<int>> outer_from;
     for (int i = 0; i < (int)outer.size(); ++i) outer_from[seq[outer[i]].c0].push_back(i);
 
@@ -553,7 +632,28 @@ bool find_grid_from_points(std::vector<PointD>& out, const std::vector<PointI>& 
         cycles.push_back(cyc);
         for (int k = 0; k < 4; ++k) used.insert(cyc.e[k]);
     }
-    if (cycles.size() < 2) return false;
+    auto dump_cycles = [&](const char* fn, int ncyc, auto&& cyc_of, auto&& label) {
+        FILE* fp = fopen(fn, "w");
+        if (!fp) return;
+        fprintf(fp, "#!/usr/bin/feedgnuplot --datai --dom --aut --square --rangesizea 3 --w 'vec size screen 0.01,20 fixed fill' --set 'yr [:] rev'\n");
+        fprintf(fp, "# fromx type fromy deltax deltay\n");
+        for (int ic = 0; ic < ncyc; ++ic)
+            for (int ie = 0; ie < 4; ++ie) {
+                const Sequence& cs = seq[outer[cyc_of(ic).e[ie]]];
+                fprintf(fp, "%f %s %f %f %f\n", (double)pts[cs.c0].x / (double)kScale, label(ic, ie).c_str(),
+                        (double)pts[cs.c0].y / (double)kScale, cs.delta_mean.x / (double)kScale, cs.delta_mean.y / (double)kScale);
+            }
+        fclose(fp);
+        make_executable(fn);
+        fprintf(stderr, "Wrote outer edge cycle dump to %s\n", fn);
+    };
+    if (debug && !cycles.empty())
+        dump_cycles("/tmp/mrgingham-5-outer-edge-cycles", (int)cycles.size(), [&](int ic) -> const Cycle& { return cycles[ic]; },
+                    [](int ic, int) { return std::to_string(ic); });
+    if (cycles.size() < 2) {
+        if (debug) fprintf(stderr, "Found too few 4-cycles. Needed at least 2, got %d\n", (int)cycles.size());
+        return false;
+    }
 
     // exactly one equal-and-opposite pair (:953-1003, :1324-1352)
     auto opposite = [&](const Cycle& a, const Cycle& b) {
@@ -575,11 +675,17 @@ bool find_grid_from_points(std::vector<PointD>& out, const std::vector<PointI>& 
     for (int i0 = 0; i0 < (int)cycles.size(); ++i0)
         for (int i1 = i0 + 1; i1 < (int)cycles.size(); ++i1)
             if (opposite(cycles[i0], cycles[i1])) {
-                if (pair[0] >= 0) return false;
+                if (pair[0] >= 0) {
+                    if (debug) fprintf(stderr, "Found more than one equal-and-opposite pair of outer-edge cycles. Giving up\n");
+                    return false;
+                }
                 pair[0] = i0;
                 pair[1] = i1;
             }
-    if (pair[0] < 0) return false;
+    if (pair[0] < 0) {
+        if (debug) fprintf(stderr, "Didn't find any equal-and-opposite pairs of outer-edge cycles. Giving up\n");
+        return false;
+    }
 
     // clockwise cycle and its top edge (:1025-1190)
     const Cycle* cyc2[2] = {&cycles[pair[0]], &cycles[pair[1]]};
@@ -625,6 +731,11 @@ bool find_grid_from_points(std::vector<PointD>& out, const std::vector<PointI>& 
         itop[ic] = ((l > 0 ? l : -l) < (rr > 0 ? rr : -rr)) ? emin[0] : emin[1];
     }
 
+    if (debug)
+        dump_cycles("/tmp/mrgingham-6-identified-outer-edge-cycle", 2, [&](int ic) -> const Cycle& { return *cyc2[ic]; },
+                    [&](int ic, int ie) {
+                        return std::string(ic == iclockwise ? "clockwise" : "counterclockwise") + (itop[ic] == ie ? "-top" : "");
+                    });
     // rows between the two vertical outer edges (:1378-1440)
     std::map<int, std::vector<int>> seq_from;
     for (int i = 0; i < (int)seq.size(); ++i) seq_from[seq[i].c0].push_back(i);
@@ -644,15 +755,22 @@ bool find_grid_from_points(std::vector<PointD>& out, const std::vector<PointI>& 
     if ((int)lp.size() != gridn || (int)rp.size() != gridn) return false;
     for (int i = 1; i < gridn; ++i) {
         const int s = seq_from_to(lp[i], rp[i]);
-        if (s < 0) return false;
+        if (s < 0) {
+            if (debug) fprintf(stderr, "Couldn't find sequence in row %d\n", i);
+            return false;
+        }
         rows[i] = s;
-        if (seq_from_to(rp[i], lp[i]) < 0) return false;
+        if (seq_from_to(rp[i], lp[i]) < 0) {
+            if (debug) fprintf(stderr, "Row %d: left-to-right sequence was found, but right-to-left sequence doesn't exist!\n", i);
+            return false;
+        }
     }
     for (int i = 0; i < gridn; ++i) {
         const std::vector<int> row = sequence_points(adj, pts, seq[rows[i]], gridn);
         if ((int)row.size() != gridn) return false;
         for (int s : row) out.push_back(PointD{(double)pts[s].x / 1000.0, (double)pts[s].y / 1000.0});  // :353-354
     }
+    if (debug) fprintf(stderr, "Success. Found grid\n");
     return true;
 }
 

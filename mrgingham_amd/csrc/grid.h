@@ -17,6 +17,12 @@ bool find_grid_from_points(std::vector<PointD>& out, const std::vector<PointI>& 
 struct GridDebugSequence { bool on; int x, y; };
 extern thread_local GridDebugSequence g_grid_debug_sequence;
 
+// The reference's `debug` argument of find_grid_from_points (find_grid.cc:1223, :1229-1442): with it the finder
+// writes its self-plotting vnlog dumps -- /tmp/mrgingham-2-voronoi.vnl (the neighbour graph), -3-candidates(.vnl,
+// -detailed.vnl), -4-outer-edges(.vnl, -detailed.vnl), -5-outer-edge-cycles, -6-identified-outer-edge-cycle -- and says
+// on stderr what it found or why it gave up.  Thread-local: set around the call.
+extern thread_local bool g_grid_debug;
+
 // visiting-order perturbations for the insensitivity tests (see grid.cpp); thread-local, default off
 struct GridPerturbation { unsigned ring_seed; bool last_match; };
 extern thread_local GridPerturbation g_grid_perturbation;

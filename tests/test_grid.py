@@ -296,3 +296,54 @@ def test_debug_sequence_trace_follows_the_board(capfd):
     # off: silent
     api.find_grid_from_points_traced(pts, 10, (-1, -1))
     assert capfd.readouterr().err == ""
+
+
+def test_debug_dumps_of_the_grid_finder(capfd):
+    """find_grid_from_points(debug = true) (find_grid.cc:385-779, :1229-1442): the self-plotting vnlog dumps with the
+    reference's names, header lines and columns, and the progress messages."""
+    import os
+    from mrgingham_amd import api
+    names = ["/tmp/mrgingham-2-voronoi.vnl", "/tmp/mrgingham-3-candidates.vnl", "/tmp/mrgingham-3-candidates-detailed.vnl",
+             "/tmp/mrgingham-4-outer-edges.vnl", "/tmp/mrgingham-4-outer-edges-detailed.vnl",
+             "/tmp/mrgingham-5-outer-edge-cycles", "/tmp/mrgingham-6-identified-outer-edge-cycle"]
+    for n in names:
+        if os.path.exists(n):
+            os.remove(n)
+    gridn = 6
+    pts, truth = _board(gridn, _rot(4), jitter=0.1, seed=9, outliers=5)
+    capfd.readouterr()
+    got = api.find_grid_from_points_traced(pts, gridn, debug=True)
+    err = capfd.readouterr().err
+    assert got is not None and np.array_equal(got, mrgingham_amd.find_grid_from_points(pts, gridn))
+    assert "got %d points" % len(pts) in err and "Success. Found grid" in err
+    nseq = int(err.split("got ")[2].split(" sequence candidates")[0])
+    for n in names:
+        assert os.path.exists(n), n
+        assert "Wrote" in err and n in err
+    vor = open(names[0]).read().splitlines()
+    assert vor[0].startswith("#!/usr/bin/feedgnuplot --domain --dataid") and vor[1] == "# x id_edge y"
+    assert (len(vor) - 2) % 2 == 0 and os.access(names[0], os.X_OK)
+    sparse = open(names[1]).read().splitlines()
+    assert sparse[1] == "# fromx fromy deltax deltay" and len(sparse) - 2 == nseq
+    dense = open(names[2]).read().splitlines()
+    assert dense[0] == "# candidateid pointid fromx fromy tox toy deltax deltay len angle"
+    assert len(dense) - 1 == nseq * gridn                        # gridn points per candidate, the last with dashes
+    last = dense[gridn].split()
+    assert last[1] == str(gridn - 1) and last[4:] == ["-"] * 6
+    # every one of the board's 4 outer edges appears in both directions among the outer-edge candidates
+    outer = np.array([[float(v) for v in ln.split()] for ln in open(names[3]).read().splitlines()[2:]])
+    corners = [truth[0], truth[gridn - 1], truth[-1], truth[-gridn]]
+    for c in corners:
+        assert (np.abs(outer[:, :2] - c / 1000.0).max(1) < 1e-3).sum() >= 2
+    ident = open(names[6]).read().splitlines()[2:]
+    kinds = [ln.split()[1] for ln in ident]
+    assert len(ident) == 8 and kinds.count("clockwise-top") == 1 and kinds.count("counterclockwise-top") == 1
+    # a failure says why
+    api.find_grid_from_points_traced(pts[:gridn * gridn - 3], gridn, debug=True)        # too few points: silent (:1217 early out)
+    rng = np.random.RandomState(2)
+    scatter = rng.randint(0, 2000000, size=(60, 2)).astype(np.int32)                  # no board in it
+    capfd.readouterr()
+    assert api.find_grid_from_points_traced(scatter, gridn, debug=True) is None
+    err = capfd.readouterr().err
+    assert "got 60 points" in err and ("Too few candidates for an outer edge" in err or "Found too few 4-cycles" in err
+                                       or "equal-and-opposite" in err)
