@@ -1448,30 +1448,32 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
     WinSel ws;
     ws.cs = -1;
     bool windowed = false;
-    if (may_select && nraw > LN) {
+    // a list only a little longer than the tables is a large board on a flat background (14x14: 2600): every hot
+    // pixel is near a point, the cells would hold them all -- bands first there, cells only if no band cut exists
+    const bool bands_first = nraw <= LN + LN / 2;
+    auto try_windows = [&]() {
         uint32_t* wbits = reinterpret_cast<uint32_t*>(&L.w);
         uint32_t* obits = reinterpret_cast<uint32_t*>(L.u.stk) + LN;
         static_assert(sizeof(L.u) >= (size_t)LN * 4 + (size_t)LN / 8, "open flags behind the accumulators");
         ws = lds_plan_windows(L, v, pts, lv, npts, level, wbits, (int)(sizeof(L.w) / 4), obits);
-        if (ws.cs >= 0) {
-            // do the marked cells hold few enough hot pixels?  (one more pass over the list; a frame whose hot pixels
-            // are all around its points -- a large board on a flat background -- is cut into bands instead)
-            if (tid == 0) L.nload = 0;
-            __syncthreads();
-            int cnt = 0;
-            scan_hot_list(v.hot_xy, nraw, [&](uint32_t e) { cnt += ws.marked((int)(e & 0xffffu), (int)(e >> 16)); });
-            if (cnt) atomicAdd(&L.nload, cnt);
-            __syncthreads();
-            windowed = L.nload <= LN;
-            __syncthreads();
-        }
-    }
+        if (ws.cs < 0) return;
+        // do the marked cells hold few enough hot pixels?  (one more pass over the list)
+        if (tid == 0) L.nload = 0;
+        __syncthreads();
+        int cnt = 0;
+        scan_hot_list(v.hot_xy, nraw, [&](uint32_t e) { cnt += ws.marked((int)(e & 0xffffu), (int)(e >> 16)); });
+        if (cnt) atomicAdd(&L.nload, cnt);
+        __syncthreads();
+        windowed = L.nload <= LN;
+        __syncthreads();
+    };
+    if (may_select && nraw > LN && !bands_first) try_windows();
+    if (!windowed && may_select) nbands = lds_plan_bands(L, v, nraw);
+    if (!windowed && nbands == 0 && may_select && nraw > LN && bands_first) try_windows();
     if (windowed) {
         if (tid == 0) { L.band_y[0] = 0; L.band_y[1] = 0; L.shear = 0; }
         nbands = 1;
         __syncthreads();
-    } else if (may_select) {
-        nbands = lds_plan_bands(L, v, nraw);
     }
     if (nbands == 0) {
         lds_decline(t, frame);

@@ -8,9 +8,13 @@ import torch
 import mrgingham_amd
 from mrgingham_amd import synth
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
-for (W, H, B, gridn, sets) in ((4096, 3072, 64, 10, 2), (4096, 3072, 64, 14, 3), (640, 480, 64, 10, 0), (1920, 1080, 32, 10, 3)):
+for (W, H, B, gridn, sets) in ((4096, 3072, 64, 10, 2), (4096, 3072, 64, 14, 3), (640, 480, 64, 10, 0), (1920, 1080, 32, 10, 3),
+                              (4096, 3072, 32, -10, 2)):      # gridn < 0: textured background (windowed refinement)
     P = 1024
-    batches = [synth.board_batch(8, W, H, gridn, 8 * k, device='cuda').repeat(B // 8, 1, 1).contiguous() for k in range(3)]
+    render = synth.board_batch
+    if gridn < 0:
+        render, gridn = synth.cluttered_board_batch, -gridn
+    batches = [render(8, W, H, gridn, 8 * k, device='cuda').repeat(B // 8, 1, 1).contiguous() for k in range(3)]
     det = mrgingham_amd.Detector(0)
     if sets:
         det.set_option("scratch_sets", sets)
