@@ -838,11 +838,17 @@ void launch_chess(const LevelBatch& lb, const CompTables& t, int frame0, int nfr
     } else if (chess_stage_override == -1) {
         stage = STAGE_GENERIC;
     }
+    // (the P0 + P1 typed staging lost to the others everywhere it was measured: instantiated in experiment builds only)
+#ifdef MRG_EXPERIMENT
+#define MRG_CASE_TYPED2(C, H) case STAGE_TYPED2: MRG_LAUNCH(C, H, STAGE_TYPED2); break;
+#else
+#define MRG_CASE_TYPED2(C, H)
+#endif
 #define MRG_LAUNCH(C, H, A) hipLaunchKernelGGL((chess_v1_kernel<C, H, A>), grid, dim3(256), lds, s, lb, t, frame0, seg)
 #define MRG_LAUNCH_ST(C, H)                                             \
     switch (stage) {                                                    \
         case STAGE_PERM16: MRG_LAUNCH(C, H, STAGE_PERM16); break;       \
-        case STAGE_TYPED2: MRG_LAUNCH(C, H, STAGE_TYPED2); break;       \
+        MRG_CASE_TYPED2(C, H)                                           \
         case STAGE_TYPED1: MRG_LAUNCH(C, H, STAGE_TYPED1); break;       \
         default: MRG_LAUNCH(C, H, STAGE_GENERIC); break;                \
     }
@@ -851,6 +857,7 @@ void launch_chess(const LevelBatch& lb, const CompTables& t, int frame0, int nfr
     else { MRG_LAUNCH_ST(false, false) }
 #undef MRG_LAUNCH_ST
 #undef MRG_LAUNCH
+#undef MRG_CASE_TYPED2
 }
 
 // Level 0 with the pyramid fused in; false when the shape does not qualify (whole cells only, 16-byte rows).
