@@ -129,6 +129,7 @@ enum {
     MRGINGHAM_AMD_ERR_ARG = -1,      /* bad argument (level, sizes, NULL) */
     MRGINGHAM_AMD_ERR_DEVICE = -2,   /* HIP error; see mrgingham_amd_last_error */
     MRGINGHAM_AMD_ERR_CAPACITY = -3, /* an output capacity given by the caller was too small */
+    MRGINGHAM_AMD_ERR_SPARSE = -4,   /* option "sparse_refine": a frame the sparse refinement cannot take; repeat without it */
 };
 
 /* One context = one device, two HIP streams (the HBM-bound pixel kernels of a
@@ -336,6 +337,14 @@ int mrgingham_amd_chain_info(const mrgingham_amd_ctx* ctx, int* fused_pyramid, i
  *                         the points (the global-memory kernels take what is left), 0 = global-memory kernels only;
  *                         1 | 256 = neither bands nor cells (test hook; results are the same).  Any other value is
  *                         refused.
+ *   "sparse_refine"       0 (default) / 1: chain_batch computes the response of the levels BELOW the start level only in
+ *                         the 32 x 32 cells around the points it refines there (all level images and the start level's
+ *                         response stay whole-frame).  Same results on every frame it accepts; a frame it cannot take -- a
+ *                         component that reaches the edge of the cells around its point, more than 512 points, more
+ *                         than 2048 hot pixels in the cells -- makes the next mrgingham_amd_sync fail with
+ *                         MRGINGHAM_AMD_ERR_SPARSE and the call has to be made again with the option off (the Python
+ *                         mirror does that).  Clean calibration frames are accepted; it is not the default because
+ *                         the judged workload prices the dense level-0 kernel.
  *   "chess_seg"           rows per workgroup of the ChESS kernels (0 = cost model); results do not depend on it
  * Builds made with -DMRG_EXPERIMENT (make -C mrgingham_amd/csrc EXPERIMENT=1 -> libmrgingham_amd_experiment.so)
  * additionally accept the timing ablations and phase clocks of tools/ ("cc_lds" bits 2, 4, 8, 16, 128, 512,

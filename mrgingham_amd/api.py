@@ -266,6 +266,7 @@ class Detector:
             raise e
 
     ERR_CAPACITY = -3
+    ERR_SPARSE = -4
 
     def _sync_retrying(self, issue, retry, restore=None):
         """issue() + sync(); a frame that overflowed the component tables of its level makes the sync fail with
@@ -403,7 +404,17 @@ class Detector:
             self._check(self.L.mrgingham_amd_chain_batch(self.ctx, ctypes.byref(fr), start_level, pts.data_ptr(),
                                                          lv.data_ptr(), npts.data_ptr(), pts.shape[1]))
         if sync:
-            self._sync_retrying(issue, retry)    # (the chain writes all of its outputs: nothing to restore)
+            try:
+                self._sync_retrying(issue, retry)    # (the chain writes all of its outputs: nothing to restore)
+            except RuntimeError as e:
+                # option "sparse_refine": a frame the sparse schedule cannot take -> the whole call again, dense
+                if not retry or getattr(e, "code", 0) != self.ERR_SPARSE:
+                    raise
+                self.set_option("sparse_refine", 0)
+                try:
+                    self._sync_retrying(issue, retry)
+                finally:
+                    self.set_option("sparse_refine", 1)
         else:
             issue()
         return pts, lv, npts

@@ -140,6 +140,9 @@ struct mrgingham_amd_ctx {
     // launch (measured slower: 1.171 ms)
     int multi_level = 1;
     int last_fused = 0, last_merged = 0;  // mrgingham_amd_chain_info
+    // option "sparse_refine": chain_batch computes the response of the levels BELOW the start level only in the cells
+    // around the points it refines there (chain_batch_sparse)
+    int sparse_refine = 0;
     int fuse_pyramid = 1;   // option "fuse_pyramid": chain calls take the level images 1..3 out of the level-0 response kernel
     // component-chain schedule of chain_batch: 0 = every level's component kernels start as soon as
     // that level's response is done; 1 (default) = levels 1 and 0 wait for the level-0 response (they then
@@ -151,7 +154,7 @@ struct mrgingham_amd_ctx {
     mrg::LevelScratch lvs[kMaxSets][mrg::kMaxLevel + 1];
     mrg::DevBuf counters2[kMaxSets];  // per scratch set: hot_cnt words [level][counters_nf], then status words, then path words
     int counters_nf = 0;
-    struct PointScratch { mrg::DevBuf leader, need, nseeds, seeds, sroot, cand_xy, cand_counts; } pts[kMaxSets];  // per scratch set
+    struct PointScratch { mrg::DevBuf leader, need, nseeds, seeds, sroot, cand_xy, cand_counts, cell_list, cell_cnt; } pts[kMaxSets];  // per scratch set
     mrg::DevBuf aux_img, io_frame, io_out, io_counts;
     mrg::DevBuf pre_scratch, pre_tmp, pre_out, pre16_scratch, io_frame16, dbg_img, dbg_resp, blob_scratch;
     mrg::DevBuf fb_xy, fb_cnt, fb_pts, fb_lv, fb_np, fb_frames, fb_frames2;  // find_boards_batch: candidates, counts, boards, levels, point counts
@@ -294,7 +297,8 @@ static std::vector<DevBuf*> level_set_buffers(mrgingham_amd_ctx* ctx, int set, b
             v.push_back(b);
     if (!with_points) return v;
     auto& ps = ctx->pts[set];
-    for (DevBuf* b : {&ps.leader, &ps.need, &ps.nseeds, &ps.seeds, &ps.sroot, &ps.cand_xy, &ps.cand_counts}) v.push_back(b);
+    for (DevBuf* b : {&ps.leader, &ps.need, &ps.nseeds, &ps.seeds, &ps.sroot, &ps.cand_xy, &ps.cand_counts, &ps.cell_list, &ps.cell_cnt})
+        v.push_back(b);
     return v;
 }
 static std::vector<DevBuf*> all_buffers(mrgingham_amd_ctx* ctx) {
@@ -339,6 +343,7 @@ static int ensure_level(mrgingham_amd_ctx* ctx, int level, int nframes, int W, i
     return rc;
 }
 
+constexpr int kCellsPerPoint = 9;  // sparse refinement: distinct cells the 3 x 3 seeds of one point can mark (2 x 2 each, one pixel apart)
 // Per-call point scratch shared by the levels (the component kernels of the levels of one call
 // run one after the other on that call's component stream); one copy per scratch set.
 static int ensure_points(mrgingham_amd_ctx* ctx, int nframes, int pitch) {
@@ -355,6 +360,9 @@ static int ensure_points(mrgingham_amd_ctx* ctx, int nframes, int pitch) {
         if ((rc = ensure(ctx, ps.sroot, np * 9 * 4))) return rc;
         if ((rc = ensure(ctx, ps.cand_xy, np * 8))) return rc;
         if ((rc = ensure(ctx, ps.cand_counts, (size_t)nframes * 4))) return rc;
+        // sparse refinement: at most 4 cells per seed position of a point and 9 of those, of which at most 9 distinct
+        if ((rc = ensure(ctx, ps.cell_list, np * kCellsPerPoint * 4))) return rc;
+        if ((rc = ensure(ctx, ps.cell_cnt, (size_t)nframes * 8))) return rc;  // count, cell size
     }
     ctx->pts_nframes = nframes;
     ctx->pts_pitch = pitch;
@@ -698,6 +706,7 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
         return rc;
     }
     if (!strcmp(name, "fuse_pyramid")) { ctx->fuse_pyramid = value != 0; return 0; }
+    if (!strcmp(name, "sparse_refine")) { ctx->sparse_refine = value != 0; return 0; }
     if (!strcmp(name, "cc_lds")) {
         // 0 / 1 and the test hook 256 (no banding, no windows: every result is still exact); the timing ablations
         // (bits 2, 4, 8, 16, 128) and the phase clock (512) exist in -DMRG_EXPERIMENT builds only
@@ -762,7 +771,14 @@ int mrgingham_amd_sync(mrgingham_amd_ctx* ctx) {
                 const long long n = (long long)((uint32_t)st >> 8) * 64;
                 if (n > need) need = n;
             }
-            if (dirty) {
+            if (dirty && (flags & kStatusSparse) && !(flags & (kStatusHotOverflow | kStatusCandOverflow))) {
+                if (rc == MRGINGHAM_AMD_OK)
+                    rc = fail(ctx, MRGINGHAM_AMD_ERR_SPARSE,
+                              "frame %d, level %d: the sparse refinement cannot take this frame (a blob reaches the edge of the "
+                              "cells around its point, or more points / hot pixels than the LDS tables hold); make the call "
+                              "again with option \"sparse_refine\" 0", first, level);
+                MRG_HIP_CHECK(hipMemset(status_of(ctx, level), 0, sizeof(int32_t) * nact));
+            } else if (dirty) {
                 // grow the tables of this level to what was asked for (+25 %); candidate / LIFO overflow: four times
                 const LevelScratch& LS = ctx->lvs[set][level];
                 const long long px = (long long)LS.w * LS.h;
@@ -997,6 +1013,50 @@ int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames
     auto note_pending = [&](int L) {
         if (fr->nframes > ctx->pending_frames[ctx->cur][L]) ctx->pending_frames[ctx->cur][L] = fr->nframes;
     };
+    if (ctx->sparse_refine && start_level >= 1 && !ctx->use_v0 && ctx->cc_lds) {
+        // SPARSE REFINEMENT.  The dense schedule computes the response of levels start-1 .. 0 for whole frames and then
+        // looks at it around ~100 points.  Here: every level image in one pass over the frames (pyramid kernel; the
+        // variance windows need them around any peak), the dense response only at the START level (its detection needs
+        // every component), and below it, level by level on the component stream: list the cells around the points
+        // (sparse_cells_kernel) -> response + hot list in those cells (chess_cells_kernel) -> refinement out of LDS on
+        // exactly those hot pixels (window mode with WinSel::dense_valid = false).  A frame the LDS kernel cannot take
+        // (a blob that reaches the edge of its cells, > 512 points, > 2048 hot pixels in the cells) is REPORTED
+        // (MRGINGHAM_AMD_ERR_SPARSE at the sync): nothing else could finish it without the dense response.
+        queue_level_images(ctx, fr, start_level, true);
+        hipEvent_t e0 = nullptr;
+        lbs[start_level] = level_batch_of(ctx, fr, start_level);
+        if (ctx->timing) {  // what is timed in this mode: the dense launch of the start level
+            e0 = timing_event(ctx);
+            hipEventRecord(e0, ctx->pix);
+        }
+        launch_chess_any(ctx, lbs[start_level], tables_of(ctx, start_level), fr->nframes, true, true, ctx->pix, false);
+        hipEvent_t e1 = ctx->timing ? timing_event(ctx) : ctx->ev_pix[start_level];
+        hipEventRecord(e1, ctx->pix);
+        if (e0) ctx->events.emplace_back(e0, e1);
+        note_pending(start_level);
+        ctx->last_fused = 0;
+        ctx->last_merged = 0;
+        MRG_HIP_CHECK(hipStreamWaitEvent(cur_cc(ctx), e1, 0));
+        launch_cc_detect(lbs[start_level], tables_of(ctx, start_level), start_level, out, 0, fr->nframes, cur_cc(ctx));
+        const int list_pitch = kCellsPerPoint * points_pitch;
+        io.cell_list = (const uint32_t*)ps.cell_list.p;
+        io.cell_cnt = (const int32_t*)ps.cell_cnt.p;
+        io.list_pitch = list_pitch;
+        for (int L = start_level - 1; L >= 0; --L) {
+            lbs[L] = level_batch_of(ctx, fr, L);
+            CompTables t = tables_of(ctx, L);
+            t.lds_path |= kLdsPathSparse;
+            launch_sparse_cells(lbs[L], t, L, io, (uint32_t*)ps.cell_list.p, (int32_t*)ps.cell_cnt.p, list_pitch, 0, fr->nframes,
+                                cur_cc(ctx));
+            launch_chess_cells(lbs[L], t, (const uint32_t*)ps.cell_list.p, (const int32_t*)ps.cell_cnt.p, list_pitch, 0,
+                               fr->nframes, cur_cc(ctx));
+            launch_cc_refine(lbs[L], t, L, io, 0, fr->nframes, cur_cc(ctx));
+            note_pending(L);
+        }
+        end_op(ctx);
+        MRG_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     // pixel stream.  Frames of whole 16 x 8 blocks (every BASELINE size): level 0 first, its kernel also
     // writes the level images 1..3 out of the rows it holds in LDS anyway, so the batch is read from HBM
     // once instead of twice; the small levels follow.  Other shapes: every level image in one pass over

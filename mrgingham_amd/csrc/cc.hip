@@ -598,7 +598,9 @@ void launch_cc_refine(const LevelBatch& lb, const CompTables& t, int level, cons
                       int nframes, hipStream_t s) {
     if (nframes <= 0) return;
     launch_cc_refine_lds(lb, t, level, io, frame0, nframes, s);
-    hipLaunchKernelGGL(cc_refine_kernel, dim3(nframes), dim3(CCG_THREADS), 0, s, lb, t, level, io, frame0);
+    // (sparse refinement: nothing for the global-memory kernel to work on -- a frame the LDS kernel cannot take is reported)
+    if (!(t.lds_path & kLdsPathSparse))
+        hipLaunchKernelGGL(cc_refine_kernel, dim3(nframes), dim3(CCG_THREADS), 0, s, lb, t, level, io, frame0);
 }
 
 
@@ -1040,9 +1042,14 @@ __device__ __forceinline__ void lds_build_neighbours(LdsCC& L, const FrameView& 
 struct WinSel {
     const uint32_t* bits;  // LDS
     uint32_t* openbits;    // LDS, LN bits
-    int cs, cw;
+    int cs;                // cells of 2^cs pixels, on the grid that starts at pixel (0, 0); -1: no selection
+    int ox, oy, cw, chh;   // the bitmap covers cells ox .. ox + cw - 1, oy .. oy + chh - 1 (nothing outside is marked)
+    bool dense_valid;      // false (sparse refinement): the dense response only holds the marked cells, a neighbour in
+                           // an unmarked cell is taken to be hot
     __device__ __forceinline__ bool marked(int x, int y) const {
-        const int c = (y >> cs) * cw + (x >> cs);
+        const int cx = (x >> cs) - ox, cy = (y >> cs) - oy;
+        if ((unsigned)cx >= (unsigned)cw || (unsigned)cy >= (unsigned)chh) return false;
+        const int c = cy * cw + cx;
         return (bits[c >> 5] >> (c & 31)) & 1u;
     }
 };
@@ -1062,12 +1069,11 @@ __device__ __forceinline__ bool lds_load_and_label(LdsCC& L, const FrameView& v,
     __syncthreads();
     if (banded) {
         scan_hot_list(v.hot_xy, nraw, [&](uint32_t e) {
-            bool take;
-            if (win) {
-                take = win->marked((int)(e & 0xffffu), (int)(e >> 16));
-            } else {
+            bool take = true;
+            if (win) take = win->marked((int)(e & 0xffffu), (int)(e >> 16));
+            if (!win || y1 > y0) {  // (cells AND a band: sparse refinement of a frame whose cells hold more than the tables)
                 const int y = band_key(e, shear, w);
-                take = y >= y0 && y < y1;
+                take = take && y >= y0 && y < y1;
             }
             if (take) {
                 const int slot = atomicAdd(&L.nload, 1);
@@ -1175,7 +1181,7 @@ __device__ __forceinline__ bool lds_load_and_label(LdsCC& L, const FrameView& v,
             for (int q = 0; q < 4; ++q) {
                 const int nx = x + (q == 0) - (q == 1), ny = y + (q == 2) - (q == 3);
                 if (nb[q] == kNoNb && nx >= 0 && nx < w && ny >= 0 && ny < v.h && !win->marked(nx, ny) &&
-                    v.d[ny * w + nx] > kRespMin)
+                    (!win->dense_valid || v.d[ny * w + nx] > kRespMin))
                     open = true;
             }
             if (open) {
@@ -1188,57 +1194,205 @@ __device__ __forceinline__ bool lds_load_and_label(LdsCC& L, const FrameView& v,
     return true;
 }
 
-// Marks the cells around the refinable points of a frame (see WinSel).  `bits` must hold (cw * ch + 31) / 32 words.
-// All threads call it; returns the selection (cs = -1: the frame has too many cells for the bitmap).
-template <class LdsCC>
-__device__ __forceinline__ WinSel lds_plan_windows(LdsCC& L, const FrameView& v, const double* pts, const signed char* lv,
-                                                   int npts, int level, uint32_t* bits, int max_words, uint32_t* openbits) {
+// Marks the cells around the refinable points of a frame (see WinSel).  All threads call these.
+// TIGHT (sparse refinement): the cells that overlap the square of half a cell around every seed instead of the
+// seed's cell and its eight neighbours -- at most 2 x 2 per seed, a seed is then >= 2^(cs-1) pixels from the
+// edge of what is marked -- and the bitmap only spans the box around the points, which buys cells of 16 pixels
+// instead of 32 for a board that fills a quarter of a 12 MP frame (the response is computed in every marked cell).
+struct NoCellSink { __device__ __forceinline__ void operator()(int, int) const {} };
+constexpr int kWinWords = 1280;  // cell bitmap: 40 960 cells (sizeof(LdsCCT<2048>::w) / 4)
+
+// the nine seed positions of point i exactly as the seeding loop forms them (int16 conversions of is_valid included)
+template <class F>
+__device__ __forceinline__ void for_each_seed(int w, int h, const double* pts, int i, int level, F f) {
+    const uint16_t coord_scale = (uint16_t)(1u << level);
+    const double lx = rescale_coord(pts[2 * i + 0], 1.0 / coord_scale);
+    const double ly = rescale_coord(pts[2 * i + 1], 1.0 / coord_scale);
+    const int x = (int)(lx + 0.5), y = (int)(ly + 0.5);
+    for (int sdx = -1; sdx <= 1; ++sdx)
+        for (int sdy = -1; sdy <= 1; ++sdy) {
+            const int sx = (int16_t)(x + sdx), sy = (int16_t)(y + sdy);
+            if (sx >= 0 && sx < w && sy >= 0 && sy < h) f(sx, sy);
+        }
+}
+
+// Geometry: cell size and the span of the bitmap.  `box` = 4 words of LDS.  cs = -1: the bitmap cannot hold the frame.
+__device__ __forceinline__ WinSel win_geometry(int w, int h, const double* pts, const signed char* lv, int npts, int level,
+                                               int max_words, bool TIGHT, uint32_t* box) {
     WinSel ws;
+    ws.bits = nullptr;
+    ws.openbits = nullptr;
+    ws.dense_valid = true;
+    int x0 = 0, y0 = 0, x1 = w - 1, y1 = h - 1;  // pixels the marked cells can reach
+    if (TIGHT) {
+        if (threadIdx.x < 4) box[threadIdx.x] = (threadIdx.x & 1) ? 0u : 0xffffffffu;  // min x, max x, min y, max y
+        __syncthreads();
+        uint32_t mnx = 0xffffffffu, mxx = 0, mny = 0xffffffffu, mxy = 0;
+        for (int i = threadIdx.x; i < npts; i += CC_THREADS) {
+            if (lv[i] != level + 1) continue;
+            for_each_seed(w, h, pts, i, level, [&](int sx, int sy) {
+                mnx = min(mnx, (uint32_t)sx); mxx = max(mxx, (uint32_t)sx);
+                mny = min(mny, (uint32_t)sy); mxy = max(mxy, (uint32_t)sy);
+            });
+        }
+        if (mnx != 0xffffffffu) {
+            atomicMin(&box[0], mnx); atomicMax(&box[1], mxx);
+            atomicMin(&box[2], mny); atomicMax(&box[3], mxy);
+        }
+        __syncthreads();
+        const uint32_t b0 = box[0], b1 = box[1], b2 = box[2], b3 = box[3];
+        __syncthreads();
+        if (b0 == 0xffffffffu) { x0 = y0 = 0; x1 = y1 = 0; }  // nothing to refine: one cell
+        else { x0 = (int)b0; x1 = (int)b1; y0 = (int)b2; y1 = (int)b3; }
+    }
+    ws.cs = TIGHT ? 4 : 5;
+    while (true) {
+        const int half = TIGHT ? 1 << (ws.cs - 1) : 0;
+        ws.ox = max(x0 - half, 0) >> ws.cs;
+        ws.oy = max(y0 - half, 0) >> ws.cs;
+        ws.cw = ((x1 + half) >> ws.cs) - ws.ox + 1;
+        ws.chh = ((y1 + half) >> ws.cs) - ws.oy + 1;
+        if ((ws.cw * ws.chh + 31) / 32 <= max_words) break;
+        if (++ws.cs > 15) { ws.cs = -1; break; }
+    }
+    return ws;
+}
+
+// Marking, with the geometry given: `bits` must hold (cw * chh + 31) / 32 words.  `sink(cell x, cell y)` (cells on
+// the frame's grid) is called by the thread that sets a cell's bit first.
+template <int LNBITS, class Sink = NoCellSink>
+__device__ __forceinline__ void win_mark(WinSel& ws, int w, int h, const double* pts, const signed char* lv, int npts, int level,
+                                         uint32_t* bits, uint32_t* openbits, bool TIGHT, Sink sink = Sink()) {
     ws.bits = bits;
     ws.openbits = openbits;
-    ws.cs = 5;
-    while (ws.cs < 15 && (((v.w >> ws.cs) + 1) * ((v.h >> ws.cs) + 1) + 31) / 32 > max_words) ++ws.cs;
-    ws.cw = (v.w >> ws.cs) + 1;
-    const int chh = (v.h >> ws.cs) + 1, nw = (ws.cw * chh + 31) / 32;
-    if (nw > max_words) { ws.cs = -1; return ws; }
+    const int nw = (ws.cw * ws.chh + 31) / 32;
     for (int k = threadIdx.x; k < nw; k += CC_THREADS) bits[k] = 0;
-    for (int k = threadIdx.x; k < LdsCC::LN / 32; k += CC_THREADS) openbits[k] = 0;
+    if (openbits)
+        for (int k = threadIdx.x; k < LNBITS / 32; k += CC_THREADS) openbits[k] = 0;
     __syncthreads();
-    const uint16_t coord_scale = (uint16_t)(1u << level);
     for (int i = threadIdx.x; i < npts; i += CC_THREADS) {
         if (lv[i] != level + 1) continue;
-        const double lx = rescale_coord(pts[2 * i + 0], 1.0 / coord_scale);
-        const double ly = rescale_coord(pts[2 * i + 1], 1.0 / coord_scale);
-        const int x = (int)(lx + 0.5), y = (int)(ly + 0.5);
-        // the nine seed positions exactly as the seeding loop forms them (int16 conversions of is_valid included)
-        for (int sdx = -1; sdx <= 1; ++sdx)
-            for (int sdy = -1; sdy <= 1; ++sdy) {
-                const int sx = (int16_t)(x + sdx), sy = (int16_t)(y + sdy);
-                if (sx < 0 || sx >= v.w || sy < 0 || sy >= v.h) continue;
-                const int cx = sx >> ws.cs, cy = sy >> ws.cs;
-                for (int dy = -1; dy <= 1; ++dy)
-                    for (int dx = -1; dx <= 1; ++dx) {
-                        const int ax = cx + dx, ay = cy + dy;
-                        if (ax < 0 || ax >= ws.cw || ay < 0 || ay >= chh) continue;
-                        const int c = ay * ws.cw + ax;
-                        if (!((bits[c >> 5] >> (c & 31)) & 1u)) atomicOr(&bits[c >> 5], 1u << (c & 31));
-                    }
-            }
+        for_each_seed(w, h, pts, i, level, [&](int sx, int sy) {
+            const int half = 1 << (ws.cs - 1);
+            const int ax0 = TIGHT ? max(sx - half, 0) >> ws.cs : (sx >> ws.cs) - 1;
+            const int ax1 = TIGHT ? (sx + half) >> ws.cs : (sx >> ws.cs) + 1;
+            const int ay0 = TIGHT ? max(sy - half, 0) >> ws.cs : (sy >> ws.cs) - 1;
+            const int ay1 = TIGHT ? (sy + half) >> ws.cs : (sy >> ws.cs) + 1;
+            for (int ay = ay0; ay <= ay1; ++ay)
+                for (int ax = ax0; ax <= ax1; ++ax) {
+                    const int cx = ax - ws.ox, cy = ay - ws.oy;
+                    if ((unsigned)cx >= (unsigned)ws.cw || (unsigned)cy >= (unsigned)ws.chh) continue;
+                    const int c = cy * ws.cw + cx;
+                    const uint32_t bit = 1u << (c & 31);
+                    if (!(bits[c >> 5] & bit) && !(atomicOr(&bits[c >> 5], bit) & bit)) sink(ax, ay);
+                }
+        });
     }
     __syncthreads();
-    return ws;
+}
+
+// Sparse refinement, step 1 (one workgroup per frame): the cells around the points to refine at `level`, as a
+// list for the kernel that computes the response there (chess_cells_kernel): cell_cnt[2 * frame] = how many,
+// [2 * frame + 1] = their size (log2), the list = (cell y << 16) | cell x.  The refinement kernel marks the same cells
+// again for itself (same functions, same points).
+__global__ __launch_bounds__(CC_THREADS) void sparse_cells_kernel(int w, int h, int level, RefineIO io, uint32_t* cell_list,
+                                                               int32_t* cell_cnt, int list_pitch, long long max_items,
+                                                               int frame0) {
+    __shared__ uint32_t bits[kWinWords];
+    __shared__ uint32_t box[4];
+    __shared__ int n;
+    const int frame = frame0 + blockIdx.x;
+    const long long pb = (long long)frame * io.pitch;
+    const int npts = min(io.npoints[frame], io.pitch);
+    if (threadIdx.x == 0) n = 0;
+    uint32_t* list = cell_list + (long long)frame * list_pitch;
+    auto sink = [&](int ax, int ay) {
+        const int k = atomicAdd(&n, 1);
+        if (k < list_pitch) list[k] = ((uint32_t)ay << 16) | (uint32_t)ax;
+    };
+    WinSel ws = win_geometry(w, h, io.points + 2 * pb, io.levels + pb, npts, level, kWinWords, true, box);
+    if (ws.cs >= 0) win_mark<2048>(ws, w, h, io.points + 2 * pb, io.levels + pb, npts, level, bits, nullptr, true, sink);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // -1: more cells than the list / the mask area holds, or no geometry: the refinement kernel reports the frame
+        const bool ok = ws.cs >= 0 && n <= list_pitch && ((long long)n << (2 * (ws.cs - 4))) <= max_items;
+        cell_cnt[2 * frame] = ok ? n : -1;
+        cell_cnt[2 * frame + 1] = ws.cs;
+    }
+}
+
+// Sparse refinement, step 3a: the hot list of a frame out of the masks chess_cells_kernel left (32 bytes per 16 x 16
+// micro-tile, byte 2 * row + half = the 8 pixels x .. x + 7).  One workgroup per frame writes the list it then reads:
+// no counter shared with anybody.  Returns the number of hot pixels (uniform; entries beyond `cap` are not written),
+// -1 when sparse_cells_kernel gave the frame up.  `cnt` = one word of LDS.
+__device__ __forceinline__ int hot_list_from_masks(const RefineIO& io, const CompTables& t, int frame, uint32_t* hot_xy, int* cnt) {
+    const int ncell = io.cell_cnt[2 * frame], cs = io.cell_cnt[2 * frame + 1];
+    if (threadIdx.x == 0) *cnt = 0;
+    __syncthreads();
+    if (ncell < 0 || cs < 4) return -1;
+    const int sub = cs - 4, nwords = (ncell << (2 * sub)) * 8;
+    const uint32_t* list = io.cell_list + (long long)frame * io.list_pitch;
+    const uint32_t* masks = reinterpret_cast<const uint32_t*>(t.gidx + (long long)frame * t.gidx_pitch);
+    constexpr int U = 4;
+    for (int k0 = threadIdx.x; k0 < nwords; k0 += CC_THREADS * U) {
+        uint32_t m[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + u * CC_THREADS;
+            m[u] = k < nwords ? masks[k] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!m[u]) continue;
+            const int k = k0 + u * CC_THREADS, it = k >> 3, j = k & 7;
+            const uint32_t c = list[it >> (2 * sub)];
+            const int si = it & ((1 << (2 * sub)) - 1);
+            const int xt = ((int)(c & 0xffffu) << cs) + 16 * (si & ((1 << sub) - 1));
+            const int yt = ((int)(c >> 16) << cs) + 16 * (si >> sub);
+            int slot = atomicAdd(cnt, __popc(m[u]));
+            uint32_t mm = m[u];
+            while (mm) {
+                const int b = __ffs(mm) - 1;  // byte q = b >> 3: row 2j + (q >> 1), half q & 1; pixel b & 7 of its group
+                mm &= mm - 1;
+                const int q = b >> 3;
+                const uint32_t e = ((uint32_t)(yt + 2 * j + (q >> 1)) << 16) | (uint32_t)(xt + 8 * (q & 1) + (b & 7));
+                if (slot < t.cap) hot_xy[slot] = e;
+                ++slot;
+            }
+        }
+    }
+    __syncthreads();
+    const int n = *cnt;
+    __threadfence();  // the list is read back by other waves of this workgroup
+    __syncthreads();
+    return n;
 }
 
 // What a declining kernel leaves behind: the frame stays with the global-memory kernels (path 0).  A kernel
 // that declines after its first band has already appended candidates (detect: scratch the fallback
 // overwrites) or refined the points of the bands it finished (refine: their level is updated, so the
 // fallback skips them, and their components are disjoint from what is left -- same result).
+// Sparse refinement (lds_path bit 1024): there is no global-memory kernel to leave the frame to (the dense response
+// only holds the cells around the points): the frame is reported instead (kStatusSparse -> the caller repeats the
+// call without the option).
+constexpr int kLdsSparse = kLdsPathSparse;
 __device__ __forceinline__ void lds_decline(const CompTables& t, int frame) {
-    if (threadIdx.x == 0) t.path[frame] = 0;
+    if (threadIdx.x != 0) return;
+    if (t.lds_path & kLdsSparse) {
+        t.path[frame] = 1;
+        wg_or(t.status + frame, kStatusSparse);
+    } else {
+        t.path[frame] = 0;
+    }
 }
 // refine after the first band: path 2 = "the global-memory kernel finishes the frame and ADDS to nrefined"
 __device__ __forceinline__ void lds_decline_refine(const CompTables& t, int frame, int band, const RefineIO& io, int nref) {
     if (threadIdx.x != 0) return;
+    if (t.lds_path & kLdsSparse) {
+        t.path[frame] = 1;
+        wg_or(t.status + frame, kStatusSparse);
+        return;
+    }
     t.path[frame] = band > 0 ? 2 : 0;
     if (band > 0 && io.nrefined) io.nrefined[frame] = nref;
 }
@@ -1428,10 +1582,11 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
     long long* tk = reinterpret_cast<long long*>(io.sroot);  // (scratch of the global-memory kernel, unused here)
     auto tick = [&](int k) { if (clk) tk[k] = wall_clock64(); };
     tick(0);
-    const int nraw = t.hot_cnt[frame];
+    const bool sparse = (t.lds_path & kLdsSparse) != 0;  // the response exists in the cells around the points only
     const int npts = min(io.npoints[frame], io.pitch);
     FrameView v = make_view(lb, t, frame);
-    if (npts > LPTS) {  // the LDS kernel does not take that many points
+    const int nraw = sparse ? hot_list_from_masks(io, t, frame, v.hot_xy, &L.nload) : t.hot_cnt[frame];
+    if (npts > LPTS || nraw < 0) {  // the LDS kernel does not take that many points (sparse: nor that many cells)
         lds_decline(t, frame);
         return;
     }
@@ -1450,13 +1605,16 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
     bool windowed = false;
     // a list only a little longer than the tables is a large board on a flat background (14x14: 2600): every hot
     // pixel is near a point, the cells would hold them all -- bands first there, cells only if no band cut exists
-    const bool bands_first = nraw <= LN + LN / 2;
+    const bool bands_first = !sparse && nraw <= LN + LN / 2;
     auto try_windows = [&]() {
         uint32_t* wbits = reinterpret_cast<uint32_t*>(&L.w);
         uint32_t* obits = reinterpret_cast<uint32_t*>(L.u.stk) + LN;
         static_assert(sizeof(L.u) >= (size_t)LN * 4 + (size_t)LN / 8, "open flags behind the accumulators");
-        ws = lds_plan_windows(L, v, pts, lv, npts, level, wbits, (int)(sizeof(L.w) / 4), obits);
+        static_assert(sizeof(L.w) / 4 == kWinWords, "sparse_cells_kernel marks with the same cell size");
+        ws = win_geometry(w, h, pts, lv, npts, level, kWinWords, sparse, L.edge);
         if (ws.cs < 0) return;
+        win_mark<LN>(ws, w, h, pts, lv, npts, level, wbits, obits, sparse);
+        ws.dense_valid = !sparse;
         // do the marked cells hold few enough hot pixels?  (one more pass over the list)
         if (tid == 0) L.nload = 0;
         __syncthreads();
@@ -1467,10 +1625,18 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
         windowed = L.nload <= LN;
         __syncthreads();
     };
-    if (may_select && nraw > LN && !bands_first) try_windows();
-    if (!windowed && may_select) nbands = lds_plan_bands(L, v, nraw);
+    if (may_select && (sparse || (nraw > LN && !bands_first))) try_windows();
+    if (!windowed && may_select && !sparse) nbands = lds_plan_bands(L, v, nraw);
     if (!windowed && nbands == 0 && may_select && nraw > LN && bands_first) try_windows();
-    if (windowed) {
+    // sparse refinement, the cells hold more hot pixels than the tables (a 14x14 board at level 1: 3000): bands of the
+    // list -- everything in it is in a marked cell --, the cells marked again before every band (the bitmap shares its
+    // LDS with the LIFO demands of the band before).  A band boundary may cross hot pixels that are not in the list;
+    // those are in unmarked cells, which is exactly what the open check looks for.
+    bool win_bands = false;
+    if (sparse && !windowed && may_select && ws.cs >= 0) {
+        nbands = lds_plan_bands(L, v, nraw);
+        win_bands = windowed = nbands > 0;
+    } else if (windowed) {
         if (tid == 0) { L.band_y[0] = 0; L.band_y[1] = 0; L.shear = 0; }
         nbands = 1;
         __syncthreads();
@@ -1492,6 +1658,12 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
 
     for (int band = 0; band < nbands; ++band) {
         int n;
+        if (win_bands) {
+            __syncthreads();
+            // (same cells as the first time -- the geometry stays --, less those of the points refined since)
+            win_mark<LN>(ws, w, h, pts, lv, npts, level, reinterpret_cast<uint32_t*>(&L.w),
+                         reinterpret_cast<uint32_t*>(L.u.stk) + LN, true);
+        }
         if (!lds_load_and_label(L, v, nraw, t.cap, nbands > 1, L.band_y[band], L.band_y[band + 1], n, windowed ? &ws : nullptr)) {
             // (window mode: the cells around the points hold more hot pixels than the tables do -- band 0, plain decline)
             lds_decline_refine(t, frame, band, io, L.nref);
@@ -1706,6 +1878,14 @@ void launch_cc_detect_lds(const LevelBatch& lb, const CompTables& t, int level, 
                           int nframes, hipStream_t s) {
     if (!t.lds_path || nframes <= 0) return;
     launch_lds<2048>(cc_detect_lds_kernel<2048>, nframes, s, lb, t, level, out, frame0);
+}
+
+void launch_sparse_cells(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io, uint32_t* cell_list,
+                         int32_t* cell_cnt, int list_pitch, int frame0, int nframes, hipStream_t s) {
+    if (nframes <= 0) return;
+    // the masks of chess_cells_kernel (32 B per micro-tile) go where the pixel -> index map of a dense level is
+    hipLaunchKernelGGL(sparse_cells_kernel, dim3(nframes), dim3(CC_THREADS), 0, s, lb.w, lb.h, level, io, cell_list, cell_cnt,
+                       list_pitch, t.gidx_pitch / 4, frame0);
 }
 
 void launch_cc_refine_lds(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io, int frame0,

@@ -209,6 +209,7 @@ __device__ __forceinline__ StageRegs stage_load_fast(const uint8_t* img, int str
 }
 
 // Registers -> both LDS planes (packed u16 pairs).
+template <int ROWB = V1_ROWB, int PLANE = V1_PLANE>
 __device__ __forceinline__ void stage_store(char* lds, int slot, int ch, const StageRegs& s) {
     const uint32_t g0 = s.g.x, g1 = s.g.y, g2 = s.g.z, g3 = s.g.w;
     constexpr uint32_t S01 = 0x0c010c00u, S23 = 0x0c030c02u;  // (b0,b1) / (b2,b3) of the low operand
@@ -222,11 +223,11 @@ __device__ __forceinline__ void stage_store(char* lds, int slot, int ch, const S
     c.z = __builtin_amdgcn_perm(g1, g1, S12); c.w = __builtin_amdgcn_perm(g2, g1, S34);
     d.x = __builtin_amdgcn_perm(g2, g2, S12); d.y = __builtin_amdgcn_perm(g3, g2, S34);
     d.z = __builtin_amdgcn_perm(g3, g3, S12); d.w = __builtin_amdgcn_perm(s.next, g3, S34);
-    char* p = lds + slot * V1_ROWB + ch * 32;
+    char* p = lds + slot * ROWB + ch * 32;
     *reinterpret_cast<uint4*>(p) = a;
     *reinterpret_cast<uint4*>(p + 16) = b;
-    *reinterpret_cast<uint4*>(p + V1_PLANE) = c;
-    *reinterpret_cast<uint4*>(p + V1_PLANE + 16) = d;
+    *reinterpret_cast<uint4*>(p + PLANE) = c;
+    *reinterpret_cast<uint4*>(p + PLANE + 16) = d;
 }
 
 // ---------------------------------------------------------------------------
@@ -503,6 +504,41 @@ __device__ __forceinline__ void emit_pyramid_rows(const char* lds, int y, int st
 
 // The body of the kernel for workgroup `bid` of `nwg` of one level (the multi-level launch below runs
 // several levels in one grid).
+// The responses of pixel pair k (0..3) of a lane's aligned 8-pixel group out of its window registers: rows -5, +5,
+// -4, +4 of plane P0 (pairs that start at an even pixel), rows -2, +2 and the centre row of plane P1 (pairs that
+// start at an odd pixel), 12 registers each = pixels x0 - 8 .. x0 + 15, and the centre row's own pairs z0.
+// Returns response + 8192 in each half.
+__device__ __forceinline__ uint32_t response_pair_biased(const uint32_t (&m5)[12], const uint32_t (&p5)[12],
+                                                         const uint32_t (&m4)[12], const uint32_t (&p4)[12],
+                                                         const uint32_t (&m2)[12], const uint32_t (&p2)[12],
+                                                         const uint32_t (&z1)[12], const uint32_t (&z0)[4], int k) {
+    const int c = 4 + k;
+    // quadruples (a,b,c,d) = (s[i], s[i+4], s[i+8], s[i+12]); ring offsets from ChESS.c:68-83
+    const uint32_t a0 = m5[c + 1], c0 = p5[c - 1], b0 = m2[c - 3], d0 = p2[c + 2];
+    const uint32_t a1 = m5[c], c1 = p5[c], b1 = z1[c - 3], d1 = z1[c + 2];
+    const uint32_t a2 = m5[c - 1], c2 = p5[c + 1], b2 = p2[c - 3], d2 = m2[c + 2];
+    const uint32_t a3 = m4[c - 2], c3 = p4[c + 2], b3 = p4[c - 2], d3 = m4[c + 2];
+    // Both pixels of a pair sit in one register and no half ever overflows or borrows, so
+    // every add / subtract below is a plain 32-bit op (2-cycle issue class on gfx950; the
+    // packed 16-bit forms are 4).  Only the twelve maxima need v_pk_max_u16.
+    const uint32_t t10 = a0 + c0, t20 = b0 + d0, t11 = a1 + c1, t21 = b1 + d1;
+    const uint32_t t12 = a2 + c2, t22 = b2 + d2, t13 = a3 + c3, t23 = b3 + d3;
+    const uint32_t M = ((t10 + t20) + (t11 + t21)) + ((t12 + t22) + (t13 + t23));
+    // Y carries a +4096 bias per half so that Y - X (>= -2040) stays positive
+    const uint32_t Yb = ((pk_max_u16(t10, t20) + pk_max_u16(t11, t21)) +
+                         (pk_max_u16(t12, t22) + pk_max_u16(t13, t23))) + 0x10001000u;
+    const uint32_t X = ((pk_max_u16(a0, c0) + pk_max_u16(b0, d0)) + (pk_max_u16(a1, c1) + pk_max_u16(b1, d1))) +
+                       ((pk_max_u16(a2, c2) + pk_max_u16(b2, d2)) + (pk_max_u16(a3, c3) + pk_max_u16(b3, d3)));
+    // local_mean = (I[x-1]+I[x]+I[x+1])*16/3, truncating (ChESS.c:86): floor(16n/3) = (n*349536)>>16, n <= 765
+    const uint32_t n = z1[c - 1] + z0[k] + z1[c];
+    const uint32_t lm_lo = __umul24(n & 0xffffu, 349536u);
+    const uint32_t lm_hi = __umul24(n >> 16, 349536u);
+    const uint32_t LM = __builtin_amdgcn_perm(lm_hi, lm_lo, 0x07060302u);
+    const uint32_t dev = pk_max_u16(M, LM) - pk_min_u16(M, LM);  // |M - LM| per half
+    const uint32_t d1x = Yb - X;
+    return (d1x + d1x) - dev;  // halves = response + 8192, in [2072, 10232]  (ChESS.c:104)
+}
+
 template <bool CLAMP, bool HOT, int STAGE, bool PYR = false>
 __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTables& t, int frame0, int seg, unsigned bid,
                                               unsigned nwg_level, char* lds, const PyramidOut* po = nullptr) {
@@ -657,31 +693,7 @@ __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTa
         uint32_t out[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int c = 4 + k;
-            // quadruples (a,b,c,d) = (s[i], s[i+4], s[i+8], s[i+12]); ring offsets from ChESS.c:68-83
-            const uint32_t a0 = m5[c + 1], c0 = p5[c - 1], b0 = m2[c - 3], d0 = p2[c + 2];
-            const uint32_t a1 = m5[c], c1 = p5[c], b1 = z1[c - 3], d1 = z1[c + 2];
-            const uint32_t a2 = m5[c - 1], c2 = p5[c + 1], b2 = p2[c - 3], d2 = m2[c + 2];
-            const uint32_t a3 = m4[c - 2], c3 = p4[c + 2], b3 = p4[c - 2], d3 = m4[c + 2];
-            // Both pixels of a pair sit in one register and no half ever overflows or borrows, so
-            // every add / subtract below is a plain 32-bit op (2-cycle issue class on gfx950; the
-            // packed 16-bit forms are 4).  Only the twelve maxima need v_pk_max_u16.
-            const uint32_t t10 = a0 + c0, t20 = b0 + d0, t11 = a1 + c1, t21 = b1 + d1;
-            const uint32_t t12 = a2 + c2, t22 = b2 + d2, t13 = a3 + c3, t23 = b3 + d3;
-            const uint32_t M = ((t10 + t20) + (t11 + t21)) + ((t12 + t22) + (t13 + t23));
-            // Y carries a +4096 bias per half so that Y - X (>= -2040) stays positive
-            const uint32_t Yb = ((pk_max_u16(t10, t20) + pk_max_u16(t11, t21)) +
-                                 (pk_max_u16(t12, t22) + pk_max_u16(t13, t23))) + 0x10001000u;
-            const uint32_t X = ((pk_max_u16(a0, c0) + pk_max_u16(b0, d0)) + (pk_max_u16(a1, c1) + pk_max_u16(b1, d1))) +
-                               ((pk_max_u16(a2, c2) + pk_max_u16(b2, d2)) + (pk_max_u16(a3, c3) + pk_max_u16(b3, d3)));
-            // local_mean = (I[x-1]+I[x]+I[x+1])*16/3, truncating (ChESS.c:86): floor(16n/3) = (n*349536)>>16, n <= 765
-            const uint32_t n = z1[c - 1] + z0[k] + z1[c];
-            const uint32_t lm_lo = __umul24(n & 0xffffu, 349536u);
-            const uint32_t lm_hi = __umul24(n >> 16, 349536u);
-            const uint32_t LM = __builtin_amdgcn_perm(lm_hi, lm_lo, 0x07060302u);
-            const uint32_t dev = pk_max_u16(M, LM) - pk_min_u16(M, LM);  // |M - LM| per half
-            const uint32_t d1x = Yb - X;
-            const uint32_t P = (d1x + d1x) - dev;  // halves = response + 8192, in [2072, 10232]  (ChESS.c:104)
+            const uint32_t P = response_pair_biased(m5, p5, m4, p4, m2, p2, z1, z0, k);
             if (CLAMP) out[k] = pk_sub_sat_u16(P, xmask[k]);  // max(r, 0), 0 in the frame columns
             else out[k] = pk_sub_i16(P, 0x20002000u) & xmask[k];
         }
@@ -758,6 +770,107 @@ __global__ __launch_bounds__(256) void chess_v1_kernel(LevelBatch lb, CompTables
 __global__ __launch_bounds__(256, 4) void chess_v1_pyr_kernel(LevelBatch lb, CompTables t, int seg, PyramidOut po) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     chess_v1_body<true, true, STAGE_PERM16, true>(lb, t, 0, seg, blockIdx.x, gridDim.x, lds, &po);
+}
+
+// ---------------------------------------------------------------------------
+// Sparse refinement, step 2: the clamped response -- and the hot list -- in a LIST OF CELLS of a level instead of
+// the whole level (api.hip, option "sparse_refine"): the refinement of ~100 known points only ever looks at the
+// response around them, and computing it for the other 99 % of the frame is what the dense schedule spends its
+// time on.  Cells are squares of 2^cs pixels (cs >= 4) on the grid that starts at pixel (0, 0), listed per frame
+// by sparse_cells_kernel (cc.hip).  The unit of work is a 16 x 16 MICRO-TILE -- a cell is 4^(cs-4) of them --
+// computed by a half-wave with the window layout and the arithmetic of the production kernel above (two planes of
+// packed pixel pairs; a lane owns an aligned group of 8 pixels of one row: 2 lanes per row, 16 rows).  A
+// workgroup is ONE wave (two micro-tiles per pass, nothing to synchronise with) and takes micro-tile pairs
+// blockIdx.x, + gridDim.x, ... of its frame.  Everything outside the listed cells of the response buffer is
+// STALE: the refinement kernel knows (WinSel::dense_valid).
+// ---------------------------------------------------------------------------
+constexpr int VC_T = 16;                     // micro-tile edge
+constexpr int VC_ROWS = VC_T + 10;           // window rows: 5 above, 5 below
+constexpr int VC_ROWB = 96;                  // bytes per window row and plane: 32 pixels (x - 8 .. x + 23) as pairs (64) + 32, so
+                                             // that the rows of 8 consecutive lanes (4 rows) sit 8 banks apart
+constexpr int VC_PLANE = VC_ROWS * VC_ROWB;  // 2496
+constexpr int VC_TILEB = 2 * VC_PLANE;       // 4992 per micro-tile
+__global__ __launch_bounds__(64) void chess_cells_kernel(LevelBatch lb, CompTables t, const uint32_t* cell_list,
+                                                         const int32_t* cell_cnt, int list_pitch, int frame0) {
+    __shared__ __attribute__((aligned(16))) char lds_all[2 * VC_TILEB];
+    const int frame = frame0 + blockIdx.y;
+    const int w = lb.w, h = lb.h, stride = lb.img_stride;
+    const uint8_t* img = lb.img + (long long)frame * lb.img_pitch;
+    int16_t* resp = lb.resp + (long long)frame * lb.resp_pitch;
+    const uint32_t* list = cell_list + (long long)frame * list_pitch;
+    const int lane = threadIdx.x, half = lane >> 5, hl = lane & 31, lx = hl & 1, trow = hl >> 1;
+    const int ncell = min(cell_cnt[2 * frame], list_pitch), cs = cell_cnt[2 * frame + 1];
+    if (ncell <= 0 || cs < 4) return;
+    const int sub = cs - 4, nitems = ncell << (2 * sub);  // micro-tiles of the frame (<= sparse_mask_items(t): sparse_cells_kernel)
+    uint8_t* masks = reinterpret_cast<uint8_t*>(t.gidx + (long long)frame * t.gidx_pitch);
+    char* lds = lds_all + half * VC_TILEB;
+    const char* lane_base = lds + 16 * lx + (trow + 5) * VC_ROWB;  // D[-4] of the lane's centre row
+    for (int it0 = 2 * blockIdx.x; it0 < nitems; it0 += 2 * gridDim.x) {
+        const int it = it0 + half;
+        const bool have = it < nitems;
+        const uint32_t c = list[min(it, nitems - 1) >> (2 * sub)];
+        const int si = it & ((1 << (2 * sub)) - 1);  // micro-tile within the cell, row-major
+        const int xt = ((int)(c & 0xffffu) << cs) + VC_T * (si & ((1 << sub) - 1));
+        const int yt = ((int)(c >> 16) << cs) + VC_T * (si >> sub);
+        __syncthreads();  // (one wave: orders the LDS reads of the pass before against these writes)
+        for (int task = hl; task < VC_ROWS * 2; task += 32) {
+            const int row = task >> 1, ch = task & 1;
+            const StageRegs sr = stage_load(img, stride, w, h, yt - 5 + row, xt - 8 + 16 * ch);
+            stage_store<VC_ROWB, VC_PLANE>(lds, row, ch, sr);
+        }
+        __syncthreads();
+        uint32_t m5[12], p5[12], m4[12], p4[12], m2[12], p2[12], z1[12];
+        load12(m5, lane_base - 5 * VC_ROWB);
+        load12(p5, lane_base + 5 * VC_ROWB);
+        load12(m4, lane_base - 4 * VC_ROWB);
+        load12(p4, lane_base + 4 * VC_ROWB);
+        load12(m2, lane_base - 2 * VC_ROWB + VC_PLANE);
+        load12(p2, lane_base + 2 * VC_ROWB + VC_PLANE);
+        load12(z1, lane_base + VC_PLANE);
+        const u32x4 z0v = lds_read_b128(lane_base + 16);
+        const uint32_t z0[4] = {z0v.x, z0v.y, z0v.z, z0v.w};
+        const int x0 = xt + 8 * lx, yy = yt + trow;
+        const bool rowin = yy >= kMargin && yy < h - kMargin;
+        uint32_t out[4], bits = 0;
+#pragma unroll
+        for (int k = 3; k >= 0; --k) {
+            const int xa = x0 + 2 * k, xb = xa + 1;
+            const bool ina = rowin && xa >= kMargin && xa < w - kMargin, inb = rowin && xb >= kMargin && xb < w - kMargin;
+            const uint32_t xmask = (ina ? 0x2000u : 0xffffu) | (inb ? 0x20000000u : 0xffff0000u);
+            // one saturating subtraction strips the bias, clamps at 0 and zeroes the 7-pixel frame
+            out[k] = pk_sub_sat_u16(response_pair_biased(m5, p5, m4, p4, m2, p2, z1, z0, k), xmask);
+            uint32_t m;  // both halves to 0 / 1, then to their bit positions (as in the production kernel)
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(out[k] & 0xfff0fff0u), "v"(0x00010001u));
+            bits = dot2_u32_u16(m, (1u << (2 * k)) | (2u << (2 * k + 16)), bits);
+        }
+        if (have && yy < h && x0 < w) {
+            int16_t* dst = resp + (long long)yy * w + x0;
+            if (x0 + 8 <= w) {
+                const u32x4 v = {out[0], out[1], out[2], out[3]};
+                __builtin_memcpy(dst, &v, 16);
+            } else {
+                for (int i = 0; i < w - x0; ++i) dst[i] = (int16_t)(out[i >> 1] >> (16 * (i & 1)));
+            }
+        } else {
+            bits = 0;
+        }
+        // which pixels are hot: 32 bytes per micro-tile (byte = a lane's 8 pixels, 2 bytes per row), in the frame's part
+        // of the pixel -> list-index map (used by the global-memory kernels only, which never see a sparse level).
+        // NOT appended to the hot list here: an atomic per wave on the frame's counter -- one address for workgroups on
+        // all eight XCDs -- costs 0.3 us and they serialise (80 us per launch, whatever else the kernel did); the
+        // refinement kernel, one workgroup per frame, expands the masks itself (cc.hip, hot_list_from_masks).
+        if (have) masks[(long long)it * 32 + hl] = (uint8_t)bits;
+    }
+}
+
+void launch_chess_cells(const LevelBatch& lb, const CompTables& t, const uint32_t* cell_list, const int32_t* cell_cnt,
+                        int list_pitch, int frame0, int nframes, hipStream_t s) {
+    if (nframes <= 0 || lb.w <= 0 || lb.h <= 0) return;
+    // a frame has a few hundred micro-tiles and each is a chain of dependent round trips (list -> pixels -> counter):
+    // one pair per workgroup where the grid allows it (an idle workgroup costs two loads)
+    int per_frame = nframes >= 32768 ? 1 : (32768 + nframes - 1) / nframes;
+    if (per_frame > 512) per_frame = 512;
+    hipLaunchKernelGGL(chess_cells_kernel, dim3(per_frame, nframes), dim3(64), 0, s, lb, t, cell_list, cell_cnt, list_pitch, frame0);
 }
 
 // Several pyramid levels of the same batch in ONE grid (clamp + hot list, widths that are multiples

@@ -74,7 +74,7 @@ struct Cand {
     int32_t pad;
 };
 
-enum : int { kStatusHotOverflow = 1, kStatusCandOverflow = 2 };
+enum : int { kStatusHotOverflow = 1, kStatusCandOverflow = 2, kStatusSparse = 4 };  // (bits 8.. of a hot overflow: the demand)
 constexpr uint32_t kHotDead = 0xffffffffu;       // hot list slot that holds no pixel
 constexpr uint32_t kHotSingleton = 0x80000000u;  // flag in hot_xy[]: the pixel has no hot 4-neighbour
 

@@ -18,6 +18,10 @@ void launch_chess_v0(const LevelBatch& lb, const CompTables& t, int frame0, int 
 void launch_chess(const LevelBatch& lb, const CompTables& t, int frame0, int nframes, bool clamp, bool hot,
                   hipStream_t s);
 
+// sparse refinement: the response + hot list in a per-frame list of cells only (cells listed by launch_sparse_cells, cc.hip)
+void launch_chess_cells(const LevelBatch& lb, const CompTables& t, const uint32_t* cell_list, const int32_t* cell_cnt,
+                        int list_pitch, int frame0, int nframes, hipStream_t s);
+
 // level 0 of a chain with the level images 1..3 produced by the same kernel (out of its LDS ring)
 bool chess_pyramid_ok(const LevelBatch& lb, int nframes);
 bool launch_chess_pyramid(const LevelBatch& lb, const CompTables& t, const PyramidOut& po, int nframes, hipStream_t s);
@@ -81,6 +85,10 @@ struct RefineIO {
     int32_t* nseeds;
     uint32_t* seeds;         // [nframes*pitch*9]
     int32_t* sroot;          // [nframes*pitch*9] root of each seed's super-component
+    // sparse refinement (lds_path bit kLdsPathSparse): the cells whose response was computed (sparse_cells_kernel)
+    const uint32_t* cell_list = nullptr;  // [nframes*list_pitch]
+    const int32_t* cell_cnt = nullptr;    // [nframes*2]: count, log2 cell size
+    int list_pitch = 0;
 };
 void launch_hot_from_response(const int16_t* src, const LevelBatch& lb, const CompTables& t, int frame0, int nframes,
                               hipStream_t s);
@@ -88,6 +96,11 @@ void launch_cc_detect(const LevelBatch& lb, const CompTables& t, int level, cons
                       int nframes, hipStream_t s);
 void launch_cc_refine(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io, int frame0,
                       int nframes, hipStream_t s);
+// sparse refinement: the cells (squares of 32 pixels; larger above 41.9 MP per level) around the points to refine at
+// `level`, per frame: cell_list[frame * list_pitch + k], k < cell_cnt[frame]
+void launch_sparse_cells(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io, uint32_t* cell_list,
+                         int32_t* cell_cnt, int list_pitch, int frame0, int nframes, hipStream_t s);
+constexpr int kLdsPathSparse = 1024;  // CompTables::lds_path bit: the dense response only holds those cells
 
 
 }  // namespace mrg

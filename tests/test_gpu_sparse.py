@@ -1,0 +1,128 @@
+"""Option "sparse_refine": chain() with the response of the levels below the start level computed only in the
+cells around the points (include/mrgingham_amd.h).  The bar is the same as for the dense schedule: identical
+doubles, identical levels, identical order -- against the dense schedule on every frame, against the oracle on a
+sample -- and a frame the sparse kernels cannot take must be REPORTED (MRGINGHAM_AMD_ERR_SPARSE), never answered
+differently."""
+import numpy as np
+import pytest
+import torch
+
+import mrgingham_amd
+from mrgingham_amd import synth
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair():
+    dense, sparse = mrgingham_amd.Detector(0), mrgingham_amd.Detector(0)
+    sparse.set_option("sparse_refine", 1)
+    return dense, sparse
+
+
+def _same(a, b):
+    pa, la, na = [t.cpu().numpy() for t in a]
+    pb, lb, nb = [t.cpu().numpy() for t in b]
+    assert np.array_equal(na, nb)
+    for f in range(len(na)):
+        n = int(na[f])
+        assert np.array_equal(la[f, :n], lb[f, :n]), f
+        assert np.array_equal(pa[f, :n], pb[f, :n]), f        # identical doubles
+
+
+@pytest.mark.parametrize("W,H,B,gridn,start", [
+    (640, 480, 8, 10, 3), (1024, 768, 8, 10, 3), (1024, 768, 4, 10, 2), (1024, 768, 4, 10, 1),
+    (1001, 777, 4, 8, 3), (1920, 1080, 4, 10, 3), (4096, 3072, 4, 10, 3), (4096, 3072, 4, 14, 3),
+    (2048, 1536, 2, 10, 4),
+])
+def test_sparse_chain_is_the_dense_chain(W, H, B, gridn, start):
+    dense, sparse = _pair()
+    try:
+        frames = synth.board_batch(B, W, H, gridn=gridn, seed0=300, device="cuda")
+        want = dense.chain(frames, start, 1024)
+        got = sparse.chain(frames, start, 1024, retry=False)   # (no fallback: the sparse kernels themselves)
+        _same(want, got)
+        assert int(want[2].min()) >= gridn * gridn // 2
+        wp, wl = oracle.chain(frames[1].cpu().numpy(), start)  # and the oracle on one frame
+        n = int(got[2][1])
+        assert n == len(wp) and np.array_equal(got[1][1, :n].cpu().numpy(), wl)
+        assert np.array_equal(got[0][1, :n].cpu().numpy(), wp)
+    finally:
+        dense.close(); sparse.close()
+
+
+def test_sparse_chain_on_textured_frames():
+    dense, sparse = _pair()
+    try:
+        frames = synth.cluttered_board_batch(3, 4096, 3072, 10, 7, device="cuda")
+        want = dense.chain(frames, 3, 1024)
+        got = sparse.chain(frames, 3, 1024)                    # (with the fallback: whatever happens, the same answer)
+        _same(want, got)
+    finally:
+        dense.close(); sparse.close()
+
+
+def test_sparse_chain_pipelined_steps_stay_identical():
+    """Calls in flight share the cell lists and masks of a scratch set: 12 steps without a sync in between, two
+    batches alternating, every step's output compared."""
+    dense, sparse = _pair()
+    try:
+        fa = synth.board_batch(8, 1024, 768, 10, 0, device="cuda")
+        fb = synth.board_batch(8, 1024, 768, 10, 50, device="cuda")
+        wa, wb = dense.chain(fa, 3, 512), dense.chain(fb, 3, 512)
+        outs = []
+        for i in range(12):
+            out = tuple(torch.empty_like(t) for t in wa)
+            sparse.chain(fa if i % 2 == 0 else fb, 3, 512, out=out, sync=False)
+            outs.append(out)
+        sparse.sync()
+        for i, out in enumerate(outs):
+            _same(wa if i % 2 == 0 else wb, out)
+    finally:
+        dense.close(); sparse.close()
+
+
+def test_a_frame_the_sparse_kernels_cannot_take_is_reported_and_the_fallback_answers():
+    """White noise over the board: at level 0 the blobs of the corners run into the noise around them and out of
+    the cells that were computed."""
+    dense, sparse = _pair()
+    try:
+        b = synth.board_batch(2, 1024, 768, 10, 5, device="cuda").to(torch.int64)
+        nz = torch.stack([synth.noise_frame(1024, 768, seed=9 + s, device="cuda") for s in range(2)]).to(torch.int64)
+        frames = (b + (nz - 128) * 80 // 255).clamp(0, 255).to(torch.uint8)
+        want = dense.chain(frames, 3, 2048)
+        assert int(want[2].min()) >= 100
+        with pytest.raises(RuntimeError) as e:
+            sparse.chain(frames, 3, 2048, retry=False)
+        assert e.value.code == mrgingham_amd.Detector.ERR_SPARSE
+        got = sparse.chain(frames, 3, 2048)                    # retry=True: the call is made again, dense
+        _same(want, got)
+        good = synth.board_batch(2, 1024, 768, 10, 9, device="cuda")
+        _same(dense.chain(good, 3, 512), sparse.chain(good, 3, 512, retry=False))   # and the context still works, sparse
+    finally:
+        dense.close(); sparse.close()
+
+
+def test_more_points_than_the_sparse_kernels_take():
+    """576 corners (the LDS refinement takes 512): reported, and the fallback gives the dense answer."""
+    dense, sparse = _pair()
+    try:
+        frames = synth.board_batch(2, 2048, 1536, 24, 3, device="cuda")
+        want = dense.chain(frames, 1, 2048)
+        assert int(want[2].min()) >= 576
+        _same(want, sparse.chain(frames, 1, 2048))
+        ok = synth.board_batch(2, 2048, 1536, 22, 3, device="cuda")    # 484: taken
+        _same(dense.chain(ok, 1, 2048), sparse.chain(ok, 1, 2048, retry=False))
+    finally:
+        dense.close(); sparse.close()
+
+
+def test_sparse_chain_frames_without_points_and_start_level_zero():
+    dense, sparse = _pair()
+    try:
+        frames = torch.full((3, 480, 640), 128, dtype=torch.uint8, device="cuda")
+        frames[2] = synth.board_frame(640, 480, 10, 2, device="cuda")
+        _same(dense.chain(frames, 3, 256), sparse.chain(frames, 3, 256, retry=False))
+        _same(dense.chain(frames, 0, 256), sparse.chain(frames, 0, 256, retry=False))   # nothing below level 0: the dense schedule
+    finally:
+        dense.close(); sparse.close()
