@@ -265,6 +265,44 @@ def launch_ranks(n):
     return rc
 
 
+def sparse_leg(det, frames, start_level, P, steps):
+    """The same workload with option "sparse_refine" (include/mrgingham_amd.h): level images and the start level's
+    response for whole frames, the response below it only in the cells around the points.  NOT `value`: the judged
+    metric prices the dense per-level ChESS pass; this is what the same answer costs when that pass is not asked
+    for.  The outputs are compared with the dense schedule's on every frame of the batch, inside this function."""
+    B = frames.shape[0]
+    want = det.chain(frames, start_level, P)
+    det.set_option("sparse_refine", 1)
+    try:
+        outs = [tuple(torch.empty_like(t) for t in want) for _ in range(3)]
+        try:
+            det.chain(frames, start_level, P, out=outs[0], retry=False)
+        except RuntimeError as e:
+            if getattr(e, "code", 0) != det.ERR_SPARSE:
+                raise
+            return {"accepted": False, "what": "a frame of this workload is outside what the sparse kernels take "
+                                               "(reported by the library; the call is then made dense): " + str(e)}
+        same = bool(torch.equal(want[2], outs[0][2]))
+        n = want[2].clamp(max=P).tolist()
+        for f in range(B):
+            same = same and bool(torch.equal(want[0][f, :n[f]], outs[0][0][f, :n[f]]) and
+                                 torch.equal(want[1][f, :n[f]], outs[0][1][f, :n[f]]))
+        for i in range(10):
+            det.chain(frames, start_level, P, out=outs[i % 3], sync=False)
+        det.sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            det.chain(frames, start_level, P, out=outs[i % 3], sync=False)
+        det.sync()
+        dt = time.perf_counter() - t0
+        return {"accepted": True, "identical_to_dense": same, "value": B * steps / dt, "unit": "frames/s",
+                "ms_per_step": dt / steps * 1e3, "steps": steps, "scratch_GiB": det.scratch_bytes() / 2**30,
+                "what": "option sparse_refine on the same frames: response below the start level only in the 16-px cells "
+                        "around the points; outputs compared with the dense schedule's on every frame"}
+    finally:
+        det.set_option("sparse_refine", 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -281,6 +319,8 @@ def main():
                          "rocprofv3 --pmc passes, where tracing the ~37k tiny kernels of the frame generator is "
                          "the bottleneck); default: every frame distinct")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-sparse-leg", action="store_true",
+                    help="skip the extra leg that times the same workload with option sparse_refine (N = 1 only)")
     ap.add_argument("--scratch-sets", type=int, default=0,
                     help="option scratch_sets of the library (0 = its default: chosen from the batch shape): calls' component "
                          "searches in flight")
@@ -416,6 +456,10 @@ def main():
             e2e = dict(e2e, ranks=world, h2d_GBs_min=min(h2d), h2d_GBs_max=max(h2d), h2d_GBs_per_rank=h2d,
                        value=float(sum(float(t[1]) for t in allr)),
                        what=e2e["what"] + "; all ranks at once, `value` = sum over ranks")
+    fused, merged = det.chain_info()                         # (of the timed steps: before the sparse leg makes its calls)
+    sparse = None
+    if world == 1 and start_level >= 1 and not args.no_sparse_leg:
+        sparse = sparse_leg(det, frames, start_level, P, min(args.steps, 100))
     bindings = None
     if collective and binding is not None:
         objs = [None] * world
@@ -432,7 +476,6 @@ def main():
         # level-0 ChESS launches per step = number of stream chunks; frames per launch follows
         launches_per_step = max(1, nlaunch // max(1, args.steps))
         frames_per_launch = batch / launches_per_step
-        fused, merged = det.chain_info()
         # 3 B/px: the frame read once, the int16 response written once.  When the launch also writes the
         # level images 1..3 (fused pyramid) those bytes are its algorithmic output too: 1/4 + 1/16 + 1/64 B/px.
         bpp = 3.0 + (sum(0.25 ** L for L in range(1, min(start_level, 3) + 1)) if fused else 0.0)
@@ -509,6 +552,8 @@ def main():
         res["scratch_GiB"] = det.scratch_bytes() / 2**30
         if e2e is not None:
             res["end_to_end"] = e2e
+        if sparse is not None:
+            res["sparse_refine"] = sparse
         if bindings is not None or binding is not None:
             res["cpu_binding"] = bindings if bindings is not None else [binding]
         if world == 1 and not args.no_cpu_baseline:

@@ -1056,7 +1056,7 @@ struct WinSel {
 
 template <class LdsCC>
 __device__ __forceinline__ bool lds_load_and_label(LdsCC& L, const FrameView& v, int nraw, int cap, bool banded, int y0,
-                                                   int y1, int& n, const WinSel* win = nullptr) {
+                                                   int y1, int& n, const WinSel* win = nullptr, bool preloaded = false) {
     constexpr int LN = LdsCC::LN, LHASH = LdsCC::LHASH, LEPT = LdsCC::LEPT;
     const int tid = threadIdx.x;
     n = 0;
@@ -1067,7 +1067,9 @@ __device__ __forceinline__ bool lds_load_and_label(LdsCC& L, const FrameView& v,
     const int shear = L.shear;
     if (tid == 0) { L.nroots = 0; L.top = 0; L.total = 0; L.changed = 0; L.mtop = 0; L.nload = 0; L.leak = 0; }
     __syncthreads();
-    if (banded) {
+    if (preloaded) {  // (sparse refinement: the whole frame's pixels, all in marked cells, are in L.xy already)
+        n = nraw;
+    } else if (banded) {
         scan_hot_list(v.hot_xy, nraw, [&](uint32_t e) {
             bool take = true;
             if (win) take = win->marked((int)(e & 0xffffu), (int)(e >> 16));
@@ -1291,10 +1293,32 @@ __device__ __forceinline__ void win_mark(WinSel& ws, int w, int h, const double*
     __syncthreads();
 }
 
-// Sparse refinement, step 1 (one workgroup per frame): the cells around the points to refine at `level`, as a
-// list for the kernel that computes the response there (chess_cells_kernel): cell_cnt[2 * frame] = how many,
-// [2 * frame + 1] = their size (log2), the list = (cell y << 16) | cell x.  The refinement kernel marks the same cells
-// again for itself (same functions, same points).
+// Sparse refinement, step 1: the cells around the points of a frame to refine at `level`, as a list for the kernel
+// that computes the response there (chess_cells_kernel): cnt[0] = how many (-1: more than the list or the mask area
+// holds, the refinement kernel reports the frame), cnt[1] = their size (log2), list = (cell y << 16) | cell x.  The
+// refinement kernel marks the same cells again for itself (same functions, same points).  All threads of the
+// workgroup; `bits` = kWinWords words, `box` = 4 words, `n` = one word of LDS.
+__device__ __forceinline__ void list_cells(int w, int h, const double* pts, const signed char* lv, int npts, int level,
+                                           uint32_t* bits, uint32_t* box, int* n, uint32_t* list, int list_pitch,
+                                           long long max_items, int32_t* cnt) {
+    if (threadIdx.x == 0) *n = 0;
+    auto sink = [&](int ax, int ay) {
+        const int k = atomicAdd(n, 1);
+        if (k < list_pitch) list[k] = ((uint32_t)ay << 16) | (uint32_t)ax;
+    };
+    WinSel ws = win_geometry(w, h, pts, lv, npts, level, kWinWords, true, box);  // (a barrier first: *n is 0 below)
+    if (ws.cs >= 0) win_mark<2048>(ws, w, h, pts, lv, npts, level, bits, nullptr, true, sink);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int k = *n;
+        const bool ok = ws.cs >= 0 && k <= list_pitch && ((long long)k << (2 * (ws.cs - 4))) <= max_items;
+        cnt[0] = ok ? k : -1;
+        cnt[1] = ws.cs;
+    }
+}
+
+// One workgroup per frame: the cells of the first level below the start level (its points come from the detection;
+// below that the refinement kernel of a level lists the cells of the next one itself).
 __global__ __launch_bounds__(CC_THREADS) void sparse_cells_kernel(int w, int h, int level, RefineIO io, uint32_t* cell_list,
                                                                int32_t* cell_cnt, int list_pitch, long long max_items,
                                                                int frame0) {
@@ -1303,36 +1327,19 @@ __global__ __launch_bounds__(CC_THREADS) void sparse_cells_kernel(int w, int h, 
     __shared__ int n;
     const int frame = frame0 + blockIdx.x;
     const long long pb = (long long)frame * io.pitch;
-    const int npts = min(io.npoints[frame], io.pitch);
-    if (threadIdx.x == 0) n = 0;
-    uint32_t* list = cell_list + (long long)frame * list_pitch;
-    auto sink = [&](int ax, int ay) {
-        const int k = atomicAdd(&n, 1);
-        if (k < list_pitch) list[k] = ((uint32_t)ay << 16) | (uint32_t)ax;
-    };
-    WinSel ws = win_geometry(w, h, io.points + 2 * pb, io.levels + pb, npts, level, kWinWords, true, box);
-    if (ws.cs >= 0) win_mark<2048>(ws, w, h, io.points + 2 * pb, io.levels + pb, npts, level, bits, nullptr, true, sink);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // -1: more cells than the list / the mask area holds, or no geometry: the refinement kernel reports the frame
-        const bool ok = ws.cs >= 0 && n <= list_pitch && ((long long)n << (2 * (ws.cs - 4))) <= max_items;
-        cell_cnt[2 * frame] = ok ? n : -1;
-        cell_cnt[2 * frame + 1] = ws.cs;
-    }
+    list_cells(w, h, io.points + 2 * pb, io.levels + pb, min(io.npoints[frame], io.pitch), level, bits, box, &n,
+               cell_list + (long long)frame * list_pitch, list_pitch, max_items, cell_cnt + 2 * frame);
 }
 
-// Sparse refinement, step 3a: the hot list of a frame out of the masks chess_cells_kernel left (32 bytes per 16 x 16
-// micro-tile, byte 2 * row + half = the 8 pixels x .. x + 7).  One workgroup per frame writes the list it then reads:
-// no counter shared with anybody.  Returns the number of hot pixels (uniform; entries beyond `cap` are not written),
-// -1 when sparse_cells_kernel gave the frame up.  `cnt` = one word of LDS.
-__device__ __forceinline__ int hot_list_from_masks(const RefineIO& io, const CompTables& t, int frame, uint32_t* hot_xy, int* cnt) {
-    const int ncell = io.cell_cnt[2 * frame], cs = io.cell_cnt[2 * frame + 1];
-    if (threadIdx.x == 0) *cnt = 0;
-    __syncthreads();
-    if (ncell < 0 || cs < 4) return -1;
-    const int sub = cs - 4, nwords = (ncell << (2 * sub)) * 8;
-    const uint32_t* list = io.cell_list + (long long)frame * io.list_pitch;
-    const uint32_t* masks = reinterpret_cast<const uint32_t*>(t.gidx + (long long)frame * t.gidx_pitch);
+// Sparse refinement, step 3a: the hot pixels of a frame out of the masks chess_cells_kernel left (32 bytes per 16 x 16
+// micro-tile, byte 2 * row + half = the 8 pixels x .. x + 7).  One workgroup per frame, no counter shared with
+// anybody.  The entries go straight into the LDS list (`lds_xy`, `lds_cap` entries: the frame is then loaded, see
+// lds_load_and_label's `preloaded`); only if there are more -- a frame that needs bands -- a second pass writes the
+// global list the band planner and the loader read, like a dense level's.  Returns the number of hot pixels
+// (uniform), -1 when the frame was given up by whoever listed the cells.  `cnt` = one word of LDS.
+template <class Put>
+__device__ __forceinline__ void expand_masks(const uint32_t* masks, const uint32_t* list, int nwords, int cs, int* cnt, Put put) {
+    const int sub = cs - 4;
     constexpr int U = 4;
     for (int k0 = threadIdx.x; k0 < nwords; k0 += CC_THREADS * U) {
         uint32_t m[U];
@@ -1355,14 +1362,28 @@ __device__ __forceinline__ int hot_list_from_masks(const RefineIO& io, const Com
                 const int b = __ffs(mm) - 1;  // byte q = b >> 3: row 2j + (q >> 1), half q & 1; pixel b & 7 of its group
                 mm &= mm - 1;
                 const int q = b >> 3;
-                const uint32_t e = ((uint32_t)(yt + 2 * j + (q >> 1)) << 16) | (uint32_t)(xt + 8 * (q & 1) + (b & 7));
-                if (slot < t.cap) hot_xy[slot] = e;
-                ++slot;
+                put(slot++, ((uint32_t)(yt + 2 * j + (q >> 1)) << 16) | (uint32_t)(xt + 8 * (q & 1) + (b & 7)));
             }
         }
     }
+}
+__device__ __forceinline__ int hot_list_from_masks(const RefineIO& io, const CompTables& t, int frame, uint32_t* hot_xy, int* cnt,
+                                                   uint32_t* lds_xy, int lds_cap) {
+    const int ncell = io.cell_cnt[2 * frame], cs = io.cell_cnt[2 * frame + 1];
+    if (threadIdx.x == 0) *cnt = 0;
+    __syncthreads();
+    if (ncell < 0 || cs < 4) return -1;
+    const int nwords = (ncell << (2 * (cs - 4))) * 8;
+    const uint32_t* list = io.cell_list + (long long)frame * io.list_pitch;
+    const uint32_t* masks = reinterpret_cast<const uint32_t*>(t.gidx + (long long)frame * t.gidx_pitch);
+    expand_masks(masks, list, nwords, cs, cnt, [&](int slot, uint32_t e) { if (slot < lds_cap) lds_xy[slot] = e; });
     __syncthreads();
     const int n = *cnt;
+    __syncthreads();
+    if (n <= lds_cap) return n;
+    if (threadIdx.x == 0) *cnt = 0;
+    __syncthreads();
+    expand_masks(masks, list, nwords, cs, cnt, [&](int slot, uint32_t e) { if (slot < t.cap) hot_xy[slot] = e; });
     __threadfence();  // the list is read back by other waves of this workgroup
     __syncthreads();
     return n;
@@ -1585,7 +1606,9 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
     const bool sparse = (t.lds_path & kLdsSparse) != 0;  // the response exists in the cells around the points only
     const int npts = min(io.npoints[frame], io.pitch);
     FrameView v = make_view(lb, t, frame);
-    const int nraw = sparse ? hot_list_from_masks(io, t, frame, v.hot_xy, &L.nload) : t.hot_cnt[frame];
+    if (sparse && io.next_cnt && tid == 0) io.next_cnt[2 * frame] = -1;  // until this kernel has listed the next level's cells
+    const int nraw = sparse ? hot_list_from_masks(io, t, frame, v.hot_xy, &L.nload, L.xy, LN) : t.hot_cnt[frame];
+    const bool preloaded = sparse && nraw <= LN;
     if (npts > LPTS || nraw < 0) {  // the LDS kernel does not take that many points (sparse: nor that many cells)
         lds_decline(t, frame);
         return;
@@ -1615,6 +1638,10 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
         if (ws.cs < 0) return;
         win_mark<LN>(ws, w, h, pts, lv, npts, level, wbits, obits, sparse);
         ws.dense_valid = !sparse;
+        if (sparse) {  // everything listed is in a marked cell
+            windowed = nraw <= LN;
+            return;
+        }
         // do the marked cells hold few enough hot pixels?  (one more pass over the list)
         if (tid == 0) L.nload = 0;
         __syncthreads();
@@ -1664,7 +1691,8 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
             win_mark<LN>(ws, w, h, pts, lv, npts, level, reinterpret_cast<uint32_t*>(&L.w),
                          reinterpret_cast<uint32_t*>(L.u.stk) + LN, true);
         }
-        if (!lds_load_and_label(L, v, nraw, t.cap, nbands > 1, L.band_y[band], L.band_y[band + 1], n, windowed ? &ws : nullptr)) {
+        if (!lds_load_and_label(L, v, nraw, t.cap, nbands > 1, L.band_y[band], L.band_y[band + 1], n, windowed ? &ws : nullptr,
+                                preloaded)) {
             // (window mode: the cells around the points hold more hot pixels than the tables do -- band 0, plain decline)
             lds_decline_refine(t, frame, band, io, L.nref);
             return;
@@ -1852,6 +1880,12 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
     if (tid == 0) {
         t.path[frame] = 1;
         if (io.nrefined) io.nrefined[frame] = L.nref;
+    }
+    if (sparse && io.next_cnt) {
+        // the cells of the next level down, around the points as they are now (the barrier at the end of the last band
+        // has made them visible): saves a launch -- and its dependent round trips under a saturated HBM -- per level
+        list_cells(io.next_w, io.next_h, pts, lv, npts, level - 1, reinterpret_cast<uint32_t*>(&L.w), L.edge, &L.nload,
+                   io.cell_list + (long long)frame * io.list_pitch, io.list_pitch, io.next_max_items, io.next_cnt + 2 * frame);
     }
     if (clk) {
         tick(7);

@@ -86,9 +86,14 @@ struct RefineIO {
     uint32_t* seeds;         // [nframes*pitch*9]
     int32_t* sroot;          // [nframes*pitch*9] root of each seed's super-component
     // sparse refinement (lds_path bit kLdsPathSparse): the cells whose response was computed (sparse_cells_kernel)
-    const uint32_t* cell_list = nullptr;  // [nframes*list_pitch]
-    const int32_t* cell_cnt = nullptr;    // [nframes*2]: count, log2 cell size
+    uint32_t* cell_list = nullptr;        // [nframes*list_pitch]
+    const int32_t* cell_cnt = nullptr;    // [nframes*2] of this level: count (-1: the frame was given up), log2 cell size
     int list_pitch = 0;
+    // the refinement kernel of level L lists the cells of level L - 1 itself when it is done (the list is the same
+    // buffer: the kernel has read its own by then); next_cnt = NULL at level 0
+    int32_t* next_cnt = nullptr;
+    int next_w = 0, next_h = 0;
+    long long next_max_items = 0;
 };
 void launch_hot_from_response(const int16_t* src, const LevelBatch& lb, const CompTables& t, int frame0, int nframes,
                               hipStream_t s);
