@@ -362,7 +362,7 @@ static int ensure_points(mrgingham_amd_ctx* ctx, int nframes, int pitch) {
         if ((rc = ensure(ctx, ps.cand_counts, (size_t)nframes * 4))) return rc;
         // sparse refinement: at most 4 cells per seed position of a point and 9 of those, of which at most 9 distinct
         if ((rc = ensure(ctx, ps.cell_list, np * kCellsPerPoint * 4))) return rc;
-        if ((rc = ensure(ctx, ps.cell_cnt, (size_t)nframes * 8 * (kMaxLevel + 1)))) return rc;  // per level: count, cell size
+        if ((rc = ensure(ctx, ps.cell_cnt, (size_t)nframes * 4 * kCellHdr * (kMaxLevel + 1)))) return rc;  // per level and frame: the list's header
     }
     ctx->pts_nframes = nframes;
     ctx->pts_pitch = pitch;
@@ -1041,22 +1041,22 @@ int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames
         const int list_pitch = kCellsPerPoint * points_pitch;
         io.cell_list = (uint32_t*)ps.cell_list.p;
         io.list_pitch = list_pitch;
-        int32_t* cnt = (int32_t*)ps.cell_cnt.p;  // [level][frame][2]
+        int32_t* cnt = (int32_t*)ps.cell_cnt.p;  // [level][frame][kCellHdr]
         for (int L = start_level - 1; L >= 0; --L) {
             lbs[L] = level_batch_of(ctx, fr, L);
             CompTables t = tables_of(ctx, L);
             t.lds_path |= kLdsPathSparse;
-            io.cell_cnt = cnt + (size_t)L * fr->nframes * 2;
+            io.cell_cnt = cnt + (size_t)L * fr->nframes * kCellHdr;
             // the cells of this level: listed by the refinement kernel of the level above, by a kernel of its own
             // for the first one (its points come out of the detection)
             if (L == start_level - 1)
-                launch_sparse_cells(lbs[L], t, L, io, io.cell_list, cnt + (size_t)L * fr->nframes * 2, list_pitch, 0,
+                launch_sparse_cells(lbs[L], t, L, io, io.cell_list, cnt + (size_t)L * fr->nframes * kCellHdr, list_pitch, 0,
                                     fr->nframes, cur_cc(ctx));
             launch_chess_cells(lbs[L], t, io.cell_list, io.cell_cnt, list_pitch, 0, fr->nframes, cur_cc(ctx));
             io.next_cnt = nullptr;
             if (L > 0) {
                 const LevelScratch& nx = cur_levels(ctx)[L - 1];
-                io.next_cnt = cnt + (size_t)(L - 1) * fr->nframes * 2;
+                io.next_cnt = cnt + (size_t)(L - 1) * fr->nframes * kCellHdr;
                 io.next_w = nx.w;
                 io.next_h = nx.h;
                 io.next_max_items = tables_of(ctx, L - 1).gidx_pitch / 4;

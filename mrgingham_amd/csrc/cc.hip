@@ -1295,8 +1295,8 @@ __device__ __forceinline__ void win_mark(WinSel& ws, int w, int h, const double*
 
 // Sparse refinement, step 1: the cells around the points of a frame to refine at `level`, as a list for the kernel
 // that computes the response there (chess_cells_kernel): cnt[0] = how many (-1: more than the list or the mask area
-// holds, the refinement kernel reports the frame), cnt[1] = their size (log2), list = (cell y << 16) | cell x.  The
-// refinement kernel marks the same cells again for itself (same functions, same points).  All threads of the
+// holds, the refinement kernel reports the frame), cnt[1] = their size (log2), cnt[2..5] = the span of the bitmap,
+// list = (cell y << 16) | cell x.  The refinement kernel marks exactly the listed cells for itself.  All threads of the
 // workgroup; `bits` = kWinWords words, `box` = 4 words, `n` = one word of LDS.
 __device__ __forceinline__ void list_cells(int w, int h, const double* pts, const signed char* lv, int npts, int level,
                                            uint32_t* bits, uint32_t* box, int* n, uint32_t* list, int list_pitch,
@@ -1314,6 +1314,7 @@ __device__ __forceinline__ void list_cells(int w, int h, const double* pts, cons
         const bool ok = ws.cs >= 0 && k <= list_pitch && ((long long)k << (2 * (ws.cs - 4))) <= max_items;
         cnt[0] = ok ? k : -1;
         cnt[1] = ws.cs;
+        cnt[2] = ws.ox; cnt[3] = ws.oy; cnt[4] = ws.cw; cnt[5] = ws.chh;
     }
 }
 
@@ -1328,7 +1329,7 @@ __global__ __launch_bounds__(CC_THREADS) void sparse_cells_kernel(int w, int h, 
     const int frame = frame0 + blockIdx.x;
     const long long pb = (long long)frame * io.pitch;
     list_cells(w, h, io.points + 2 * pb, io.levels + pb, min(io.npoints[frame], io.pitch), level, bits, box, &n,
-               cell_list + (long long)frame * list_pitch, list_pitch, max_items, cell_cnt + 2 * frame);
+               cell_list + (long long)frame * list_pitch, list_pitch, max_items, cell_cnt + kCellHdr * frame);
 }
 
 // Sparse refinement, step 3a: the hot pixels of a frame out of the masks chess_cells_kernel left (32 bytes per 16 x 16
@@ -1340,7 +1341,7 @@ __global__ __launch_bounds__(CC_THREADS) void sparse_cells_kernel(int w, int h, 
 template <class Put>
 __device__ __forceinline__ void expand_masks(const uint32_t* masks, const uint32_t* list, int nwords, int cs, int* cnt, Put put) {
     const int sub = cs - 4;
-    constexpr int U = 4;
+    constexpr int U = 8;  // (a clean 10x10 board at 16-pixel cells: ~3800 words, two rounds of 256 x 8)
     for (int k0 = threadIdx.x; k0 < nwords; k0 += CC_THREADS * U) {
         uint32_t m[U];
 #pragma unroll
@@ -1367,23 +1368,48 @@ __device__ __forceinline__ void expand_masks(const uint32_t* masks, const uint32
         }
     }
 }
+// the cell bitmap of a frame straight from its list: what is marked IS what was computed
+__device__ __forceinline__ void mark_listed_cells(const WinSel& ws, const uint32_t* list, int ncell, uint32_t* bits,
+                                                  uint32_t* openbits, int nopen_words) {
+    const int nw = (ws.cw * ws.chh + 31) / 32;
+    for (int k = threadIdx.x; k < nw; k += CC_THREADS) bits[k] = 0;
+    for (int k = threadIdx.x; k < nopen_words; k += CC_THREADS) openbits[k] = 0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < ncell; k += CC_THREADS) {
+        const uint32_t c = list[k];
+        const int cx = (int)(c & 0xffffu) - ws.ox, cy = (int)(c >> 16) - ws.oy;
+        if ((unsigned)cx < (unsigned)ws.cw && (unsigned)cy < (unsigned)ws.chh) {
+            const int b = cy * ws.cw + cx;
+            atomicOr(&bits[b >> 5], 1u << (b & 31));
+        }
+    }
+    __syncthreads();
+}
+// -> number of hot pixels (uniform; -1: the frame was given up), `ws` = the selection (cells marked in `bits`)
 __device__ __forceinline__ int hot_list_from_masks(const RefineIO& io, const CompTables& t, int frame, uint32_t* hot_xy, int* cnt,
-                                                   uint32_t* lds_xy, int lds_cap) {
-    const int ncell = io.cell_cnt[2 * frame], cs = io.cell_cnt[2 * frame + 1];
+                                                   uint32_t* lds_xy, int lds_cap, WinSel& ws, uint32_t* bits, uint32_t* openbits,
+                                                   int nopen_words) {
+    const int32_t* hdr = io.cell_cnt + kCellHdr * frame;
+    const int ncell = hdr[0];
+    ws.cs = hdr[1]; ws.ox = hdr[2]; ws.oy = hdr[3]; ws.cw = hdr[4]; ws.chh = hdr[5];
+    ws.bits = bits;
+    ws.openbits = openbits;
+    ws.dense_valid = false;
     if (threadIdx.x == 0) *cnt = 0;
     __syncthreads();
-    if (ncell < 0 || cs < 4) return -1;
-    const int nwords = (ncell << (2 * (cs - 4))) * 8;
+    if (ncell < 0 || ws.cs < 4 || (ws.cw * ws.chh + 31) / 32 > kWinWords) return -1;
+    const int nwords = (ncell << (2 * (ws.cs - 4))) * 8;
     const uint32_t* list = io.cell_list + (long long)frame * io.list_pitch;
     const uint32_t* masks = reinterpret_cast<const uint32_t*>(t.gidx + (long long)frame * t.gidx_pitch);
-    expand_masks(masks, list, nwords, cs, cnt, [&](int slot, uint32_t e) { if (slot < lds_cap) lds_xy[slot] = e; });
+    mark_listed_cells(ws, list, ncell, bits, openbits, nopen_words);
+    expand_masks(masks, list, nwords, ws.cs, cnt, [&](int slot, uint32_t e) { if (slot < lds_cap) lds_xy[slot] = e; });
     __syncthreads();
     const int n = *cnt;
     __syncthreads();
     if (n <= lds_cap) return n;
     if (threadIdx.x == 0) *cnt = 0;
     __syncthreads();
-    expand_masks(masks, list, nwords, cs, cnt, [&](int slot, uint32_t e) { if (slot < t.cap) hot_xy[slot] = e; });
+    expand_masks(masks, list, nwords, ws.cs, cnt, [&](int slot, uint32_t e) { if (slot < t.cap) hot_xy[slot] = e; });
     __threadfence();  // the list is read back by other waves of this workgroup
     __syncthreads();
     return n;
@@ -1606,8 +1632,17 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
     const bool sparse = (t.lds_path & kLdsSparse) != 0;  // the response exists in the cells around the points only
     const int npts = min(io.npoints[frame], io.pitch);
     FrameView v = make_view(lb, t, frame);
-    if (sparse && io.next_cnt && tid == 0) io.next_cnt[2 * frame] = -1;  // until this kernel has listed the next level's cells
-    const int nraw = sparse ? hot_list_from_masks(io, t, frame, v.hot_xy, &L.nload, L.xy, LN) : t.hot_cnt[frame];
+    if (sparse && io.next_cnt && tid == 0) io.next_cnt[kCellHdr * frame] = -1;  // until this kernel has listed the next level's cells
+    // The cell bitmap lives in L.w (dead until the LIFO demands are written), the open flags behind the
+    // accumulators in L.u (dead until the fills).
+    WinSel ws;
+    ws.cs = -1;
+    uint32_t* const wbits = reinterpret_cast<uint32_t*>(&L.w);
+    uint32_t* const obits = reinterpret_cast<uint32_t*>(L.u.stk) + LN;
+    static_assert(sizeof(L.u) >= (size_t)LN * 4 + (size_t)LN / 8, "open flags behind the accumulators");
+    static_assert(sizeof(L.w) / 4 == kWinWords, "list_cells sizes the bitmap for kWinWords");
+    const int nraw = sparse ? hot_list_from_masks(io, t, frame, v.hot_xy, &L.nload, L.xy, LN, ws, wbits, obits, LN / 32)
+                            : t.hot_cnt[frame];
     const bool preloaded = sparse && nraw <= LN;
     if (npts > LPTS || nraw < 0) {  // the LDS kernel does not take that many points (sparse: nor that many cells)
         lds_decline(t, frame);
@@ -1621,27 +1656,15 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
     const bool may_select = nraw <= t.cap && !(nraw > LN && (t.lds_path & 256));
     // More hot pixels than the tables hold: first try to load only the cells around the points (one pass over the
     // list; a textured scene has 10^4 - 10^5 hot pixels of which the refinement needs ~10^3), then bands.
-    // The cell bitmap lives in L.w (dead until the LIFO demands are written), the open flags behind the
-    // accumulators in L.u (dead until the fills).
-    WinSel ws;
-    ws.cs = -1;
-    bool windowed = false;
+    // (sparse refinement: the selection is what was computed, marked above, and every listed pixel is in it)
+    bool windowed = sparse && nraw <= LN;
     // a list only a little longer than the tables is a large board on a flat background (14x14: 2600): every hot
     // pixel is near a point, the cells would hold them all -- bands first there, cells only if no band cut exists
     const bool bands_first = !sparse && nraw <= LN + LN / 2;
     auto try_windows = [&]() {
-        uint32_t* wbits = reinterpret_cast<uint32_t*>(&L.w);
-        uint32_t* obits = reinterpret_cast<uint32_t*>(L.u.stk) + LN;
-        static_assert(sizeof(L.u) >= (size_t)LN * 4 + (size_t)LN / 8, "open flags behind the accumulators");
-        static_assert(sizeof(L.w) / 4 == kWinWords, "sparse_cells_kernel marks with the same cell size");
-        ws = win_geometry(w, h, pts, lv, npts, level, kWinWords, sparse, L.edge);
+        ws = win_geometry(w, h, pts, lv, npts, level, kWinWords, false, L.edge);
         if (ws.cs < 0) return;
-        win_mark<LN>(ws, w, h, pts, lv, npts, level, wbits, obits, sparse);
-        ws.dense_valid = !sparse;
-        if (sparse) {  // everything listed is in a marked cell
-            windowed = nraw <= LN;
-            return;
-        }
+        win_mark<LN>(ws, w, h, pts, lv, npts, level, wbits, obits, false);
         // do the marked cells hold few enough hot pixels?  (one more pass over the list)
         if (tid == 0) L.nload = 0;
         __syncthreads();
@@ -1652,7 +1675,7 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
         windowed = L.nload <= LN;
         __syncthreads();
     };
-    if (may_select && (sparse || (nraw > LN && !bands_first))) try_windows();
+    if (may_select && !sparse && nraw > LN && !bands_first) try_windows();
     if (!windowed && may_select && !sparse) nbands = lds_plan_bands(L, v, nraw);
     if (!windowed && nbands == 0 && may_select && nraw > LN && bands_first) try_windows();
     // sparse refinement, the cells hold more hot pixels than the tables (a 14x14 board at level 1: 3000): bands of the
@@ -1687,9 +1710,7 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
         int n;
         if (win_bands) {
             __syncthreads();
-            // (same cells as the first time -- the geometry stays --, less those of the points refined since)
-            win_mark<LN>(ws, w, h, pts, lv, npts, level, reinterpret_cast<uint32_t*>(&L.w),
-                         reinterpret_cast<uint32_t*>(L.u.stk) + LN, true);
+            mark_listed_cells(ws, io.cell_list + (long long)frame * io.list_pitch, io.cell_cnt[kCellHdr * frame], wbits, obits, LN / 32);
         }
         if (!lds_load_and_label(L, v, nraw, t.cap, nbands > 1, L.band_y[band], L.band_y[band + 1], n, windowed ? &ws : nullptr,
                                 preloaded)) {
@@ -1885,7 +1906,7 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
         // the cells of the next level down, around the points as they are now (the barrier at the end of the last band
         // has made them visible): saves a launch -- and its dependent round trips under a saturated HBM -- per level
         list_cells(io.next_w, io.next_h, pts, lv, npts, level - 1, reinterpret_cast<uint32_t*>(&L.w), L.edge, &L.nload,
-                   io.cell_list + (long long)frame * io.list_pitch, io.list_pitch, io.next_max_items, io.next_cnt + 2 * frame);
+                   io.cell_list + (long long)frame * io.list_pitch, io.list_pitch, io.next_max_items, io.next_cnt + kCellHdr * frame);
     }
     if (clk) {
         tick(7);

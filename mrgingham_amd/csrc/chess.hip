@@ -799,7 +799,7 @@ __global__ __launch_bounds__(64) void chess_cells_kernel(LevelBatch lb, CompTabl
     int16_t* resp = lb.resp + (long long)frame * lb.resp_pitch;
     const uint32_t* list = cell_list + (long long)frame * list_pitch;
     const int lane = threadIdx.x, half = lane >> 5, hl = lane & 31, lx = hl & 1, trow = hl >> 1;
-    const int ncell = min(cell_cnt[2 * frame], list_pitch), cs = cell_cnt[2 * frame + 1];
+    const int ncell = min(cell_cnt[kCellHdr * frame], list_pitch), cs = cell_cnt[kCellHdr * frame + 1];
     if (ncell <= 0 || cs < 4) return;
     const int sub = cs - 4, nitems = ncell << (2 * sub);  // micro-tiles of the frame (<= sparse_mask_items(t): sparse_cells_kernel)
     uint8_t* masks = reinterpret_cast<uint8_t*>(t.gidx + (long long)frame * t.gidx_pitch);

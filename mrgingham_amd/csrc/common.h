@@ -75,6 +75,9 @@ struct Cand {
 };
 
 enum : int { kStatusHotOverflow = 1, kStatusCandOverflow = 2, kStatusSparse = 4 };  // (bits 8.. of a hot overflow: the demand)
+// sparse refinement: words per frame of the cell-list header -- count (-1: the frame was given up), log2 cell size,
+// then the span of the cell bitmap: first cell x, y, cells per row, rows
+constexpr int kCellHdr = 8;
 constexpr uint32_t kHotDead = 0xffffffffu;       // hot list slot that holds no pixel
 constexpr uint32_t kHotSingleton = 0x80000000u;  // flag in hot_xy[]: the pixel has no hot 4-neighbour
 

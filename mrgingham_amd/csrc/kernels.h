@@ -87,7 +87,7 @@ struct RefineIO {
     int32_t* sroot;          // [nframes*pitch*9] root of each seed's super-component
     // sparse refinement (lds_path bit kLdsPathSparse): the cells whose response was computed (sparse_cells_kernel)
     uint32_t* cell_list = nullptr;        // [nframes*list_pitch]
-    const int32_t* cell_cnt = nullptr;    // [nframes*2] of this level: count (-1: the frame was given up), log2 cell size
+    const int32_t* cell_cnt = nullptr;    // [nframes*kCellHdr] of this level (common.h)
     int list_pitch = 0;
     // the refinement kernel of level L lists the cells of level L - 1 itself when it is done (the list is the same
     // buffer: the kernel has read its own by then); next_cnt = NULL at level 0
