@@ -319,6 +319,9 @@ def main():
                          "rocprofv3 --pmc passes, where tracing the ~37k tiny kernels of the frame generator is "
                          "the bottleneck); default: every frame distinct")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--sparse-refine", action="store_true",
+                    help="run the TIMED steps with option sparse_refine (not the judged configuration: `config.sparse_refine` "
+                         "says so, and `roofline` then describes the kernel that reads the frames, pyramid_fast_kernel)")
     ap.add_argument("--no-sparse-leg", action="store_true",
                     help="skip the extra leg that times the same workload with option sparse_refine (N = 1 only)")
     ap.add_argument("--scratch-sets", type=int, default=0,
@@ -380,6 +383,8 @@ def main():
     det = mrgingham_amd.Detector(local_rank)
     if args.scratch_sets:
         det.set_option("scratch_sets", args.scratch_sets)
+    if args.sparse_refine:
+        det.set_option("sparse_refine", 1)
     P = args.max_points
     # Output ring: consecutive steps overlap on the device (step N+1's pixel kernels run while step
     # N's component kernels and gather finish), so a step must not overwrite a predecessor whose
@@ -458,7 +463,7 @@ def main():
                        what=e2e["what"] + "; all ranks at once, `value` = sum over ranks")
     fused, merged = det.chain_info()                         # (of the timed steps: before the sparse leg makes its calls)
     sparse = None
-    if world == 1 and start_level >= 1 and not args.no_sparse_leg:
+    if world == 1 and start_level >= 1 and not args.no_sparse_leg and not args.sparse_refine:
         sparse = sparse_leg(det, frames, start_level, P, min(args.steps, 100))
     bindings = None
     if collective and binding is not None:
@@ -479,6 +484,9 @@ def main():
         # 3 B/px: the frame read once, the int16 response written once.  When the launch also writes the
         # level images 1..3 (fused pyramid) those bytes are its algorithmic output too: 1/4 + 1/16 + 1/64 B/px.
         bpp = 3.0 + (sum(0.25 ** L for L in range(1, min(start_level, 3) + 1)) if fused else 0.0)
+        sparse_step = merged < 0
+        if sparse_step:      # the timed launch is pyramid_fast_kernel: the frame read once, the level images written once
+            bpp = 1.0 + sum(0.25 ** L for L in range(1, min(start_level, 3) + 1))
         alg_bytes = frames_per_launch * W * H * bpp
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         # HBM-side bytes per launch: PMC counters cannot be read from inside this process, so the
@@ -487,7 +495,7 @@ def main():
         traffic, traffic_src = None, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "chess_l0_traffic.json")))
-            if (tj["width"], tj["height"]) == (W, H) and start_level >= 0:
+            if (tj["width"], tj["height"]) == (W, H) and start_level >= 0 and not sparse_step:
                 traffic = tj["bytes_per_pixel"] * frames_per_launch * W * H
                 traffic_src = tj["source"]
         except (OSError, KeyError, ValueError):
@@ -497,7 +505,7 @@ def main():
         valu = None
         try:
             vj = json.load(open(os.path.join(ROOT, "profiles", "chess_l0_valu.json")))
-            if (vj["width"], vj["height"]) == (W, H):
+            if (vj["width"], vj["height"]) == (W, H) and not sparse_step:
                 valu = {"bound": "valu_issue", "frac": vj["valu_issue_frac"], "unit": "fraction of SIMD quad-cycle issue slots "
                         "carrying a VALU instruction (4 waves per SIMD)", "valu_insts_per_512px": vj["valu_insts_per_wave_iteration"],
                         "wave_parked_frac": vj["wait_any_frac"], "source": vj["source"]}
@@ -522,22 +530,27 @@ def main():
                                    f"detect at level {start_level} + refine to level 0, corner lists "
                                    f"{'gathered to rank 0' if collective else 'left on the device'}",
                        "frames_per_gpu": batch, "width": W, "height": H, "gridn": gridn, "background": background,
-                       "start_level": start_level, "parallelism": f"frames sharded x{world}",
+                       "start_level": start_level, "sparse_refine": bool(args.sparse_refine),
+                       "parallelism": f"frames sharded x{world}",
                        "frames_with_full_grid_last_step": found},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "level-0 ChESS response (+clamp +hot-pixel compaction" +
+                         "kernel": "pyramid_fast_kernel (level images 1..3 from the frames; option sparse_refine)" if sparse_step else
+                                   "level-0 ChESS response (+clamp +hot-pixel compaction" +
                                    (" +level images 1..3)" if fused else ")"),
-                         "bytes_model": ("%.4f B/px (u8 read once + int16 written once + u8 level images 1..3 "
+                         "bytes_model": ("%.4f B/px (u8 read once + u8 level images written once)" % bpp) if sparse_step else
+                                        ("%.4f B/px (u8 read once + int16 written once + u8 level images 1..3 "
                                          "written once)" % bpp) if fused else
                                         "3 B/px (u8 read once + int16 written once)",
                          "bytes_per_launch": alg_bytes, "avg_launch_ms": kern_ms,
                          # the same launch on SURVEY.md 8d's two other ways of counting: its ChESS-pass model alone
                          # (3 B/px, as if the level images were free), and what the unfused schedule moves for the same
                          # outputs (ChESS pass 3 B/px + decimation pass 1 B/px read + the level images written)
-                         "frac_3Bpx_chess_pass_model": (frames_per_launch * W * H * 3.0 / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                         "frac_3Bpx_chess_pass_model": None if sparse_step else
+                                                       (frames_per_launch * W * H * 3.0 / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
                                                        if kern_ms > 0 else 0.0,
-                         "frac_two_pass_equivalent": (frames_per_launch * W * H * (bpp + (1.0 if fused else 0.0)) /
+                         "frac_two_pass_equivalent": None if sparse_step else
+                                                     (frames_per_launch * W * H * (bpp + (1.0 if fused else 0.0)) /
                                                       (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kern_ms > 0 else 0.0,
                          "launches_timed": nlaunch, "binding": valu},
         }

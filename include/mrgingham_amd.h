@@ -308,7 +308,8 @@ long long mrgingham_amd_scratch_bytes(const mrgingham_amd_ctx* ctx);
 /* How the most recent mrgingham_amd_chain_batch call was launched (for benchmarks that price the level-0
  * kernel): *fused_pyramid = 1 when the level-0 response kernel also wrote the level images 1..3 (frames of
  * whole 16 x 8 blocks, option "fuse_pyramid"), 0 when a separate pyramid kernel did; *merged_levels = number
- * of levels whose responses shared one launch (0 = one launch per level).  Either pointer may be NULL. */
+ * of levels whose responses shared one launch (0 = one launch per level; -1 = the call ran with option
+ * "sparse_refine", where the timed launch is the one that writes the level images).  Either pointer may be NULL. */
 int mrgingham_amd_chain_info(const mrgingham_amd_ctx* ctx, int* fused_pyramid, int* merged_levels);
 
 /* Tunables outside the reference's surface.  Known names:

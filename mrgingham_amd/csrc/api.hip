@@ -1022,20 +1022,26 @@ int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames
         // exactly those hot pixels (window mode with WinSel::dense_valid = false).  A frame the LDS kernel cannot take
         // (a blob that reaches the edge of its cells, > 512 points, > 2048 hot pixels in the cells) is REPORTED
         // (MRGINGHAM_AMD_ERR_SPARSE at the sync): nothing else could finish it without the dense response.
-        queue_level_images(ctx, fr, start_level, true);
+        // what is timed in this mode (mrgingham_amd_chess_kernel_ms): the kernel that reads the frames, i.e. the launch
+        // that writes the level images (the dominant kernel of a sparse step; 1 B/px read + 0.328 B/px written)
         hipEvent_t e0 = nullptr;
-        lbs[start_level] = level_batch_of(ctx, fr, start_level);
-        if (ctx->timing) {  // what is timed in this mode: the dense launch of the start level
+        if (ctx->timing) {
             e0 = timing_event(ctx);
             hipEventRecord(e0, ctx->pix);
         }
+        queue_level_images(ctx, fr, start_level, true);
+        if (e0) {
+            hipEvent_t em = timing_event(ctx);
+            hipEventRecord(em, ctx->pix);
+            ctx->events.emplace_back(e0, em);
+        }
+        lbs[start_level] = level_batch_of(ctx, fr, start_level);
         launch_chess_any(ctx, lbs[start_level], tables_of(ctx, start_level), fr->nframes, true, true, ctx->pix, false);
-        hipEvent_t e1 = ctx->timing ? timing_event(ctx) : ctx->ev_pix[start_level];
+        hipEvent_t e1 = ctx->ev_pix[start_level];
         hipEventRecord(e1, ctx->pix);
-        if (e0) ctx->events.emplace_back(e0, e1);
         note_pending(start_level);
         ctx->last_fused = 0;
-        ctx->last_merged = 0;
+        ctx->last_merged = -1;  // (mrgingham_amd_chain_info: a sparse step)
         MRG_HIP_CHECK(hipStreamWaitEvent(cur_cc(ctx), e1, 0));
         launch_cc_detect(lbs[start_level], tables_of(ctx, start_level), start_level, out, 0, fr->nframes, cur_cc(ctx));
         const int list_pitch = kCellsPerPoint * points_pitch;

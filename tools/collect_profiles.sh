@@ -34,14 +34,19 @@ timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace_clut -o t -- python $
 timeout 600 python $R/bench.py --workload c3_cluttered --no-cpu-baseline --no-end-to-end > $OUT/bench_cluttered.json 2> $OUT/bench_cluttered.err
 timeout 900 python $R/bench.py --workload c4_4096x3072_shard256 --force-gather --bind-numa --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_c4.json 2> $OUT/bench_c4.err
 timeout 600 python $R/bench.py --workload c3_4096x3072_14x14_chain --no-cpu-baseline --no-end-to-end > $OUT/bench_14x14.json 2> $OUT/bench_14x14.err
+# 4d. option sparse_refine as the timed schedule: kernel trace at 64 frames, bench lines at 64 and 256 frames
+timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace_sparse -o t -- python $R/bench.py --sparse-refine --steps 40 --warmup 5 --no-cpu-baseline --no-end-to-end > $OUT/trace_sparse_bench.json 2> $OUT/trace_sparse.err
+timeout 600 python $R/bench.py --sparse-refine --no-cpu-baseline --no-end-to-end > $OUT/bench_sparse.json 2> $OUT/bench_sparse.err
+timeout 900 python $R/bench.py --sparse-refine --workload c4_4096x3072_shard256 --steps 50 --warmup 5 --no-cpu-baseline --no-end-to-end > $OUT/bench_sparse_c4.json 2> $OUT/bench_sparse_c4.err
 # 5. preprocessing kernels (row (f)-2)
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/pre -o t -- python $R/tools/preprocess_bench.py > $OUT/prebench.txt 2> $OUT/pre.err
 # summaries on the box (the raw rocprofv3 output is too big to travel back), then drop the raw files
 python $R/tools/rocprof_summary.py $OUT/trace/t_results.db > $OUT/bench_kernel_trace.txt 2>> $OUT/trace.err
 python $R/tools/rocprof_summary.py $OUT/pre/t_results.db > $OUT/preprocess_kernel_trace.txt 2>> $OUT/pre.err
 python $R/tools/rocprof_summary.py $OUT/trace_clut/t_results.db > $OUT/cluttered_kernel_trace.txt 2>> $OUT/trace_clut.err
+python $R/tools/rocprof_summary.py $OUT/trace_sparse/t_results.db > $OUT/sparse_kernel_trace.txt 2>> $OUT/trace_sparse.err
 for d in pmc_rd pmc_wr pmc_fetch pmc_write pmc_sq1 pmc_sq2 pmc_sqp1 pmc_sqp2; do
     python $R/tools/pmc_summary.py $OUT/$d/p_counter_collection.csv > $OUT/$d.txt 2>> $OUT/$d.err
 done
-rm -rf $OUT/trace $OUT/pre $OUT/trace_clut $OUT/pmc_rd $OUT/pmc_wr $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sqp1 $OUT/pmc_sqp2
+rm -rf $OUT/trace $OUT/pre $OUT/trace_clut $OUT/trace_sparse $OUT/pmc_rd $OUT/pmc_wr $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sqp1 $OUT/pmc_sqp2
 ls -la $OUT

@@ -94,6 +94,8 @@ if os.path.exists(os.path.join(R, "pmc_sqp1.txt")):
 for n, out in [("cluttered_kernel_trace.txt", f"{RND}_cluttered_kernel_trace.txt")]:
     if os.path.exists(os.path.join(R, n)):
         open(os.path.join(P, out), "w").write("# rocprofv3 --kernel-trace --stats -- python bench.py --workload c3_cluttered --steps 40 --warmup 5 --no-cpu-baseline --no-end-to-end\n" + strip(rd(n)))
-for n in ("bench_cluttered.json", "bench_c4.json", "bench_14x14.json"):
+if os.path.exists(os.path.join(R, "sparse_kernel_trace.txt")):
+    open(os.path.join(P, f"{RND}_sparse_kernel_trace.txt"), "w").write("# rocprofv3 --kernel-trace --stats -- python bench.py --sparse-refine --steps 40 --warmup 5 --no-cpu-baseline --no-end-to-end\n" + strip(rd("sparse_kernel_trace.txt")))
+for n in ("bench_cluttered.json", "bench_c4.json", "bench_14x14.json", "bench_sparse.json", "bench_sparse_c4.json"):
     if os.path.exists(os.path.join(R, n)) and rd(n).strip():
         open(os.path.join(P, f"{RND}_{n}"), "w").write(rd(n))
