@@ -34,6 +34,8 @@ def _same(a, b):
     (640, 480, 8, 10, 3), (1024, 768, 8, 10, 3), (1024, 768, 4, 10, 2), (1024, 768, 4, 10, 1),
     (1001, 777, 4, 8, 3), (1920, 1080, 4, 10, 3), (4096, 3072, 4, 10, 3), (4096, 3072, 4, 14, 3),
     (2048, 1536, 2, 10, 4),
+    (4608, 4608, 2, 10, 3),      # the box around the points has > 40 960 cells of 16 px: cells of 32 (4 micro-tiles each)
+    (8192, 8192, 1, 12, 3),      # ... and of 64 (16 micro-tiles each)
 ])
 def test_sparse_chain_is_the_dense_chain(W, H, B, gridn, start):
     dense, sparse = _pair()
@@ -43,10 +45,11 @@ def test_sparse_chain_is_the_dense_chain(W, H, B, gridn, start):
         got = sparse.chain(frames, start, 1024, retry=False)   # (no fallback: the sparse kernels themselves)
         _same(want, got)
         assert int(want[2].min()) >= gridn * gridn // 2
-        wp, wl = oracle.chain(frames[1].cpu().numpy(), start)  # and the oracle on one frame
-        n = int(got[2][1])
-        assert n == len(wp) and np.array_equal(got[1][1, :n].cpu().numpy(), wl)
-        assert np.array_equal(got[0][1, :n].cpu().numpy(), wp)
+        f = B - 1
+        wp, wl = oracle.chain(frames[f].cpu().numpy(), start)  # and the oracle on one frame
+        n = int(got[2][f])
+        assert n == len(wp) and np.array_equal(got[1][f, :n].cpu().numpy(), wl)
+        assert np.array_equal(got[0][f, :n].cpu().numpy(), wp)
     finally:
         dense.close(); sparse.close()
 
