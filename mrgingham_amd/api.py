@@ -243,6 +243,7 @@ class Detector:
         self.ctx = self.L.mrgingham_amd_create(self.device.index)
         if not self.ctx:
             raise RuntimeError("mrgingham_amd_create failed")
+        self._options = {}
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -258,6 +259,8 @@ class Detector:
     def set_option(self, name, value):
         if self.L.mrgingham_amd_set_option(self.ctx, name.encode(), int(value)) != 0:
             raise ValueError(f"bad option {name}={value}")
+        if name == "sparse_refine" and int(value) != 0:
+            self._options[name] = int(value)     # (what chain() goes back to after a dense repeat)
 
     def _check(self, rc):
         if rc != 0:
@@ -414,7 +417,7 @@ class Detector:
                 try:
                     self._sync_retrying(issue, retry)
                 finally:
-                    self.set_option("sparse_refine", 1)
+                    self.set_option("sparse_refine", self._options.get("sparse_refine", 1))
         else:
             issue()
         return pts, lv, npts

@@ -343,6 +343,7 @@ static int ensure_level(mrgingham_amd_ctx* ctx, int level, int nframes, int W, i
     return rc;
 }
 
+constexpr long long kSparsePaysPixels = 96ll << 20;  // option "sparse_refine" 1: calls with at least this many frame pixels
 constexpr int kCellsPerPoint = 9;  // sparse refinement: distinct cells the 3 x 3 seeds of one point can mark (2 x 2 each, one pixel apart)
 // Per-call point scratch shared by the levels (the component kernels of the levels of one call
 // run one after the other on that call's component stream); one copy per scratch set.
@@ -706,7 +707,11 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
         return rc;
     }
     if (!strcmp(name, "fuse_pyramid")) { ctx->fuse_pyramid = value != 0; return 0; }
-    if (!strcmp(name, "sparse_refine")) { ctx->sparse_refine = value != 0; return 0; }
+    if (!strcmp(name, "sparse_refine")) {
+        if (value < 0 || value > 2) return MRGINGHAM_AMD_ERR_ARG;
+        ctx->sparse_refine = value;
+        return 0;
+    }
     if (!strcmp(name, "cc_lds")) {
         // 0 / 1 and the test hook 256 (no banding, no windows: every result is still exact); the timing ablations
         // (bits 2, 4, 8, 16, 128) and the phase clock (512) exist in -DMRG_EXPERIMENT builds only
@@ -1013,7 +1018,10 @@ int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames
     auto note_pending = [&](int L) {
         if (fr->nframes > ctx->pending_frames[ctx->cur][L]) ctx->pending_frames[ctx->cur][L] = fr->nframes;
     };
-    if (ctx->sparse_refine && start_level >= 1 && !ctx->use_v0 && ctx->cc_lds) {
+    // (1 = where it pays: the dense response of a small call is cheaper than the longer chain -- measured crossover
+    // at 80-100 Mpx per call, e.g. 64 x 1280x960 or 8 x 4096x3072; 2 = always)
+    const bool sparse_pays = ctx->sparse_refine == 2 || (long long)fr->width * fr->height * fr->nframes >= kSparsePaysPixels;
+    if (ctx->sparse_refine && sparse_pays && start_level >= 1 && !ctx->use_v0 && ctx->cc_lds) {
         // SPARSE REFINEMENT.  The dense schedule computes the response of levels start-1 .. 0 for whole frames and then
         // looks at it around ~100 points.  Here: every level image in one pass over the frames (pyramid kernel; the
         // variance windows need them around any peak), the dense response only at the START level (its detection needs

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 def _pair():
     dense, sparse = mrgingham_amd.Detector(0), mrgingham_amd.Detector(0)
-    sparse.set_option("sparse_refine", 1)
+    sparse.set_option("sparse_refine", 2)      # 2: always (1 would leave the small test frames to the dense schedule)
     return dense, sparse
 
 
@@ -129,3 +129,20 @@ def test_sparse_chain_frames_without_points_and_start_level_zero():
         _same(dense.chain(frames, 0, 256), sparse.chain(frames, 0, 256, retry=False))   # nothing below level 0: the dense schedule
     finally:
         dense.close(); sparse.close()
+
+
+def test_sparse_refine_1_leaves_small_calls_to_the_dense_schedule():
+    """Option value 1: sparse only where it pays (>= 96 Mi frame pixels per call); chain_info says which ran."""
+    det = mrgingham_amd.Detector(0)
+    try:
+        det.set_option("sparse_refine", 1)
+        small = synth.board_batch(4, 1024, 768, 10, 0, device="cuda")
+        det.chain(small, 3, 256)
+        assert det.chain_info()[1] >= 0                        # dense
+        big = synth.board_batch(8, 4096, 3072, 10, 0, device="cuda")
+        det.chain(big, 3, 256)
+        assert det.chain_info()[1] == -1                       # sparse
+        with pytest.raises(ValueError):
+            det.set_option("sparse_refine", 3)
+    finally:
+        det.close()

@@ -25,7 +25,7 @@ for (W, H, B, gridn, sets) in ((4096, 3072, 64, 10, 2), (4096, 3072, 64, 14, 3),
         p, l, n = det.chain(fr, 3, P)
         refs.append((p.clone(), l.clone(), n.clone()))
     if sparse:
-        det.set_option("sparse_refine", 1)
+        det.set_option("sparse_refine", 2)
     outs = [(torch.empty((B, P, 2), dtype=torch.float64, device='cuda'), torch.empty((B, P), dtype=torch.int8, device='cuda'),
              torch.empty((B,), dtype=torch.int32, device='cuda')) for _ in range(4)]
     bad = torch.zeros(1, dtype=torch.int32, device='cuda')

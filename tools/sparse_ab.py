@@ -13,7 +13,7 @@ def run(W, H, B, gridn, clutter, steps=30):
     res = {}
     for mode in (0, 1):
         det = Detector(0)
-        det.set_option("sparse_refine", mode)
+        det.set_option("sparse_refine", 2 * mode)
         try:
             out = det.chain(frames, 3, 1024, retry=False)
         except RuntimeError as e:

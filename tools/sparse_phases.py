@@ -9,7 +9,7 @@ mode = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 frames = synth.board_batch(8, 4096, 3072, 10, 0, device="cuda").repeat(8, 1, 1).contiguous()
 det = mrgingham_amd.Detector(0)
 det.set_option("cc_lds", 1 | 512)
-det.set_option("sparse_refine", mode)
+det.set_option("sparse_refine", 2 * mode)
 names = ["plan (sparse: masks -> list, cells)", "load + label", "R1 seeds", "R2 groups", "R3 demand + neighbour table", "R4 fills", "rest"]
 for rep in range(3):
     det.chain(frames, 3, 1024)
