@@ -1027,7 +1027,7 @@ int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames
         // variance windows need them around any peak), the dense response only at the START level (its detection needs
         // every component), and below it, level by level on the component stream: list the cells around the points
         // (sparse_cells_kernel) -> response + hot list in those cells (chess_cells_kernel) -> refinement out of LDS on
-        // exactly those hot pixels (window mode with WinSel::dense_valid = false).  A frame the LDS kernel cannot take
+        // exactly those hot pixels (window mode, `marked<BOXED = true>`).  A frame the LDS kernel cannot take
         // (a blob that reaches the edge of its cells, > 512 points, > 2048 hot pixels in the cells) is REPORTED
         // (MRGINGHAM_AMD_ERR_SPARSE at the sync): nothing else could finish it without the dense response.
         // what is timed in this mode (mrgingham_amd_chess_kernel_ms): the kernel that reads the frames, i.e. the launch

@@ -1044,17 +1044,26 @@ struct WinSel {
     uint32_t* openbits;    // LDS, LN bits
     int cs;                // cells of 2^cs pixels, on the grid that starts at pixel (0, 0); -1: no selection
     int ox, oy, cw, chh;   // the bitmap covers cells ox .. ox + cw - 1, oy .. oy + chh - 1 (nothing outside is marked)
-    bool dense_valid;      // false (sparse refinement): the dense response only holds the marked cells, a neighbour in
-                           // an unmarked cell is taken to be hot
+    // BOXED = false: the bitmap spans the frame from cell (0, 0) (the dense schedule's selection): no bounds to check,
+    // and the kernel that only ever asks this way does not keep the span in registers.  BOXED = true is a level of a
+    // sparse chain: the dense response only holds the marked cells, and a neighbour in an unmarked cell is taken to be
+    // hot.  (A template parameter, not a flag in here: as a run-time flag in the two scans over a textured frame's 6e4
+    // hot pixels it cost the dense schedule 95 us per refinement launch.)
+    template <bool BOXED>
     __device__ __forceinline__ bool marked(int x, int y) const {
-        const int cx = (x >> cs) - ox, cy = (y >> cs) - oy;
-        if ((unsigned)cx >= (unsigned)cw || (unsigned)cy >= (unsigned)chh) return false;
-        const int c = cy * cw + cx;
+        int c;
+        if (!BOXED) {
+            c = (y >> cs) * cw + (x >> cs);
+        } else {
+            const int cx = (x >> cs) - ox, cy = (y >> cs) - oy;
+            if ((unsigned)cx >= (unsigned)cw || (unsigned)cy >= (unsigned)chh) return false;
+            c = cy * cw + cx;
+        }
         return (bits[c >> 5] >> (c & 31)) & 1u;
     }
 };
 
-template <class LdsCC>
+template <bool BOXED = false, class LdsCC>
 __device__ __forceinline__ bool lds_load_and_label(LdsCC& L, const FrameView& v, int nraw, int cap, bool banded, int y0,
                                                    int y1, int& n, const WinSel* win = nullptr, bool preloaded = false) {
     constexpr int LN = LdsCC::LN, LHASH = LdsCC::LHASH, LEPT = LdsCC::LEPT;
@@ -1072,8 +1081,9 @@ __device__ __forceinline__ bool lds_load_and_label(LdsCC& L, const FrameView& v,
     } else if (banded) {
         scan_hot_list(v.hot_xy, nraw, [&](uint32_t e) {
             bool take = true;
-            if (win) take = win->marked((int)(e & 0xffffu), (int)(e >> 16));
-            if (!win || y1 > y0) {  // (cells AND a band: sparse refinement of a frame whose cells hold more than the tables)
+            if (win) take = win->template marked<BOXED>((int)(e & 0xffffu), (int)(e >> 16));
+            // (BOXED: cells AND a band for a frame of a sparse level whose cells hold more than the tables)
+            if (!win || (BOXED && y1 > y0)) {
                 const int y = band_key(e, shear, w);
                 take = take && y >= y0 && y < y1;
             }
@@ -1182,8 +1192,8 @@ __device__ __forceinline__ bool lds_load_and_label(LdsCC& L, const FrameView& v,
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int nx = x + (q == 0) - (q == 1), ny = y + (q == 2) - (q == 3);
-                if (nb[q] == kNoNb && nx >= 0 && nx < w && ny >= 0 && ny < v.h && !win->marked(nx, ny) &&
-                    (!win->dense_valid || v.d[ny * w + nx] > kRespMin))
+                if (nb[q] == kNoNb && nx >= 0 && nx < w && ny >= 0 && ny < v.h && !win->template marked<BOXED>(nx, ny) &&
+                    (BOXED || v.d[ny * w + nx] > kRespMin))  // (BOXED: a sparse level, nothing computed there -- taken to be hot)
                     open = true;
             }
             if (open) {
@@ -1224,7 +1234,6 @@ __device__ __forceinline__ WinSel win_geometry(int w, int h, const double* pts, 
     WinSel ws;
     ws.bits = nullptr;
     ws.openbits = nullptr;
-    ws.dense_valid = true;
     int x0 = 0, y0 = 0, x1 = w - 1, y1 = h - 1;  // pixels the marked cells can reach
     if (TIGHT) {
         if (threadIdx.x < 4) box[threadIdx.x] = (threadIdx.x & 1) ? 0u : 0xffffffffu;  // min x, max x, min y, max y
@@ -1282,7 +1291,7 @@ __device__ __forceinline__ void win_mark(WinSel& ws, int w, int h, const double*
             const int ay1 = TIGHT ? (sy + half) >> ws.cs : (sy >> ws.cs) + 1;
             for (int ay = ay0; ay <= ay1; ++ay)
                 for (int ax = ax0; ax <= ax1; ++ax) {
-                    const int cx = ax - ws.ox, cy = ay - ws.oy;
+                    const int cx = TIGHT ? ax - ws.ox : ax, cy = TIGHT ? ay - ws.oy : ay;  // (not TIGHT: the span starts at cell (0, 0))
                     if ((unsigned)cx >= (unsigned)ws.cw || (unsigned)cy >= (unsigned)ws.chh) continue;
                     const int c = cy * ws.cw + cx;
                     const uint32_t bit = 1u << (c & 31);
@@ -1394,7 +1403,6 @@ __device__ __forceinline__ int hot_list_from_masks(const RefineIO& io, const Com
     ws.cs = hdr[1]; ws.ox = hdr[2]; ws.oy = hdr[3]; ws.cw = hdr[4]; ws.chh = hdr[5];
     ws.bits = bits;
     ws.openbits = openbits;
-    ws.dense_valid = false;
     if (threadIdx.x == 0) *cnt = 0;
     __syncthreads();
     if (ncell < 0 || ws.cs < 4 || (ws.cw * ws.chh + 31) / 32 > kWinWords) return -1;
@@ -1614,7 +1622,9 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_detect_lds_kernel(LevelBatch
     emit_detect_outputs(v, keys, nvalid, level, out, frame);
 }
 
-template <int N>
+// SPARSE: the instantiation behind a level of a sparse chain (kLdsPathSparse).  Two kernels, so that what the sparse
+// schedule adds (mask expansion, the next level's cell list) costs the dense one neither registers nor spills.
+template <int N, bool SPARSE>
 __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch lb, CompTables t, int level,
                                                                    RefineIO io, int frame0) {
     using LdsCC = LdsCCT<N>;
@@ -1629,7 +1639,7 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
     long long* tk = reinterpret_cast<long long*>(io.sroot);  // (scratch of the global-memory kernel, unused here)
     auto tick = [&](int k) { if (clk) tk[k] = wall_clock64(); };
     tick(0);
-    const bool sparse = (t.lds_path & kLdsSparse) != 0;  // the response exists in the cells around the points only
+    constexpr bool sparse = SPARSE;  // the response exists in the cells around the points only
     const int npts = min(io.npoints[frame], io.pitch);
     FrameView v = make_view(lb, t, frame);
     if (sparse && io.next_cnt && tid == 0) io.next_cnt[kCellHdr * frame] = -1;  // until this kernel has listed the next level's cells
@@ -1669,7 +1679,7 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
         if (tid == 0) L.nload = 0;
         __syncthreads();
         int cnt = 0;
-        scan_hot_list(v.hot_xy, nraw, [&](uint32_t e) { cnt += ws.marked((int)(e & 0xffffu), (int)(e >> 16)); });
+        scan_hot_list(v.hot_xy, nraw, [&](uint32_t e) { cnt += ws.template marked<false>((int)(e & 0xffffu), (int)(e >> 16)); });
         if (cnt) atomicAdd(&L.nload, cnt);
         __syncthreads();
         windowed = L.nload <= LN;
@@ -1712,8 +1722,8 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
             __syncthreads();
             mark_listed_cells(ws, io.cell_list + (long long)frame * io.list_pitch, io.cell_cnt[kCellHdr * frame], wbits, obits, LN / 32);
         }
-        if (!lds_load_and_label(L, v, nraw, t.cap, nbands > 1, L.band_y[band], L.band_y[band + 1], n, windowed ? &ws : nullptr,
-                                preloaded)) {
+        if (!lds_load_and_label<SPARSE>(L, v, nraw, t.cap, nbands > 1, L.band_y[band], L.band_y[band + 1], n,
+                                        windowed ? &ws : nullptr, preloaded)) {
             // (window mode: the cells around the points hold more hot pixels than the tables do -- band 0, plain decline)
             lds_decline_refine(t, frame, band, io, L.nref);
             return;
@@ -1946,7 +1956,8 @@ void launch_sparse_cells(const LevelBatch& lb, const CompTables& t, int level, c
 void launch_cc_refine_lds(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io, int frame0,
                           int nframes, hipStream_t s) {
     if (!t.lds_path || nframes <= 0) return;
-    launch_lds<2048>(cc_refine_lds_kernel<2048>, nframes, s, lb, t, level, io, frame0);
+    if (t.lds_path & kLdsPathSparse) launch_lds<2048>(cc_refine_lds_kernel<2048, true>, nframes, s, lb, t, level, io, frame0);
+    else launch_lds<2048>(cc_refine_lds_kernel<2048, false>, nframes, s, lb, t, level, io, frame0);
 }
 
 }  // namespace mrg

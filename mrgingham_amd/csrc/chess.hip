@@ -782,7 +782,7 @@ __global__ __launch_bounds__(256, 4) void chess_v1_pyr_kernel(LevelBatch lb, Com
 // packed pixel pairs; a lane owns an aligned group of 8 pixels of one row: 2 lanes per row, 16 rows).  A
 // workgroup is ONE wave (two micro-tiles per pass, nothing to synchronise with) and takes micro-tile pairs
 // blockIdx.x, + gridDim.x, ... of its frame.  Everything outside the listed cells of the response buffer is
-// STALE: the refinement kernel knows (WinSel::dense_valid).
+// STALE: the refinement kernel knows (its SPARSE instantiation, WinSel::marked<true>).
 // ---------------------------------------------------------------------------
 constexpr int VC_T = 16;                     // micro-tile edge
 constexpr int VC_ROWS = VC_T + 10;           // window rows: 5 above, 5 below

@@ -10,7 +10,8 @@ serial = int(sys.argv[9]) if len(sys.argv) > 9 else 0      # 1: wait for every s
 dev = torch.device("cuda:0")
 frames = (synth.cluttered_board_batch if clutter else synth.board_batch)(B, W, H, gridn, 0, device=dev)
 det = Detector(0)
-det.set_option("sparse_refine", 2 * mode)       # 2: always, whatever the size of the call
+if mode:
+    det.set_option("sparse_refine", 2 * mode)   # 2: always, whatever the size of the call
 if sets:
     det.set_option("scratch_sets", sets)
 out = det.chain(frames, 3, 1024)
