@@ -462,6 +462,7 @@ def main():
                        value=float(sum(float(t[1]) for t in allr)),
                        what=e2e["what"] + "; all ranks at once, `value` = sum over ranks")
     fused, merged = det.chain_info()                         # (of the timed steps: before the sparse leg makes its calls)
+    scratch_gib = det.scratch_bytes() / 2**30                # (likewise: a context that runs sparse chains keeps a third set)
     sparse = None
     if world == 1 and start_level >= 1 and not args.no_sparse_leg and not args.sparse_refine:
         sparse = sparse_leg(det, frames, start_level, P, min(args.steps, 100))
@@ -562,7 +563,7 @@ def main():
                         "run ~5-7 % below the steady state (clock ramp), which is why `setup_prime_steps` untimed "
                         "set-up passes precede the W warm-up steps; a timed region shorter than ~0.1 s still "
                         "under-reads the steady state slightly")
-        res["scratch_GiB"] = det.scratch_bytes() / 2**30
+        res["scratch_GiB"] = scratch_gib
         if e2e is not None:
             res["end_to_end"] = e2e
         if sparse is not None:

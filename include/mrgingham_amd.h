@@ -318,7 +318,8 @@ int mrgingham_amd_chain_info(const mrgingham_amd_ctx* ctx, int* fused_pyramid, i
  *   "scratch_sets"        how many calls' component searches may be in flight while the pixel kernels of the next call
  *                         run (each set is a full copy of the level scratch): 0 (default) = chosen per batch shape --
  *                         three while three sets stay below 8 GB (small frames, whose search chain is longer than two
- *                         steps of the pixel kernels), two otherwise --, 2 or 3 = fixed.  Synchronises.
+ *                         steps of the pixel kernels; 16 GB once option "sparse_refine" has been on), two otherwise --,
+ *                         2 or 3 = fixed.  Synchronises.
  *   "hot_capacity_shift"  per-frame capacity of the hot-pixel / component tables of a pyramid level is
  *                         (level width * height) >> shift entries, at least 4096 (default 7: 0.35 bytes of tables per
  *                         pixel; 0 = one entry per pixel).  Derived limits at shift > 0: candidates per frame

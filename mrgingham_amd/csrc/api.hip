@@ -143,6 +143,7 @@ struct mrgingham_amd_ctx {
     // option "sparse_refine": chain_batch computes the response of the levels BELOW the start level only in the cells
     // around the points it refines there (chain_batch_sparse)
     int sparse_refine = 0;
+    bool sparse_seen = false;  // the option has been on (choose_sets)
     int fuse_pyramid = 1;   // option "fuse_pyramid": chain calls take the level images 1..3 out of the level-0 response kernel
     // component-chain schedule of chain_batch: 0 = every level's component kernels start as soon as
     // that level's response is done; 1 (default) = levels 1 and 0 wait for the level-0 response (they then
@@ -323,7 +324,10 @@ static int choose_sets(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr) {
     if (ctx->nsets_fixed) return 0;
     const double per_set = 5.0 * (double)fr->nframes * fr->width * fr->height;  // bytes; measured 4.9 per frame pixel at the default table size
     if (per_set > ctx->max_set_bytes) ctx->max_set_bytes = per_set;  // the largest batch so far decides (scratch only grows)
-    const int want = 3.0 * ctx->max_set_bytes <= 8e9 ? 3 : 2;
+    // (a context that has run sparse chains keeps three sets up to 16 GB: their component chain is what limits a step,
+    // (pixel kernels + chain) / sets -- 64 x 4096x3072: 0.47 -> 0.39 ms per step for 11 instead of 7.3 GiB.  Sticky, so
+    // that a dense repeat of one call does not free and reallocate a set.)
+    const int want = 3.0 * ctx->max_set_bytes <= (ctx->sparse_seen ? 16e9 : 8e9) ? 3 : 2;
     if (want == ctx->nsets) return 0;
     const int rc = mrgingham_amd_sync(ctx);
     if (want < ctx->nsets)  // the sets that leave the rotation give their scratch back (a larger batch has arrived)
@@ -710,6 +714,7 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
     if (!strcmp(name, "sparse_refine")) {
         if (value < 0 || value > 2) return MRGINGHAM_AMD_ERR_ARG;
         ctx->sparse_refine = value;
+        if (value) ctx->sparse_seen = true;
         return 0;
     }
     if (!strcmp(name, "cc_lds")) {
