@@ -23,4 +23,6 @@ t0 = time.perf_counter()
 for i in range(steps):
     det.chain(frames, 3, 1024, out=outs[i % 4], sync=bool(serial))
 det.sync()
+same = all(torch.equal(out[2], o[2]) and torch.equal(out[0][:, :64], o[0][:, :64]) for o in outs[1:])
+print("outputs of the steps in flight equal the first call's:", same)
 print(f"sparse={mode} {W}x{H} B={B} gridn={gridn} clutter={clutter} sets={sets}: {(time.perf_counter() - t0) / steps * 1e3:.3f} ms/step")
