@@ -157,7 +157,7 @@ struct mrgingham_amd_ctx {
     int counters_nf = 0;
     struct PointScratch { mrg::DevBuf leader, need, nseeds, seeds, sroot, cand_xy, cand_counts, cell_list, cell_cnt; } pts[kMaxSets];  // per scratch set
     mrg::DevBuf aux_img, io_frame, io_out, io_counts;
-    mrg::DevBuf pre_scratch, pre_tmp, pre_out, pre16_scratch, io_frame16, dbg_img, dbg_resp, blob_scratch;
+    mrg::DevBuf pre_scratch, pre_tmp, pre_out, pre16_scratch, io_frame16, dbg_img, dbg_resp, blob_scratch, blob_nodes, blob_out;
     mrg::DevBuf fb_xy, fb_cnt, fb_pts, fb_lv, fb_np, fb_frames, fb_frames2;  // find_boards_batch: candidates, counts, boards, levels, point counts
     // find_boards_batch's frame-by-frame retries (full-capacity detect, 1-by-1 refine) run on a single-frame
     // context of THIS context's device, created on first use -- not on the calling thread's default context, which
@@ -309,7 +309,7 @@ static std::vector<DevBuf*> all_buffers(mrgingham_amd_ctx* ctx) {
         v.push_back(&ctx->counters2[set]);
     }
     for (DevBuf* b : {&ctx->io_counts, &ctx->aux_img, &ctx->io_frame, &ctx->io_out, &ctx->pre_scratch, &ctx->pre_tmp,
-                      &ctx->pre_out, &ctx->pre16_scratch, &ctx->io_frame16, &ctx->dbg_img, &ctx->dbg_resp, &ctx->blob_scratch,
+                      &ctx->pre_out, &ctx->pre16_scratch, &ctx->io_frame16, &ctx->dbg_img, &ctx->dbg_resp, &ctx->blob_scratch, &ctx->blob_nodes, &ctx->blob_out,
                       &ctx->fb_xy, &ctx->fb_cnt, &ctx->fb_pts, &ctx->fb_lv, &ctx->fb_np, &ctx->fb_frames, &ctx->fb_frames2})
         v.push_back(b);
     return v;
@@ -1446,7 +1446,10 @@ static bool blobs_on_device(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* 
                             std::vector<int32_t>& xy) {
     if (ensure(ctx, ctx->blob_scratch, blob_scratch_bytes(fr->width, fr->height, nullptr))) return false;
     std::string err;
-    if (!blob_detect(fr->frames, fr->stride, h_img, h_stride, fr->width, fr->height, ctx->blob_scratch.p, ctx->pix, xy, err)) {
+    auto nodes = [&](size_t bytes) -> void* { return ensure(ctx, ctx->blob_nodes, bytes) ? nullptr : ctx->blob_nodes.p; };
+    auto outs = [&](size_t bytes) -> void* { return ensure(ctx, ctx->blob_out, bytes) ? nullptr : ctx->blob_out.p; };
+    if (!blob_detect(fr->frames, fr->stride, h_img, h_stride, fr->width, fr->height, ctx->blob_scratch.p, nodes, outs, ctx->pix, xy,
+                     err)) {
         fail(ctx, MRGINGHAM_AMD_ERR_CAPACITY, "%s", err.c_str());
         return false;
     }

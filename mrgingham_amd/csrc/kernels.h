@@ -1,5 +1,6 @@
 // Launchers of the HIP kernels (host side declarations).
 #pragma once
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -55,12 +56,13 @@ bool launch_preprocess16(const uint16_t* frames, long long pitch, int nframes, i
 
 // blobs.hip: cv::SimpleBlobDetector as find_blobs.cc:14-46 configures it (device border following, host filters)
 struct BlobScratchLayout {
-    int wpr, cand_cap, rec_cap, pts_cap;
-    size_t o_counters, o_bits, o_cand, o_recs, o_pts;
+    int wpr;
+    size_t o_counters, o_bits, o_wordpre, o_rowcnt, o_rowoff;
 };
 size_t blob_scratch_bytes(int w, int h, BlobScratchLayout* lay);
 bool blob_detect(const uint8_t* d_img, int d_stride, const uint8_t* h_img, int h_stride, int w, int h, void* scratch,
-                 hipStream_t s, std::vector<int32_t>& xy_out, std::string& err);
+                 const std::function<void*(size_t)>& node_scratch, const std::function<void*(size_t)>& out_scratch, hipStream_t s,
+                 std::vector<int32_t>& xy_out, std::string& err);
 
 // cc.hip
 struct DetectOut {

@@ -115,3 +115,58 @@ def test_cli_blobs(tmp_path):
     assert want is not None and len(rows) == gridn * gridn
     g = np.array([(x, y) for x, y, _ in rows])
     assert np.abs(g - want).max() < 1e-6 and all(lv == 0 for _, _, lv in rows)
+
+
+def _random_scene(rng, h, w):
+    """Random strokes and shapes on a random background: discs, rings, rectangles, one-pixel-wide horizontal /
+    vertical / diagonal lines (borders whose outer-type and hole-type starts coincide), shapes cut by every edge of
+    the frame (the last column included), grey levels on both sides of several thresholds, optional noise."""
+    img = np.full((h, w), rng.choice([40, 120, 200, 250]), np.float64)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for _ in range(rng.randrange(5, 40)):
+        kind = rng.choice(["disc", "ring", "rect", "hline", "vline", "dline", "dot"])
+        v = rng.choice([0, 30, 55, 95, 125, 160, 205, 255])
+        cx, cy = rng.randrange(-5, w + 5), rng.randrange(-5, h + 5)
+        if kind == "disc":
+            img[(xx - cx) ** 2 + (yy - cy) ** 2 <= rng.uniform(1.5, 40) ** 2] = v
+        elif kind == "ring":
+            r = rng.uniform(6, 40)
+            d2 = (xx - cx) ** 2 + (yy - cy) ** 2
+            img[(d2 <= r * r) & (d2 >= (r * rng.uniform(0.3, 0.9)) ** 2)] = v
+        elif kind == "rect":
+            x1, y1 = cx + rng.randrange(1, 120), cy + rng.randrange(1, 120)
+            img[max(cy, 0):max(y1, 0), max(cx, 0):max(x1, 0)] = v
+        elif kind == "hline":
+            if 0 <= cy < h:
+                img[cy, max(cx, 0):max(cx + rng.randrange(2, 200), 0)] = v
+        elif kind == "vline":
+            if 0 <= cx < w:
+                img[max(cy, 0):max(cy + rng.randrange(2, 200), 0), cx] = v
+        elif kind == "dline":
+            n, sgn = rng.randrange(2, 150), rng.choice([-1, 1])
+            for i in range(n):
+                x, y = cx + i, cy + sgn * i
+                if 0 <= x < w and 0 <= y < h:
+                    img[y, x] = v
+        else:
+            if 0 <= cx < w and 0 <= cy < h:
+                img[cy, cx] = v
+    if rng.random() < 0.5:
+        nz = synth.noise_frame(w, h, rng.randrange(1 << 16), smooth=rng.choice([0, 1, 2])).numpy().astype(np.float64)
+        img += (nz - 128) * rng.choice([0.05, 0.2, 0.6])
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def test_random_scenes_against_the_oracle():
+    """Short by default; MRG_FUZZ_ITERS=1500 for the long form (run on the GPU box: 0 mismatches)."""
+    import os
+    import random
+    rng = random.Random(int(os.environ.get("MRG_FUZZ_SEED", "3")))
+    for it in range(int(os.environ.get("MRG_FUZZ_ITERS", "40"))):
+        w, h = rng.randrange(8, 700), rng.randrange(8, 500)
+        if rng.random() < 0.3:
+            w = rng.choice([31, 32, 33, 63, 64, 65, 96, 256, 257])       # word boundaries of the bit planes
+        img = _random_scene(rng, h, w)
+        want = oracle.find_blobs(img)
+        got = _blobs(img)
+        assert got.shape == (len(want), 2) and np.array_equal(got, want.astype(np.int64)), (it, w, h)
