@@ -36,34 +36,11 @@ constexpr int kThresh0 = 50, kThreshStep = 10;
 struct BitPlanes {
     const uint32_t* bits;  // [kNumThresh][h][wpr]
     int w, h, wpr;
-    __device__ __forceinline__ int at(int t, int x, int y) const {  // 0 outside the image: OpenCV pads with zeros
-        if ((unsigned)x >= (unsigned)w || (unsigned)y >= (unsigned)h) return 0;
-        return (bits[((long long)t * h + y) * wpr + (x >> 5)] >> (x & 31)) & 1u;
-    }
 };
 
 // direction codes of the border follower: 0 = +x, then counter-clockwise on the screen (y down)
 __device__ __constant__ int kDX[8] = {1, 1, 0, -1, -1, -1, 0, 1};
 __device__ __constant__ int kDY[8] = {0, -1, -1, -1, 0, 1, 1, 1};
-
-// bits (x-1, x, x+1) of row y of plane t, 0 outside the image
-__device__ __forceinline__ uint32_t row3(const BitPlanes& bp, int t, int x, int y) {
-    if ((unsigned)y >= (unsigned)bp.h) return 0u;
-    const uint32_t* row = bp.bits + ((long long)t * bp.h + y) * bp.wpr;
-    const int wx = x >> 5, b = x & 31;
-    const uint32_t cur = row[wx];
-    if (b == 0) return ((cur << 1) | (wx > 0 ? row[wx - 1] >> 31 : 0u)) & 7u;
-    if (b == 31) return ((cur >> 30) | (wx + 1 < bp.wpr ? (row[wx + 1] & 1u) << 2 : 0u)) & 7u;
-    return (cur >> (b - 1)) & 7u;
-}
-
-// The 8 neighbours of (x, y) as a mask, bit s = the pixel in direction s: three independent loads, after
-// which every search of the follower is register work.
-__device__ __forceinline__ uint32_t neighbours(const BitPlanes& bp, int t, int x, int y) {
-    const uint32_t up = row3(bp, t, x, y - 1), mid = row3(bp, t, x, y), dn = row3(bp, t, x, y + 1);
-    return ((mid >> 2) & 1u) | (((up >> 2) & 1u) << 1) | (((up >> 1) & 1u) << 2) | ((up & 1u) << 3) |
-           ((mid & 1u) << 4) | ((dn & 1u) << 5) | (((dn >> 1) & 1u) << 6) | (((dn >> 2) & 1u) << 7);
-}
 
 // first set direction going clockwise (decreasing code) from `from` (exclusive, wrapping back to it); -1 if none
 __device__ __forceinline__ int first_cw(uint32_t m, int from) {
