@@ -40,7 +40,11 @@ B = 32
 frames = synth.board_batch(4, 4090, 3070, 10, 0, device="cuda").repeat(B // 4, 1, 1).contiguous()
 out = torch.empty((B, 3070, 4090), dtype=torch.int16, device="cuda")
 for st, name in [(0, "generic (divergent edge handling)"), (3, "typed P0 + alignbit P1"), (2, "typed P0 + P1")]:
-    det.set_option("chess_stage", st)
+    try:
+        det.set_option("chess_stage", st)
+    except ValueError:
+        print("(staging variants: experiment builds only -- make -C mrgingham_amd/csrc EXPERIMENT=1, MRGINGHAM_AMD_LIB)")
+        break
     for _ in range(10): det.chess_response(frames, 0, clamp=True, out=out)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(20): det.chess_response(frames, 0, clamp=True, out=out)
