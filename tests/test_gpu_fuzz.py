@@ -77,3 +77,37 @@ def test_random_frames_against_the_oracle():
         print(f"{iters} calls, {compared} frames identical to the oracle, {reported} calls reported unfit by the sparse schedule")
     finally:
         dense.close(); sparse.close()
+
+
+def test_random_images_through_the_preprocessing():
+    """normalize + CLAHE(8) + box blur, 8 and 16 bit, on random sizes (tiles that do not divide evenly, tiny frames),
+    random contents (boards, noise, flat, two-valued, narrow ranges) and random blur radii, against the oracle."""
+    iters = int(os.environ.get("MRG_FUZZ_ITERS", "40"))
+    rng = random.Random(int(os.environ.get("MRG_FUZZ_SEED", "5")) + 1000)
+    nrng = np.random.default_rng(rng.randrange(1 << 30))
+    for it in range(iters):
+        W, H = rng.randrange(9, 900), rng.randrange(9, 700)
+        kind = rng.choice(["board", "noise", "flat", "two", "narrow", "ramp"])
+        if kind == "board" and W >= 64 and H >= 64:
+            img = synth.board_frame(W, H, rng.choice([4, 6, 10]), rng.randrange(100)).numpy()
+        elif kind == "noise":
+            img = nrng.integers(0, 256, (H, W), dtype=np.uint8)
+        elif kind == "flat":
+            img = np.full((H, W), rng.randrange(256), np.uint8)
+        elif kind == "two":
+            img = (nrng.integers(0, 2, (H, W)) * rng.randrange(1, 256)).astype(np.uint8)
+        elif kind == "narrow":
+            lo = rng.randrange(0, 250)
+            img = nrng.integers(lo, lo + 6, (H, W)).astype(np.uint8)
+        else:
+            img = ((np.arange(W)[None, :] * 255 // max(W - 1, 1)) + np.zeros((H, 1), np.int64)).astype(np.uint8)
+        clahe, blur = rng.random() < 0.7, rng.choice([0, 1, 1, 2, 3])
+        got = mrgingham_amd.preprocess(img, clahe=clahe, blur_radius=blur)
+        want = oracle.preprocess(img, clahe=clahe, blur_radius=blur)
+        assert np.array_equal(got, want), ("8 bit", it, W, H, kind, clahe, blur)
+        img16 = (img.astype(np.uint16) * rng.choice([1, 17, 120, 257]) + rng.randrange(0, 200)).astype(np.uint16)
+        if rng.random() < 0.3:
+            img16 = nrng.integers(0, 65536, (H, W)).astype(np.uint16)
+        got16 = mrgingham_amd.api.preprocess16(img16, clahe=clahe, blur_radius=blur)
+        want16 = oracle.preprocess16(img16, clahe=clahe, blur_radius=blur)
+        assert np.array_equal(got16, want16), ("16 bit", it, W, H, kind, clahe, blur)
