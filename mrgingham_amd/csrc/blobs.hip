@@ -196,53 +196,57 @@ __global__ __launch_bounds__(256) void blob_count_kernel(BitPlanes bp, uint32_t*
     if (tid == 0) rowcnt[t * bp.h + y] = carry;
 }
 
-// pass 2: first node of every row (planes one after the other), nodes per plane, first node of every plane, total.
-// One workgroup.  counters: [3] = N, [4 + t] = nodes of plane t, [4 + kNumThresh + t] = first node of plane t.
+// pass 2: first node of every row WITHIN its plane and the nodes per plane (one workgroup per plane), then the first
+// node of every plane and the total (blob_bases_kernel).  counters: [3] = N, [4 + t] = nodes of plane t,
+// [4 + kNumThresh + t] = first node of plane t.
 __global__ __launch_bounds__(256) void blob_rowscan_kernel(int h, const uint32_t* rowcnt, uint32_t* rowoff, int* counters) {
     __shared__ uint32_t part[256];
     __shared__ uint32_t carry;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, t = blockIdx.x;
     if (tid == 0) carry = 0;
     __syncthreads();
-    for (int t = 0; t < kNumThresh; ++t) {
-        const uint32_t base = carry;
-        for (int y0 = 0; y0 < h; y0 += 256) {
-            const int y = y0 + tid;
-            const uint32_t c = y < h ? rowcnt[t * h + y] : 0u;
-            part[tid] = c;
+    for (int y0 = 0; y0 < h; y0 += 256) {
+        const int y = y0 + tid;
+        const uint32_t c = y < h ? rowcnt[t * h + y] : 0u;
+        part[tid] = c;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            const uint32_t v = tid >= d ? part[tid - d] : 0u;
             __syncthreads();
-            for (int d = 1; d < 256; d <<= 1) {
-                const uint32_t v = tid >= d ? part[tid - d] : 0u;
-                __syncthreads();
-                part[tid] += v;
-                __syncthreads();
-            }
-            if (y < h) rowoff[t * h + y] = carry + part[tid] - c;
-            __syncthreads();
-            if (tid == 255) carry += part[255];
+            part[tid] += v;
             __syncthreads();
         }
-        if (tid == 0) {
-            counters[4 + t] = (int)(carry - base);
-            counters[4 + kNumThresh + t] = (int)base;
-        }
+        if (y < h) rowoff[t * h + y] = carry + part[tid] - c;
+        __syncthreads();
+        if (tid == 255) carry += part[255];
+        __syncthreads();
     }
-    if (tid == 0) counters[3] = (int)carry;
+    if (tid == 0) counters[4 + t] = (int)carry;
+}
+__global__ void blob_bases_kernel(int* counters) {
+    if (threadIdx.x != 0) return;
+    uint32_t base = 0;
+    for (int t = 0; t < kNumThresh; ++t) {
+        counters[4 + kNumThresh + t] = (int)base;
+        base += (uint32_t)counters[4 + t];
+    }
+    counters[3] = (int)base;
 }
 
 // node of candidate (x, type) of row y of plane t; `r1` = the row as 34 bits around word x >> 5 (row34)
 __device__ __forceinline__ uint32_t node_of(const BitPlanes& bp, int t, int x, int y, int type, unsigned long long r1,
-                                            const uint32_t* wordpre, const uint32_t* rowoff) {
+                                            const uint32_t* wordpre, const uint32_t* rowoff, uint32_t plane_base) {
     const int wx = x >> 5, b = x & 31;
     uint32_t outer, hole;
     word_candidates((uint32_t)(r1 >> 1), (uint32_t)(r1 & 1ull), (uint32_t)(r1 >> 33) & 1u, wx, bp.w, outer, hole);
     const uint32_t below = (1u << b) - 1u;
-    return rowoff[t * bp.h + y] + wordpre[((long long)t * bp.h + y) * bp.wpr + wx] + __popc(outer & below) + __popc(hole & below) +
-           (type ? (outer >> b) & 1u : 0u);
+    return plane_base + rowoff[t * bp.h + y] + wordpre[((long long)t * bp.h + y) * bp.wpr + wx] + __popc(outer & below) +
+           __popc(hole & below) + (type ? (outer >> b) & 1u : 0u);
 }
 
 // pass 3: the keys of the nodes, in place (thread per word)
-__global__ __launch_bounds__(256) void blob_keys_kernel(BitPlanes bp, const uint32_t* wordpre, const uint32_t* rowoff, uint32_t* key) {
+__global__ __launch_bounds__(256) void blob_keys_kernel(BitPlanes bp, const uint32_t* wordpre, const uint32_t* rowoff, uint32_t* key,
+                                                        const int* counters) {
     const int wx = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, t = blockIdx.z;
     if (wx >= bp.wpr) return;
     const uint32_t* row = bp.bits + ((long long)t * bp.h + y) * bp.wpr;
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(256) void blob_keys_kernel(BitPlanes bp, const uint
     if (cur == 0) return;
     uint32_t outer, hole;
     word_candidates(cur, wx > 0 ? row[wx - 1] >> 31 : 0u, wx + 1 < bp.wpr ? row[wx + 1] & 1u : 0u, wx, bp.w, outer, hole);
-    uint32_t k = rowoff[t * bp.h + y] + wordpre[((long long)t * bp.h + y) * bp.wpr + wx];
+    uint32_t k = (uint32_t)counters[4 + kNumThresh + t] + rowoff[t * bp.h + y] + wordpre[((long long)t * bp.h + y) * bp.wpr + wx];
     uint32_t both = outer | hole;
     while (both) {
         const int i = __ffs(both) - 1;
@@ -266,8 +270,8 @@ __global__ __launch_bounds__(256) void blob_keys_kernel(BitPlanes bp, const uint
 // successor.  WRITE = true: stores the arc's points ((y << 16) | x) to pts[0 .. steps).
 template <bool WRITE>
 __device__ __forceinline__ void blob_arc(const BitPlanes& bp, int t, uint32_t key, uint32_t self, const uint32_t* wordpre,
-                                         const uint32_t* rowoff, uint32_t& next, uint32_t& steps, unsigned long long& a00,
-                                         uint32_t* pts, int* err) {
+                                         const uint32_t* rowoff, uint32_t plane_base, uint32_t& next, uint32_t& steps,
+                                         unsigned long long& a00, uint32_t* pts, int* err) {
     const int x0 = (int)((key >> 1) & 0x7fffu), y0 = (int)(key >> 16), is_hole = (int)(key & 1u);
     next = self;
     steps = 0;
@@ -321,7 +325,7 @@ __device__ __forceinline__ void blob_arc(const BitPlanes& bp, int t, uint32_t ke
         const bool outer_c = !(m & 0x10u) && first_cw(m, 4) == s;
         const bool hole_c = !(m & 1u) && first_cw(m, 0) == s;  // (the last column too: pseudo_node)
         if (outer_c || hole_c) {  // a candidate's start state (possibly this arc's own: a border of one arc)
-            if (!WRITE) next = node_of(bp, t, x3, y3, outer_c ? 0 : 1, wn.r[1], wordpre, rowoff);
+            if (!WRITE) next = node_of(bp, t, x3, y3, outer_c ? 0 : 1, wn.r[1], wordpre, rowoff, plane_base);
             break;
         }
         if (n >= (uint32_t)kMaxArc) {
@@ -347,7 +351,8 @@ __global__ __launch_bounds__(256) void blob_arcs_kernel(BitPlanes bp, const uint
     if (i >= N) return;
     uint32_t next, steps;
     unsigned long long a00;
-    blob_arc<false>(bp, plane_of(i, counters), nd.key[i], i, wordpre, rowoff, next, steps, a00, nullptr, counters + 2);
+    const int t = plane_of(i, counters);
+    blob_arc<false>(bp, t, nd.key[i], i, wordpre, rowoff, (uint32_t)counters[4 + kNumThresh + t], next, steps, a00, nullptr, counters + 2);
     nd.next[i] = next;
     nd.n[i] = steps;
     nd.a00[i] = a00;
@@ -447,7 +452,7 @@ __global__ __launch_bounds__(256) void blob_points_kernel(BitPlanes bp, const ui
     const uint32_t total = nd.sn[rk][L], at = total - nd.sn[rk][i];
     uint32_t next, steps;
     unsigned long long a00;
-    blob_arc<true>(bp, plane_of(i, counters), nd.key[i], i, wordpre, rowoff, next, steps, a00, pts + off + at, nullptr);
+    blob_arc<true>(bp, plane_of(i, counters), nd.key[i], i, wordpre, rowoff, 0u, next, steps, a00, pts + off + at, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -614,7 +619,8 @@ bool blob_detect(const uint8_t* d_img, int d_stride, const uint8_t* h_img, int h
     const dim3 grid_rows((L.wpr + 255) / 256, h);
     hipLaunchKernelGGL(blob_bitplanes_kernel, grid_rows, dim3(256), 0, s, d_img, d_stride, w, h, L.wpr, bits);
     hipLaunchKernelGGL(blob_count_kernel, dim3(h, kNumThresh), dim3(256), 0, s, bp, wordpre, rowcnt);
-    hipLaunchKernelGGL(blob_rowscan_kernel, dim3(1), dim3(256), 0, s, h, (const uint32_t*)rowcnt, rowoff, counters);
+    hipLaunchKernelGGL(blob_rowscan_kernel, dim3(kNumThresh), dim3(256), 0, s, h, (const uint32_t*)rowcnt, rowoff, counters);
+    hipLaunchKernelGGL(blob_bases_kernel, dim3(1), dim3(64), 0, s, counters);
     int hc[64];
     if (hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess) {
@@ -648,7 +654,7 @@ bool blob_detect(const uint8_t* d_img, int d_stride, const uint8_t* h_img, int h
         while ((1ll << rounds) < maxn) ++rounds;
         const dim3 gn((unsigned)((N + 255) / 256));
         hipLaunchKernelGGL(blob_keys_kernel, dim3(grid_rows.x, grid_rows.y, kNumThresh), dim3(256), 0, s, bp, (const uint32_t*)wordpre,
-                           (const uint32_t*)rowoff, nd.key);
+                           (const uint32_t*)rowoff, nd.key, (const int*)counters);
         hipLaunchKernelGGL(blob_arcs_kernel, gn, dim3(256), 0, s, bp, (const uint32_t*)wordpre, (const uint32_t*)rowoff, nd, counters);
         for (int r = 0; r < (rounds + 1) / 2 * 2; ++r)  // (an even number: the result is back in (jmp, leader))
             if (r & 1)
