@@ -713,7 +713,7 @@ bool blob_detect(const uint8_t* d_img, int d_stride, const uint8_t* h_img, int h
             }
         };
         const unsigned hw = std::thread::hardware_concurrency();
-        const size_t nthr = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 8), hpts.size() / 16384 + 1);
+        const size_t nthr = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 16), hpts.size() / 16384 + 1);
         if (nthr <= 1) {
             work(0, hrec.size());
         } else {  // contiguous ranges of about equal point counts
