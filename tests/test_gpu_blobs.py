@@ -170,3 +170,19 @@ def test_random_scenes_against_the_oracle():
         want = oracle.find_blobs(img)
         got = _blobs(img)
         assert got.shape == (len(want), 2) and np.array_equal(got, want.astype(np.int64)), (it, w, h)
+
+
+def test_product_against_the_committed_vectors(golden_dir):
+    """The HIP path against tests/golden/blobs_golden.npz directly (no oracle in the loop): blob keypoints and the
+    8 / 16 bit preprocessing."""
+    import hashlib
+    import os
+    from test_oracle import _blob_scenes
+    z = np.load(os.path.join(golden_dir, "blobs_golden.npz"))
+    for name, img in _blob_scenes().items():
+        assert hashlib.sha256(img.tobytes()).digest() == z["sha_" + name].tobytes(), name
+        assert np.array_equal(_blobs(img), z["blobs_" + name]), name
+    pre = synth.board_frame(333, 251, 6, 3).numpy()
+    assert np.array_equal(mrgingham_amd.preprocess(pre, clahe=True, blur_radius=1), z["pre8_board_333x251"])
+    pre16 = (pre.astype(np.uint16) * 120 + 9000).astype(np.uint16)
+    assert np.array_equal(mrgingham_amd.api.preprocess16(pre16, clahe=True, blur_radius=1), z["pre16_board_333x251"])

@@ -211,3 +211,27 @@ def test_oracle_normalize_and_clahe_properties():
     p = oracle.preprocess(img, clahe=True, blur_radius=1)
     assert np.array_equal(p, oracle.box_blur(oracle.clahe(oracle.normalize_minmax(img)), 1))
     assert np.array_equal(oracle.preprocess(img, clahe=False, blur_radius=0), img)
+
+
+def _blob_scenes():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    return {"shapes_320x360": mg.blob_scene(320, 360), "dots_333x251": synth.dots_frame(333, 251, 4, 1).numpy(),
+            "dots_640x480": synth.dots_frame(640, 480, 10, 0).numpy(),
+            "noise_320x240_smooth2": synth.noise_frame(320, 240, 1, smooth=2).numpy()}
+
+
+def test_blob_and_preprocess_restatements_regression(golden_dir):
+    """oracle/blobs_oracle.c and the preprocessing restatement against the committed vectors (regression anchors of
+    restatements of OpenCV's published algorithms -- parity with OpenCV itself stays unpinned)."""
+    z = np.load(os.path.join(golden_dir, "blobs_golden.npz"))
+    for name, img in _blob_scenes().items():
+        assert hashlib.sha256(img.tobytes()).digest() == z["sha_" + name].tobytes(), name
+        assert np.array_equal(oracle.find_blobs(img).astype(np.int64), z["blobs_" + name]), name
+    pre = synth.board_frame(333, 251, 6, 3).numpy()
+    assert np.array_equal(oracle.preprocess(pre, clahe=True, blur_radius=1), z["pre8_board_333x251"])
+    pre16 = (pre.astype(np.uint16) * 120 + 9000).astype(np.uint16)
+    assert np.array_equal(oracle.preprocess16(pre16, clahe=True, blur_radius=1), z["pre16_board_333x251"])
+    assert len(z["blobs_dots_640x480"]) == 100
