@@ -465,7 +465,7 @@ def main():
     scratch_gib = det.scratch_bytes() / 2**30                # (likewise: a context that runs sparse chains keeps a third set)
     sparse = None
     if world == 1 and start_level >= 1 and not args.no_sparse_leg and not args.sparse_refine:
-        sparse = sparse_leg(det, frames, start_level, P, min(args.steps, 100))
+        sparse = sparse_leg(det, frames, start_level, P, 100)   # (its own length: not the timed region of the contract)
     bindings = None
     if collective and binding is not None:
         objs = [None] * world
