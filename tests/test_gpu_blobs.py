@@ -186,3 +186,20 @@ def test_product_against_the_committed_vectors(golden_dir):
     assert np.array_equal(mrgingham_amd.preprocess(pre, clahe=True, blur_radius=1), z["pre8_board_333x251"])
     pre16 = (pre.astype(np.uint16) * 120 + 9000).astype(np.uint16)
     assert np.array_equal(mrgingham_amd.api.preprocess16(pre16, clahe=True, blur_radius=1), z["pre16_board_333x251"])
+
+
+@pytest.mark.parametrize("kind", ["dots_4096x3072", "board_4096x3072", "noise_2048x1536", "random_3000x2000"])
+def test_large_frames(kind):
+    """Arcs that cross many words and rows, the frame's edges at full length, ~10^6 candidates per call."""
+    import random
+    if kind == "dots_4096x3072":
+        img = synth.dots_frame(4096, 3072, 10, 1).numpy()
+    elif kind == "board_4096x3072":
+        img = synth.board_frame(4096, 3072, 10, 4).numpy()
+    elif kind == "noise_2048x1536":
+        img = synth.noise_frame(2048, 1536, 3, smooth=2).numpy()
+    else:
+        img = _random_scene(random.Random(77), 2000, 3000)
+    want = oracle.find_blobs(img)
+    got = _blobs(img)
+    assert got.shape == (len(want), 2) and np.array_equal(got, want.astype(np.int64)), kind
