@@ -23,8 +23,6 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
-#include <map>
-#include <set>
 #include <string>
 #include <vector>
 
@@ -65,6 +63,19 @@ inline int incircle(const PointI& a, const PointI& b, const PointI& c, const Poi
     const i64 ax = (i64)a.x - d.x, ay = (i64)a.y - d.y;
     const i64 bx = (i64)b.x - d.x, by = (i64)b.y - d.y;
     const i64 cx = (i64)c.x - d.x, cy = (i64)c.y - d.y;
+    {
+        // floating-point filter: with differences below 2^26 (every coordinate this library produces: 32767 px * 1000
+        // < 2^25) the squared lengths and the 2x2 minors are exact in double, each of the three products is rounded
+        // once and the two additions once each: a determinant further from 0 than 5 half-ulps of the terms has its sign
+        const double fa2 = (double)(ax * ax + ay * ay), fb2 = (double)(bx * bx + by * by), fc2 = (double)(cx * cx + cy * cy);
+        const double t1 = fa2 * (double)(bx * cy - by * cx), t2 = fb2 * (double)(ax * cy - ay * cx),
+                     t3 = fc2 * (double)(ax * by - ay * bx);
+        const double det = t1 - t2 + t3;
+        const double bound = 1e-15 * (std::fabs(t1) + std::fabs(t2) + std::fabs(t3));
+        auto in26 = [](i64 v) { return v > -(1ll << 26) && v < (1ll << 26); };
+        const bool small = in26(ax) && in26(ay) && in26(bx) && in26(by) && in26(cx) && in26(cy);
+        if (small && (det > bound || det < -bound)) return det > 0 ? 1 : -1;
+    }
     const i128 a2 = (i128)ax * ax + (i128)ay * ay;
     const i128 b2 = (i128)bx * bx + (i128)by * by;
     const i128 c2 = (i128)cx * cx + (i128)cy * cy;
@@ -80,6 +91,7 @@ public:
     // false when there is no triangle at all (fewer than 3 distinct points, or all collinear)
     bool build() {
         const int n = (int)p.size();
+        tris.reserve(2 * (size_t)n + 8);
         order.resize(n);
         for (int i = 0; i < n; ++i) order[i] = i;
         std::sort(order.begin(), order.end(), [&](int a, int b) {
@@ -132,6 +144,8 @@ private:
     std::vector<int> hull_next, hull_prev;
     // hull edge a -> hull_next[a] belongs to triangle hull_tri[a], opposite its vertex slot hull_slot[a]
     std::vector<int> hull_tri, hull_slot;
+    std::vector<int> fresh;                      // scratch of insert_outside
+    std::vector<std::pair<int, int>> flip_stack;  // scratch of legalize
 
     void note_hull_edges(int t) {
         for (int k = 0; k < 3; ++k)
@@ -183,7 +197,7 @@ private:
             // strictly beyond the sweep line unless the hull is degenerate; nothing visible.
             return;
         }
-        std::vector<int> fresh;
+        fresh.clear();
         int prev = -1;
         for (int a = lo; a != hi;) {
             const int b = hull_next[a];
@@ -195,12 +209,14 @@ private:
         hull_next[q] = hi; hull_prev[hi] = q;
         // vertices strictly between lo and hi left the hull; the two new hull edges are lo -> q, q -> hi
         for (int t : fresh) note_hull_edges(t);
-        for (int t : fresh) legalize(t, 2);
+        for (size_t i = 0; i < fresh.size(); ++i) legalize(fresh[i], 2);
     }
 
     // Lawson: the edge of triangle t opposite its vertex slot k
     void legalize(int t0, int k0) {
-        std::vector<std::pair<int, int>> stack{{t0, k0}};
+        std::vector<std::pair<int, int>>& stack = flip_stack;
+        stack.clear();
+        stack.push_back({t0, k0});
         while (!stack.empty()) {
             auto [t, k] = stack.back();
             stack.pop_back();
@@ -241,15 +257,13 @@ private:
 // neighbouring sites, whether consecutive neighbours close a triangle with the site, and the
 // site on the far side of that triangle's outer edge (find_grid.cc:41-87).
 // ---------------------------------------------------------------------------------------------
-struct Ring {
-    std::vector<int> nbr;   // neighbour sites, counter-clockwise
-    std::vector<char> tri;  // tri[k]: (site, nbr[k], nbr[k+1]) is a triangle
-    std::vector<int> far;   // far[k]: the site opposite `site` across edge (nbr[k], nbr[k+1]), or -1
-};
-
+// (flat: ring of site v = entries [off[v], off[v + 1]) of nbr / tri / far)
 struct SiteGraph {
     std::vector<int> order;  // sites in cell order
-    std::vector<Ring> ring;
+    std::vector<int> off;    // n + 1
+    std::vector<int> nbr;    // neighbour sites, counter-clockwise
+    std::vector<char> tri;   // tri[k]: (site, nbr[k], nbr[k+1]) is a triangle
+    std::vector<int> far;    // far[k]: the site opposite `site` across edge (nbr[k], nbr[k+1]), or -1
 };
 
 bool build_site_graph(const std::vector<PointI>& pts, SiteGraph& g) {
@@ -257,7 +271,10 @@ bool build_site_graph(const std::vector<PointI>& pts, SiteGraph& g) {
     if (!dt.build()) return false;
     const int n = (int)pts.size();
     g.order = dt.order;
-    g.ring.assign(n, Ring());
+    g.off.assign((size_t)n + 1, 0);
+    const size_t guess = 3 * dt.tris.size() + (size_t)n;
+    g.nbr.clear(); g.tri.clear(); g.far.clear();
+    g.nbr.reserve(guess); g.tri.reserve(guess); g.far.reserve(guess);
     // one incident triangle per vertex, preferring one whose clockwise side is open (hull start)
     std::vector<int> inc(n, -1);
     for (int t = 0; t < (int)dt.tris.size(); ++t)
@@ -268,8 +285,9 @@ bool build_site_graph(const std::vector<PointI>& pts, SiteGraph& g) {
             if (inc[v] < 0 || dt.tris[t].n[(k + 2) % 3] < 0) inc[v] = t;
         }
     for (int v = 0; v < n; ++v) {
+        g.off[v] = (int)g.nbr.size();
         if (inc[v] < 0) continue;  // duplicate of another point: no cell of its own
-        Ring& r = g.ring[v];
+        const size_t first = g.nbr.size();
         // walk counter-clockwise around v starting at inc[v]
         int t = inc[v];
         const int t_first = t;
@@ -278,28 +296,29 @@ bool build_site_graph(const std::vector<PointI>& pts, SiteGraph& g) {
             int k = 0;
             while (dt.tris[t].v[k] != v) ++k;
             const int b = dt.tris[t].v[(k + 1) % 3], c = dt.tris[t].v[(k + 2) % 3];
-            if (r.nbr.empty()) r.nbr.push_back(b);
-            r.tri.push_back(1);
+            if (g.nbr.size() == first) g.nbr.push_back(b);
+            g.tri.push_back(1);
             // far vertex across (b,c): the triangle opposite v
             const int u = dt.tris[t].n[k];
             int d = -1;
             if (u >= 0)
                 for (int j = 0; j < 3; ++j)
                     if (dt.tris[u].v[j] != b && dt.tris[u].v[j] != c) d = dt.tris[u].v[j];
-            r.far.push_back(d);
+            g.far.push_back(d);
             // next triangle counter-clockwise: across edge (v, c), which is opposite slot (k+1)%3
             const int nx = dt.tris[t].n[(k + 1) % 3];
             if (nx == t_first) { closed = true; break; }
-            r.nbr.push_back(c);
+            g.nbr.push_back(c);
             if (nx < 0) break;
             t = nx;
         }
         if (!closed) {
             // hull site: the step from the last neighbour back to the first has no triangle
-            r.tri.push_back(0);
-            r.far.push_back(-1);
+            g.tri.push_back(0);
+            g.far.push_back(-1);
         }
     }
+    g.off[n] = (int)g.nbr.size();
     return true;
 }
 
@@ -308,8 +327,9 @@ bool build_site_graph(const std::vector<PointI>& pts, SiteGraph& g) {
 // angularly between the two (find_grid.cc:88-140).
 template <typename F>
 bool for_each_adjacent(const SiteGraph& g, const std::vector<PointI>& pts, int c, F&& visit) {
-    const Ring& r = g.ring[c];
-    const int deg = (int)r.nbr.size();
+    struct { const int* nbr; const char* tri; const int* far; } r{g.nbr.data() + g.off[c], g.tri.data() + g.off[c],
+                                                                   g.far.data() + g.off[c]};
+    const int deg = g.off[c + 1] - g.off[c];
     const PointI& pt = pts[c];
     int start = 0;
     if (g_grid_perturbation.ring_seed && deg > 0) {
@@ -343,26 +363,42 @@ constexpr double kSpacingCos = 0.984;
 constexpr double kLenRatioMin = 0.7, kLenRatioMax = 1.4, kLenRatioDev = 0.35;
 
 // The adjacency of every site in the reference's visiting order, built once: the sequence search
-// walks it tens of thousands of times per frame.
+// walks it tens of thousands of times per frame.  Flat: site c's entries are [off[c], off[c + 1]).
 struct Adj {
     int site;
     PointI delta;
+    double dx, dy;  // delta again, as the doubles the angle test multiplies
     double len;
 };
-using AdjLists = std::vector<std::vector<Adj>>;
+struct AdjLists {
+    std::vector<int> off;
+    std::vector<Adj> a;
+    struct Range {
+        const Adj *b, *e;
+        const Adj* begin() const { return b; }
+        const Adj* end() const { return e; }
+    };
+    Range operator[](int c) const { return Range{a.data() + off[c], a.data() + off[c + 1]}; }
+};
 
 AdjLists build_adjacency(const SiteGraph& g, const std::vector<PointI>& pts) {
-    AdjLists adj(pts.size());
-    for (int c = 0; c < (int)pts.size(); ++c)
+    AdjLists adj;
+    adj.off.assign(pts.size() + 1, 0);
+    adj.a.reserve(2 * g.nbr.size());
+    for (int c = 0; c < (int)pts.size(); ++c) {
+        adj.off[c] = (int)adj.a.size();
         for_each_adjacent(g, pts, c, [&](int cand, PointI delta) {
-            adj[c].push_back(Adj{cand, delta, std::hypot((double)delta.x, (double)delta.y)});
+            adj.a.push_back(Adj{cand, delta, (double)delta.x, (double)delta.y, std::hypot((double)delta.x, (double)delta.y)});
             return false;
         });
+    }
+    adj.off[pts.size()] = (int)adj.a.size();
     return adj;
 }
 
 struct SeqStats {  // HypothesisStatistics, :166-172
     PointI delta_last;
+    double lx, ly;  // delta_last as doubles
     double last_len;
     double ratio_sum;
     int ratio_n;
@@ -374,20 +410,26 @@ int next_along_sequence(const AdjLists& adj, int c, SeqStats& st, const std::vec
     const Adj* chosen = nullptr;
     double chosen_ratio = 0.0;
     const int S = kScale;
+    const double lx = st.lx, ly = st.ly, last_len = st.last_len;
+    const bool last_match = g_grid_perturbation.last_match;
     for (const Adj& a : adj[c]) {
         if (trace)
             fprintf(stderr, "Considering connection in sequence from (%d,%d) -> (%d,%d); delta (%d,%d) ..... \n",
                     (*trace)[c].x / S, (*trace)[c].y / S, (*trace)[a.site].x / S, (*trace)[a.site].y / S, a.delta.x / S,
                     a.delta.y / S);
-        const double cos_err = ((double)st.delta_last.x * (double)a.delta.x + (double)st.delta_last.y * (double)a.delta.y) /
-                               (st.last_len * a.len);
+        const double dot = lx * a.dx + ly * a.dy;
+        const double den = last_len * a.len;
+        // most neighbours point somewhere else entirely: decided without the division wherever the quotient is
+        // further from the threshold than any rounding could move it (the quotient itself is the reference's, :257-260)
+        if (!trace && dot < (kSpacingCos - 1e-6) * den) continue;
+        const double cos_err = dot / den;
         if (cos_err < kSpacingCos) {
             if (trace)
                 fprintf(stderr, "..... rejecting. Angle is wrong. I wanted cos_err>=threshold, but saw %f<%f\n", cos_err,
                         kSpacingCos);
             continue;
         }
-        const double ratio = a.len / st.last_len;
+        const double ratio = a.len / last_len;
         if (ratio < kLenRatioMin || ratio > kLenRatioMax) {
             if (trace)
                 fprintf(stderr, "..... rejecting. Lengths are wrong. I wanted abs(length_ratio)<=threshold, but saw %f<%f or %f>%f\n",
@@ -406,12 +448,14 @@ int next_along_sequence(const AdjLists& adj, int c, SeqStats& st, const std::vec
         chosen = &a;
         chosen_ratio = ratio;
         if (trace) fprintf(stderr, "..... accepting!\n\n");
-        if (!g_grid_perturbation.last_match) break;  // the reference: the first match (:216-222)
+        if (!last_match) break;  // the reference: the first match (:216-222)
     }
     if (!chosen) return -1;
     st.ratio_sum += chosen_ratio;
     st.ratio_n++;
     st.delta_last = chosen->delta;
+    st.lx = chosen->dx;
+    st.ly = chosen->dy;
     st.last_len = chosen->len;
     return chosen->site;
 }
@@ -422,9 +466,11 @@ struct Sequence {  // CandidateSequence, :148-162
 };
 
 // walks n_remaining steps from c along delta; fills `path` (if given) with the sites visited
+// (`delta_len` = hypot(delta) when the caller has it already -- the adjacency lists do --, < 0 otherwise)
 int walk_sequence(const AdjLists& adj, PointI delta, int c, int n_remaining, PointD* delta_mean, std::vector<int>* path,
-                  const std::vector<PointI>* trace = nullptr) {
-    SeqStats st{delta, std::hypot((double)delta.x, (double)delta.y), 0.0, 0};
+                  const std::vector<PointI>* trace = nullptr, double delta_len = -1.0) {
+    SeqStats st{delta, (double)delta.x, (double)delta.y,
+                delta_len >= 0.0 ? delta_len : std::hypot((double)delta.x, (double)delta.y), 0.0, 0};
     double sx = delta.x, sy = delta.y;
     int last = -1;
     for (int i = 0; i < n_remaining; ++i) {
@@ -437,6 +483,63 @@ int walk_sequence(const AdjLists& adj, PointI delta, int c, int n_remaining, Poi
         c = nx;
     }
     if (delta_mean) { delta_mean->x = sx / (double)(n_remaining + 1); delta_mean->y = sy / (double)(n_remaining + 1); }
+    return last;
+}
+
+// The sequence-candidate search (:502-569) walks from EVERY adjacency of every site.  While fewer than three length
+// ratios have been seen (:289: the deviation test needs length_ratio_N > 2) the neighbour that continues a walk is a
+// function of the edge it arrived by alone: the first neighbour that passes the angle and length-ratio tests against
+// that edge.  Found once per edge and remembered; with the deviation test on, the scan starts at that neighbour
+// (whatever comes before it fails a test that does not depend on the history).  Same neighbours, same sums as
+// walk_sequence, ~3x fewer tests.
+struct WalkMemo {
+    std::vector<int> nxt;       // per adjacency entry: -2 not looked at yet, -1 none, else the continuing entry
+    std::vector<double> ratio;  // its length ratio
+};
+inline bool continues(const Adj& in, const Adj& a, double* ratio_out) {
+    const double dot = in.dx * a.dx + in.dy * a.dy;
+    const double den = in.len * a.len;
+    if (dot < (kSpacingCos - 1e-6) * den) return false;  // (see next_along_sequence)
+    if (dot / den < kSpacingCos) return false;
+    const double ratio = a.len / in.len;
+    if (ratio < kLenRatioMin || ratio > kLenRatioMax) return false;
+    *ratio_out = ratio;
+    return true;
+}
+int walk_sequence_memo(const AdjLists& adj, WalkMemo& m, int e0, int n_remaining, PointD* delta_mean) {
+    int e = e0;
+    double sx = adj.a[e].delta.x, sy = adj.a[e].delta.y, ratio_sum = 0.0;
+    int ratio_n = 0, last = -1;
+    for (int i = 0; i < n_remaining; ++i) {
+        const Adj& in = adj.a[e];
+        int f = m.nxt[e];
+        if (f == -2) {
+            f = -1;
+            for (int k = adj.off[in.site]; k < adj.off[in.site + 1]; ++k)
+                if (continues(in, adj.a[k], &m.ratio[e])) { f = k; break; }
+            m.nxt[e] = f;
+        }
+        if (f < 0) return -1;
+        double ratio = m.ratio[e];
+        if (ratio_n > 2) {
+            const double mean = ratio_sum / (double)ratio_n;
+            for (;; ) {
+                const double dev = ratio - mean;
+                if (!(dev < -kLenRatioDev || dev > kLenRatioDev)) break;
+                for (++f; f < adj.off[in.site + 1]; ++f)
+                    if (continues(in, adj.a[f], &ratio)) break;
+                if (f >= adj.off[in.site + 1]) return -1;
+            }
+        }
+        ratio_sum += ratio;
+        ratio_n++;
+        sx += adj.a[f].delta.x;
+        sy += adj.a[f].delta.y;
+        last = adj.a[f].site;
+        e = f;
+    }
+    delta_mean->x = sx / (double)(n_remaining + 1);
+    delta_mean->y = sy / (double)(n_remaining + 1);
     return last;
 }
 
@@ -466,7 +569,8 @@ struct Cycle { int e[4]; };
 struct CycleSearch {
     const std::vector<Sequence>& seq;
     const std::vector<int>& outer;  // indices into seq
-    const std::map<int, std::vector<int>>& outer_from;  // start site -> positions in `outer`
+    const std::vector<int>& from_off;  // start site -> positions in `outer`: from_pos[from_off[site] .. from_off[site + 1])
+    const std::vector<int>& from_pos;
     const std::vector<PointI>& pts;
 
     // next_outer_edge, :825-951
@@ -474,9 +578,8 @@ struct CycleSearch {
         bool found = false;
         Cycle best{};
         const Sequence& cur = seq[outer[cyc.e[count - 1]]];
-        auto it = outer_from.find(cur.clast);
-        if (it == outer_from.end()) return false;
-        for (int pos : it->second) {
+        for (int q = from_off[cur.clast]; q < from_off[cur.clast + 1]; ++q) {
+            const int pos = from_pos[q];
             const Sequence& nx = seq[outer[pos]];
             if (nx.clast == cur.c0) continue;  // straight back
             if (count != 3) {
@@ -591,13 +694,24 @@ bool find_grid_from_points(std::vector<PointD>& out, const std::vector<PointI>& 
             fprintf(stderr, "============== Looking at sequences from (%d,%d)\n", pts[tracing].x / kScale,
                     pts[tracing].y / kScale);
     }
+    // (the memoised walk takes the first matching neighbour: the perturbed and the traced search take the plain one)
+    const bool plain = g_grid_perturbation.last_match || tracing >= 0;
+    WalkMemo memo;
+    if (!plain) {
+        memo.nxt.assign(adj.a.size(), -2);
+        memo.ratio.assign(adj.a.size(), 0.0);
+    }
+    seq.reserve(adj.a.size() / 4 + 16);
     for (int c : g.order)
-        for (const Adj& a : adj[c]) {
+        for (int e = adj.off[c]; e < adj.off[c + 1]; ++e) {
+            const Adj& a = adj.a[e];
             if (c == tracing)
                 fprintf(stderr, "\n\n====== Looking at adjacent point (%d,%d)\n", pts[a.site].x / kScale,
                         pts[a.site].y / kScale);
             PointD mean;
-            const int clast = walk_sequence(adj, a.delta, a.site, gridn - 2, &mean, nullptr, c == tracing ? &pts : nullptr);
+            const int clast = plain ? walk_sequence(adj, a.delta, a.site, gridn - 2, &mean, nullptr,
+                                                    c == tracing ? &pts : nullptr, a.len)
+                                    : walk_sequence_memo(adj, memo, e, gridn - 2, &mean);
             if (clast >= 0) seq.push_back(Sequence{c, a.site, clast, mean});
         }
 
@@ -607,7 +721,8 @@ bool find_grid_from_points(std::vector<PointD>& out, const std::vector<PointI>& 
         fprintf(stderr, "got %zd sequence candidates\n", seq.size());
     }
     // outer-edge candidates: sequences whose start site starts at least two sequences (:1246-1262)
-    std::map<int, int> started;
+    const int nsites = (int)pts.size();
+    std::vector<int> started((size_t)nsites, 0);
     for (const Sequence& s : seq) started[s.c0]++;
     std::vector<int> outer;
     for (int i = 0; i < (int)seq.size(); ++i)
@@ -617,20 +732,29 @@ bool find_grid_from_points(std::vector<PointD>& out, const std::vector<PointI>& 
         return false;
     }
     if (debug) dump_sequences("/tmp/mrgingham-4-outer-edges", seq, &outer, adj, pts, gridn);
-    std::map<int, std::vector<int>> outer_from;
-    for (int i = 0; i < (int)outer.size(); ++i) outer_from[seq[outer[i]].c0].push_back(i);
+    // positions in `outer` by start site, ascending within a site
+    auto by_site = [&](int n, auto&& site_of, std::vector<int>& off, std::vector<int>& pos) {
+        off.assign((size_t)nsites + 1, 0);
+        for (int i = 0; i < n; ++i) off[site_of(i) + 1]++;
+        for (int v = 0; v < nsites; ++v) off[v + 1] += off[v];
+        pos.resize((size_t)n);
+        std::vector<int> fill(off.begin(), off.end() - 1);
+        for (int i = 0; i < n; ++i) pos[fill[site_of(i)]++] = i;
+    };
+    std::vector<int> from_off, from_pos;
+    by_site((int)outer.size(), [&](int i) { return seq[outer[i]].c0; }, from_off, from_pos);
 
     // 4-cycles of outer edges (:1287-1322)
     std::vector<Cycle> cycles;
-    std::set<int> used;
-    const CycleSearch search{seq, outer, outer_from, pts};
+    std::vector<char> used(outer.size(), 0);
+    const CycleSearch search{seq, outer, from_off, from_pos, pts};
     for (int i = 0; i < (int)outer.size(); ++i) {
-        if (used.count(i)) continue;
+        if (used[i]) continue;
         Cycle cyc{};
         cyc.e[0] = i;
         if (!search.extend(cyc, 1, seq[outer[i]].c0)) continue;
         cycles.push_back(cyc);
-        for (int k = 0; k < 4; ++k) used.insert(cyc.e[k]);
+        for (int k = 0; k < 4; ++k) used[cyc.e[k]] = 1;
     }
     auto dump_cycles = [&](const char* fn, int ncyc, auto&& cyc_of, auto&& label) {
         FILE* fp = fopen(fn, "w");
@@ -737,13 +861,11 @@ bool find_grid_from_points(std::vector<PointD>& out, const std::vector<PointI>& 
                         return std::string(ic == iclockwise ? "clockwise" : "counterclockwise") + (itop[ic] == ie ? "-top" : "");
                     });
     // rows between the two vertical outer edges (:1378-1440)
-    std::map<int, std::vector<int>> seq_from;
-    for (int i = 0; i < (int)seq.size(); ++i) seq_from[seq[i].c0].push_back(i);
+    std::vector<int> sf_off, sf_pos;
+    by_site((int)seq.size(), [&](int i) { return seq[i].c0; }, sf_off, sf_pos);
     auto seq_from_to = [&](int from, int to) {
-        auto it = seq_from.find(from);
-        if (it == seq_from.end()) return -1;
-        for (int i : it->second)
-            if (seq[i].clast == to) return i;
+        for (int q = sf_off[from]; q < sf_off[from + 1]; ++q)
+            if (seq[sf_pos[q]].clast == to) return sf_pos[q];
         return -1;
     };
     std::vector<int> rows(gridn);
