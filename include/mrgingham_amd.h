@@ -129,7 +129,6 @@ enum {
     MRGINGHAM_AMD_ERR_ARG = -1,      /* bad argument (level, sizes, NULL) */
     MRGINGHAM_AMD_ERR_DEVICE = -2,   /* HIP error; see mrgingham_amd_last_error */
     MRGINGHAM_AMD_ERR_CAPACITY = -3, /* an output capacity given by the caller was too small */
-    MRGINGHAM_AMD_ERR_SPARSE = -4,   /* option "sparse_refine": a frame the sparse refinement cannot take; repeat without it */
 };
 
 /* One context = one device, two HIP streams (the HBM-bound pixel kernels of a
@@ -143,6 +142,10 @@ const char* mrgingham_amd_last_error(const mrgingham_amd_ctx* ctx);
 int mrgingham_amd_abi_version(void);
 /* Number of usable HIP devices (0 = none: every entry point will fail, there is no CPU path). */
 int mrgingham_amd_device_count(void);
+
+/* How many frames the sparse refinement (option "sparse_refine") handed back to the dense kernels since the last call
+ * of this function (they are repeated inside the call that met them; the outputs do not depend on it).  Synchronises. */
+int mrgingham_amd_sparse_fallbacks(mrgingham_amd_ctx* ctx);
 
 /* Size of pyramid level `level` of a width x height frame: what
  * cv::resize(.., 1/2^level, 1/2^level) produces (find_chessboard_corners.cc:449-450). */
@@ -339,15 +342,13 @@ int mrgingham_amd_chain_info(const mrgingham_amd_ctx* ctx, int* fused_pyramid, i
  *                         the points (the global-memory kernels take what is left), 0 = global-memory kernels only;
  *                         1 | 256 = neither bands nor cells (test hook; results are the same).  Any other value is
  *                         refused.
- *   "sparse_refine"       0 (default), 1, 2: chain_batch computes the response of the levels BELOW the start level only in
+ *   "sparse_refine"       1 (default), 0, 2: chain_batch computes the response of the levels BELOW the start level only in
  *                         the 16 x 16 cells around the points it refines there (all level images and the start level's
  *                         response stay whole-frame): 2 = always, 1 = for calls of at least 96 Mi frame pixels (smaller
- *                         calls are faster dense).  Same results on every frame it accepts; a frame it cannot take -- a
- *                         component that leaves the cells around its point, more than 512 points -- makes the next
- *                         mrgingham_amd_sync fail with MRGINGHAM_AMD_ERR_SPARSE and the call has to be made again with
- *                         the option 0 (the Python mirror does that).  Clean and textured calibration frames are
- *                         accepted; off by default because the benchmark this library is judged on prices the dense
- *                         per-level response.
+ *                         calls are faster dense), 0 = never (the dense per-level response of the reference, what bench.py's
+ *                         `value` is measured with).  Same outputs on every frame: a frame the sparse kernels cannot take
+ *                         -- a component that leaves the cells around its point, more than 512 points -- is repeated densely
+ *                         by the library, on the device, inside the same call (mrgingham_amd_sparse_fallbacks counts them).
  *   "chess_seg"           rows per workgroup of the ChESS kernels (0 = cost model); results do not depend on it
  * Builds made with -DMRG_EXPERIMENT (make -C mrgingham_amd/csrc EXPERIMENT=1 -> libmrgingham_amd_experiment.so)
  * additionally accept the timing ablations and phase clocks of tools/ ("cc_lds" bits 2, 4, 8, 16, 128, 512,

@@ -34,7 +34,7 @@ EXPORTS = [
     "mrgingham_amd_detect_batch", "mrgingham_amd_refine_batch", "mrgingham_amd_chain_batch",
     "mrgingham_amd_find_boards_batch", "mrgingham_amd_cc_on_response_batch", "mrgingham_amd_scratch_bytes", "mrgingham_amd_chain_info", "mrgingham_amd_debug_refine_clock", "mrgingham_amd_debug_paths", "mrgingham_amd_read_image",
     "mrgingham_amd_set_option", "mrgingham_amd_sync", "mrgingham_amd_stream_wait", "mrgingham_amd_after_stream", "mrgingham_amd_set_kernel_timing",
-    "mrgingham_amd_chess_kernel_ms",
+    "mrgingham_amd_chess_kernel_ms", "mrgingham_amd_sparse_fallbacks",
 ]
 
 
@@ -108,6 +108,7 @@ def lib():
     L.mrgingham_amd_scratch_bytes.restype = ctypes.c_longlong
     L.mrgingham_amd_set_option.argtypes = [c_vp, ctypes.c_char_p, c_int]
     L.mrgingham_amd_sync.argtypes = [c_vp]
+    L.mrgingham_amd_sparse_fallbacks.argtypes = [c_vp]
     L.mrgingham_amd_stream_wait.argtypes = [c_vp, c_vp]
     L.mrgingham_amd_after_stream.argtypes = [c_vp, c_vp]
     L.mrgingham_amd_set_kernel_timing.argtypes = [c_vp, c_int]

@@ -259,8 +259,7 @@ class Detector:
     def set_option(self, name, value):
         if self.L.mrgingham_amd_set_option(self.ctx, name.encode(), int(value)) != 0:
             raise ValueError(f"bad option {name}={value}")
-        if name == "sparse_refine" and int(value) != 0:
-            self._options[name] = int(value)     # (what chain() goes back to after a dense repeat)
+        self._options[name] = int(value)
 
     def _check(self, rc):
         if rc != 0:
@@ -269,7 +268,6 @@ class Detector:
             raise e
 
     ERR_CAPACITY = -3
-    ERR_SPARSE = -4
 
     def _sync_retrying(self, issue, retry, restore=None):
         """issue() + sync(); a frame that overflowed the component tables of its level makes the sync fail with
@@ -407,17 +405,7 @@ class Detector:
             self._check(self.L.mrgingham_amd_chain_batch(self.ctx, ctypes.byref(fr), start_level, pts.data_ptr(),
                                                          lv.data_ptr(), npts.data_ptr(), pts.shape[1]))
         if sync:
-            try:
-                self._sync_retrying(issue, retry)    # (the chain writes all of its outputs: nothing to restore)
-            except RuntimeError as e:
-                # option "sparse_refine": a frame the sparse schedule cannot take -> the whole call again, dense
-                if not retry or getattr(e, "code", 0) != self.ERR_SPARSE:
-                    raise
-                self.set_option("sparse_refine", 0)
-                try:
-                    self._sync_retrying(issue, retry)
-                finally:
-                    self.set_option("sparse_refine", self._options.get("sparse_refine", 1))
+            self._sync_retrying(issue, retry)    # (the chain writes all of its outputs: nothing to restore)
         else:
             issue()
         return pts, lv, npts
@@ -482,6 +470,14 @@ class Detector:
                                                            int(image_pyramid_level), boards.ctypes.data,
                                                            found.ctypes.data, int(nthreads)))
         return boards, found
+
+    def sparse_fallbacks(self):
+        """Frames the sparse refinement (option "sparse_refine") handed back to the dense kernels since the last
+        call of this method; the library repeats them inside the call that met them.  Synchronises."""
+        n = self.L.mrgingham_amd_sparse_fallbacks(self.ctx)
+        if n < 0:
+            self._check(n)
+        return n
 
     def debug_paths(self, level, nframes):
         """Test hook: per frame of the most recent call at `level`, 1 = component search out of LDS, 0 = the

@@ -142,8 +142,9 @@ struct mrgingham_amd_ctx {
     int last_fused = 0, last_merged = 0;  // mrgingham_amd_chain_info
     // option "sparse_refine": chain_batch computes the response of the levels BELOW the start level only in the cells
     // around the points it refines there (chain_batch_sparse)
-    int sparse_refine = 0;
-    bool sparse_seen = false;  // the option has been on (choose_sets)
+    int sparse_refine = 1;     // (default: where it pays)
+    bool sparse_seen = false;  // a chain has taken the sparse schedule (choose_sets)
+    mrg::DevBuf sparse_stat;   // [0]: frames the sparse schedule reported and the library repeated densely (mrgingham_amd_sparse_fallbacks)
     int fuse_pyramid = 1;   // option "fuse_pyramid": chain calls take the level images 1..3 out of the level-0 response kernel
     // component-chain schedule of chain_batch: 0 = every level's component kernels start as soon as
     // that level's response is done; 1 (default) = levels 1 and 0 wait for the level-0 response (they then
@@ -308,6 +309,7 @@ static std::vector<DevBuf*> all_buffers(mrgingham_amd_ctx* ctx) {
         for (DevBuf* b : level_set_buffers(ctx, set, true)) v.push_back(b);
         v.push_back(&ctx->counters2[set]);
     }
+    v.push_back(&ctx->sparse_stat);
     for (DevBuf* b : {&ctx->io_counts, &ctx->aux_img, &ctx->io_frame, &ctx->io_out, &ctx->pre_scratch, &ctx->pre_tmp,
                       &ctx->pre_out, &ctx->pre16_scratch, &ctx->io_frame16, &ctx->dbg_img, &ctx->dbg_resp, &ctx->blob_scratch, &ctx->blob_nodes, &ctx->blob_out,
                       &ctx->fb_xy, &ctx->fb_cnt, &ctx->fb_pts, &ctx->fb_lv, &ctx->fb_np, &ctx->fb_frames, &ctx->fb_frames2})
@@ -408,6 +410,7 @@ static CompTables tables_of(mrgingham_amd_ctx* ctx, int level) {
     t.status = status_of(ctx, level);
     t.path = path_of(ctx, level);
     t.lds_path = ctx->cc_lds;
+    t.only = nullptr;
     return t;
 }
 
@@ -546,6 +549,68 @@ static LevelBatch queue_level_chess(mrgingham_amd_ctx* ctx, const mrgingham_amd_
     return lb;
 }
 
+
+// SPARSE REFINEMENT of the points in `io` (at pyramid level `top`, level images of all levels in the current set's
+// scratch) through levels top-1 .. 0, on the current set's component stream, level by level: list the cells around the
+// points (sparse_cells_kernel for the first level, the refinement kernel of the level above for the others) ->
+// response + hot masks in those cells (chess_cells_kernel) -> refinement out of LDS on exactly those hot pixels
+// (window mode, `marked<BOXED = true>`).  A frame the LDS kernel cannot take (a blob that reaches the edge of its
+// cells, > 512 points, > 2048 hot pixels in the cells that no band cut separates) sets kStatusSparse in its status
+// words -- at that level and, because nobody lists its cells any more, at every level below -- and is REPEATED DENSELY
+// behind the last sparse level, on the device, before the call completes: its points go back to where they started
+// (`restore`), then per level the ordinary response kernel and the ordinary refinement kernels run with
+// CompTables::only set, i.e. on the flagged frames alone (every other workgroup reads one word and leaves: ~25 us per
+// call when no frame is flagged), and the flags are cleared.  So the outputs are the dense schedule's on every frame,
+// with no host round trip and nothing for the caller to repeat.
+static int queue_sparse_levels(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int top, RefineIO io,
+                               const SparseRestore& restore) {
+    auto& ps = ctx->pts[ctx->cur];
+    const int nf = fr->nframes;
+    hipStream_t cc = cur_cc(ctx);
+    LevelBatch lbs[kMaxLevel + 1];
+    const int list_pitch = kCellsPerPoint * io.pitch;
+    io.cell_list = (uint32_t*)ps.cell_list.p;
+    io.list_pitch = list_pitch;
+    int32_t* cnt = (int32_t*)ps.cell_cnt.p;  // [level][frame][kCellHdr]
+    for (int L = top - 1; L >= 0; --L) {
+        lbs[L] = level_batch_of(ctx, fr, L);
+        CompTables t = tables_of(ctx, L);
+        t.lds_path |= kLdsPathSparse;
+        io.cell_cnt = cnt + (size_t)L * nf * kCellHdr;
+        // the cells of this level: listed by the refinement kernel of the level above, by a kernel of its own
+        // for the first one (its points come out of the detection / from the caller)
+        if (L == top - 1)
+            launch_sparse_cells(lbs[L], t, L, io, io.cell_list, cnt + (size_t)L * nf * kCellHdr, list_pitch, 0, nf, cc);
+        launch_chess_cells(lbs[L], t, io.cell_list, io.cell_cnt, list_pitch, 0, nf, cc);
+        io.next_cnt = nullptr;
+        if (L > 0) {
+            const LevelScratch& nx = cur_levels(ctx)[L - 1];
+            io.next_cnt = cnt + (size_t)(L - 1) * nf * kCellHdr;
+            io.next_w = nx.w;
+            io.next_h = nx.h;
+            io.next_max_items = tables_of(ctx, L - 1).gidx_pitch / 4;
+        }
+        launch_cc_refine(lbs[L], t, L, io, 0, nf, cc);
+        if (nf > ctx->pending_frames[ctx->cur][L]) ctx->pending_frames[ctx->cur][L] = nf;
+    }
+    // the dense repeat of what was reported (flag = the level-0 status word: a frame given up at any level is given up
+    // at every level below it)
+    int32_t* flags = status_of(ctx, 0);
+    launch_sparse_restore(flags, restore, io.points, io.levels, io.npoints, io.pitch, nf, cc);
+    RefineIO dio = io;
+    dio.cell_list = nullptr;
+    dio.cell_cnt = nullptr;
+    dio.list_pitch = 0;
+    dio.next_cnt = nullptr;
+    for (int L = top - 1; L >= 0; --L) {
+        CompTables t = tables_of(ctx, L);
+        t.only = flags;
+        launch_chess(lbs[L], t, 0, nf, true, true, cc);
+        launch_cc_refine(lbs[L], t, L, dio, 0, nf, cc);
+    }
+    launch_sparse_clear(flags, ctx->counters_nf, top, (int32_t*)ctx->sparse_stat.p, nf, cc);
+    return 0;
+}
 }  // namespace mrg
 
 using namespace mrg;
@@ -681,6 +746,17 @@ long long mrgingham_amd_scratch_bytes(const mrgingham_amd_ctx* ctx) {
 
 const char* mrgingham_amd_last_error(const mrgingham_amd_ctx* ctx) { return ctx ? ctx->err.c_str() : "no context"; }
 
+int mrgingham_amd_sparse_fallbacks(mrgingham_amd_ctx* ctx) {
+    if (!ctx) return MRGINGHAM_AMD_ERR_ARG;
+    if (!ctx->sparse_stat.p) return 0;
+    MRG_HIP_CHECK(hipSetDevice(ctx->device));
+    MRG_HIP_CHECK(hipDeviceSynchronize());
+    int32_t n = 0;
+    MRG_HIP_CHECK(hipMemcpy(&n, ctx->sparse_stat.p, sizeof(n), hipMemcpyDeviceToHost));
+    MRG_HIP_CHECK(hipMemset(ctx->sparse_stat.p, 0, sizeof(n)));
+    return n;
+}
+
 void mrgingham_amd_set_kernel_timing(mrgingham_amd_ctx* ctx, int enable) {
     if (ctx) ctx->timing = enable != 0;
 }
@@ -714,7 +790,6 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
     if (!strcmp(name, "sparse_refine")) {
         if (value < 0 || value > 2) return MRGINGHAM_AMD_ERR_ARG;
         ctx->sparse_refine = value;
-        if (value) ctx->sparse_seen = true;
         return 0;
     }
     if (!strcmp(name, "cc_lds")) {
@@ -782,11 +857,9 @@ int mrgingham_amd_sync(mrgingham_amd_ctx* ctx) {
                 if (n > need) need = n;
             }
             if (dirty && (flags & kStatusSparse) && !(flags & (kStatusHotOverflow | kStatusCandOverflow))) {
+                // cannot happen: the dense repeat behind every sparse refinement clears the flag (queue_sparse_levels)
                 if (rc == MRGINGHAM_AMD_OK)
-                    rc = fail(ctx, MRGINGHAM_AMD_ERR_SPARSE,
-                              "frame %d, level %d: the sparse refinement cannot take this frame (a blob reaches the edge of the "
-                              "cells around its point, or more points / hot pixels than the LDS tables hold); make the call "
-                              "again with option \"sparse_refine\" 0", first, level);
+                    rc = fail(ctx, MRGINGHAM_AMD_ERR_DEVICE, "internal: frame %d, level %d left a sparse-refinement flag behind", first, level);
                 MRG_HIP_CHECK(hipMemset(status_of(ctx, level), 0, sizeof(int32_t) * nact));
             } else if (dirty) {
                 // grow the tables of this level to what was asked for (+25 %); candidate / LIFO overflow: four times
@@ -1000,10 +1073,19 @@ int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames
     if (!d_points || !d_levels || !d_npoints || points_pitch <= 0)
         return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "NULL point buffers");
     MRG_HIP_CHECK(hipSetDevice(ctx->device));
+    // (option "sparse_refine" 1 = where it pays: the dense response of a small call is cheaper than the longer chain --
+    // measured crossover at 80-100 Mpx per call, e.g. 64 x 1280x960 or 8 x 4096x3072; 2 = always)
+    const bool sparse_pays = ctx->sparse_refine == 2 || (long long)fr->width * fr->height * fr->nframes >= kSparsePaysPixels;
+    const bool sparse_now = ctx->sparse_refine && sparse_pays && start_level >= 1 && !ctx->use_v0 && ctx->cc_lds;
+    if (sparse_now) ctx->sparse_seen = true;
     if ((rc = choose_sets(ctx, fr))) return rc;
     for (int L = 0; L <= start_level; ++L)
         if ((rc = ensure_level(ctx, L, fr->nframes, fr->width, fr->height, points_pitch))) return rc;
     if ((rc = ensure_points(ctx, fr->nframes, points_pitch))) return rc;
+    if (sparse_now && !ctx->sparse_stat.p) {
+        if ((rc = ensure(ctx, ctx->sparse_stat, 256))) return rc;
+        MRG_HIP_CHECK(hipMemset(ctx->sparse_stat.p, 0, 256));
+    }
     begin_op(ctx, start_level);
     auto& ps = ctx->pts[ctx->cur];
     DetectOut out{(int32_t*)ps.cand_xy.p, points_pitch, (int32_t*)ps.cand_counts.p};
@@ -1023,18 +1105,11 @@ int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames
     auto note_pending = [&](int L) {
         if (fr->nframes > ctx->pending_frames[ctx->cur][L]) ctx->pending_frames[ctx->cur][L] = fr->nframes;
     };
-    // (1 = where it pays: the dense response of a small call is cheaper than the longer chain -- measured crossover
-    // at 80-100 Mpx per call, e.g. 64 x 1280x960 or 8 x 4096x3072; 2 = always)
-    const bool sparse_pays = ctx->sparse_refine == 2 || (long long)fr->width * fr->height * fr->nframes >= kSparsePaysPixels;
-    if (ctx->sparse_refine && sparse_pays && start_level >= 1 && !ctx->use_v0 && ctx->cc_lds) {
+    if (sparse_now) {
         // SPARSE REFINEMENT.  The dense schedule computes the response of levels start-1 .. 0 for whole frames and then
         // looks at it around ~100 points.  Here: every level image in one pass over the frames (pyramid kernel; the
         // variance windows need them around any peak), the dense response only at the START level (its detection needs
-        // every component), and below it, level by level on the component stream: list the cells around the points
-        // (sparse_cells_kernel) -> response + hot list in those cells (chess_cells_kernel) -> refinement out of LDS on
-        // exactly those hot pixels (window mode, `marked<BOXED = true>`).  A frame the LDS kernel cannot take
-        // (a blob that reaches the edge of its cells, > 512 points, > 2048 hot pixels in the cells) is REPORTED
-        // (MRGINGHAM_AMD_ERR_SPARSE at the sync): nothing else could finish it without the dense response.
+        // every component), and below it, level by level on the component stream: queue_sparse_levels.
         // what is timed in this mode (mrgingham_amd_chess_kernel_ms): the kernel that reads the frames, i.e. the launch
         // that writes the level images (the dominant kernel of a sparse step; 1 B/px read + 0.328 B/px written)
         hipEvent_t e0 = nullptr;
@@ -1057,32 +1132,8 @@ int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames
         ctx->last_merged = -1;  // (mrgingham_amd_chain_info: a sparse step)
         MRG_HIP_CHECK(hipStreamWaitEvent(cur_cc(ctx), e1, 0));
         launch_cc_detect(lbs[start_level], tables_of(ctx, start_level), start_level, out, 0, fr->nframes, cur_cc(ctx));
-        const int list_pitch = kCellsPerPoint * points_pitch;
-        io.cell_list = (uint32_t*)ps.cell_list.p;
-        io.list_pitch = list_pitch;
-        int32_t* cnt = (int32_t*)ps.cell_cnt.p;  // [level][frame][kCellHdr]
-        for (int L = start_level - 1; L >= 0; --L) {
-            lbs[L] = level_batch_of(ctx, fr, L);
-            CompTables t = tables_of(ctx, L);
-            t.lds_path |= kLdsPathSparse;
-            io.cell_cnt = cnt + (size_t)L * fr->nframes * kCellHdr;
-            // the cells of this level: listed by the refinement kernel of the level above, by a kernel of its own
-            // for the first one (its points come out of the detection)
-            if (L == start_level - 1)
-                launch_sparse_cells(lbs[L], t, L, io, io.cell_list, cnt + (size_t)L * fr->nframes * kCellHdr, list_pitch, 0,
-                                    fr->nframes, cur_cc(ctx));
-            launch_chess_cells(lbs[L], t, io.cell_list, io.cell_cnt, list_pitch, 0, fr->nframes, cur_cc(ctx));
-            io.next_cnt = nullptr;
-            if (L > 0) {
-                const LevelScratch& nx = cur_levels(ctx)[L - 1];
-                io.next_cnt = cnt + (size_t)(L - 1) * fr->nframes * kCellHdr;
-                io.next_w = nx.w;
-                io.next_h = nx.h;
-                io.next_max_items = tables_of(ctx, L - 1).gidx_pitch / 4;
-            }
-            launch_cc_refine(lbs[L], t, L, io, 0, fr->nframes, cur_cc(ctx));
-            note_pending(L);
-        }
+        SparseRestore src{out.xy, out.capacity, start_level, nullptr, nullptr};
+        if ((rc = queue_sparse_levels(ctx, fr, start_level, io, src))) return rc;
         end_op(ctx);
         MRG_HIP_CHECK(hipGetLastError());
         return 0;

@@ -479,6 +479,7 @@ __global__ __launch_bounds__(CCG_THREADS, 4) void cc_refine_kernel(LevelBatch lb
     __shared__ unsigned long long s_arena_top;
     __builtin_amdgcn_s_setprio(3);
     const int frame = frame0 + blockIdx.x;
+    if (t.only && !(t.only[frame] & kStatusSparse)) return;  // dense repeat of a sparse chain: the reported frames only
     if (t.lds_path && t.path[frame] == 1) return;  // done out of LDS
     if (t.hot_cnt[frame] > t.cap) {
         if (threadIdx.x == 0) {
@@ -1633,6 +1634,7 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
     LdsCC& L = *reinterpret_cast<LdsCC*>(lds_cc_raw);
     if (!MRG_EXP(t.lds_path & 16)) __builtin_amdgcn_s_setprio(3);
     const int frame = frame0 + blockIdx.x, tid = threadIdx.x;
+    if (!SPARSE && t.only && !(t.only[frame] & kStatusSparse)) return;  // dense repeat of a sparse chain: the reported frames only
     // phase clock (cc_lds bit 512, mrgingham_amd_debug_refine_clock, tools/cc_phases.py): thread 0 of the first
     // frame leaves 100 MHz ticks of the phase boundaries of its first band in the scratch of the global-memory kernel
     const bool clk = MRG_EXP(t.lds_path & 512) && blockIdx.x == 0 && tid == 0;
@@ -1951,6 +1953,45 @@ void launch_sparse_cells(const LevelBatch& lb, const CompTables& t, int level, c
     // the masks of chess_cells_kernel (32 B per micro-tile) go where the pixel -> index map of a dense level is
     hipLaunchKernelGGL(sparse_cells_kernel, dim3(nframes), dim3(CC_THREADS), 0, s, lb.w, lb.h, level, io, cell_list, cell_cnt,
                        list_pitch, t.gidx_pitch / 4, frame0);
+}
+
+// The frames a sparse chain reported (flags[f] & kStatusSparse): points and level tags as they were before its first
+// sparse level.  One workgroup per frame.
+__global__ __launch_bounds__(CC_THREADS) void sparse_restore_kernel(const int32_t* flags, SparseRestore src, double* points,
+                                                                 signed char* levels, const int32_t* npoints, int pitch) {
+    const int frame = blockIdx.x;
+    if (!(flags[frame] & kStatusSparse)) return;
+    const int n = min(npoints[frame], pitch);
+    const long long pb = (long long)frame * pitch;
+    for (int i = threadIdx.x; i < n; i += CC_THREADS) {
+        if (src.xy) {  // emit_detect_outputs' hand-over, again
+            const int32_t* xy = src.xy + ((long long)frame * src.xy_pitch + i) * 2;
+            points[2 * (pb + i) + 0] = (double)xy[0] / kGridScale;
+            points[2 * (pb + i) + 1] = (double)xy[1] / kGridScale;
+            levels[pb + i] = (signed char)src.level;
+        } else {
+            points[2 * (pb + i) + 0] = src.pts0[2 * (pb + i) + 0];
+            points[2 * (pb + i) + 1] = src.pts0[2 * (pb + i) + 1];
+            levels[pb + i] = src.lv0[pb + i];
+        }
+    }
+}
+void launch_sparse_restore(const int32_t* flags, const SparseRestore& src, double* points, signed char* levels,
+                           const int32_t* npoints, int pitch, int nframes, hipStream_t s) {
+    if (nframes <= 0) return;
+    hipLaunchKernelGGL(sparse_restore_kernel, dim3(nframes), dim3(CC_THREADS), 0, s, flags, src, points, levels, npoints, pitch);
+}
+__global__ __launch_bounds__(256) void sparse_clear_kernel(int32_t* status0, int level_stride, int nlevels, int32_t* counter,
+                                                           int nframes) {
+    const int frame = blockIdx.x * 256 + threadIdx.x;
+    if (frame >= nframes || !(status0[frame] & kStatusSparse)) return;
+    for (int L = 0; L < nlevels; ++L) atomicAnd(status0 + (long long)L * level_stride + frame, ~(int)kStatusSparse);
+    if (counter) atomicAdd(counter, 1);
+}
+void launch_sparse_clear(int32_t* status_level0, int level_stride, int nlevels, int32_t* counter, int nframes, hipStream_t s) {
+    if (nframes <= 0) return;
+    hipLaunchKernelGGL(sparse_clear_kernel, dim3((nframes + 255) / 256), dim3(256), 0, s, status_level0, level_stride, nlevels,
+                       counter, nframes);
 }
 
 void launch_cc_refine_lds(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io, int frame0,

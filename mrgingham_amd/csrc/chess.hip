@@ -539,7 +539,7 @@ __device__ __forceinline__ uint32_t response_pair_biased(const uint32_t (&m5)[12
     return (d1x + d1x) - dev;  // halves = response + 8192, in [2072, 10232]  (ChESS.c:104)
 }
 
-template <bool CLAMP, bool HOT, int STAGE, bool PYR = false>
+template <bool CLAMP, bool HOT, int STAGE, bool PYR = false, bool FILTER = false>
 __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTables& t, int frame0, int seg, unsigned bid,
                                               unsigned nwg_level, char* lds, const PyramidOut* po = nullptr) {
     // XCD-aware work order: workgroup b is dispatched to XCD b % 8 (observed, used
@@ -556,6 +556,8 @@ __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTa
     }
     const int strip = work % nstrips, rest = work / nstrips;
     const int frame = frame0 + rest / nsegs;
+    // the dense repeat of a sparse chain (CompTables::only): every frame but the reported ones is left alone
+    if (FILTER && !(t.only[frame] & kStatusSparse)) return;  // workgroup-uniform
     const int w = lb.w, h = lb.h, stride = lb.img_stride;
     const uint8_t* img = lb.img + (long long)frame * lb.img_pitch;
     int16_t* resp = lb.resp + (long long)frame * lb.resp_pitch;
@@ -760,10 +762,10 @@ __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTa
     if (HOT) flush_hot(hsink, hotcnt, wvu, t, frame);
 }
 
-template <bool CLAMP, bool HOT, int STAGE>
+template <bool CLAMP, bool HOT, int STAGE, bool FILTER = false>
 __global__ __launch_bounds__(256) void chess_v1_kernel(LevelBatch lb, CompTables t, int frame0, int seg) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    chess_v1_body<CLAMP, HOT, STAGE>(lb, t, frame0, seg, blockIdx.x, gridDim.x, lds);
+    chess_v1_body<CLAMP, HOT, STAGE, false, FILTER>(lb, t, frame0, seg, blockIdx.x, gridDim.x, lds);
 }
 
 // Level 0 of the chain: response + clamp + hot list + the level images 1..3 (see emit_pyramid_rows).
@@ -965,7 +967,14 @@ void launch_chess(const LevelBatch& lb, const CompTables& t, int frame0, int nfr
         case STAGE_TYPED1: MRG_LAUNCH(C, H, STAGE_TYPED1); break;       \
         default: MRG_LAUNCH(C, H, STAGE_GENERIC); break;                \
     }
-    if (hot) { MRG_LAUNCH_ST(true, true) }
+    if (hot && t.only) {  // only the frames a sparse chain reported (see chess_v1_body)
+        switch (stage) {
+            case STAGE_PERM16: hipLaunchKernelGGL((chess_v1_kernel<true, true, STAGE_PERM16, true>), grid, dim3(256), lds, s, lb, t, frame0, seg); break;
+            case STAGE_TYPED1: hipLaunchKernelGGL((chess_v1_kernel<true, true, STAGE_TYPED1, true>), grid, dim3(256), lds, s, lb, t, frame0, seg); break;
+            default: hipLaunchKernelGGL((chess_v1_kernel<true, true, STAGE_GENERIC, true>), grid, dim3(256), lds, s, lb, t, frame0, seg); break;
+        }
+    }
+    else if (hot) { MRG_LAUNCH_ST(true, true) }
     else if (clamp) { MRG_LAUNCH_ST(true, false) }
     else { MRG_LAUNCH_ST(false, false) }
 #undef MRG_LAUNCH_ST

@@ -62,6 +62,10 @@ struct CompTables {
     // a banded refinement was begun there and the global-memory kernel finishes it.
     int32_t* path;            // [nframes]
     int lds_path;             // 0: the LDS kernels are not launched and path[] is not consulted
+    // Dense repeat of the frames a sparse refinement could not take (api.hip, queue_sparse_fallback): when set, the
+    // response kernel and the refinement kernels only work on frames f with only[f] & kStatusSparse and leave at once
+    // for every other frame.  NULL everywhere else.
+    const int32_t* only;      // [nframes]
 };
 
 // A component that passed the size / peak / margin tests and waits for the

@@ -108,6 +108,20 @@ void launch_cc_refine(const LevelBatch& lb, const CompTables& t, int level, cons
 void launch_sparse_cells(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io, uint32_t* cell_list,
                          int32_t* cell_cnt, int list_pitch, int frame0, int nframes, hipStream_t s);
 constexpr int kLdsPathSparse = 1024;  // CompTables::lds_path bit: the dense response only holds those cells
+// Sparse refinement, the frames it could not take (flags[f] & kStatusSparse): their points go back to what they were
+// before the first sparse level -- the detection's candidates (xy != NULL: (double)xy / 1000 at `level`,
+// find_grid.cc:353-354) or a copy the caller kept (pts0 / lv0) -- so that the dense repeat replays every level.
+struct SparseRestore {
+    const int32_t* xy;  // [nframes * xy_pitch * 2] or NULL
+    int xy_pitch, level;
+    const double* pts0;  // [nframes * pitch * 2]
+    const signed char* lv0;
+};
+void launch_sparse_restore(const int32_t* flags, const SparseRestore& src, double* points, signed char* levels,
+                           const int32_t* npoints, int pitch, int nframes, hipStream_t s);
+// ... and when the repeat is done: the flag leaves the status words of levels [0, nlevels) (words of consecutive levels
+// are level_stride apart) and every repeated frame is counted in *counter
+void launch_sparse_clear(int32_t* status_level0, int level_stride, int nlevels, int32_t* counter, int nframes, hipStream_t s);
 
 
 }  // namespace mrg

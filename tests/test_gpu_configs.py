@@ -89,12 +89,17 @@ def test_scratch_for_64_frames():
     d = mrgingham_amd.Detector(0)
     try:
         frames = synth.board_batch(2, W, H, gridn=10, seed0=1, device="cuda").repeat(32, 1, 1)
+        d.set_option("sparse_refine", 0)                       # the dense schedule (bench.py's): two scratch sets
         d.chain(frames, start_level=3, max_points=256)
         gib = d.scratch_bytes() / 2**30
         print(f"scratch for 64 frames of {W}x{H}, both sets: {gib:.2f} GiB")
         # round 1 held 4 B/px of dense index per level and set: 64 * 12.58 MB * 4 * 1.33 * 2 = 8.6 GB for
         # that table alone, ~31 GiB in total; the bound below fails if anything of that size comes back
         assert gib <= 8, gib                                   # (round 2: 19.7 GiB)
+        d.set_option("sparse_refine", 1)                       # the library's default: a call of this size goes sparse,
+        d.chain(frames, start_level=3, max_points=256)         # and a context that has done that keeps a third set
+        assert d.chain_info()[1] == -1
+        assert d.scratch_bytes() / 2**30 <= 12
     finally:
         d.close()
 

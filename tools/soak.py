@@ -18,6 +18,7 @@ for (W, H, B, gridn, sets) in ((4096, 3072, 64, 10, 2), (4096, 3072, 64, 14, 3),
         render, gridn = synth.cluttered_board_batch, -gridn
     batches = [render(8, W, H, gridn, 8 * k, device='cuda').repeat(B // 8, 1, 1).contiguous() for k in range(3)]
     det = mrgingham_amd.Detector(0)
+    det.set_option("sparse_refine", 0)          # the reference outputs below: the dense schedule
     if sets:
         det.set_option("scratch_sets", sets)
     refs = []
