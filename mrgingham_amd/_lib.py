@@ -34,7 +34,8 @@ EXPORTS = [
     "mrgingham_amd_detect_batch", "mrgingham_amd_refine_batch", "mrgingham_amd_chain_batch",
     "mrgingham_amd_find_boards_batch", "mrgingham_amd_cc_on_response_batch", "mrgingham_amd_scratch_bytes", "mrgingham_amd_chain_info", "mrgingham_amd_debug_refine_clock", "mrgingham_amd_debug_paths", "mrgingham_amd_read_image",
     "mrgingham_amd_set_option", "mrgingham_amd_sync", "mrgingham_amd_stream_wait", "mrgingham_amd_after_stream", "mrgingham_amd_set_kernel_timing",
-    "mrgingham_amd_chess_kernel_ms", "mrgingham_amd_sparse_fallbacks",
+    "mrgingham_amd_chess_kernel_ms", "mrgingham_amd_sparse_fallbacks", "mrgingham_amd_find_boards_submit",
+    "mrgingham_amd_find_boards_collect",
 ]
 
 
@@ -97,6 +98,8 @@ def lib():
     L.mrgingham_amd_refine_batch.argtypes = [c_vp, FP, c_int, c_vp, c_vp, c_vp, c_int, c_vp]
     L.mrgingham_amd_chain_batch.argtypes = [c_vp, FP, c_int, c_vp, c_vp, c_vp, c_int]
     L.mrgingham_amd_find_boards_batch.argtypes = [c_vp, FP, c_int, c_int, c_vp, c_vp, c_int]
+    L.mrgingham_amd_find_boards_submit.argtypes = [c_vp, FP, c_int, c_int, c_vp, c_vp, c_int]
+    L.mrgingham_amd_find_boards_collect.argtypes = [c_vp, c_int]
     L.mrgingham_amd_cc_on_response_batch.argtypes = [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp,
                                                      c_vp, c_vp, c_vp, c_int, c_vp]
     L.mrgingham_amd_read_image.argtypes = [ctypes.c_char_p, c_int, c_vp, ctypes.c_size_t, ctypes.POINTER(c_int),

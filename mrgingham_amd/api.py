@@ -471,6 +471,26 @@ class Detector:
                                                            found.ctypes.data, int(nthreads)))
         return boards, found
 
+    def find_boards_submit(self, frames, gridn=10, image_pyramid_level=-1, nthreads=0):
+        """First half of find_boards: queues the device passes of the batch and returns a job to hand to
+        find_boards_collect.  Submit the next batch(es) before collecting this one and the device passes, the host's
+        grid finder and the refinement of consecutive batches overlap (include/mrgingham_amd.h)."""
+        t = self.torch
+        fr, B, H, W = self._frames(frames)
+        boards = np.full((B, gridn * gridn, 2), np.nan, dtype=np.float64)
+        found = np.full((B,), -1, dtype=np.int8)
+        t.cuda.current_stream(frames.device).synchronize()
+        ticket = self.L.mrgingham_amd_find_boards_submit(self.ctx, ctypes.byref(fr), int(gridn), int(image_pyramid_level),
+                                                         boards.ctypes.data, found.ctypes.data, int(nthreads))
+        if ticket < 0:
+            self._check(ticket)
+        return (ticket, boards, found, frames)                 # (the frames must outlive the job)
+
+    def find_boards_collect(self, job):
+        """Second half: waits for the job -> (boards float64 [B, gridn*gridn, 2], found_level int8 [B])."""
+        self._check(self.L.mrgingham_amd_find_boards_collect(self.ctx, job[0]))
+        return job[1], job[2]
+
     def sparse_fallbacks(self):
         """Frames the sparse refinement (option "sparse_refine") handed back to the dense kernels since the last
         call of this method; the library repeats them inside the call that met them.  Synchronises."""

@@ -66,25 +66,33 @@ struct HostPool {
             if (--running == 0) cv_done.notify_all();
         }
     }
-    // runs f on n threads (the caller is one of them) and returns when all of them are done
-    void run(int n, const std::function<void()>& f) {
-        if (n <= 1) { f(); return; }
+    // starts f on n pool threads (the caller is not one of them) and returns; wait() returns when they are done
+    void start(int n, const std::function<void()>& f) {
+        if (n <= 0) return;
         {
             std::unique_lock<std::mutex> lk(m);
-            while ((int)threads.size() < n - 1) {
+            while ((int)threads.size() < n) {
                 const int id = (int)threads.size();
                 threads.emplace_back([this, id] { loop(id); });
             }
             job = f;
-            wanted = n - 1;
-            running = n - 1;
+            wanted = n;
+            running = n;
             ++generation;
         }
         cv_start.notify_all();
-        f();
+    }
+    void wait() {
         std::unique_lock<std::mutex> lk(m);
         cv_done.wait(lk, [&] { return running == 0; });
         wanted = 0;
+    }
+    // runs f on n threads (the caller is one of them) and returns when all of them are done
+    void run(int n, const std::function<void()>& f) {
+        if (n <= 1) { f(); return; }
+        start(n - 1, f);
+        f();
+        wait();
     }
     ~HostPool() {
         {
@@ -165,6 +173,35 @@ struct mrgingham_amd_ctx {
     // lives on MRGINGHAM_AMD_DEVICE / device 0 and cannot touch another GPU's frames
     mrgingham_amd_ctx* one = nullptr;
     HostPool pool;  // preprocessing: extrema + tile histograms + LUTs, CLAHE output before the blur
+    // mrgingham_amd_find_boards_submit / _collect: one job per scratch set (its level images stay in the set's scratch
+    // between the first pass and the refinement)
+    struct BoardsJob {
+        int state = 0;  // 0 free, 1 first pass queued, 2 host part done (refinement queued, or nothing to refine)
+        int ticket = -1, set = 0;
+        mrgingham_amd_frames fr{};
+        int gridn = 0, level_arg = 0, nthreads = 0, nlev = 0, levs[3] = {0, 0, 0}, cap = 0;
+        double* h_boards = nullptr;
+        signed char* h_found = nullptr;
+        hipEvent_t ev_a = nullptr, ev_b = nullptr;
+        bool refine_queued = false;
+        int top = 0;  // the highest level a board of the job was found at (levels below it are refined)
+        mrg::DevBuf d_xy, d_cnt, d_pts, d_lv, d_np, d_pts0, d_lv0;
+        void* pin = nullptr;  // pinned host staging: counts, candidates | boards, levels, point counts
+        size_t pin_bytes = 0;
+        // the host part in progress (fb_host_begin .. fb_host_end): candidate lists of frames re-run at full capacity,
+        // the frame counter of the grid-finder threads
+        std::vector<std::vector<int32_t>> big;
+        std::atomic<int> next{0};
+        bool grid_running = false;
+        int nworkers = 0;
+    } jobs[kMaxSets];
+    int next_ticket = 0;
+    std::vector<std::pair<int, int>> done_tickets;  // (ticket, status) of jobs completed before they were collected
+    int fb_pipeline = 1;  // option "find_boards_pipeline"
+#ifdef MRG_EXPERIMENT
+    double fb_prof[10] = {};  // host milliseconds by phase of submit / collect (printed by destroy; tools/find_boards_bench.py)
+    long fb_prof_n = 0;
+#endif
     int pts_nframes = 0, pts_pitch = 0;
     // levels (and frame counts) whose status words must be checked at the next sync
     int pending_frames[kMaxSets][mrg::kMaxLevel + 1] = {};
@@ -310,6 +347,8 @@ static std::vector<DevBuf*> all_buffers(mrgingham_amd_ctx* ctx) {
         v.push_back(&ctx->counters2[set]);
     }
     v.push_back(&ctx->sparse_stat);
+    for (auto& j : ctx->jobs)
+        for (DevBuf* b : {&j.d_xy, &j.d_cnt, &j.d_pts, &j.d_lv, &j.d_np, &j.d_pts0, &j.d_lv0}) v.push_back(b);
     for (DevBuf* b : {&ctx->io_counts, &ctx->aux_img, &ctx->io_frame, &ctx->io_out, &ctx->pre_scratch, &ctx->pre_tmp,
                       &ctx->pre_out, &ctx->pre16_scratch, &ctx->io_frame16, &ctx->dbg_img, &ctx->dbg_resp, &ctx->blob_scratch, &ctx->blob_nodes, &ctx->blob_out,
                       &ctx->fb_xy, &ctx->fb_cnt, &ctx->fb_pts, &ctx->fb_lv, &ctx->fb_np, &ctx->fb_frames, &ctx->fb_frames2})
@@ -562,12 +601,24 @@ static LevelBatch queue_level_chess(mrgingham_amd_ctx* ctx, const mrgingham_amd_
 // CompTables::only set, i.e. on the flagged frames alone (every other workgroup reads one word and leaves: ~25 us per
 // call when no frame is flagged), and the flags are cleared.  So the outputs are the dense schedule's on every frame,
 // with no host round trip and nothing for the caller to repeat.
+// `dense_only`: no sparse pass at all -- the ordinary kernels on every frame, level by level, on the component stream
+// (the refinement of find_boards_submit when the sparse schedule is switched off or does not pay).
 static int queue_sparse_levels(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int top, RefineIO io,
-                               const SparseRestore& restore) {
+                               const SparseRestore& restore, bool dense_only = false) {
     auto& ps = ctx->pts[ctx->cur];
     const int nf = fr->nframes;
     hipStream_t cc = cur_cc(ctx);
     LevelBatch lbs[kMaxLevel + 1];
+    if (dense_only) {
+        for (int L = top - 1; L >= 0; --L) {
+            lbs[L] = level_batch_of(ctx, fr, L);
+            const CompTables t = tables_of(ctx, L);
+            launch_chess_any(ctx, lbs[L], t, nf, true, true, cc, false);
+            launch_cc_refine(lbs[L], t, L, io, 0, nf, cc);
+            if (nf > ctx->pending_frames[ctx->cur][L]) ctx->pending_frames[ctx->cur][L] = nf;
+        }
+        return 0;
+    }
     const int list_pitch = kCellsPerPoint * io.pitch;
     io.cell_list = (uint32_t*)ps.cell_list.p;
     io.list_pitch = list_pitch;
@@ -692,6 +743,14 @@ mrgingham_amd_ctx* mrgingham_amd_create(int device_ordinal) {
 
 void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx) {
     if (!ctx) return;
+#ifdef MRG_EXPERIMENT
+    if (ctx->fb_prof_n > 0 && getenv("MRG_DBG_FB")) {
+        static const char* names[10] = {"submit: checks + scratch", "submit: host part begins (big frames, threads start)", "submit: device passes queued",
+                                        "host part: grid finder joined", "host part: refinement queued", "collect: wait for the refinement",
+                                        "collect: boards copied", "", "", ""};
+        for (int i = 0; i < 7; ++i) fprintf(stderr, "  [fb] %-56s %8.3f ms per batch\n", names[i], ctx->fb_prof[i] / ctx->fb_prof_n);
+    }
+#endif
     if (ctx->one) mrgingham_amd_destroy(ctx->one);
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
@@ -704,6 +763,11 @@ void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx) {
     for (hipEvent_t e : ctx->ev_cc_done)
         if (e) hipEventDestroy(e);
     if (ctx->ev_ext) hipEventDestroy(ctx->ev_ext);
+    for (auto& j : ctx->jobs) {
+        if (j.ev_a) hipEventDestroy(j.ev_a);
+        if (j.ev_b) hipEventDestroy(j.ev_b);
+        if (j.pin) hipHostFree(j.pin);
+    }
     if (ctx->pix) hipStreamDestroy(ctx->pix);
     for (hipStream_t c : ctx->ccs)
         if (c) hipStreamDestroy(c);
@@ -787,6 +851,7 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
         return rc;
     }
     if (!strcmp(name, "fuse_pyramid")) { ctx->fuse_pyramid = value != 0; return 0; }
+    if (!strcmp(name, "find_boards_pipeline")) { ctx->fb_pipeline = value != 0; return 0; }
     if (!strcmp(name, "sparse_refine")) {
         if (value < 0 || value > 2) return MRGINGHAM_AMD_ERR_ARG;
         ctx->sparse_refine = value;
@@ -823,6 +888,57 @@ double mrgingham_amd_chess_kernel_ms(mrgingham_amd_ctx* ctx, int* nlaunches) {
     return n ? total / n : 0.;
 }
 
+// The status words of one (scratch set, level): inspected and cleared; a table overflow grows the tables of the level
+// to what the fullest frame asked for.  *rc keeps the first error.  Nothing of that set may be running at that level.
+static int harvest_status(mrgingham_amd_ctx* ctx, int set, int level, int* rc, bool quiet = false) {
+    const int nact = ctx->pending_frames[set][level];
+    ctx->pending_frames[set][level] = 0;
+    if (nact <= 0 || !ctx->counters2[set].p) return 0;
+    const int saved = ctx->cur;
+    ctx->cur = set;
+    int32_t* const words = status_of(ctx, level);
+    ctx->cur = saved;
+    ctx->host_status.resize(nact);
+    MRG_HIP_CHECK(hipMemcpy(ctx->host_status.data(), words, sizeof(int32_t) * nact, hipMemcpyDeviceToHost));
+    // every pending status block is inspected and cleared; only the first error is reported
+    bool dirty = false;
+    int flags = 0, first = -1;
+    long long need = 0;  // hot pixels the fullest frame asked for (status words carry it in units of 64)
+    for (int f = 0; f < nact; ++f) {
+        const int st = ctx->host_status[f];
+        if (!st) continue;
+        dirty = true;
+        if (first < 0) first = f;
+        flags |= st & 0xff;
+        const long long n = (long long)((uint32_t)st >> 8) * 64;
+        if (n > need) need = n;
+    }
+    if (!dirty) return 0;
+    if ((flags & kStatusSparse) && !(flags & (kStatusHotOverflow | kStatusCandOverflow))) {
+        // cannot happen: the dense repeat behind every sparse refinement clears the flag (queue_sparse_levels)
+        if (*rc == MRGINGHAM_AMD_OK)
+            *rc = fail(ctx, MRGINGHAM_AMD_ERR_DEVICE, "internal: frame %d, level %d left a sparse-refinement flag behind", first, level);
+    } else {
+        // grow the tables of this level to what was asked for (+25 %); candidate / LIFO overflow: four times
+        const LevelScratch& LS = ctx->lvs[set][level];
+        const long long px = (long long)LS.w * LS.h;
+        int sh = LS.shift;
+        if (flags & kStatusHotOverflow)
+            while (sh > 0 && (px >> sh) < need + need / 4) --sh;
+        if (flags & kStatusCandOverflow) sh = sh >= 2 ? (sh - 2 < LS.shift - 2 ? sh - 2 : LS.shift - 2) : 0;
+        if (sh < 0) sh = 0;
+        if (sh < ctx->grown_shift[level]) ctx->grown_shift[level] = sh;
+        if (quiet) *rc = MRGINGHAM_AMD_ERR_CAPACITY;  // (the caller has dealt with the frames; the tables grow for the next batch)
+        else if (*rc == MRGINGHAM_AMD_OK)
+            *rc = fail(ctx, MRGINGHAM_AMD_ERR_CAPACITY,
+                       "frame %d, level %d: component tables overflowed (status %d, %lld hot pixels asked for); "
+                       "the tables of this level grow from 1/%d to 1/%d of its pixels: make the call again",
+                       first, level, flags, need, 1 << LS.shift, 1 << sh);
+    }
+    MRG_HIP_CHECK(hipMemset(words, 0, sizeof(int32_t) * nact));
+    return 0;
+}
+
 int mrgingham_amd_sync(mrgingham_amd_ctx* ctx) {
     if (!ctx) return MRGINGHAM_AMD_ERR_ARG;
     MRG_HIP_CHECK(hipSetDevice(ctx->device));
@@ -833,53 +949,11 @@ int mrgingham_amd_sync(mrgingham_amd_ctx* ctx) {
     }
     MRG_HIP_CHECK(hipGetLastError());
     int rc = MRGINGHAM_AMD_OK;
-    const int saved = ctx->cur;
     for (int set = 0; set < kMaxSets; ++set)
         for (int level = 0; level <= kMaxLevel; ++level) {
-            const int nact = ctx->pending_frames[set][level];
-            ctx->pending_frames[set][level] = 0;
-            if (nact <= 0 || !ctx->counters2[set].p) continue;
-            ctx->cur = set;
-            ctx->host_status.resize(nact);
-            MRG_HIP_CHECK(hipMemcpy(ctx->host_status.data(), status_of(ctx, level), sizeof(int32_t) * nact,
-                                    hipMemcpyDeviceToHost));
-            // every pending status block is inspected and cleared; only the first error is reported
-            bool dirty = false;
-            int flags = 0, first = -1;
-            long long need = 0;  // hot pixels the fullest frame asked for (status words carry it in units of 64)
-            for (int f = 0; f < nact; ++f) {
-                const int st = ctx->host_status[f];
-                if (!st) continue;
-                dirty = true;
-                if (first < 0) first = f;
-                flags |= st & 0xff;
-                const long long n = (long long)((uint32_t)st >> 8) * 64;
-                if (n > need) need = n;
-            }
-            if (dirty && (flags & kStatusSparse) && !(flags & (kStatusHotOverflow | kStatusCandOverflow))) {
-                // cannot happen: the dense repeat behind every sparse refinement clears the flag (queue_sparse_levels)
-                if (rc == MRGINGHAM_AMD_OK)
-                    rc = fail(ctx, MRGINGHAM_AMD_ERR_DEVICE, "internal: frame %d, level %d left a sparse-refinement flag behind", first, level);
-                MRG_HIP_CHECK(hipMemset(status_of(ctx, level), 0, sizeof(int32_t) * nact));
-            } else if (dirty) {
-                // grow the tables of this level to what was asked for (+25 %); candidate / LIFO overflow: four times
-                const LevelScratch& LS = ctx->lvs[set][level];
-                const long long px = (long long)LS.w * LS.h;
-                int sh = LS.shift;
-                if (flags & kStatusHotOverflow)
-                    while (sh > 0 && (px >> sh) < need + need / 4) --sh;
-                if (flags & kStatusCandOverflow) sh = sh >= 2 ? (sh - 2 < LS.shift - 2 ? sh - 2 : LS.shift - 2) : 0;
-                if (sh < 0) sh = 0;
-                if (sh < ctx->grown_shift[level]) ctx->grown_shift[level] = sh;
-                if (rc == MRGINGHAM_AMD_OK)
-                    rc = fail(ctx, MRGINGHAM_AMD_ERR_CAPACITY,
-                              "frame %d, level %d: component tables overflowed (status %d, %lld hot pixels asked for); "
-                              "the tables of this level grow from 1/%d to 1/%d of its pixels: make the call again",
-                              first, level, flags, need, 1 << LS.shift, 1 << sh);
-                MRG_HIP_CHECK(hipMemset(status_of(ctx, level), 0, sizeof(int32_t) * nact));
-            }
+            const int r = harvest_status(ctx, set, level, &rc);
+            if (r) return r;
         }
-    ctx->cur = saved;
     return rc;
 }
 
@@ -1924,30 +1998,27 @@ int mrgingham_amd_process_image(const uint8_t* image, int width, int height, int
     return mrgingham_amd_process_image_ex(image, 8, width, height, stride, &o, xy_out, levels_out);
 }
 
-/* Batch form of the full detector (the reference's default schedule, image_pyramid_level < 0, per
- * frame: mrgingham.cc:116-139 and :81-99): the GPU runs the candidate detector of a level for the
- * whole batch, host threads run the grid finder on the frames that have no board yet, and the
- * corners of the frames whose board was found at that level are refined level by level on the
- * GPU.  Synchronous.  h_boards: nframes x gridn*gridn x 2 doubles (host); h_found_level[f] is the
- * level at which frame f's grid was found, -1 if none. */
-int mrgingham_amd_find_boards_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int gridn,
-                                    int image_pyramid_level, double* h_boards, signed char* h_found_level,
-                                    int nthreads) {
-    int rc = validate_frames(ctx, fr);
-    if (rc) return rc;
-    if (gridn < 2 || image_pyramid_level > kMaxLevel || !h_boards || !h_found_level)
-        return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "bad gridn / level / NULL outputs");
-    const int B = fr->nframes, N = gridn * gridn;
-    if (B == 0) return 0;
-    MRG_HIP_CHECK(hipSetDevice(ctx->device));
-    const int first = image_pyramid_level >= 0 ? image_pyramid_level : 3;
-    const int last = image_pyramid_level >= 0 ? image_pyramid_level : 0;
-    const int cap = 4 * N + 64;  // candidates kept per frame for the grid finder
-    if (nthreads <= 0) {  // the grid finder takes ~0.3 ms per frame: a few dozen threads cover a batch
+// grid-finder threads of the find_boards calls: <= 0 = one per core the process may use, at most 32 (the grid finder
+// takes ~0.1 ms per frame and level: a few dozen threads cover a batch)
+static int fb_threads(int nthreads) {
+    if (nthreads <= 0) {
         nthreads = (int)std::thread::hardware_concurrency();
         if (nthreads > 32) nthreads = 32;
     }
-    if (nthreads <= 0) nthreads = 1;
+    return nthreads > 0 ? nthreads : 1;
+}
+
+// The level search of mrgingham_amd_find_boards_batch, SYNCHRONOUS form: per level from `first` down to `last` one
+// batched device pass over the frames still open (`open0`, ascending; the others must have h_found_level >= 0
+// already), the grid finder on host threads, the boards found at the level refined densely level by level.  The
+// pipelined form (find_boards_submit / _collect below) uses it for what its first pass leaves open, and option
+// "find_boards_pipeline" 0 for everything.
+static int find_boards_sync_levels(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int gridn, int first, int last,
+                                   double* h_boards, signed char* h_found_level, int nthreads, std::vector<int> open) {
+    int rc = 0;
+    const int B = fr->nframes, N = gridn * gridn;
+    const int cap = 4 * N + 64;  // candidates kept per frame for the grid finder
+    nthreads = fb_threads(nthreads);
 
     DevBuf &d_xy = ctx->fb_xy, &d_cnt = ctx->fb_cnt, &d_pts = ctx->fb_pts, &d_lv = ctx->fb_lv, &d_np = ctx->fb_np;
     if ((rc = ensure(ctx, d_xy, (size_t)B * cap * 8)) || (rc = ensure(ctx, d_cnt, (size_t)B * 4)) ||
@@ -1957,7 +2028,6 @@ int mrgingham_amd_find_boards_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_
     std::vector<int32_t> h_xy((size_t)B * cap * 2), h_cnt(B), h_np(B, 0);
     std::vector<signed char> h_lv((size_t)B * N, 0);
     std::vector<double> h_pts((size_t)B * N * 2);
-    for (int f = 0; f < B; ++f) h_found_level[f] = -1;
 
     // A dense copy of a few frames of the batch, so that a late level only runs on the frames that
     // still need it (one straggler must not cost the whole batch another two ChESS passes).
@@ -1983,9 +2053,8 @@ int mrgingham_amd_find_boards_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_
     double t_prev = now();
     auto lap = [&](const char* what, int L, int n) { if (dbg_t) { const double t = now(); fprintf(stderr, "  [fb] L%d %-14s %3d frames %7.3f ms\n", L, what, n, t - t_prev); t_prev = t; } };
 
-    std::vector<int> open(B);  // frames without a board yet, ascending
-    for (int f = 0; f < B; ++f) open[f] = f;
-    std::vector<int> cur_idx = open;         // original index of every frame of the batch the detector runs on
+    std::vector<int> cur_idx(B);             // original index of every frame of the batch the detector runs on
+    for (int f = 0; f < B; ++f) cur_idx[f] = f;
     mrgingham_amd_frames cur = *fr, rsub;
 
     for (int L = first; L >= last && !open.empty(); --L) {
@@ -2115,6 +2184,446 @@ int mrgingham_amd_find_boards_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_
         lap("refine+D2H", L, nr);
     }
     return rc;
+}
+
+/* ------------------------------------------------------------------------ */
+/* The full detector over a batch, pipelined                                 */
+/* ------------------------------------------------------------------------ */
+// What mrgingham::find_chessboard_from_image_array does per frame (mrgingham.cc:106-140) is a chain of dependent
+// steps that alternate between device and host: candidates at level 3 -> grid finder -> (none: level 2 -> grid
+// finder ...) -> refinement of the found board level by level.  One batch at a time that leaves the device idle
+// while the host threads run the grid finder and the host idle during the device passes (round 3: 3.8 ms per 64
+// frames of 4096x3072 against 0.98 ms for the chain).  Here a batch is a JOB in three parts:
+//   A  (device, queued by submit)  all level images in one pass over the frames, the response + candidates of
+//      levels 3 AND 2 (level 2 speculatively: it is a quarter of level 3's neighbour in cost and where 12 MP boards
+//      are found), candidates to pinned host memory;
+//   H  (host, run by the NEXT submit or by collect)  grid finder per frame, level 3 first, then level 2
+//      (mrgingham.cc:127-138) on the context's host threads; the boards that were found go back to the device;
+//   B  (device, queued by H on the job's component stream)  refinement of the found boards down to level 0
+//      (mrgingham.cc:81-99) with the sparse schedule -- response only in the cells around the corners, frames it
+//      cannot take repeated densely on the device (queue_sparse_levels) --, boards to pinned host memory.
+// A job owns one scratch set from A to the end of B (B reads A's level images), so up to `scratch sets` jobs are in
+// flight; submit(N+1) queues A(N+1) and THEN runs H(N), so the grid finder of batch N works while the device runs
+// the first pass of batch N+1, and B(N) runs on its own stream underneath that.  Frames without a board at levels 3
+// and 2 (no board in view, or one that needs level 1 / 0) finish through the synchronous level search above, after
+// the other jobs in flight have been completed.  Results are the synchronous dense schedule's, double for double.
+
+static int fb_complete(mrgingham_amd_ctx* ctx, mrgingham_amd_ctx::BoardsJob& job);
+#ifdef MRG_EXPERIMENT
+static double fb_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define FB_LAP(i) do { const double t_ = fb_now(); ctx->fb_prof[i] += t_ - fb_t; fb_t = t_; } while (0)
+#define FB_T0 double fb_t = fb_now()
+#else
+#define FB_LAP(i) do { } while (0)
+#define FB_T0 do { } while (0)
+#endif
+
+static size_t fb_align(size_t v) { return (v + 255) & ~(size_t)255; }
+struct FbPinned { int32_t *cnt, *xy; double* pts; signed char* lv; int32_t *np, *st; size_t bytes; };
+static FbPinned fb_layout(void* base, int nlev, int B, int cap, int N) {
+    FbPinned L;
+    size_t o = 0;
+    char* b = (char*)base;
+    L.cnt = (int32_t*)(b + o); o += fb_align((size_t)nlev * B * 4);
+    L.xy = (int32_t*)(b + o); o += fb_align((size_t)nlev * B * cap * 8);
+    L.pts = (double*)(b + o); o += fb_align((size_t)B * N * 16);
+    L.lv = (signed char*)(b + o); o += fb_align((size_t)B * N);
+    L.np = (int32_t*)(b + o); o += fb_align((size_t)B * 4);
+    L.st = (int32_t*)(b + o); o += fb_align((size_t)(kMaxLevel + 1) * B * 4);  // status words of the refinement, [level][frame]
+    L.bytes = o;
+    return L;
+}
+
+// part H, first half: waits for part A, deals with the frames whose candidate lists did not fit, and STARTS the grid
+// finder (mrgingham.cc:51) on the context's host threads -- level by level per frame.  The caller may do something
+// else before fb_host_end (submit queues the next batch's device passes there).
+static void fb_grid_worker(mrgingham_amd_ctx::BoardsJob* job) {
+    const int B = job->fr.nframes, N = job->gridn * job->gridn, cap = job->cap, nlev = job->nlev;
+    const FbPinned pin = fb_layout(job->pin, nlev, B, cap, N);
+    std::vector<PointI> cand;
+    std::vector<PointD> board;
+    for (int k; (k = job->next.fetch_add(1)) < B;) {
+        for (int li = 0; li < nlev; ++li) {
+            const int n = pin.cnt[(size_t)li * B + k];
+            if (n < N) continue;
+            const std::vector<int32_t>& bg = job->big[(size_t)li * B + k];
+            const int32_t* src = bg.empty() ? pin.xy + ((size_t)li * B + k) * cap * 2 : bg.data();
+            cand.resize((size_t)n);
+            for (int i = 0; i < n; ++i) cand[i] = PointI{src[2 * i], src[2 * i + 1]};
+            board.clear();
+            if (find_grid_from_points(board, cand, job->gridn) && (int)board.size() == N) {
+                memcpy(job->h_boards + (size_t)k * N * 2, board.data(), sizeof(double) * 2 * N);
+                job->h_found[k] = (signed char)job->levs[li];
+                break;
+            }
+        }
+    }
+}
+static int fb_host_begin(mrgingham_amd_ctx* ctx, mrgingham_amd_ctx::BoardsJob& job) {
+    const int B = job.fr.nframes, N = job.gridn * job.gridn, cap = job.cap, nlev = job.nlev;
+    const mrgingham_amd_frames* fr = &job.fr;
+    job.state = 2;
+    job.refine_queued = false;
+    job.grid_running = false;
+    MRG_HIP_CHECK(hipEventSynchronize(job.ev_a));
+    const FbPinned pin = fb_layout(job.pin, nlev, B, cap, N);
+    int rc = 0;
+    // Frames with more candidates than the batch buffer keeps (clutter), or whose component tables overflowed (dense
+    // texture, count -1): the reference runs the grid finder on ALL candidates (mrgingham.cc:50-51), so these are
+    // re-run one by one with exact capacity on the single-frame context of this device; the tables of the level grow
+    // for the batches to come.
+    job.big.assign((size_t)nlev * B, std::vector<int32_t>());
+    bool overflowed = false;
+    for (int li = 0; li < nlev && !rc; ++li)
+        for (int k = 0; k < B && !rc; ++k) {
+            int32_t& c = pin.cnt[(size_t)li * B + k];
+            if (c >= 0 && c <= cap) continue;
+            overflowed |= c < 0;
+            mrgingham_amd_ctx* one = same_device_ctx(ctx);
+            if (!one) { rc = fail(ctx, MRGINGHAM_AMD_ERR_DEVICE, "no single-frame context"); break; }
+            const mrgingham_amd_frames f1{fr->frames + (size_t)k * fr->frame_pitch, fr->frame_pitch, 1, fr->width, fr->height,
+                                          fr->stride};
+            int32_t n1 = 0;
+            if (!detect_one_frame_all(one, &f1, job.levs[li], job.big[(size_t)li * B + k], &n1))
+                rc = fail(ctx, MRGINGHAM_AMD_ERR_DEVICE, "frame %d, level %d: full-capacity detect failed", k, job.levs[li]);
+            c = n1;
+        }
+    if (rc) return rc;
+    if (overflowed)
+        for (int li = 0; li < nlev; ++li) {
+            int grew = 0;
+            harvest_status(ctx, job.set, job.levs[li], &grew, true);
+        }
+    const int nthreads = fb_threads(job.nthreads);
+    job.next.store(0);
+    job.nworkers = (nthreads < B ? nthreads : B) - 1;  // + the calling thread, in fb_host_end
+    mrgingham_amd_ctx::BoardsJob* jp = &job;
+    if (job.nworkers > 0) {
+        ctx->pool.start(job.nworkers, [jp] { fb_grid_worker(jp); });
+        job.grid_running = true;
+    }
+    return 0;
+}
+
+// part H, second half: joins the grid finder and queues part B -- the boards found above level 0, refined level by level
+// (mrgingham.cc:81-99) on the job's component stream.
+static int fb_host_end(mrgingham_amd_ctx* ctx, mrgingham_amd_ctx::BoardsJob& job) {
+    const int B = job.fr.nframes, N = job.gridn * job.gridn, cap = job.cap, nlev = job.nlev;
+    const mrgingham_amd_frames* fr = &job.fr;
+    FB_T0;
+    fb_grid_worker(&job);
+    if (job.grid_running) {
+        ctx->pool.wait();
+        job.grid_running = false;
+    }
+    FB_LAP(3);
+    const FbPinned pin = fb_layout(job.pin, nlev, B, cap, N);
+    int rc = 0;
+    int top = 0, nref = 0;
+    for (int k = 0; k < B; ++k) {
+        const int L = job.h_found[k];
+        pin.np[k] = L >= 1 ? N : 0;
+        if (L < 1) continue;
+        ++nref;
+        top = L > top ? L : top;
+        memset(pin.lv + (size_t)k * N, L, (size_t)N);
+        memcpy(pin.pts + (size_t)k * N * 2, job.h_boards + (size_t)k * N * 2, sizeof(double) * 2 * N);
+    }
+    if (nref > 0) {
+        const int saved = ctx->cur;
+        ctx->cur = job.set;  // (the helpers below address the current set)
+        hipStream_t cc = cur_cc(ctx);
+        const size_t pb = (size_t)B * N * 16, lb = (size_t)B * N;
+        hipError_t e = hipMemcpyAsync(job.d_pts.p, pin.pts, pb, hipMemcpyHostToDevice, cc);
+        if (e == hipSuccess) e = hipMemcpyAsync(job.d_lv.p, pin.lv, lb, hipMemcpyHostToDevice, cc);
+        if (e == hipSuccess) e = hipMemcpyAsync(job.d_np.p, pin.np, (size_t)B * 4, hipMemcpyHostToDevice, cc);
+        if (e == hipSuccess) e = hipMemcpyAsync(job.d_pts0.p, job.d_pts.p, pb, hipMemcpyDeviceToDevice, cc);
+        if (e == hipSuccess) e = hipMemcpyAsync(job.d_lv0.p, job.d_lv.p, lb, hipMemcpyDeviceToDevice, cc);
+        if (e == hipSuccess) {
+            auto& ps = ctx->pts[job.set];
+            RefineIO io{(double*)job.d_pts.p, (signed char*)job.d_lv.p, (const int32_t*)job.d_np.p, N, nullptr,
+                        (int32_t*)ps.leader.p, (int32_t*)ps.need.p, (int32_t*)ps.nseeds.p, (uint32_t*)ps.seeds.p,
+                        (int32_t*)ps.sroot.p};
+            const SparseRestore src{nullptr, 0, 0, (const double*)job.d_pts0.p, (const signed char*)job.d_lv0.p};
+            const bool sparse = ctx->cc_lds && !ctx->use_v0 &&
+                                (ctx->sparse_refine == 2 ||
+                                 (ctx->sparse_refine == 1 && (long long)fr->width * fr->height * B >= kSparsePaysPixels));
+            rc = queue_sparse_levels(ctx, fr, top, io, src, !sparse);
+            job.top = top;
+            e = hipMemcpyAsync(pin.pts, job.d_pts.p, pb, hipMemcpyDeviceToHost, cc);
+            for (int L = 0; L < top && e == hipSuccess; ++L)  // (a frame whose tables overflowed at a level was not refined there)
+                e = hipMemcpyAsync(pin.st + (size_t)L * B, status_of(ctx, L), (size_t)B * 4, hipMemcpyDeviceToHost, cc);
+            if (e == hipSuccess) e = hipEventRecord(job.ev_b, cc);
+            end_op(ctx);
+            job.refine_queued = true;
+        }
+        ctx->cur = saved;
+        if (e != hipSuccess) return fail_hip(ctx, e, "find_boards refinement", __FILE__, __LINE__);
+        if (rc) return rc;
+    }
+    FB_LAP(4);
+    return 0;
+}
+
+// the rest of a job: wait for part B, boards into the caller's array, then the frames still open (level_arg < 0 only)
+static int fb_finish(mrgingham_amd_ctx* ctx, mrgingham_amd_ctx::BoardsJob& job) {
+    const int B = job.fr.nframes, N = job.gridn * job.gridn;
+    int rc = 0;
+    FB_T0;
+    if (job.refine_queued) {
+        MRG_HIP_CHECK(hipEventSynchronize(job.ev_b));
+        FB_LAP(5);
+        const FbPinned pin = fb_layout(job.pin, job.nlev, B, job.cap, N);
+        bool overflowed = false;
+        for (int k = 0; k < B && !rc; ++k) {
+            const int Lf = job.h_found[k];
+            if (Lf < 1) continue;
+            int bad = 0;
+            for (int L = 0; L < Lf; ++L) bad |= pin.st[(size_t)L * B + k] & (kStatusHotOverflow | kStatusCandOverflow);
+            if (!bad) {
+                memcpy(job.h_boards + (size_t)k * N * 2, pin.pts + (size_t)k * N * 2, sizeof(double) * 2 * N);
+                continue;
+            }
+            // The component tables of a level overflowed for this frame (dense texture): it was not refined there.  Its
+            // board -- still the grid finder's in h_boards -- is refined on the single-frame context, which retries with
+            // a table entry per pixel; the tables of this context grow for the batches to come.
+            overflowed = true;
+            mrgingham_amd_ctx* one = same_device_ctx(ctx);
+            if (!one) { rc = fail(ctx, MRGINGHAM_AMD_ERR_DEVICE, "no single-frame context"); break; }
+            const mrgingham_amd_frames f1{job.fr.frames + (size_t)k * job.fr.frame_pitch, job.fr.frame_pitch, 1, job.fr.width,
+                                          job.fr.height, job.fr.stride};
+            std::vector<signed char> lv1((size_t)N, (signed char)Lf);
+            for (int l = Lf - 1; l >= 0; --l)
+                if (refine_on_device(one, &f1, job.h_boards + (size_t)k * N * 2, lv1.data(), N, l) <= 0) break;
+        }
+        if (overflowed)
+            for (int L = 0; L < job.top; ++L) {
+                int grew = 0;
+                harvest_status(ctx, job.set, L, &grew, true);
+            }
+        job.refine_queued = false;
+        FB_LAP(6);
+    }
+    const int lowest = job.levs[job.nlev - 1];
+    std::vector<int> open;
+    if (job.level_arg < 0 && lowest > 0)
+        for (int k = 0; k < B; ++k)
+            if (job.h_found[k] < 0) open.push_back(k);
+    job.state = 0;  // the set is this job's no longer
+    if (!open.empty()) {
+        // what is left (no board in view, or one that only shows at full resolution): level by level, synchronously, on
+        // the single-frame context of this device -- its own streams and scratch, so the jobs in flight here stay so
+        mrgingham_amd_ctx* one = same_device_ctx(ctx);
+        if (!one) return fail(ctx, MRGINGHAM_AMD_ERR_DEVICE, "no single-frame context");
+        rc = find_boards_sync_levels(one, &job.fr, job.gridn, lowest - 1, 0, job.h_boards, job.h_found, job.nthreads, open);
+        if (rc) ctx->err = one->err;
+    }
+    return rc;
+}
+
+static int fb_abandon(mrgingham_amd_ctx* ctx, mrgingham_amd_ctx::BoardsJob& job, int rc) {
+    if (job.grid_running) ctx->pool.wait();
+    job.grid_running = false;
+    hipStreamSynchronize(ctx->ccs[job.set]);  // nothing of this job may stay queued behind an error
+    job.state = 0;
+    job.refine_queued = false;
+    return rc;
+}
+static int fb_complete(mrgingham_amd_ctx* ctx, mrgingham_amd_ctx::BoardsJob& job) {
+    int rc = 0;
+    if (job.state == 1) {
+        rc = fb_host_begin(ctx, job);
+        if (!rc) rc = fb_host_end(ctx, job);
+    }
+    if (rc) return fb_abandon(ctx, job, rc);
+    return fb_finish(ctx, job);
+}
+
+int mrgingham_amd_find_boards_submit(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int gridn,
+                                     int image_pyramid_level, double* h_boards, signed char* h_found_level, int nthreads) {
+    int rc = validate_frames(ctx, fr);
+    if (rc) return rc;
+    if (gridn < 2 || image_pyramid_level > kMaxLevel || !h_boards || !h_found_level)
+        return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "bad gridn / level / NULL outputs");
+    const int B = fr->nframes, N = gridn * gridn;
+    const int ticket = ctx->next_ticket++ & 0x3fffffff;
+    FB_T0;
+    for (int f = 0; f < B; ++f) h_found_level[f] = -1;
+    if (B == 0) {
+        ctx->done_tickets.emplace_back(ticket, 0);
+        return ticket;
+    }
+    MRG_HIP_CHECK(hipSetDevice(ctx->device));
+    if (!ctx->fb_pipeline) {  // option "find_boards_pipeline" 0: the synchronous dense schedule, at once
+        for (auto& j : ctx->jobs)
+            if (j.state != 0) ctx->done_tickets.emplace_back(j.ticket, fb_complete(ctx, j));
+        const int first = image_pyramid_level >= 0 ? image_pyramid_level : 3;
+        const int last = image_pyramid_level >= 0 ? image_pyramid_level : 0;
+        std::vector<int> open(B);
+        for (int f = 0; f < B; ++f) open[f] = f;
+        ctx->done_tickets.emplace_back(ticket, find_boards_sync_levels(ctx, fr, gridn, first, last, h_boards, h_found_level, nthreads, open));
+        return ticket;
+    }
+    // levels searched in the first pass: the one asked for, or 3, 2 and 1 (levels 2 and 1 speculatively: together they
+    // cost the device a third of a level-0 pass, 12 MP boards are found at level 2, and the one frame in fifty that
+    // needs level 1 would otherwise hold up its whole batch); level 0 only for what is still open after them
+    const int top = image_pyramid_level >= 0 ? image_pyramid_level : 3;
+    const int nlev = image_pyramid_level >= 0 ? 1 : 3;
+    const int cap = 4 * N + 64;  // candidates kept per frame for the grid finder
+    // the refinement takes the sparse schedule where it pays: such a context keeps three scratch sets (choose_sets)
+    if (ctx->sparse_refine && top >= 1 && ctx->cc_lds && !ctx->use_v0) ctx->sparse_seen = true;
+    {   // a change of the rotation (another batch shape) synchronises and may free a set: no job may be in flight then
+        const double per_set = 5.0 * (double)B * fr->width * fr->height;
+        const double mx = per_set > ctx->max_set_bytes ? per_set : ctx->max_set_bytes;
+        const int want = ctx->nsets_fixed ? ctx->nsets : (3.0 * mx <= (ctx->sparse_seen ? 16e9 : 8e9) ? 3 : 2);
+        if (want != ctx->nsets)
+            for (auto& j : ctx->jobs)
+                if (j.state != 0) ctx->done_tickets.emplace_back(j.ticket, fb_complete(ctx, j));
+    }
+    if ((rc = choose_sets(ctx, fr))) return rc;
+    // the set this job is going to take may still belong to an earlier one: that one is completed first
+    {
+        auto& occupant = ctx->jobs[(ctx->cur + 1) % ctx->nsets];
+        if (occupant.state != 0) ctx->done_tickets.emplace_back(occupant.ticket, fb_complete(ctx, occupant));
+    }
+    // (growing a buffer synchronises the device and frees the old one: only with nothing in flight)
+    bool fits = true;
+    for (int L = 0; L <= top && fits; ++L) {
+        int w, h;
+        level_dims(fr->width, fr->height, L, &w, &h);
+        for (int set = 0; set < ctx->nsets; ++set) {
+            const LevelScratch& S = ctx->lvs[set][L];
+            const int shift = ctx->cap_shift < ctx->grown_shift[L] ? ctx->cap_shift : ctx->grown_shift[L];
+            fits = fits && B <= S.nframes && w == S.w && h == S.h && N <= S.pitch && S.shift == shift;
+        }
+    }
+    fits = fits && B <= ctx->pts_nframes && N <= ctx->pts_pitch;
+    if (!fits)
+        for (auto& j : ctx->jobs)
+            if (j.state != 0) ctx->done_tickets.emplace_back(j.ticket, fb_complete(ctx, j));
+    for (int L = 0; L <= top; ++L)
+        if ((rc = ensure_level(ctx, L, B, fr->width, fr->height, N))) return rc;
+    if ((rc = ensure_points(ctx, B, N))) return rc;
+    if (!ctx->sparse_stat.p) {
+        if ((rc = ensure(ctx, ctx->sparse_stat, 256))) return rc;
+        MRG_HIP_CHECK(hipMemset(ctx->sparse_stat.p, 0, 256));
+    }
+    begin_op(ctx, top);
+    auto& job = ctx->jobs[ctx->cur];
+    job.set = ctx->cur;
+    job.ticket = ticket;
+    job.fr = *fr;
+    job.gridn = gridn;
+    job.level_arg = image_pyramid_level;
+    job.nthreads = nthreads;
+    job.nlev = nlev;
+    for (int li = 0; li < 3; ++li) job.levs[li] = top - li;
+    job.cap = cap;
+    job.h_boards = h_boards;
+    job.h_found = h_found_level;
+    job.refine_queued = false;
+    if ((rc = ensure(ctx, job.d_xy, (size_t)nlev * B * cap * 8)) || (rc = ensure(ctx, job.d_cnt, (size_t)nlev * B * 4)) ||
+        (rc = ensure(ctx, job.d_pts, (size_t)B * N * 16)) || (rc = ensure(ctx, job.d_lv, (size_t)B * N)) ||
+        (rc = ensure(ctx, job.d_np, (size_t)B * 4)) || (rc = ensure(ctx, job.d_pts0, (size_t)B * N * 16)) ||
+        (rc = ensure(ctx, job.d_lv0, (size_t)B * N)))
+        return rc;
+    const size_t need = fb_layout(nullptr, nlev, B, cap, N).bytes;
+    if (need > job.pin_bytes) {
+        if (job.pin) hipHostFree(job.pin);
+        job.pin = nullptr;
+        job.pin_bytes = 0;
+        MRG_HIP_CHECK(hipHostMalloc(&job.pin, need + need / 4, hipHostMallocDefault));
+        job.pin_bytes = need + need / 4;
+    }
+    if (!job.ev_a) MRG_HIP_CHECK(hipEventCreateWithFlags(&job.ev_a, hipEventDisableTiming));
+    if (!job.ev_b) MRG_HIP_CHECK(hipEventCreateWithFlags(&job.ev_b, hipEventDisableTiming));
+    // The host part of the job before this one runs inside this call: its grid-finder threads are started first when
+    // its candidates have already arrived (the steady state), so that they work while this thread queues the device
+    // passes below; otherwise after them.
+    mrgingham_amd_ctx::BoardsJob* prev = nullptr;
+    for (auto& other : ctx->jobs)
+        if (&other != &job && other.state == 1) prev = &other;
+    bool prev_begun = false;
+    FB_LAP(0);
+    if (prev && hipEventQuery(prev->ev_a) == hipSuccess) {
+        const int r = fb_host_begin(ctx, *prev);
+        if (r) {
+            ctx->done_tickets.emplace_back(prev->ticket, fb_abandon(ctx, *prev, r));
+            prev = nullptr;
+        }
+        prev_begun = true;
+    }
+    FB_LAP(1);
+    order_after_previous(ctx, {}, {});
+    // part A: level images of every level up to the top in one pass (the refinement's variance windows and cells read
+    // them too), the responses of the levels searched, their candidates
+    queue_level_images(ctx, fr, top, true);
+    LevelBatch lbs[3];
+    bool merged = false;
+    if (job.nlev >= 2 && !ctx->use_v0 && ctx->multi_level) {
+        LevelBatch mlb[3];
+        CompTables mt[3];
+        for (int k = 0; k < job.nlev; ++k) {  // largest level first
+            mlb[k] = level_batch_of(ctx, fr, job.levs[job.nlev - 1 - k]);
+            mt[k] = tables_of(ctx, job.levs[job.nlev - 1 - k]);
+        }
+        if (chess_multi_ok(mlb, job.nlev, B) && launch_chess_multi(mlb, mt, job.nlev, B, ctx->pix)) {
+            merged = true;
+            for (int k = 0; k < job.nlev; ++k) lbs[job.nlev - 1 - k] = mlb[k];
+            hipEventRecord(ctx->ev_pix[top], ctx->pix);
+            for (int li = 0; li < job.nlev; ++li)
+                if (B > ctx->pending_frames[ctx->cur][job.levs[li]]) ctx->pending_frames[ctx->cur][job.levs[li]] = B;
+        }
+    }
+    if (!merged)
+        for (int li = 0; li < job.nlev; ++li) lbs[li] = queue_level_chess(ctx, fr, job.levs[li]);
+    hipStream_t cc = cur_cc(ctx);
+    hipError_t e = hipStreamWaitEvent(cc, ctx->ev_pix[merged ? top : job.levs[job.nlev - 1]], 0);
+    for (int li = 0; li < job.nlev; ++li)
+        launch_cc_detect(lbs[li], tables_of(ctx, job.levs[li]), job.levs[li],
+                         DetectOut{(int32_t*)job.d_xy.p + (size_t)li * B * cap * 2, cap, (int32_t*)job.d_cnt.p + (size_t)li * B}, 0,
+                         B, cc);
+    const FbPinned pin = fb_layout(job.pin, job.nlev, B, cap, N);
+    if (e == hipSuccess) e = hipMemcpyAsync(pin.cnt, job.d_cnt.p, (size_t)job.nlev * B * 4, hipMemcpyDeviceToHost, cc);
+    if (e == hipSuccess) e = hipMemcpyAsync(pin.xy, job.d_xy.p, (size_t)job.nlev * B * cap * 8, hipMemcpyDeviceToHost, cc);
+    if (e == hipSuccess) e = hipEventRecord(job.ev_a, cc);
+    end_op(ctx);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) job.state = 1;
+    FB_LAP(2);
+#ifdef MRG_EXPERIMENT
+    ++ctx->fb_prof_n;
+#endif
+    // ... and while the device works on that: the (rest of the) host part of the job before this one
+    if (prev) {
+        int r = prev_begun ? 0 : fb_host_begin(ctx, *prev);
+        if (!r) r = fb_host_end(ctx, *prev);
+        if (r) ctx->done_tickets.emplace_back(prev->ticket, fb_abandon(ctx, *prev, r));
+    }
+    if (e != hipSuccess) return fail_hip(ctx, e, "find_boards first pass", __FILE__, __LINE__);
+    return ticket;
+}
+
+int mrgingham_amd_find_boards_collect(mrgingham_amd_ctx* ctx, int ticket) {
+    if (!ctx) return MRGINGHAM_AMD_ERR_ARG;
+    MRG_HIP_CHECK(hipSetDevice(ctx->device));
+    for (auto& j : ctx->jobs)
+        if (j.state != 0 && j.ticket == ticket) return fb_complete(ctx, j);
+    for (size_t i = 0; i < ctx->done_tickets.size(); ++i)
+        if (ctx->done_tickets[i].first == ticket) {
+            const int rc = ctx->done_tickets[i].second;
+            ctx->done_tickets.erase(ctx->done_tickets.begin() + (long)i);
+            return rc;
+        }
+    return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "find_boards_collect: no such ticket (%d)", ticket);
+}
+
+int mrgingham_amd_find_boards_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int gridn,
+                                    int image_pyramid_level, double* h_boards, signed char* h_found_level,
+                                    int nthreads) {
+    const int ticket = mrgingham_amd_find_boards_submit(ctx, fr, gridn, image_pyramid_level, h_boards, h_found_level, nthreads);
+    if (ticket < 0) return ticket;
+    return mrgingham_amd_find_boards_collect(ctx, ticket);
 }
 
 }  // extern "C"

@@ -118,3 +118,84 @@ def test_find_boards_batch_adaptive_levels():
         if s is not None:
             assert np.array_equal(b1[f], s)
     det.close()
+
+
+def _mixed_batch(seed0, W=1280, H=960):
+    """Boards found at level 3, one that needs a finer level, one with noise over it, one frame without a board."""
+    import torch
+    imgs = [synth.board_frame(W, H, 10, seed0 + s).numpy() for s in (0, 1)]
+    small = np.full((H, W), 200, np.uint8)
+    small[:H // 2, :W // 2] = synth.board_frame(W // 2, H // 2, 10, seed0 + 4).numpy()
+    imgs.append(small)
+    noisy = imgs[0].astype(np.int64) + (synth.noise_frame(W, H, seed0 + 9).numpy().astype(np.int64) - 128) * 60 // 255
+    imgs.append(np.clip(noisy, 0, 255).astype(np.uint8))
+    imgs.append(synth.noise_frame(W, H, seed0 + 3, smooth=1).numpy())
+    return torch.from_numpy(np.stack(imgs)).cuda()
+
+
+@pytest.mark.parametrize("sparse", [0, 2])
+def test_find_boards_pipelined_equals_the_synchronous_dense_schedule(sparse):
+    """submit / collect with several batches in flight (device passes of batch n+1 under the grid finder of batch n,
+    refinement on its own stream, with option sparse_refine 2: out of the cells around the corners, frames the sparse
+    kernels cannot take repeated densely on the device): boards and levels are those of the synchronous dense
+    schedule (option find_boards_pipeline 0), double for double, whatever the interleaving."""
+    ref, det = mrgingham_amd.Detector(0), mrgingham_amd.Detector(0)
+    try:
+        ref.set_option("find_boards_pipeline", 0)
+        ref.set_option("sparse_refine", 0)
+        det.set_option("sparse_refine", sparse)
+        batches = [_mixed_batch(10 * i) for i in range(5)]
+        want = [ref.find_boards(b, gridn=10, nthreads=4) for b in batches]
+        assert any((w[1] == 3).any() for w in want) and any(((w[1] >= 0) & (w[1] < 3)).any() for w in want)
+        assert all(w[1][4] == -1 for w in want)
+        # depth 1 (submit + collect), depth 2, depth 3 (more than the sets: the oldest is completed by the submit)
+        for depth in (1, 2, 3, 4):
+            jobs, got = [], []
+            for b in batches:
+                jobs.append(det.find_boards_submit(b, gridn=10, nthreads=4))
+                if len(jobs) >= depth:
+                    got.append(det.find_boards_collect(jobs.pop(0)))
+            while jobs:
+                got.append(det.find_boards_collect(jobs.pop(0)))
+            for i, ((wb, wf), (gb, gf)) in enumerate(zip(want, got)):
+                assert np.array_equal(wf, gf), (depth, i, wf, gf)
+                for f in range(len(wf)):
+                    if wf[f] >= 0:
+                        assert np.array_equal(wb[f], gb[f]), (depth, i, f)
+        # collected out of order, and a single level asked for
+        j0 = det.find_boards_submit(batches[0], gridn=10, image_pyramid_level=2)
+        j1 = det.find_boards_submit(batches[1], gridn=10, image_pyramid_level=1)
+        (b1, f1), (b0, f0) = det.find_boards_collect(j1), det.find_boards_collect(j0)
+        for (bb, ff, batch, lvl) in ((b0, f0, batches[0], 2), (b1, f1, batches[1], 1)):
+            wb, wf = ref.find_boards(batch, gridn=10, image_pyramid_level=lvl)
+            assert np.array_equal(wf, ff) and set(ff.tolist()) <= {-1, lvl}
+            for f in range(len(wf)):
+                if wf[f] >= 0:
+                    assert np.array_equal(wb[f], bb[f]), (lvl, f)
+    finally:
+        ref.close(); det.close()
+
+
+def test_find_boards_pipelined_at_4096x3072_against_the_single_frame_detector():
+    """The bench shape of tools/find_boards_bench.py: 12 MP frames (found at level 2, refined sparsely to level 0)
+    in a pipeline of depth 2, against find_board() on every frame."""
+    import torch
+    det = mrgingham_amd.Detector(0)
+    try:
+        frames = synth.board_batch(6, 4096, 3072, 10, 40, device="cuda")
+        batches = [frames[:3].contiguous(), frames[3:].contiguous(), frames[:3].contiguous(), frames.repeat(3, 1, 1)]
+        jobs = [det.find_boards_submit(b, gridn=10) for b in batches[:2]]
+        out = [det.find_boards_collect(jobs[0])]
+        jobs.append(det.find_boards_submit(batches[2], gridn=10))
+        out.append(det.find_boards_collect(jobs[1]))
+        jobs.append(det.find_boards_submit(batches[3], gridn=10))         # another batch size: the rotation is re-planned
+        out.append(det.find_boards_collect(jobs[2]))
+        out.append(det.find_boards_collect(jobs[3]))
+        single = [mrgingham_amd.find_board(frames[f].cpu().numpy(), gridn=10) for f in range(6)]
+        assert all(s is not None for s in single)
+        for (bb, ff), idx in zip(out, ([0, 1, 2], [3, 4, 5], [0, 1, 2], list(range(6)) * 3)):
+            assert (ff >= 0).all() and (ff < 3).all(), ff
+            for k, f in enumerate(idx):
+                assert np.array_equal(bb[k], single[f]), (k, f)
+    finally:
+        det.close()
