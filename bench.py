@@ -265,6 +265,58 @@ def launch_ranks(n):
     return rc
 
 
+def find_boards_leg(device_index, frames, gridn, batches=150, depth=3):
+    """The reference's product call -- find_chessboard_from_image_array: level search + host grid finder + refinement
+    (mrgingham.cc:106-140) -- over the bench frames, pipelined (mrgingham_amd_find_boards_submit / _collect, `depth`
+    batches in flight) and one batch at a time.  NOT `value`: it is host-bound (the grid finder on this box's cores);
+    the boards of the first pipelined batch are compared with the synchronous dense schedule's, double for double."""
+    import numpy as np
+    import mrgingham_amd
+    ref = mrgingham_amd.Detector(device_index)
+    ref.set_option("find_boards_pipeline", 0)
+    ref.set_option("sparse_refine", 0)
+    want = ref.find_boards(frames, gridn=gridn)
+    t0 = time.perf_counter()
+    nsync = 10
+    for _ in range(nsync):
+        ref.find_boards(frames, gridn=gridn)
+    sync_ms = (time.perf_counter() - t0) / nsync * 1e3
+    ref.close()
+    det = mrgingham_amd.Detector(device_index)
+    try:
+        jobs, first, last = [], None, None
+        def step():
+            nonlocal first, last
+            jobs.append(det.find_boards_submit(frames, gridn=gridn))
+            if len(jobs) >= depth:
+                last = det.find_boards_collect(jobs.pop(0))
+                if first is None:
+                    first = (last[0].copy(), last[1].copy())
+        for _ in range(10):
+            step()
+        t0 = time.perf_counter()
+        for _ in range(batches):
+            step()
+        while jobs:
+            last = det.find_boards_collect(jobs.pop(0))
+        dt = (time.perf_counter() - t0) / batches
+        ok = bool(np.array_equal(first[1], want[1]))
+        for f in range(len(want[1])):
+            if want[1][f] >= 0:
+                ok = ok and bool(np.array_equal(first[0][f], want[0][f]))
+        B = frames.shape[0]
+        return {"value": B / dt, "unit": "frames/s", "ms_per_batch": dt * 1e3, "batches": batches, "in_flight": depth,
+                "one_batch_at_a_time_synchronous_ms": sync_ms, "one_batch_at_a_time_synchronous_frames_per_s": B / (sync_ms / 1e3),
+                "boards_found": int((want[1] >= 0).sum()), "found_at_level": np.bincount(want[1][want[1] >= 0], minlength=4).tolist(),
+                "identical_to_synchronous_dense": ok, "repeated_densely_by_the_library": det.sparse_fallbacks(),
+                "host_threads": "one per core the process may use, at most 32",
+                "what": "find_boards over the bench frames already in HBM, boards (gridn^2 refined corners per frame) on the host: "
+                        "first pass (level images, responses + candidates of levels 3, 2, 1) on the device, grid finder on "
+                        "the host threads under the next batch's first pass, refinement out of the cells around the corners"}
+    finally:
+        det.close()
+
+
 def sparse_leg(det, frames, start_level, P, steps):
     """The same workload with option "sparse_refine" (include/mrgingham_amd.h): level images and the start level's
     response for whole frames, the response below it only in the cells around the points.  NOT `value`: the judged
@@ -317,6 +369,8 @@ def main():
     ap.add_argument("--sparse-refine", action="store_true",
                     help="run the TIMED steps with option sparse_refine (not the judged configuration: `config.sparse_refine` "
                          "says so, and `roofline` then describes the kernel that reads the frames, pyramid_fast_kernel)")
+    ap.add_argument("--no-find-boards", action="store_true",
+                    help="skip the leg that times the full detector (level search + host grid finder + refinement; N = 1 only)")
     ap.add_argument("--no-sparse-leg", action="store_true",
                     help="skip the extra leg that times the same workload with option sparse_refine (N = 1 only)")
     ap.add_argument("--scratch-sets", type=int, default=0,
@@ -462,6 +516,9 @@ def main():
     sparse = None
     if world == 1 and start_level >= 1 and not args.no_sparse_leg and not args.sparse_refine:
         sparse = sparse_leg(det, frames, start_level, P, 100)   # (its own length: not the timed region of the contract)
+    fboards = None
+    if world == 1 and not args.no_find_boards:
+        fboards = find_boards_leg(local_rank, frames, gridn)
     bindings = None
     if collective and binding is not None:
         objs = [None] * world
@@ -528,6 +585,10 @@ def main():
                                    f"{'gathered to rank 0' if collective else 'left on the device'}",
                        "frames_per_gpu": batch, "width": W, "height": H, "gridn": gridn, "background": background,
                        "start_level": start_level, "sparse_refine": bool(args.sparse_refine),
+                       "sparse_refine_note": "the library's default (1: response below the start level only around the "
+                                             "points, where that pays) is switched OFF for the timed steps: `value` prices "
+                                             "the reference's dense per-level ChESS pass" if not args.sparse_refine else
+                                             "timed WITH option sparse_refine: not the judged configuration",
                        "parallelism": f"frames sharded x{world}",
                        "frames_with_full_grid_last_step": found},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -566,6 +627,8 @@ def main():
             res["end_to_end"] = e2e
         if sparse is not None:
             res["sparse_refine"] = sparse
+        if fboards is not None:
+            res["find_boards"] = fboards
         if bindings is not None or binding is not None:
             res["cpu_binding"] = bindings if bindings is not None else [binding]
         if world == 1 and not args.no_cpu_baseline:

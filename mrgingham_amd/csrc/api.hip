@@ -164,7 +164,7 @@ struct mrgingham_amd_ctx {
     mrg::LevelScratch lvs[kMaxSets][mrg::kMaxLevel + 1];
     mrg::DevBuf counters2[kMaxSets];  // per scratch set: hot_cnt words [level][counters_nf], then status words, then path words
     int counters_nf = 0;
-    struct PointScratch { mrg::DevBuf leader, need, nseeds, seeds, sroot, cand_xy, cand_counts, cell_list, cell_cnt; } pts[kMaxSets];  // per scratch set
+    struct PointScratch { mrg::DevBuf leader, need, nseeds, seeds, sroot, cand_xy, cand_counts, cell_list, cell_cnt, flag_list; } pts[kMaxSets];  // per scratch set
     mrg::DevBuf aux_img, io_frame, io_out, io_counts;
     mrg::DevBuf pre_scratch, pre_tmp, pre_out, pre16_scratch, io_frame16, dbg_img, dbg_resp, blob_scratch, blob_nodes, blob_out;
     mrg::DevBuf fb_xy, fb_cnt, fb_pts, fb_lv, fb_np, fb_frames, fb_frames2;  // find_boards_batch: candidates, counts, boards, levels, point counts
@@ -336,7 +336,7 @@ static std::vector<DevBuf*> level_set_buffers(mrgingham_amd_ctx* ctx, int set, b
             v.push_back(b);
     if (!with_points) return v;
     auto& ps = ctx->pts[set];
-    for (DevBuf* b : {&ps.leader, &ps.need, &ps.nseeds, &ps.seeds, &ps.sroot, &ps.cand_xy, &ps.cand_counts, &ps.cell_list, &ps.cell_cnt})
+    for (DevBuf* b : {&ps.leader, &ps.need, &ps.nseeds, &ps.seeds, &ps.sroot, &ps.cand_xy, &ps.cand_counts, &ps.cell_list, &ps.cell_cnt, &ps.flag_list})
         v.push_back(b);
     return v;
 }
@@ -409,6 +409,7 @@ static int ensure_points(mrgingham_amd_ctx* ctx, int nframes, int pitch) {
         // sparse refinement: at most 4 cells per seed position of a point and 9 of those, of which at most 9 distinct
         if ((rc = ensure(ctx, ps.cell_list, np * kCellsPerPoint * 4))) return rc;
         if ((rc = ensure(ctx, ps.cell_cnt, (size_t)nframes * 4 * kCellHdr * (kMaxLevel + 1)))) return rc;  // per level and frame: the list's header
+        if ((rc = ensure(ctx, ps.flag_list, ((size_t)nframes + 1) * 4))) return rc;  // the frames a sparse chain reported
     }
     ctx->pts_nframes = nframes;
     ctx->pts_pitch = pitch;
@@ -597,10 +598,9 @@ static LevelBatch queue_level_chess(mrgingham_amd_ctx* ctx, const mrgingham_amd_
 // cells, > 512 points, > 2048 hot pixels in the cells that no band cut separates) sets kStatusSparse in its status
 // words -- at that level and, because nobody lists its cells any more, at every level below -- and is REPEATED DENSELY
 // behind the last sparse level, on the device, before the call completes: its points go back to where they started
-// (`restore`), then per level the ordinary response kernel and the ordinary refinement kernels run with
-// CompTables::only set, i.e. on the flagged frames alone (every other workgroup reads one word and leaves: ~25 us per
-// call when no frame is flagged), and the flags are cleared.  So the outputs are the dense schedule's on every frame,
-// with no host round trip and nothing for the caller to repeat.
+// (`restore`), the ordinary response kernel computes its levels and the global-memory refinement replays them, on
+// the flagged frames alone (see the end of this function), and the flags are cleared.  So the outputs are the dense
+// schedule's on every frame, with no host round trip and nothing for the caller to repeat.
 // `dense_only`: no sparse pass at all -- the ordinary kernels on every frame, level by level, on the component stream
 // (the refinement of find_boards_submit when the sparse schedule is switched off or does not pay).
 static int queue_sparse_levels(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int top, RefineIO io,
@@ -645,23 +645,34 @@ static int queue_sparse_levels(mrgingham_amd_ctx* ctx, const mrgingham_amd_frame
         if (nf > ctx->pending_frames[ctx->cur][L]) ctx->pending_frames[ctx->cur][L] = nf;
     }
     // the dense repeat of what was reported (flag = the level-0 status word: a frame given up at any level is given up
-    // at every level below it)
+    // at every level below it): three small launches -- the flagged frames as a list; their dense responses at every
+    // level (one grid, laid out for kOnlySlots frames whatever the batch); per listed frame restore + the refinement of
+    // every level + clear.  Every kernel boundary of this chain costs ~10 us whether or not a frame is flagged, and a
+    // full-size grid of the response kernel that finds nothing to do still waits for LDS and registers on a chip the
+    // pixel stream keeps full: eleven full-size launches were 8 % of a sparse step.
     int32_t* flags = status_of(ctx, 0);
-    launch_sparse_restore(flags, restore, io.points, io.levels, io.npoints, io.pitch, nf, cc);
+    int32_t* list = (int32_t*)ps.flag_list.p;
+    launch_sparse_flag_list(flags, nf, list, cc);
     RefineIO dio = io;
     dio.cell_list = nullptr;
     dio.cell_cnt = nullptr;
     dio.list_pitch = 0;
     dio.next_cnt = nullptr;
-    for (int L = top - 1; L >= 0; --L) {
-        CompTables t = tables_of(ctx, L);
-        t.only = flags;
-        launch_chess(lbs[L], t, 0, nf, true, true, cc);
-        launch_cc_refine(lbs[L], t, L, dio, 0, nf, cc);
+    LevelBatch mlb[kRefineLevelsMax];   // largest level first (launch_chess_multi)
+    CompTables mt[kRefineLevelsMax], lt[kRefineLevelsMax];
+    for (int L = 0; L < top; ++L) {
+        lt[L] = tables_of(ctx, L);
+        mlb[L] = lbs[L];
+        mt[L] = lt[L];
+        mt[L].only = list;
     }
-    launch_sparse_clear(flags, ctx->counters_nf, top, (int32_t*)ctx->sparse_stat.p, nf, cc);
+    const bool merged = top >= 2 && chess_multi_ok(mlb, top, nf) && launch_chess_multi(mlb, mt, top, nf, cc);
+    if (!merged)
+        for (int L = top - 1; L >= 0; --L) launch_chess(lbs[L], mt[L], 0, nf, true, true, cc);
+    launch_cc_refine_flagged_levels(lbs, lt, top, dio, restore, list, flags, ctx->counters_nf, (int32_t*)ctx->sparse_stat.p, cc);
     return 0;
 }
+
 }  // namespace mrg
 
 using namespace mrg;
@@ -1150,7 +1161,8 @@ int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames
     // (option "sparse_refine" 1 = where it pays: the dense response of a small call is cheaper than the longer chain --
     // measured crossover at 80-100 Mpx per call, e.g. 64 x 1280x960 or 8 x 4096x3072; 2 = always)
     const bool sparse_pays = ctx->sparse_refine == 2 || (long long)fr->width * fr->height * fr->nframes >= kSparsePaysPixels;
-    const bool sparse_now = ctx->sparse_refine && sparse_pays && start_level >= 1 && !ctx->use_v0 && ctx->cc_lds;
+    const bool sparse_now = ctx->sparse_refine && sparse_pays && start_level >= 1 && start_level <= kRefineLevelsMax &&
+                            !ctx->use_v0 && ctx->cc_lds;
     if (sparse_now) ctx->sparse_seen = true;
     if ((rc = choose_sets(ctx, fr))) return rc;
     for (int L = 0; L <= start_level; ++L)
@@ -2345,7 +2357,7 @@ static int fb_host_end(mrgingham_amd_ctx* ctx, mrgingham_amd_ctx::BoardsJob& job
                         (int32_t*)ps.leader.p, (int32_t*)ps.need.p, (int32_t*)ps.nseeds.p, (uint32_t*)ps.seeds.p,
                         (int32_t*)ps.sroot.p};
             const SparseRestore src{nullptr, 0, 0, (const double*)job.d_pts0.p, (const signed char*)job.d_lv0.p};
-            const bool sparse = ctx->cc_lds && !ctx->use_v0 &&
+            const bool sparse = ctx->cc_lds && !ctx->use_v0 && top <= kRefineLevelsMax &&
                                 (ctx->sparse_refine == 2 ||
                                  (ctx->sparse_refine == 1 && (long long)fr->width * fr->height * B >= kSparsePaysPixels));
             rc = queue_sparse_levels(ctx, fr, top, io, src, !sparse);

@@ -473,13 +473,11 @@ void launch_cc_detect(const LevelBatch& lb, const CompTables& t, int level, cons
 // ---------------------------------------------------------------------------
 // Refine: process_connected_components, points_refinement branch (:356-397)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(CCG_THREADS, 4) void cc_refine_kernel(LevelBatch lb, CompTables t, int level,
-                                                               RefineIO io, int frame0) {
+// (the body: cc_refine_kernel runs it for one level, cc_refine_flagged_levels_kernel level after level)
+__device__ __forceinline__ void cc_refine_frame(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io,
+                                                int frame) {
     __shared__ int s_changed, s_nref, s_arena_full;
     __shared__ unsigned long long s_arena_top;
-    __builtin_amdgcn_s_setprio(3);
-    const int frame = frame0 + blockIdx.x;
-    if (t.only && !(t.only[frame] & kStatusSparse)) return;  // dense repeat of a sparse chain: the reported frames only
     if (t.lds_path && t.path[frame] == 1) return;  // done out of LDS
     if (t.hot_cnt[frame] > t.cap) {
         if (threadIdx.x == 0) {
@@ -593,6 +591,92 @@ __global__ __launch_bounds__(CCG_THREADS, 4) void cc_refine_kernel(LevelBatch lb
         const int before = (t.lds_path && t.path[frame] == 2 && io.nrefined) ? io.nrefined[frame] : 0;
         if (io.nrefined) io.nrefined[frame] = s_arena_full ? -1 : before + s_nref;
     }
+}
+
+__global__ __launch_bounds__(CCG_THREADS, 4) void cc_refine_kernel(LevelBatch lb, CompTables t, int level,
+                                                               RefineIO io, int frame0) {
+    __builtin_amdgcn_s_setprio(3);
+    cc_refine_frame(lb, t, level, io, frame0 + blockIdx.x);
+}
+
+// The dense repeat of the frames a sparse chain reported, in one launch (kernels.h, launch_cc_refine_flagged_levels).
+struct RefineLevels {
+    LevelBatch lb[kRefineLevelsMax];  // indexed by level
+    CompTables t[kRefineLevelsMax];
+    int n;
+    RefineIO io;
+    SparseRestore restore;
+    const int32_t* list;  // the frames (launch_sparse_flag_list)
+    int32_t* status0;
+    int level_stride;
+    int32_t* counter;
+};
+constexpr int kFlaggedSlots = 8;  // workgroups of cc_refine_flagged_levels_kernel: workgroup b takes frames b, b + 8, ... of the list
+__global__ __launch_bounds__(CCG_THREADS, 8) void cc_refine_flagged_levels_kernel(RefineLevels a) {  // (<= 64 VGPRs: see CCG_THREADS)
+    __builtin_amdgcn_s_setprio(3);
+    const int nlisted = a.list[0];
+    for (int li = blockIdx.x; li < nlisted; li += kFlaggedSlots) {
+        const int frame = a.list[1 + li];
+        {   // the points as they were before the first sparse level
+            const int n = min(a.io.npoints[frame], a.io.pitch);
+            const long long pb = (long long)frame * a.io.pitch;
+            for (int i = threadIdx.x; i < n; i += CCG_THREADS) {
+                if (a.restore.xy) {  // emit_detect_outputs' hand-over, again
+                    const int32_t* xy = a.restore.xy + ((long long)frame * a.restore.xy_pitch + i) * 2;
+                    a.io.points[2 * (pb + i) + 0] = (double)xy[0] / kGridScale;
+                    a.io.points[2 * (pb + i) + 1] = (double)xy[1] / kGridScale;
+                    a.io.levels[pb + i] = (signed char)a.restore.level;
+                } else {
+                    a.io.points[2 * (pb + i) + 0] = a.restore.pts0[2 * (pb + i) + 0];
+                    a.io.points[2 * (pb + i) + 1] = a.restore.pts0[2 * (pb + i) + 1];
+                    a.io.levels[pb + i] = a.restore.lv0[pb + i];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int L = a.n - 1; L >= 0; --L) {
+            cc_refine_frame(a.lb[L], a.t[L], L, a.io, frame);
+            __syncthreads();  // the level below reads the points and level tags this one wrote
+        }
+        if (threadIdx.x == 0) {
+            for (int L = 0; L < a.n; ++L) atomicAnd(a.status0 + (long long)L * a.level_stride + frame, ~(int)kStatusSparse);
+            if (a.counter) atomicAdd(a.counter, 1);
+        }
+    }
+}
+void launch_cc_refine_flagged_levels(const LevelBatch* lbs, const CompTables* ts, int nlevels, const RefineIO& io,
+                                     const SparseRestore& restore, const int32_t* list, int32_t* status_level0,
+                                     int level_stride, int32_t* counter, hipStream_t s) {
+    if (nlevels <= 0 || nlevels > kRefineLevelsMax) return;
+    RefineLevels a;
+    for (int L = 0; L < kRefineLevelsMax; ++L) {
+        a.lb[L] = lbs[L < nlevels ? L : 0];
+        a.t[L] = ts[L < nlevels ? L : 0];
+        a.t[L].lds_path = 0;  // every listed frame is this kernel's
+        a.t[L].only = nullptr;
+    }
+    a.n = nlevels;
+    a.io = io;
+    a.restore = restore;
+    a.list = list;
+    a.status0 = status_level0;
+    a.level_stride = level_stride;
+    a.counter = counter;
+    hipLaunchKernelGGL(cc_refine_flagged_levels_kernel, dim3(kFlaggedSlots), dim3(CCG_THREADS), 0, s, a);
+}
+// The frames a sparse chain reported, as a list: list[0] = how many, list[1 ..] = which (any order).  One workgroup.
+__global__ __launch_bounds__(256) void sparse_flag_list_kernel(const int32_t* status0, int nframes, int32_t* list) {
+    __shared__ int n;
+    if (threadIdx.x == 0) n = 0;
+    __syncthreads();
+    for (int f = threadIdx.x; f < nframes; f += 256)
+        if (status0[f] & kStatusSparse) list[1 + atomicAdd(&n, 1)] = f;
+    __syncthreads();
+    if (threadIdx.x == 0) list[0] = n;
+}
+void launch_sparse_flag_list(const int32_t* status_level0, int nframes, int32_t* list, hipStream_t s) {
+    hipLaunchKernelGGL(sparse_flag_list_kernel, dim3(1), dim3(256), 0, s, status_level0, nframes, list);
 }
 
 void launch_cc_refine(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io, int frame0,
@@ -1634,7 +1718,6 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
     LdsCC& L = *reinterpret_cast<LdsCC*>(lds_cc_raw);
     if (!MRG_EXP(t.lds_path & 16)) __builtin_amdgcn_s_setprio(3);
     const int frame = frame0 + blockIdx.x, tid = threadIdx.x;
-    if (!SPARSE && t.only && !(t.only[frame] & kStatusSparse)) return;  // dense repeat of a sparse chain: the reported frames only
     // phase clock (cc_lds bit 512, mrgingham_amd_debug_refine_clock, tools/cc_phases.py): thread 0 of the first
     // frame leaves 100 MHz ticks of the phase boundaries of its first band in the scratch of the global-memory kernel
     const bool clk = MRG_EXP(t.lds_path & 512) && blockIdx.x == 0 && tid == 0;
@@ -1953,45 +2036,6 @@ void launch_sparse_cells(const LevelBatch& lb, const CompTables& t, int level, c
     // the masks of chess_cells_kernel (32 B per micro-tile) go where the pixel -> index map of a dense level is
     hipLaunchKernelGGL(sparse_cells_kernel, dim3(nframes), dim3(CC_THREADS), 0, s, lb.w, lb.h, level, io, cell_list, cell_cnt,
                        list_pitch, t.gidx_pitch / 4, frame0);
-}
-
-// The frames a sparse chain reported (flags[f] & kStatusSparse): points and level tags as they were before its first
-// sparse level.  One workgroup per frame.
-__global__ __launch_bounds__(CC_THREADS) void sparse_restore_kernel(const int32_t* flags, SparseRestore src, double* points,
-                                                                 signed char* levels, const int32_t* npoints, int pitch) {
-    const int frame = blockIdx.x;
-    if (!(flags[frame] & kStatusSparse)) return;
-    const int n = min(npoints[frame], pitch);
-    const long long pb = (long long)frame * pitch;
-    for (int i = threadIdx.x; i < n; i += CC_THREADS) {
-        if (src.xy) {  // emit_detect_outputs' hand-over, again
-            const int32_t* xy = src.xy + ((long long)frame * src.xy_pitch + i) * 2;
-            points[2 * (pb + i) + 0] = (double)xy[0] / kGridScale;
-            points[2 * (pb + i) + 1] = (double)xy[1] / kGridScale;
-            levels[pb + i] = (signed char)src.level;
-        } else {
-            points[2 * (pb + i) + 0] = src.pts0[2 * (pb + i) + 0];
-            points[2 * (pb + i) + 1] = src.pts0[2 * (pb + i) + 1];
-            levels[pb + i] = src.lv0[pb + i];
-        }
-    }
-}
-void launch_sparse_restore(const int32_t* flags, const SparseRestore& src, double* points, signed char* levels,
-                           const int32_t* npoints, int pitch, int nframes, hipStream_t s) {
-    if (nframes <= 0) return;
-    hipLaunchKernelGGL(sparse_restore_kernel, dim3(nframes), dim3(CC_THREADS), 0, s, flags, src, points, levels, npoints, pitch);
-}
-__global__ __launch_bounds__(256) void sparse_clear_kernel(int32_t* status0, int level_stride, int nlevels, int32_t* counter,
-                                                           int nframes) {
-    const int frame = blockIdx.x * 256 + threadIdx.x;
-    if (frame >= nframes || !(status0[frame] & kStatusSparse)) return;
-    for (int L = 0; L < nlevels; ++L) atomicAnd(status0 + (long long)L * level_stride + frame, ~(int)kStatusSparse);
-    if (counter) atomicAdd(counter, 1);
-}
-void launch_sparse_clear(int32_t* status_level0, int level_stride, int nlevels, int32_t* counter, int nframes, hipStream_t s) {
-    if (nframes <= 0) return;
-    hipLaunchKernelGGL(sparse_clear_kernel, dim3((nframes + 255) / 256), dim3(256), 0, s, status_level0, level_stride, nlevels,
-                       counter, nframes);
 }
 
 void launch_cc_refine_lds(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io, int frame0,

@@ -555,9 +555,12 @@ __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTa
         work = (int)((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j);
     }
     const int strip = work % nstrips, rest = work / nstrips;
-    const int frame = frame0 + rest / nsegs;
-    // the dense repeat of a sparse chain (CompTables::only): every frame but the reported ones is left alone
-    if (FILTER && !(t.only[frame] & kStatusSparse)) return;  // workgroup-uniform
+    // FILTER, the dense repeat of a sparse chain (CompTables::only): the grid is laid out for kOnlySlots frames and
+    // the workgroup takes frames slot, slot + kOnlySlots, ... of the list (usually none: it leaves at once)
+    const int nlisted = FILTER ? t.only[0] : 0;
+  for (int li = rest / nsegs; FILTER ? li < nlisted : li == rest / nsegs; li += kOnlySlots) {
+    const int frame = FILTER ? t.only[1 + li] : frame0 + li;
+    if (FILTER && li != rest / nsegs) __syncthreads();  // the ring and the record buffer of the frame before are free
     const int w = lb.w, h = lb.h, stride = lb.img_stride;
     const uint8_t* img = lb.img + (long long)frame * lb.img_pitch;
     int16_t* resp = lb.resp + (long long)frame * lb.resp_pitch;
@@ -760,6 +763,7 @@ __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTa
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     }
     if (HOT) flush_hot(hsink, hotcnt, wvu, t, frame);
+  }
 }
 
 template <bool CLAMP, bool HOT, int STAGE, bool FILTER = false>
@@ -888,6 +892,7 @@ struct ChessMulti {
     int seg[kMultiMax];
     int n;
 };
+template <bool FILTER>  // FILTER: only the frames a sparse chain reported (CompTables::only, see chess_v1_body)
 __global__ __launch_bounds__(256, 4) void chess_v1_multi_kernel(ChessMulti a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int b = blockIdx.x;
@@ -897,7 +902,7 @@ __global__ __launch_bounds__(256, 4) void chess_v1_multi_kernel(ChessMulti a) {
         if (j < a.n && b >= a.first_wg[j]) k = j;
     const int rel = b - a.first_wg[k];
     if (rel >= a.nwg[k]) return;  // padding between slots
-    chess_v1_body<true, true, STAGE_PERM16>(a.lb[k], a.t[k], 0, a.seg[k], (unsigned)rel, (unsigned)a.nwg[k], lds);
+    chess_v1_body<true, true, STAGE_PERM16, false, FILTER>(a.lb[k], a.t[k], 0, a.seg[k], (unsigned)rel, (unsigned)a.nwg[k], lds);
 }
 
 
@@ -938,6 +943,7 @@ static int pick_segment(int w, int h, int nframes, int min_blocks = 0) {
 // Production entry point.
 void launch_chess(const LevelBatch& lb, const CompTables& t, int frame0, int nframes, bool clamp, bool hot,
                   hipStream_t s) {
+    if (hot && t.only) nframes = kOnlySlots;  // a frame list: the grid is laid out for that many frames (chess_v1_body)
     const int seg = pick_segment(lb.w, lb.h, nframes);
     dim3 grid(((lb.w + V1_SW - 1) / V1_SW) * ((lb.h + seg - 1) / seg) * nframes);
     const size_t lds = 2 * V1_PLANE + (hot ? (V1_HOTBUF + 12) * sizeof(int) : 0);
@@ -1016,6 +1022,7 @@ bool chess_multi_ok(const LevelBatch* lbs, int n, int nframes) {
 
 bool launch_chess_multi(const LevelBatch* lbs, const CompTables* ts, int n, int nframes, hipStream_t s) {
     if (!chess_multi_ok(lbs, n, nframes)) return false;
+    if (ts[0].only) nframes = kOnlySlots;  // a frame list: the grid is laid out for that many frames (chess_v1_body)
     ChessMulti a;
     a.n = n;
     int total = 0;
@@ -1031,7 +1038,8 @@ bool launch_chess_multi(const LevelBatch* lbs, const CompTables* ts, int n, int 
         total += (a.nwg[k] + 7) / 8 * 8;
     }
     const size_t lds = 2 * V1_PLANE + (V1_HOTBUF + 12) * sizeof(int);
-    hipLaunchKernelGGL(chess_v1_multi_kernel, dim3(total), dim3(256), lds, s, a);
+    if (ts[0].only) hipLaunchKernelGGL(chess_v1_multi_kernel<true>, dim3(total), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(chess_v1_multi_kernel<false>, dim3(total), dim3(256), lds, s, a);
     return true;
 }
 

@@ -62,10 +62,12 @@ struct CompTables {
     // a banded refinement was begun there and the global-memory kernel finishes it.
     int32_t* path;            // [nframes]
     int lds_path;             // 0: the LDS kernels are not launched and path[] is not consulted
-    // Dense repeat of the frames a sparse refinement could not take (api.hip, queue_sparse_fallback): when set, the
-    // response kernel and the refinement kernels only work on frames f with only[f] & kStatusSparse and leave at once
-    // for every other frame.  NULL everywhere else.
-    const int32_t* only;      // [nframes]
+    // Dense repeat of the frames a sparse refinement could not take (api.hip, queue_sparse_levels): when set, the
+    // response kernels work on the frames LISTED here -- only[0] = how many, only[1 ..] = which -- with a grid that is
+    // laid out for kOnlySlots frames (a workgroup takes frames slot, slot + kOnlySlots, ... of the list): the list is
+    // nearly always empty, and a workgroup of the response kernel that finds nothing to do has still waited for 40 KB
+    // of LDS and 500 registers on a chip the pixel stream keeps full.  NULL everywhere else.
+    const int32_t* only;      // [1 + nframes]
 };
 
 // A component that passed the size / peak / margin tests and waits for the
@@ -82,6 +84,7 @@ enum : int { kStatusHotOverflow = 1, kStatusCandOverflow = 2, kStatusSparse = 4 
 // sparse refinement: words per frame of the cell-list header -- count (-1: the frame was given up), log2 cell size,
 // then the span of the cell bitmap: first cell x, y, cells per row, rows
 constexpr int kCellHdr = 8;
+constexpr int kOnlySlots = 2;  // frames the grid of a response launch restricted to a frame list (CompTables::only) is laid out for
 constexpr uint32_t kHotDead = 0xffffffffu;       // hot list slot that holds no pixel
 constexpr uint32_t kHotSingleton = 0x80000000u;  // flag in hot_xy[]: the pixel has no hot 4-neighbour
 

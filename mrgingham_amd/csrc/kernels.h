@@ -108,20 +108,26 @@ void launch_cc_refine(const LevelBatch& lb, const CompTables& t, int level, cons
 void launch_sparse_cells(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io, uint32_t* cell_list,
                          int32_t* cell_cnt, int list_pitch, int frame0, int nframes, hipStream_t s);
 constexpr int kLdsPathSparse = 1024;  // CompTables::lds_path bit: the dense response only holds those cells
-// Sparse refinement, the frames it could not take (flags[f] & kStatusSparse): their points go back to what they were
-// before the first sparse level -- the detection's candidates (xy != NULL: (double)xy / 1000 at `level`,
-// find_grid.cc:353-354) or a copy the caller kept (pts0 / lv0) -- so that the dense repeat replays every level.
+// Sparse refinement, the frames it could not take (kStatusSparse in their level-0 status word): REPEATED DENSELY,
+// on the device, in three small launches (api.hip, queue_sparse_levels):
+//   launch_sparse_flag_list          the frames as a list (list[0] = how many, list[1 ..] = which);
+//   launch_chess / launch_chess_multi with CompTables::only = that list: their dense responses + hot lists;
+//   launch_cc_refine_flagged_levels  per listed frame: its points back to what they were before the first sparse
+//                                    level -- the detection's candidates (xy != NULL: (double)xy / 1000 at `level`,
+//                                    find_grid.cc:353-354) or a copy the caller kept (pts0 / lv0) --, the refinement
+//                                    of levels nlevels-1 .. 0 with the global-memory kernel's body (lbs / ts indexed
+//                                    by level), the flag cleared from the status words of those levels (words of
+//                                    consecutive levels are level_stride apart) and the frame counted in *counter.
 struct SparseRestore {
     const int32_t* xy;  // [nframes * xy_pitch * 2] or NULL
     int xy_pitch, level;
     const double* pts0;  // [nframes * pitch * 2]
     const signed char* lv0;
 };
-void launch_sparse_restore(const int32_t* flags, const SparseRestore& src, double* points, signed char* levels,
-                           const int32_t* npoints, int pitch, int nframes, hipStream_t s);
-// ... and when the repeat is done: the flag leaves the status words of levels [0, nlevels) (words of consecutive levels
-// are level_stride apart) and every repeated frame is counted in *counter
-void launch_sparse_clear(int32_t* status_level0, int level_stride, int nlevels, int32_t* counter, int nframes, hipStream_t s);
-
+constexpr int kRefineLevelsMax = 4;
+void launch_sparse_flag_list(const int32_t* status_level0, int nframes, int32_t* list, hipStream_t s);
+void launch_cc_refine_flagged_levels(const LevelBatch* lbs, const CompTables* ts, int nlevels, const RefineIO& io,
+                                     const SparseRestore& restore, const int32_t* list, int32_t* status_level0,
+                                     int level_stride, int32_t* counter, hipStream_t s);
 
 }  // namespace mrg

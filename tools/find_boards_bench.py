@@ -3,6 +3,7 @@ per-frame adaptive pyramid depth, device candidates + refinement, host grid-find
 synchronous.  usage: python tools/find_boards_bench.py [out.json] [--quick] [--one W H B depth nthreads]
 (MRGINGHAM_AMD_LIB=.../libmrgingham_amd_experiment.so MRG_DBG_FB=1: host milliseconds by phase on stderr)"""
 import sys, os, time, json; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # a context uses four HIP streams that must overlap (as bench.py)
 import numpy as np
 import torch
 import mrgingham_amd
