@@ -18,6 +18,7 @@
  */
 #pragma once
 #include <stdbool.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -146,6 +147,44 @@ int mrgingham_amd_device_count(void);
 /* How many frames the sparse refinement (option "sparse_refine") handed back to the dense kernels since the last call
  * of this function (they are repeated inside the call that met them; the outputs do not depend on it).  Synchronises. */
 int mrgingham_amd_sparse_fallbacks(mrgingham_amd_ctx* ctx);
+
+/* ---- several GPUs ---------------------------------------------------------------------------------------------
+ * The reference-symbol wrappers of section (1) (and mrgingham_amd_process_image*, the file entry points) work on the
+ * CALLING THREAD's context.  Which device that context lives on: MRGINGHAM_AMD_DEVICE if the variable is set (every
+ * thread on that device); otherwise the k-th thread that calls into the library gets device k modulo the number of
+ * devices -- the reference parallelises over worker threads with image i on worker i % N (mrgingham-from-image.cc:50,
+ * :374-379), and mapped this way its workers spread over the GPUs of a node by themselves; a thread can also choose:
+ * mrgingham_amd_set_thread_device (before its first call, or later: its context is then rebuilt on the new device). */
+int mrgingham_amd_device_for_thread(int thread_index, int ndevices, const char* env_value);  /* the policy, as a function */
+int mrgingham_amd_set_thread_device(int device_ordinal);
+int mrgingham_amd_thread_device(void);  /* the device of the calling thread's context (created if need be); -1: none */
+
+/* Host memory the device can read directly (page-locked, usable with every device): a frame handed to the wrappers
+ * out of such memory is uploaded at the speed of the link, with no staging copy and no pinning on the fly (12 MB:
+ * ~0.25 ms instead of ~0.45).  _register does the same for memory the caller already owns (it must stay allocated
+ * until _unregister). */
+void* mrgingham_amd_host_alloc(size_t bytes);
+void mrgingham_amd_host_free(void* p);
+int mrgingham_amd_host_register(void* p, size_t bytes);
+int mrgingham_amd_host_unregister(void* p);
+
+/* Contiguous shards of `total` frames over n contexts / ranks: shard k = frames [*first, *first + *count), the first
+ * total % n shards one frame longer (the split bench.py and mrgingham_amd/parallel.py use). */
+int mrgingham_amd_shard_range(int total, int k, int n, int* first, int* count);
+
+/* mrgingham_amd_chain_batch over several contexts -- one per device of a node -- in ONE call: context k takes
+ * shards[k], a batch in the memory of ITS device (shards[k].nframes may be 0), and the corner lists of every shard
+ * arrive in d_points / d_levels / d_npoints: buffers on the device of ctxs[0], laid out like mrgingham_amd_chain_batch's
+ * for the sum of the shards' frames, shard after shard (frame-major).  A shard on the first context's device writes its
+ * block in place; any other writes into buffers of its own context and the block travels device to device behind its
+ * chain (a peer copy: xGMI between the GPUs of a node) -- the one exchange of the path.  Asynchronous like chain_batch;
+ * consecutive calls need their own output buffers.  mrgingham_amd_sync_multi waits for every context and every gather
+ * and returns the first error (MRGINGHAM_AMD_ERR_CAPACITY: as mrgingham_amd_sync -- make the call again);
+ * mrgingham_amd_stream_wait_multi makes `stream` wait for them on the device instead.  Call these from one thread. */
+int mrgingham_amd_chain_multi(mrgingham_amd_ctx* const* ctxs, int nctx, const mrgingham_amd_frames* shards, int start_level,
+                              double* d_points, signed char* d_levels, int32_t* d_npoints, int points_pitch);
+int mrgingham_amd_sync_multi(mrgingham_amd_ctx* const* ctxs, int nctx);
+int mrgingham_amd_stream_wait_multi(mrgingham_amd_ctx* const* ctxs, int nctx, void* stream);
 
 /* Size of pyramid level `level` of a width x height frame: what
  * cv::resize(.., 1/2^level, 1/2^level) produces (find_chessboard_corners.cc:449-450). */

@@ -35,7 +35,10 @@ EXPORTS = [
     "mrgingham_amd_find_boards_batch", "mrgingham_amd_cc_on_response_batch", "mrgingham_amd_scratch_bytes", "mrgingham_amd_chain_info", "mrgingham_amd_debug_refine_clock", "mrgingham_amd_debug_paths", "mrgingham_amd_read_image",
     "mrgingham_amd_set_option", "mrgingham_amd_sync", "mrgingham_amd_stream_wait", "mrgingham_amd_after_stream", "mrgingham_amd_set_kernel_timing",
     "mrgingham_amd_chess_kernel_ms", "mrgingham_amd_sparse_fallbacks", "mrgingham_amd_find_boards_submit",
-    "mrgingham_amd_find_boards_collect",
+    "mrgingham_amd_find_boards_collect", "mrgingham_amd_device_for_thread", "mrgingham_amd_set_thread_device",
+    "mrgingham_amd_thread_device", "mrgingham_amd_host_alloc", "mrgingham_amd_host_free", "mrgingham_amd_host_register",
+    "mrgingham_amd_host_unregister", "mrgingham_amd_shard_range", "mrgingham_amd_chain_multi", "mrgingham_amd_sync_multi",
+    "mrgingham_amd_stream_wait_multi",
 ]
 
 
@@ -100,6 +103,18 @@ def lib():
     L.mrgingham_amd_find_boards_batch.argtypes = [c_vp, FP, c_int, c_int, c_vp, c_vp, c_int]
     L.mrgingham_amd_find_boards_submit.argtypes = [c_vp, FP, c_int, c_int, c_vp, c_vp, c_int]
     L.mrgingham_amd_find_boards_collect.argtypes = [c_vp, c_int]
+    L.mrgingham_amd_device_for_thread.argtypes = [c_int, c_int, ctypes.c_char_p]
+    L.mrgingham_amd_set_thread_device.argtypes = [c_int]
+    L.mrgingham_amd_host_alloc.argtypes = [ctypes.c_size_t]
+    L.mrgingham_amd_host_alloc.restype = c_vp
+    L.mrgingham_amd_host_free.argtypes = [c_vp]
+    L.mrgingham_amd_host_free.restype = None
+    L.mrgingham_amd_host_register.argtypes = [c_vp, ctypes.c_size_t]
+    L.mrgingham_amd_host_unregister.argtypes = [c_vp]
+    L.mrgingham_amd_shard_range.argtypes = [c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
+    L.mrgingham_amd_chain_multi.argtypes = [ctypes.POINTER(c_vp), c_int, FP, c_int, c_vp, c_vp, c_vp, c_int]
+    L.mrgingham_amd_sync_multi.argtypes = [ctypes.POINTER(c_vp), c_int]
+    L.mrgingham_amd_stream_wait_multi.argtypes = [ctypes.POINTER(c_vp), c_int, c_vp]
     L.mrgingham_amd_cc_on_response_batch.argtypes = [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp,
                                                      c_vp, c_vp, c_vp, c_int, c_vp]
     L.mrgingham_amd_read_image.argtypes = [ctypes.c_char_p, c_int, c_vp, ctypes.c_size_t, ctypes.POINTER(c_int),

@@ -124,6 +124,94 @@ def read_image(filename, cli_scaling=False):
     return out
 
 
+def device_for_thread(thread_index, ndevices, env_value=None):
+    """The library's policy for the device of the k-th thread that calls a reference symbol (include/mrgingham_amd.h,
+    "several GPUs"): MRGINGHAM_AMD_DEVICE if set, else k modulo the number of devices.  Host only."""
+    env = None if env_value is None else str(env_value).encode()
+    return _lib.lib().mrgingham_amd_device_for_thread(int(thread_index), int(ndevices), env)
+
+
+def shard_range(total, k, n):
+    """(first, count) of shard k of n over `total` frames (mrgingham_amd_shard_range).  Host only."""
+    a, b = ctypes.c_int(), ctypes.c_int()
+    if _lib.lib().mrgingham_amd_shard_range(int(total), int(k), int(n), ctypes.byref(a), ctypes.byref(b)) != 0:
+        raise ValueError("bad shard arguments")
+    return a.value, b.value
+
+
+def set_thread_device(device):
+    """The calling thread's single-image calls (ChESS_response_5, find_points, find_board ...) run on this device."""
+    if _lib.lib().mrgingham_amd_set_thread_device(int(device)) != 0:
+        raise ValueError(f"no such device: {device}")
+
+
+def thread_device():
+    """Device of the calling thread's context (created on first use: see device_for_thread); -1 without a device."""
+    return _lib.lib().mrgingham_amd_thread_device()
+
+
+class PinnedArray:
+    """A numpy array over page-locked host memory (mrgingham_amd_host_alloc): a frame handed to find_points /
+    find_board / ChESS_response_5 out of it is uploaded at the speed of the link, with no pinning on the fly.
+    Keep the object alive as long as `.array` is in use."""
+
+    def __init__(self, shape, dtype=np.uint8):
+        self._L = _lib.lib()
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._p = self._L.mrgingham_amd_host_alloc(max(n, 1))
+        if not self._p:
+            raise RuntimeError("mrgingham_amd_host_alloc failed (no device?)")
+        buf = (ctypes.c_char * max(n, 1)).from_address(self._p)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            self._L.mrgingham_amd_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def chain_multi(detectors, shards, start_level=3, max_points=1024, sync=True):
+    """mrgingham_amd_chain_multi: Detector k (its own device, or several on one) takes shards[k], a uint8 tensor
+    [B_k, H, W] on that device; -> (points f64 [sum B, P, 2], levels int8 [sum B, P], npoints int32 [sum B]) on the
+    FIRST detector's device, shard after shard -- one call, one gather."""
+    import torch
+    assert len(detectors) == len(shards) and len(detectors) > 0
+    L = _lib.lib()
+    root = detectors[0]
+    frs = (_lib.Frames * len(shards))()
+    total = 0
+    for k, (d, fr) in enumerate(zip(detectors, shards)):
+        assert fr.device == d.device, "every shard must live on its detector's device"
+        f, B, H, W = d._frames(fr)
+        frs[k] = f
+        total += B
+        torch.cuda.current_stream(fr.device).synchronize()
+    P = int(max_points)
+    pts = torch.empty((total, P, 2), dtype=torch.float64, device=root.device)
+    lv = torch.empty((total, P), dtype=torch.int8, device=root.device)
+    npts = torch.empty((total,), dtype=torch.int32, device=root.device)
+    torch.cuda.current_stream(root.device).synchronize()
+    ctxs = (ctypes.c_void_p * len(detectors))(*[d.ctx for d in detectors])
+    for attempt in range(4):
+        root._check(L.mrgingham_amd_chain_multi(ctxs, len(detectors), frs, int(start_level), pts.data_ptr(), lv.data_ptr(),
+                                                npts.data_ptr(), P))
+        if not sync:
+            break
+        rc = L.mrgingham_amd_sync_multi(ctxs, len(detectors))
+        if rc == 0:
+            break
+        if rc != Detector.ERR_CAPACITY or attempt == 3:     # (the tables have grown: the same call again)
+            root._check(rc)
+    return pts, lv, npts
+
+
 def find_grid_from_points(points_scaled, gridn=10):
     """mrgingham::find_grid_from_points (find_grid.cc:1216-1445), host only: int (N,2) candidates
     (pixel coordinates * 1000) -> float64 (gridn*gridn, 2) corners in board order, or None."""

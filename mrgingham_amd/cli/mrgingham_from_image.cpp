@@ -21,6 +21,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <cmath>
 #include <string>
 #include <vector>
@@ -36,13 +37,14 @@ using mrg::read_image;
 struct Options {
     glob_t globbed;
     int jobs = 1, blur_radius = 1, gridn = 10, level = -1;
+    int gpus = 0;  // --gpus: 0 = not given (the library's default: worker k on device k % devices, or MRGINGHAM_AMD_DEVICE)
     bool doclahe = true, do_refine = true, debug = false, doblobs = false;
     int debug_sequence_x = -1, debug_sequence_y = -1;
 } opt;
 
 const char* kUsage =
     "Usage: %s [--gridn N] [--noclahe] [--blur radius] [--level l] [--no-refine] [--jobs N]\n"
-    "          [--debug] [--debug-sequence x,y] imageglobs...\n"
+    "          [--gpus N|all] [--debug] [--debug-sequence x,y] imageglobs...\n"
     "\n"
     "Finds the chessboard in every image (binary PGM or PNG) and writes a vnlog table\n"
     "\n"
@@ -58,6 +60,9 @@ const char* kUsage =
     "  --level L       pyramid level to search at; default -1 = try 3, 2, 1, 0 in turn\n"
     "  --no-refine     keep the corners of the level the board was found at\n"
     "  --jobs N, -j N  worker threads (image i is handled by worker i mod N)\n"
+    "  --gpus N|all    GPUs to use: worker k works on device k mod N (default: every GPU of the node,\n"
+    "                  or the one named by MRGINGHAM_AMD_DEVICE); --jobs several times the GPU count keeps\n"
+    "                  each GPU busy while other workers read and decode\n"
     "  --blobs         find a grid of dark circles instead of a chessboard (no --level, no refinement)\n"
     "  --debug         one image only: write the preprocessed image, the level images, the ChESS\n"
     "                  responses and the corner vnlogs to /tmp like the reference does\n"
@@ -69,8 +74,23 @@ void* worker(void* arg) {
     std::vector<double> xy((size_t)N * 2);
     std::vector<signed char> lv((size_t)N);
     Image im;  // reused: its buffers keep their pages from image to image
+    if (opt.gpus > 0) mrgingham_amd_set_thread_device(ijob % opt.gpus);
+    // the decoded pixels are page-locked where they lie, so that the upload runs at the speed of the link (re-done
+    // when an image of another size moves the buffer)
+    void* locked = nullptr;
+    auto lock_pixels = [&](void* p, size_t bytes) {
+        if (p == locked) return;
+        if (locked) mrgingham_amd_host_unregister(locked);
+        locked = mrgingham_amd_host_register(p, bytes) == 0 ? p : nullptr;
+    };
+    // MRGINGHAM_AMD_CLI_TIMING=1: where a worker's time goes (stderr, at its end)
+    static const bool timing = getenv("MRGINGHAM_AMD_CLI_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_read = 0, t_proc = 0, t_out = 0;
+    int nimg = 0;
     for (int i = ijob; i < (int)opt.globbed.gl_pathc; i += opt.jobs) {
         const char* filename = opt.globbed.gl_pathv[i];
+        const double t0 = now();
         if (!read_image(filename, im)) {  // mrgingham-from-image.cc:58-68
             fprintf(stderr, "Couldn't open image '%s'\n", filename);
             flockfile(stdout);
@@ -90,10 +110,14 @@ void* worker(void* arg) {
         o.debug_sequence_x = opt.debug_sequence_x;
         o.debug_sequence_y = opt.debug_sequence_y;
         o.filename = filename;
+        if (im.depth == 16) lock_pixels(im.px16.data(), im.px16.capacity() * 2);
+        else lock_pixels(im.px8.data(), im.px8.capacity());
+        const double t1 = now();
         // 8- and 16-bit images go to the device as they are (mrgingham-from-image.cc:71-92)
         const int level = im.depth == 16
                               ? mrgingham_amd_process_image_ex(im.px16.data(), 16, im.w, im.h, im.w, &o, xy.data(), lv.data())
                               : mrgingham_amd_process_image_ex(im.px8.data(), 8, im.w, im.h, im.w, &o, xy.data(), lv.data());
+        const double t2 = now();
         flockfile(stdout);
         if (level >= 0)  // mrgingham-from-image.cc:174-183
             for (int k = 0; k < N; ++k)
@@ -101,7 +125,12 @@ void* worker(void* arg) {
         else
             printf("%s - - -\n", filename);
         funlockfile(stdout);
+        t_read += t1 - t0; t_proc += t2 - t1; t_out += now() - t2; ++nimg;
     }
+    if (timing && nimg)
+        fprintf(stderr, "worker %d: %d images; per image: read + decode %.3f ms, upload + device + grid finder %.3f ms, output %.3f ms\n",
+                ijob, nimg, t_read / nimg, t_proc / nimg, t_out / nimg);
+    if (locked) mrgingham_amd_host_unregister(locked);
     return nullptr;
 }
 
@@ -114,6 +143,7 @@ int main(int argc, char* argv[]) {
         {"no-refine", no_argument, nullptr, 'R'},      {"jobs", required_argument, nullptr, 'j'},
         {"gridn", required_argument, nullptr, 'N'},    {"debug", no_argument, nullptr, 'd'},
         {"debug-sequence", required_argument, nullptr, 'D'}, {"help", no_argument, nullptr, 'h'},
+        {"gpus", required_argument, nullptr, 'G'},
         {nullptr, 0, nullptr, 0}};
     bool doblobs = false;
     int c;
@@ -139,6 +169,7 @@ int main(int argc, char* argv[]) {
             case 'b': opt.blur_radius = atoi(optarg); break;
             case 'l': opt.level = atoi(optarg); break;
             case 'j': opt.jobs = atoi(optarg); break;
+            case 'G': opt.gpus = !strcmp(optarg, "all") ? -1 : atoi(optarg); if (opt.gpus == 0) opt.gpus = -2; break;
             default:
                 fprintf(stderr, "Unknown option\n");
                 fprintf(stderr, kUsage, argv[0]);
@@ -183,9 +214,19 @@ int main(int argc, char* argv[]) {
     // every worker's context overlaps three HIP streams; HIP maps streams onto GPU_MAX_HW_QUEUES
     // hardware queues (default 4) and streams that share one serialise (must be set before HIP starts)
     setenv("GPU_MAX_HW_QUEUES", "8", 0);
-    if (mrgingham_amd_device_count() <= 0) {
+    const int ndev = mrgingham_amd_device_count();
+    if (ndev <= 0) {
         fprintf(stderr, "mrgingham-amd-from-image: no HIP device: this tool has no CPU path\n");
         return 2;
+    }
+    if (opt.gpus == -2 || opt.gpus < -2) {
+        fprintf(stderr, "--gpus takes a positive count or 'all'\n");
+        return 1;
+    }
+    if (opt.gpus == -1) opt.gpus = ndev;
+    if (opt.gpus > ndev) {
+        fprintf(stderr, "mrgingham-amd-from-image: --gpus %d, but this node has %d: using %d\n", opt.gpus, ndev, ndev);
+        opt.gpus = ndev;
     }
     printf("## generated with");
     for (int i = 0; i < argc; ++i) printf(" %s", argv[i]);

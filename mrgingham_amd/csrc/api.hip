@@ -195,6 +195,11 @@ struct mrgingham_amd_ctx {
         bool grid_running = false;
         int nworkers = 0;
     } jobs[kMaxSets];
+    // mrgingham_amd_chain_multi: this context's shard of the outputs before it travels to the first context's device
+    mrg::DevBuf mg_pts, mg_lv, mg_np;
+    hipStream_t mg_stream = nullptr;
+    hipEvent_t mg_done = nullptr;
+    bool mg_pending = false;
     int next_ticket = 0;
     std::vector<std::pair<int, int>> done_tickets;  // (ticket, status) of jobs completed before they were collected
     int fb_pipeline = 1;  // option "find_boards_pipeline"
@@ -347,6 +352,7 @@ static std::vector<DevBuf*> all_buffers(mrgingham_amd_ctx* ctx) {
         v.push_back(&ctx->counters2[set]);
     }
     v.push_back(&ctx->sparse_stat);
+    for (DevBuf* b : {&ctx->mg_pts, &ctx->mg_lv, &ctx->mg_np}) v.push_back(b);
     for (auto& j : ctx->jobs)
         for (DevBuf* b : {&j.d_xy, &j.d_cnt, &j.d_pts, &j.d_lv, &j.d_np, &j.d_pts0, &j.d_lv0}) v.push_back(b);
     for (DevBuf* b : {&ctx->io_counts, &ctx->aux_img, &ctx->io_frame, &ctx->io_out, &ctx->pre_scratch, &ctx->pre_tmp,
@@ -774,6 +780,8 @@ void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx) {
     for (hipEvent_t e : ctx->ev_cc_done)
         if (e) hipEventDestroy(e);
     if (ctx->ev_ext) hipEventDestroy(ctx->ev_ext);
+    if (ctx->mg_done) hipEventDestroy(ctx->mg_done);
+    if (ctx->mg_stream) hipStreamDestroy(ctx->mg_stream);
     for (auto& j : ctx->jobs) {
         if (j.ev_a) hipEventDestroy(j.ev_a);
         if (j.ev_b) hipEventDestroy(j.ev_b);
@@ -1412,19 +1420,174 @@ static mrgingham_amd_ctx* same_device_ctx(mrgingham_amd_ctx* ctx) {
     return ctx->one;
 }
 
+// Which device the k-th thread that calls a reference symbol gets when nobody said otherwise: MRGINGHAM_AMD_DEVICE
+// (every thread on that device) or, with the variable unset, k modulo the number of devices -- the reference's own
+// parallelism is N worker threads with image i on worker i % N (mrgingham-from-image.cc:50, :374-379), and mapped this
+// way its workers spread over the GPUs of a node by themselves.
+static std::atomic<int> g_thread_counter{0};
+struct ThreadCtxHolder {
+    mrgingham_amd_ctx* ctx = nullptr;
+    int requested = -1;  // mrgingham_amd_set_thread_device
+    ~ThreadCtxHolder() { /* leaked on purpose: HIP may already be torn down at thread exit */ }
+};
+static thread_local ThreadCtxHolder t_holder;
+
 static mrgingham_amd_ctx* thread_ctx() {
     // One context per calling thread: the reference is called from N worker
     // pthreads at once (mrgingham-from-image.cc:374-379).
-    struct Holder {
-        mrgingham_amd_ctx* ctx = nullptr;
-        ~Holder() { /* leaked on purpose: HIP may already be torn down at thread exit */ }
-    };
-    static thread_local Holder h;
+    ThreadCtxHolder& h = t_holder;
     if (!h.ctx) {
-        const char* d = getenv("MRGINGHAM_AMD_DEVICE");
-        h.ctx = mrgingham_amd_create(d ? atoi(d) : 0);
+        int dev = h.requested;
+        if (dev < 0) dev = mrgingham_amd_device_for_thread(g_thread_counter.fetch_add(1), mrgingham_amd_device_count(),
+                                                           getenv("MRGINGHAM_AMD_DEVICE"));
+        h.ctx = mrgingham_amd_create(dev);
     }
     return h.ctx;
+}
+
+int mrgingham_amd_device_for_thread(int thread_index, int ndevices, const char* env_value) {
+    if (env_value && *env_value) return atoi(env_value);
+    if (ndevices <= 0) return 0;
+    return (int)((unsigned)(thread_index < 0 ? 0 : thread_index) % (unsigned)ndevices);
+}
+
+int mrgingham_amd_set_thread_device(int device_ordinal) {
+    const int ndev = mrgingham_amd_device_count();
+    if (device_ordinal < 0 || device_ordinal >= ndev) {
+        fprintf(stderr, "mrgingham_amd: device ordinal %d out of range (%d device(s))\n", device_ordinal, ndev);
+        return MRGINGHAM_AMD_ERR_ARG;
+    }
+    ThreadCtxHolder& h = t_holder;
+    h.requested = device_ordinal;
+    if (h.ctx && h.ctx->device != device_ordinal) {
+        mrgingham_amd_destroy(h.ctx);
+        h.ctx = nullptr;
+    }
+    return MRGINGHAM_AMD_OK;
+}
+
+int mrgingham_amd_thread_device(void) {
+    mrgingham_amd_ctx* ctx = thread_ctx();
+    return ctx ? ctx->device : -1;
+}
+
+void* mrgingham_amd_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) return nullptr;
+    return p;
+}
+void mrgingham_amd_host_free(void* p) {
+    if (p) hipHostFree(p);
+}
+int mrgingham_amd_host_register(void* p, size_t bytes) {
+    if (!p || bytes == 0) return MRGINGHAM_AMD_ERR_ARG;
+    return hipHostRegister(p, bytes, hipHostRegisterPortable) == hipSuccess ? MRGINGHAM_AMD_OK : MRGINGHAM_AMD_ERR_DEVICE;
+}
+int mrgingham_amd_host_unregister(void* p) {
+    if (!p) return MRGINGHAM_AMD_ERR_ARG;
+    return hipHostUnregister(p) == hipSuccess ? MRGINGHAM_AMD_OK : MRGINGHAM_AMD_ERR_DEVICE;
+}
+
+int mrgingham_amd_shard_range(int total, int k, int n, int* first, int* count) {
+    if (total < 0 || n <= 0 || k < 0 || k >= n || !first || !count) return MRGINGHAM_AMD_ERR_ARG;
+    const int q = total / n, r = total % n;  // the first r shards take one frame more
+    *first = k * q + (k < r ? k : r);
+    *count = q + (k < r ? 1 : 0);
+    return MRGINGHAM_AMD_OK;
+}
+
+/* chain_batch over several contexts -- one per device of a node, or several on one -- in ONE call: context k takes
+ * shards[k] (frames in the memory of ITS device), and the corner lists of every shard arrive in d_points / d_levels /
+ * d_npoints, buffers on the device of ctxs[0] laid out for the sum of the shards' frames in shard order (frame-major):
+ * a shard on that device writes its block in place, a shard elsewhere writes into its own context's buffers and the
+ * block travels device to device behind its chain (hipMemcpyPeerAsync: xGMI between the GPUs of a node) -- the ONE
+ * exchange of the path.  Asynchronous; mrgingham_amd_sync_multi waits for everything. */
+int mrgingham_amd_chain_multi(mrgingham_amd_ctx* const* ctxs, int nctx, const mrgingham_amd_frames* shards, int start_level,
+                              double* d_points, signed char* d_levels, int32_t* d_npoints, int points_pitch) {
+    if (!ctxs || nctx <= 0 || !shards || !ctxs[0]) return MRGINGHAM_AMD_ERR_ARG;
+    mrgingham_amd_ctx* root = ctxs[0];
+    if (!d_points || !d_levels || !d_npoints || points_pitch <= 0)
+        return fail(root, MRGINGHAM_AMD_ERR_ARG, "NULL point buffers");
+    for (int k = 0; k < nctx; ++k) {
+        if (!ctxs[k]) return fail(root, MRGINGHAM_AMD_ERR_ARG, "NULL context %d", k);
+        for (int j = 0; j < k; ++j)
+            if (ctxs[j] == ctxs[k]) return fail(root, MRGINGHAM_AMD_ERR_ARG, "context %d is context %d again: one context per shard", k, j);
+    }
+    size_t off = 0;  // frames in front of shard k
+    for (int k = 0; k < nctx; ++k) {
+        mrgingham_amd_ctx* ctx = ctxs[k];
+        const int B = shards[k].nframes;
+        int rc = validate_frames(ctx, &shards[k]);
+        if (rc) return rc;
+        if (B == 0) continue;
+        const size_t np = (size_t)B * points_pitch;
+        double* dst_p = d_points + off * points_pitch * 2;
+        signed char* dst_l = d_levels + off * points_pitch;
+        int32_t* dst_n = d_npoints + off;
+        off += (size_t)B;
+        if (ctx->device == root->device) {
+            if ((rc = mrgingham_amd_chain_batch(ctx, &shards[k], start_level, dst_p, dst_l, dst_n, points_pitch))) return rc;
+            ctx->mg_pending = false;
+            continue;
+        }
+        MRG_HIP_CHECK(hipSetDevice(ctx->device));
+        if (!ctx->mg_stream) {
+            MRG_HIP_CHECK(hipStreamCreateWithFlags(&ctx->mg_stream, hipStreamNonBlocking));
+            MRG_HIP_CHECK(hipEventCreateWithFlags(&ctx->mg_done, hipEventDisableTiming));
+            int can = 0;  // direct peer copies where the link allows them (otherwise HIP stages through the host)
+            if (hipDeviceCanAccessPeer(&can, ctx->device, root->device) == hipSuccess && can) {
+                hipError_t e = hipDeviceEnablePeerAccess(root->device, 0);
+                if (e != hipSuccess) (void)hipGetLastError();  // (already enabled, or refused: the copy still works)
+            }
+        }
+        if ((rc = ensure(ctx, ctx->mg_pts, np * 16)) || (rc = ensure(ctx, ctx->mg_lv, np)) || (rc = ensure(ctx, ctx->mg_np, (size_t)B * 4)))
+            return rc;
+        if (ctx->mg_pending) MRG_HIP_CHECK(hipStreamWaitEvent(ctx->pix, ctx->mg_done, 0));  // the gather before this one has read the buffers
+        if ((rc = mrgingham_amd_chain_batch(ctx, &shards[k], start_level, (double*)ctx->mg_pts.p, (signed char*)ctx->mg_lv.p,
+                                            (int32_t*)ctx->mg_np.p, points_pitch)))
+            return rc;
+        if ((rc = mrgingham_amd_stream_wait(ctx, ctx->mg_stream))) return rc;
+        MRG_HIP_CHECK(hipMemcpyPeerAsync(dst_p, root->device, ctx->mg_pts.p, ctx->device, np * 16, ctx->mg_stream));
+        MRG_HIP_CHECK(hipMemcpyPeerAsync(dst_l, root->device, ctx->mg_lv.p, ctx->device, np, ctx->mg_stream));
+        MRG_HIP_CHECK(hipMemcpyPeerAsync(dst_n, root->device, ctx->mg_np.p, ctx->device, (size_t)B * 4, ctx->mg_stream));
+        MRG_HIP_CHECK(hipEventRecord(ctx->mg_done, ctx->mg_stream));
+        ctx->mg_pending = true;
+    }
+    return MRGINGHAM_AMD_OK;
+}
+
+int mrgingham_amd_sync_multi(mrgingham_amd_ctx* const* ctxs, int nctx) {
+    if (!ctxs || nctx <= 0) return MRGINGHAM_AMD_ERR_ARG;
+    int rc = MRGINGHAM_AMD_OK;
+    for (int k = 0; k < nctx; ++k) {
+        mrgingham_amd_ctx* ctx = ctxs[k];
+        if (!ctx) return MRGINGHAM_AMD_ERR_ARG;
+        const int r = mrgingham_amd_sync(ctx);
+        if (r && !rc) rc = r;
+        if (ctx->mg_stream) {
+            MRG_HIP_CHECK(hipSetDevice(ctx->device));
+            MRG_HIP_CHECK(hipStreamSynchronize(ctx->mg_stream));
+        }
+        ctx->mg_pending = false;
+    }
+    return rc;
+}
+
+/* Device-side alternative to mrgingham_amd_sync_multi: `stream` (a hipStream_t of any device, normally the first
+ * context's) waits for the chains and the gathers of the most recent mrgingham_amd_chain_multi. */
+int mrgingham_amd_stream_wait_multi(mrgingham_amd_ctx* const* ctxs, int nctx, void* stream) {
+    if (!ctxs || nctx <= 0) return MRGINGHAM_AMD_ERR_ARG;
+    for (int k = 0; k < nctx; ++k) {
+        mrgingham_amd_ctx* ctx = ctxs[k];
+        if (!ctx) return MRGINGHAM_AMD_ERR_ARG;
+        if (ctx->mg_pending) {
+            MRG_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, ctx->mg_done, 0));
+        } else {
+            const int r = mrgingham_amd_stream_wait(ctx, stream);
+            if (r) return r;
+        }
+    }
+    return MRGINGHAM_AMD_OK;
 }
 
 // Upload one host frame as a dense device image; fills `fr`.
@@ -1433,9 +1596,14 @@ static int upload_frame(mrgingham_amd_ctx* ctx, const void* host, int rows, int 
     int rc;
     if ((rc = ensure(ctx, ctx->io_frame, (size_t)rows * cols + 64))) return rc;
     // stream-ordered on streams[0]: the kernels that read it are queued on the same stream
-    if (rows > 0 && cols > 0)
-        MRG_HIP_CHECK(hipMemcpy2DAsync(ctx->io_frame.p, cols, host, stride, cols, rows, hipMemcpyHostToDevice,
-                                       ctx->pix));
+    // (a dense frame as ONE copy: the 2-D form goes through a slower path of the runtime even when the rows are contiguous)
+    if (rows > 0 && cols > 0) {
+        if (stride == cols)
+            MRG_HIP_CHECK(hipMemcpyAsync(ctx->io_frame.p, host, (size_t)rows * cols, hipMemcpyHostToDevice, ctx->pix));
+        else
+            MRG_HIP_CHECK(hipMemcpy2DAsync(ctx->io_frame.p, cols, host, stride, cols, rows, hipMemcpyHostToDevice,
+                                           ctx->pix));
+    }
     fr->frames = (const uint8_t*)ctx->io_frame.p;
     fr->frame_pitch = (int64_t)rows * cols;
     fr->nframes = 1;

@@ -151,9 +151,50 @@ static bool decode_png(const std::vector<uint8_t>& b, Image& im) {
     return true;
 }
 
+// 8-bit binary PGM, the format a calibration run usually feeds the tool: the pixels go from the file straight into
+// px8 -- no copy of the whole file in between (a 12 MB image: one pass over memory less per image).  Returns 1 = done,
+// 0 = not such a file (the general path decides), -1 = such a file, but broken.
+static int read_pgm8_direct(const char* path, Image& im) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return -1;
+    uint8_t head[128];
+    const size_t got = fread(head, 1, sizeof(head), f);
+    int rc = 0;
+    if (got >= 8 && head[0] == 'P' && head[1] == '5') {
+        size_t p = 2;
+        int v[3] = {0, 0, 0};
+        bool ok = true;
+        for (int k = 0; k < 3 && ok; ++k) {
+            for (;;) {
+                while (p < got && (head[p] == ' ' || head[p] == '\t' || head[p] == '\n' || head[p] == '\r')) ++p;
+                if (p < got && head[p] == '#') { while (p < got && head[p] != '\n') ++p; continue; }
+                break;
+            }
+            if (p >= got || head[p] < '0' || head[p] > '9') { ok = false; break; }
+            long x = 0;
+            while (p < got && head[p] >= '0' && head[p] <= '9') { x = x * 10 + (head[p] - '0'); if (x > 1 << 30) { ok = false; break; } ++p; }
+            v[k] = (int)x;
+        }
+        // (a header with a long comment does not fit the 128 bytes: the general path takes it)
+        if (ok && p < got && v[2] > 0 && v[2] < 256 && v[0] > 0 && v[1] > 0 && v[0] <= kMaxSide && v[1] <= kMaxSide) {
+            ++p;  // the single whitespace after maxval
+            const size_t n = (size_t)v[0] * v[1];
+            im.w = v[0]; im.h = v[1]; im.depth = 8;
+            im.px8.resize(n);
+            const size_t have = got - p < n ? got - p : n;
+            memcpy(im.px8.data(), head + p, have);
+            rc = fread(im.px8.data() + have, 1, n - have, f) == n - have ? 1 : -1;
+        }
+    }
+    fclose(f);
+    return rc;
+}
+
 bool read_image(const char* path, Image& im) {
     // never throws: the callers are extern "C" entry points and detached worker threads
     try {
+        const int direct = read_pgm8_direct(path, im);
+        if (direct != 0) return direct > 0;
         std::vector<uint8_t>& b = im.file;
         if (!read_file(path, b) || b.size() < 8) return false;
         if (b[0] == 'P' && b[1] == '5') return decode_pgm(b, im);

@@ -140,3 +140,25 @@ def test_reference_module_name_is_importable():
     for name in mrgingham.__all__:
         assert getattr(mrgingham, name) is getattr(mrgingham_amd, name)
     assert mrgingham.find_chessboard is mrgingham.find_board and mrgingham.find_chessboard_corners is mrgingham.find_points
+
+
+def test_thread_to_device_policy_and_shard_ranges():
+    """Multi-GPU at the C boundary, the host-only parts: the k-th calling thread gets device k % devices unless
+    MRGINGHAM_AMD_DEVICE names one (the reference's worker model -- image i on worker i % N,
+    mrgingham-from-image.cc:50 -- mapped onto devices), and the contiguous shard split of mrgingham_amd_chain_multi's
+    callers is the one parallel.py uses."""
+    from mrgingham_amd import api, parallel
+    assert [api.device_for_thread(k, 8) for k in range(18)] == [k % 8 for k in range(18)]
+    assert [api.device_for_thread(k, 1) for k in range(4)] == [0, 0, 0, 0]
+    assert [api.device_for_thread(k, 8, "5") for k in range(4)] == [5, 5, 5, 5]      # the variable wins, for every thread
+    assert api.device_for_thread(3, 8, "") == 3                                        # (set but empty: not a choice)
+    assert api.device_for_thread(7, 0) == 0
+    for total in (0, 1, 7, 64, 2048, 2051):
+        for n in (1, 2, 3, 8):
+            got = [api.shard_range(total, k, n) for k in range(n)]
+            assert [(a, a + c) for a, c in got] == [parallel.shard_range(total, k, n) for k in range(n)]
+            assert sum(c for _, c in got) == total and got[0][0] == 0
+            assert all(got[k][0] + got[k][1] == got[k + 1][0] for k in range(n - 1))
+            assert max(c for _, c in got) - min(c for _, c in got) <= 1
+    with pytest.raises(ValueError):
+        api.shard_range(10, 3, 3)

@@ -20,6 +20,13 @@ def med(f, n=15, warm=3):
 
 for (w, h) in [(640, 480), (1920, 1080), (4096, 3072)]:
     img = synth.board_frame(w, h, 10, 1, device="cuda").cpu().numpy()
+    pin = mrgingham_amd.api.PinnedArray(img.shape)          # the same frame in page-locked memory (mrgingham_amd_host_alloc)
+    pin.array[...] = img
+    pimg = pin.array
+    print(f"{w}x{h} from page-locked host memory: ChESS_response_5 {med(lambda: mrgingham_amd.ChESS_response_5(pimg)):.2f} ms, "
+          f"find_points L0 {med(lambda: mrgingham_amd.find_points(pimg, 0)):.2f} ms, "
+          f"find_points L2 {med(lambda: mrgingham_amd.find_points(pimg, 2)):.2f} ms, "
+          f"find_board (level search + refinement) {med(lambda: mrgingham_amd.find_board(pimg)):.2f} ms", flush=True)
     print(f"{w}x{h}: ChESS_response_5 {med(lambda: mrgingham_amd.ChESS_response_5(img)):.2f} ms, "
           f"find_points L0 {med(lambda: mrgingham_amd.find_points(img, 0)):.2f} ms, "
           f"find_points L2 {med(lambda: mrgingham_amd.find_points(img, 2)):.2f} ms, "
