@@ -546,12 +546,18 @@ def main():
         # HBM-side bytes per launch: PMC counters cannot be read from inside this process, so the
         # figure is the per-pixel traffic measured by the committed rocprofv3 --pmc passes of this
         # same command (profiles/chess_l0_traffic.json), scaled to this launch; null if absent.
+        # Both replayed figures carry the id of the kernel sources they were collected on (tools/make_profiles.py); a
+        # library built from other sources gets null, not somebody else's counters.
+        kernel_id = mrgingham_amd._lib.lib().mrgingham_amd_kernel_id().decode()
         traffic, traffic_src = None, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "chess_l0_traffic.json")))
             if (tj["width"], tj["height"]) == (W, H) and start_level >= 0 and not sparse_step:
-                traffic = tj["bytes_per_pixel"] * frames_per_launch * W * H
-                traffic_src = tj["source"]
+                if tj.get("kernel_id") == kernel_id:
+                    traffic = tj["bytes_per_pixel"] * frames_per_launch * W * H
+                    traffic_src = tj["source"]
+                else:
+                    traffic_src = f"none: {tj.get('source')} was collected on kernel sources {tj.get('kernel_id')}, this library is {kernel_id}"
         except (OSError, KeyError, ValueError):
             pass
         # What binds the kernel (it moves its bytes once and is not waiting for them): the issue slots of the SIMDs.
@@ -559,7 +565,7 @@ def main():
         valu = None
         try:
             vj = json.load(open(os.path.join(ROOT, "profiles", "chess_l0_valu.json")))
-            if (vj["width"], vj["height"]) == (W, H) and not sparse_step:
+            if (vj["width"], vj["height"]) == (W, H) and not sparse_step and vj.get("kernel_id") == kernel_id:
                 valu = {"bound": "valu_issue", "frac": vj["valu_issue_frac"], "unit": "fraction of SIMD quad-cycle issue slots "
                         "carrying a VALU instruction (4 waves per SIMD)", "valu_insts_per_512px": vj["valu_insts_per_wave_iteration"],
                         "wave_parked_frac": vj["wait_any_frac"], "source": vj["source"]}
@@ -571,6 +577,7 @@ def main():
             "value": total_frames / dt,
             "unit": "frames/s",
             "n_gpus": world,
+            "kernel_id": kernel_id,
             "ranks_seen": ranks_seen,
             "steps": args.steps,
             "warmup": args.warmup,

@@ -141,6 +141,10 @@ mrgingham_amd_ctx* mrgingham_amd_create(int device_ordinal);
 void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx);
 const char* mrgingham_amd_last_error(const mrgingham_amd_ctx* ctx);
 int mrgingham_amd_abi_version(void);
+/* Identity of the ChESS kernel sources the library was built from (16 hex digits of a SHA-256 over chess.hip and the
+ * headers it includes): bench.py replays counter evidence collected in an earlier run (profiles/chess_l0_*.json) only
+ * when that run used a library with the same id. */
+const char* mrgingham_amd_kernel_id(void);
 /* Number of usable HIP devices (0 = none: every entry point will fail, there is no CPU path). */
 int mrgingham_amd_device_count(void);
 
@@ -393,7 +397,6 @@ int mrgingham_amd_chain_info(const mrgingham_amd_ctx* ctx, int* fused_pyramid, i
  *                         far stay refined) -- and the tables of that level GROW to what the frame asked for, so
  *                         the same call succeeds when it is made again (refinement is idempotent: points already at
  *                         the level are skipped).  Setting the option resets what has grown.
- *   "chess_v0"            1 = use the plain reference-shaped ChESS kernel (cross-check)
  *   "multi_level_launch"  chain_batch: 0 = one ChESS launch per pyramid level, 1 (default) = levels 3..1 in one
  *                         launch, 2 = all levels in one launch
  *   "cc_lds"              1 (default) = component search out of LDS: frames with at most 2048 hot pixels in one
@@ -414,7 +417,8 @@ int mrgingham_amd_chain_info(const mrgingham_amd_ctx* ctx, int* fused_pyramid, i
  *   "chess_seg"           rows per workgroup of the ChESS kernels (0 = cost model); results do not depend on it
  * Builds made with -DMRG_EXPERIMENT (make -C mrgingham_amd/csrc EXPERIMENT=1 -> libmrgingham_amd_experiment.so)
  * additionally accept the timing ablations and phase clocks of tools/ ("cc_lds" bits 2, 4, 8, 16, 128, 512,
- * "cc_schedule", "chess_stage", "chess_multi_min_blocks", the MRGINGHAM_AMD_PYR_SKIP / _CC_LDS_PAD / _CC_CUS /
+ * "cc_schedule", "chess_stage", "chess_multi_min_blocks", "chess_v0" = the reference-shaped ChESS kernel as an on-device
+ * cross-check, the MRGINGHAM_AMD_PYR_SKIP / _CC_LDS_PAD / _CC_CUS /
  * _PIX_COMPLEMENT / _CHESS_V0 environment variables): some of them produce wrong results on purpose, which is why the
  * shipped library has none of them and reads no environment variable except MRGINGHAM_AMD_DEVICE. */
 int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value);

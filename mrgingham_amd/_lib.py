@@ -38,7 +38,7 @@ EXPORTS = [
     "mrgingham_amd_find_boards_collect", "mrgingham_amd_device_for_thread", "mrgingham_amd_set_thread_device",
     "mrgingham_amd_thread_device", "mrgingham_amd_host_alloc", "mrgingham_amd_host_free", "mrgingham_amd_host_register",
     "mrgingham_amd_host_unregister", "mrgingham_amd_shard_range", "mrgingham_amd_chain_multi", "mrgingham_amd_sync_multi",
-    "mrgingham_amd_stream_wait_multi",
+    "mrgingham_amd_stream_wait_multi", "mrgingham_amd_kernel_id",
 ]
 
 
@@ -91,6 +91,7 @@ def lib():
     L.mrgingham_amd_last_error.argtypes = [c_vp]
     L.mrgingham_amd_last_error.restype = ctypes.c_char_p
     L.mrgingham_amd_abi_version.restype = c_int
+    L.mrgingham_amd_kernel_id.restype = ctypes.c_char_p
     L.mrgingham_amd_device_count.restype = c_int
     L.mrgingham_amd_level_dims.argtypes = [c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     L.mrgingham_amd_chess_response_batch.argtypes = [c_vp, FP, c_int, c_int, c_vp, c_vp]

@@ -362,16 +362,24 @@ class Detector:
         ERR_CAPACITY *after the tables have grown to what it asked for* (include/mrgingham_amd.h,
         "hot_capacity_shift"), so the same call is simply made again -- like the reference-symbol wrappers of the
         library do it.  `restore` puts in/out arguments back first."""
-        for attempt in range(4):
-            issue()
-            try:
-                self.sync()
-                return
-            except RuntimeError as e:
-                if not retry or getattr(e, "code", 0) != self.ERR_CAPACITY or attempt == 3:
-                    raise
-                if restore:
-                    restore()
+        full = False
+        try:
+            for attempt in range(4):
+                issue()
+                try:
+                    self.sync()
+                    return
+                except RuntimeError as e:
+                    if not retry or getattr(e, "code", 0) != self.ERR_CAPACITY or attempt == 3:
+                        raise
+                    if restore:
+                        restore()
+                    if attempt == 2:      # the last try takes a table entry for every pixel, like the C wrappers
+                        self.L.mrgingham_amd_set_option(self.ctx, b"hot_capacity_shift", 0)
+                        full = True
+        finally:
+            if full:                      # (back to the default; what has grown starts over)
+                self.L.mrgingham_amd_set_option(self.ctx, b"hot_capacity_shift", self._options.get("hot_capacity_shift", 7))
 
     def _frames(self, frames):
         t = self.torch

@@ -476,8 +476,11 @@ static void launch_chess_any(mrgingham_amd_ctx* ctx, const LevelBatch& lb, const
         hipEventRecord(e0, s);
     }
     if (lb.w > 0 && lb.h > 0 && n > 0) {
+#ifdef MRG_EXPERIMENT
         if (ctx->use_v0) launch_chess_v0(lb, t, 0, n, clamp, hot, s);
-        else launch_chess(lb, t, 0, n, clamp, hot, s);
+        else
+#endif
+            launch_chess(lb, t, 0, n, clamp, hot, s);
     }
     if (e0) {
         hipEventRecord(e1, s);
@@ -687,6 +690,11 @@ extern "C" {
 
 int mrgingham_amd_abi_version(void) { return MRGINGHAM_AMD_ABI_VERSION; }
 
+#ifndef MRG_KERNEL_ID
+#define MRG_KERNEL_ID "unknown"
+#endif
+const char* mrgingham_amd_kernel_id(void) { return MRG_KERNEL_ID; }
+
 int mrgingham_amd_device_count(void) {
     int n = 0;
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
@@ -853,7 +861,9 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
         for (int& g : ctx->grown_shift) g = 31;  // an explicit choice starts over
         return 0;
     }
+#ifdef MRG_EXPERIMENT
     if (!strcmp(name, "chess_v0")) { ctx->use_v0 = value != 0; return 0; }
+#endif
     if (!strcmp(name, "multi_level_launch")) { ctx->multi_level = value < 0 ? 0 : value > 2 ? 2 : value; return 0; }
 #ifdef MRG_EXPERIMENT
     if (!strcmp(name, "cc_schedule")) { ctx->cc_schedule = value; return 0; }

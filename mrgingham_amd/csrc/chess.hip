@@ -22,6 +22,7 @@
 
 namespace mrg {
 
+#ifdef MRG_EXPERIMENT  // the reference-shaped kernel: on-device cross-check of the tuned one (option "chess_v0"), experiment builds only
 // ---------------------------------------------------------------------------
 // v0 epilogue: a wave holds 64 consecutive pixels of one row (x0 a multiple of 64), one per lane.
 // The first lane of every aligned group of 8 appends the group.  Uniform control flow required.
@@ -107,6 +108,8 @@ void launch_chess_v0(const LevelBatch& lb, const CompTables& t, int frame0, int 
     else
         hipLaunchKernelGGL((chess_v0_kernel<false, false>), grid, dim3(256), 0, s, lb, t, frame0);
 }
+
+#endif  // MRG_EXPERIMENT
 
 // ---------------------------------------------------------------------------
 // v1: the production kernel.  HBM-bound design for gfx950 (wave64):

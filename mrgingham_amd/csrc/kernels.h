@@ -14,8 +14,10 @@ struct PyramidOut {
 };
 
 // chess.hip
+#ifdef MRG_EXPERIMENT
 void launch_chess_v0(const LevelBatch& lb, const CompTables& t, int frame0, int nframes, bool clamp, bool hot,
                      hipStream_t s);
+#endif
 void launch_chess(const LevelBatch& lb, const CompTables& t, int frame0, int nframes, bool clamp, bool hot,
                   hipStream_t s);
 
@@ -103,7 +105,7 @@ void launch_cc_detect(const LevelBatch& lb, const CompTables& t, int level, cons
                       int nframes, hipStream_t s);
 void launch_cc_refine(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io, int frame0,
                       int nframes, hipStream_t s);
-// sparse refinement: the cells (squares of 32 pixels; larger above 41.9 MP per level) around the points to refine at
+// sparse refinement: the cells (squares of 16 pixels; 32, 64 ... when the box around the points has more than 40 960 of them) around the points to refine at
 // `level`, per frame: cell_list[frame * list_pitch + k], k < cell_cnt[frame]
 void launch_sparse_cells(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io, uint32_t* cell_list,
                          int32_t* cell_cnt, int list_pitch, int frame0, int nframes, hipStream_t s);

@@ -194,11 +194,20 @@ class WorkQueue:
 
     The counter lives in the process group's key-value store (`store.add` is an atomic fetch-and-add served by
     rank 0's TCPStore: one small round trip per UNIT, not per frame), so it needs no GPU, no collective and no
-    symmetric participation: a rank that never gets a unit never blocks the others."""
+    symmetric participation: a rank that never gets a unit never blocks the others.
+
+    Every queue counts under a key of its OWN: the name plus the number of queues of that name this process has built
+    so far.  Ranks build their queues in the same order (one per stream / pass, like every collective call), so they
+    agree on the key without talking -- and a second queue never starts from the exhausted counter of the first
+    (which would hand every rank None at once and skip the whole stream without an error)."""
+
+    _generation = {}                         # name -> queues of that name built so far in this process
 
     def __init__(self, nunits, name="mrgingham_amd/wq", store=None):
         self.n = int(nunits)
-        self.key = name
+        gen = WorkQueue._generation.get(name, 0)
+        WorkQueue._generation[name] = gen + 1
+        self.key = f"{name}#{gen}"
         if store is None and dist.is_available() and dist.is_initialized():
             store = dist.distributed_c10d._get_default_store()
         self.store = store

@@ -92,11 +92,15 @@ def test_chess_strided_device_frames(det):
 
 
 def test_chess_v0_cross_check(det):
-    """The plain reference-shaped kernel and the tuned kernel agree on the device."""
+    """The plain reference-shaped kernel and the tuned kernel agree on the device (experiment builds only:
+    make -C mrgingham_amd/csrc EXPERIMENT=1, MRGINGHAM_AMD_LIB; the shipped library does not carry the second kernel)."""
     frames = _cuda(np.stack([synth.board_frame(640, 480, 10, s).numpy() for s in range(2)] +
                             [synth.noise_frame(640, 480, 3).numpy()]))
     a = det.chess_response(frames, 0).cpu()
-    det.set_option("chess_v0", 1)
+    try:
+        det.set_option("chess_v0", 1)
+    except ValueError:
+        pytest.skip("the reference-shaped kernel exists in experiment builds only")
     try:
         b = det.chess_response(frames, 0).cpu()
     finally:

@@ -161,11 +161,22 @@ def _queue_worker(rank, world, port, ret):
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     got = [None] * world
     dist.all_gather_object(got, mine)
+    # two queues with the DEFAULT name back to back (the next stream, the next pass): each counts from its own key, so the
+    # second does not start from the exhausted counter of the first
+    dist.barrier()
+    second = []
+    for n in (7, 5):
+        q2 = parallel.WorkQueue(n)
+        mine2 = list(q2)
+        got2 = [None] * world
+        dist.all_gather_object(got2, mine2)
+        second.append(sorted(u for g in got2 for u in g) == list(range(n)))
+        dist.barrier()
     if rank == 0:
         ideal = 1.2 / world
         every = sorted(u for g in got for u in g)
         ret.put({"lpt": float(tt[0]) / ideal, "queue": float(tt[1]) / ideal, "complete": every == list(range(len(units))),
-                 "both_worked": all(len(g) > 0 for g in got)})
+                 "both_worked": all(len(g) > 0 for g in got), "default_named_queues_back_to_back": second})
     dist.barrier()
     dist.destroy_process_group()
 
@@ -185,6 +196,7 @@ def test_work_queue_balances_where_the_static_plan_cannot():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res["complete"] and res["both_worked"], res       # every unit done exactly once
+    assert res["default_named_queues_back_to_back"] == [True, True], res
     assert res["queue"] <= 1.15, res                          # within 15 % of the ideal makespan
     assert res["lpt"] >= 1.3, res                             # the static plan on the wrong model is not
     print(res)

@@ -14,6 +14,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     gridn = int(os.environ.get("GRIDN", "10"))
     frames = synth.board_batch(8, W, H, gridn, 0, device='cuda').repeat(B // 8, 1, 1).contiguous()
     det = mrgingham_amd.Detector(0)
+    try:
+        det.set_option("sparse_refine", 0)      # the dense schedule (the library's default is 1 since round 4)
+    except ValueError:
+        pass
     for kv in os.environ.get("OPTIONS", "").split(","):
         if kv:
             k, v = kv.split("=")

@@ -52,6 +52,7 @@ j["algorithmic_bytes_per_pixel"] = 3.328125 if fused else 3.0
 j["_comment"] = re.sub(r"mrg::chess_v1\w*(<true,true>)?", j["kernel"].split(" ")[0], j["_comment"])
 j["source"] = f"profiles/{RND}_bench_pmc_ea_traffic.txt"
 j["_comment"] = j["_comment"].replace("round 1, profiles/r01_bench_pmc_ea_traffic.txt", f"round {RND[1:]}, profiles/{RND}_bench_pmc_ea_traffic.txt")
+j["kernel_id"] = b.get("kernel_id")   # the library the passes ran on (bench.py prints it; mrgingham_amd_kernel_id)
 j.update(read_bytes=int(rdb), write_bytes=int(wrb), fetch_size_kib_raw=grab("pmc_fetch", kg, "FETCH_SIZE"),
          write_size_kib_raw=grab("pmc_write", kg, "WRITE_SIZE"), bytes_per_pixel=round((rdb + wrb) / px, 4))
 json.dump(j, open(os.path.join(P, "chess_l0_traffic.json"), "w"), indent=1)
@@ -85,7 +86,7 @@ if os.path.exists(os.path.join(R, "pmc_sqp1.txt")):
                     f"passes of the bench command (profiles/{RND}_bench_sq_counters.txt).  A SIMD issues at most one VALU instruction per quad-cycle "
                     "from one wave; with 4 waves resident per SIMD the wall quad-cycles per wave-iteration are SQ_WAVE_CYCLES / 4 / wave-iterations, "
                     "and valu_issue_frac = SQ_INSTS_VALU / (SQ_WAVE_CYCLES / 4): the fraction of the SIMDs' quad-cycle issue slots that carry a VALU instruction.",
-        "kernel": "mrg::chess_v1_pyr_kernel", "frames": 64, "width": 4096, "height": 3072,
+        "kernel": "mrg::chess_v1_pyr_kernel", "kernel_id": b.get("kernel_id"), "frames": 64, "width": 4096, "height": 3072,
         "valu_insts_per_wave_iteration": insts / wi, "wave_quad_cycles_per_wave_iteration": wavecyc / wi,
         "waves_per_simd": 4, "valu_issue_frac": insts / (wavecyc / 4.0),
         "wait_any_frac": grab("pmc_sqp1", kgq, "SQ_WAIT_ANY") / wavecyc, "wait_inst_any_frac": grab("pmc_sqp1", kgq, "SQ_WAIT_INST_ANY") / wavecyc,
