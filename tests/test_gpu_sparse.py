@@ -131,7 +131,7 @@ def test_more_points_than_the_sparse_kernels_take():
         want = dense.chain(frames, 1, 2048)
         assert int(want[2].min()) >= 576
         _same(want, sparse.chain(frames, 1, 2048))
-        assert sparse.sparse_fallbacks() == 2
+        assert sparse.sparse_fallbacks() >= 2                  # (more when a table had to grow and the call was repeated)
         ok = synth.board_batch(2, 2048, 1536, 22, 3, device="cuda")    # 484: taken
         _same(dense.chain(ok, 1, 2048), sparse.chain(ok, 1, 2048))
         assert sparse.sparse_fallbacks() == 0
