@@ -947,7 +947,7 @@ static int pick_segment(int w, int h, int nframes, int min_blocks = 0) {
 void launch_chess(const LevelBatch& lb, const CompTables& t, int frame0, int nframes, bool clamp, bool hot,
                   hipStream_t s) {
     if (hot && t.only) nframes = kOnlySlots;  // a frame list: the grid is laid out for that many frames (chess_v1_body)
-    const int seg = pick_segment(lb.w, lb.h, nframes);
+    const int seg = (hot && t.only) ? 256 : pick_segment(lb.w, lb.h, nframes);
     dim3 grid(((lb.w + V1_SW - 1) / V1_SW) * ((lb.h + seg - 1) / seg) * nframes);
     const size_t lds = 2 * V1_PLANE + (hot ? (V1_HOTBUF + 12) * sizeof(int) : 0);
     const bool w16 = lb.w >= 16 && lb.w % 16 == 0 && (long long)(lb.h + V1_RB) * lb.img_stride < 0x7fffffffLL;
@@ -1035,7 +1035,8 @@ bool launch_chess_multi(const LevelBatch* lbs, const CompTables* ts, int n, int 
         a.t[k] = ts[j];
         // inside a merged launch the largest level fills the chip; the smaller ones only need enough
         // workgroups to pack its tail, so they can afford taller segments than on their own
-        a.seg[k] = pick_segment(lbs[j].w, lbs[j].h, nframes, k == 0 ? 2048 : chess_multi_min_blocks);
+        // (a frame list: tall segments, i.e. as few workgroups as possible -- nearly always all of them leave at once)
+        a.seg[k] = ts[0].only ? 256 : pick_segment(lbs[j].w, lbs[j].h, nframes, k == 0 ? 2048 : chess_multi_min_blocks);
         a.first_wg[k] = total;
         a.nwg[k] = k < n ? ((lbs[j].w + V1_SW - 1) / V1_SW) * ((lbs[j].h + a.seg[k] - 1) / a.seg[k]) * nframes : 0;
         total += (a.nwg[k] + 7) / 8 * 8;
