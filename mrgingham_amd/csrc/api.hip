@@ -2676,23 +2676,14 @@ int mrgingham_amd_find_boards_submit(mrgingham_amd_ctx* ctx, const mrgingham_amd
         auto& occupant = ctx->jobs[(ctx->cur + 1) % ctx->nsets];
         if (occupant.state != 0) ctx->done_tickets.emplace_back(occupant.ticket, fb_complete(ctx, occupant));
     }
-    // (growing a buffer synchronises the device and frees the old one: only with nothing in flight)
-    bool fits = true;
-    for (int L = 0; L <= top && fits; ++L) {
-        int w, h;
-        level_dims(fr->width, fr->height, L, &w, &h);
-        for (int set = 0; set < ctx->nsets; ++set) {
-            const LevelScratch& S = ctx->lvs[set][L];
-            const int shift = ctx->cap_shift < ctx->grown_shift[L] ? ctx->cap_shift : ctx->grown_shift[L];
-            fits = fits && B <= S.nframes && w == S.w && h == S.h && N <= S.pitch && S.shift == shift;
-        }
+    // Level scratch of THAT set alone (the other sets belong to jobs in flight, possibly of another frame size: a stream
+    // of mixed resolutions keeps every job's level sizes with its own set).  Buffers only ever grow; a buffer that has
+    // to grow synchronises the device first, which the jobs in flight survive.
+    {
+        const int target = (ctx->cur + 1) % ctx->nsets;
+        for (int L = 0; L <= top; ++L)
+            if ((rc = ensure_level_set(ctx, target, L, B, fr->width, fr->height, N))) return rc;
     }
-    fits = fits && B <= ctx->pts_nframes && N <= ctx->pts_pitch;
-    if (!fits)
-        for (auto& j : ctx->jobs)
-            if (j.state != 0) ctx->done_tickets.emplace_back(j.ticket, fb_complete(ctx, j));
-    for (int L = 0; L <= top; ++L)
-        if ((rc = ensure_level(ctx, L, B, fr->width, fr->height, N))) return rc;
     if ((rc = ensure_points(ctx, B, N))) return rc;
     if (!ctx->sparse_stat.p) {
         if ((rc = ensure(ctx, ctx->sparse_stat, 256))) return rc;

