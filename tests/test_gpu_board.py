@@ -227,3 +227,15 @@ def test_find_boards_pipelined_with_mixed_resolutions_in_flight():
                 assert np.array_equal(wb, gb), (depth, i)
     finally:
         ref.close(); det.close()
+
+
+def test_find_boards_fuzz_never_differs_from_the_synchronous_dense_schedule():
+    """tools/find_boards_fuzz.py, short form: random sizes / boards / noise / textures / frames without a board /
+    requested levels / batch sizes / pipeline depths through submit / collect; boards and levels equal the synchronous
+    dense schedule's on every frame."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "find_boards_fuzz.py"), "40", "3"], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " 0 mismatching" in r.stdout
