@@ -349,8 +349,9 @@ int mrgingham_amd_find_boards_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_
  * "find_boards_pipeline" 0), double for double.
  * The frames, h_boards and h_found_level of a batch must stay valid and untouched until its _collect returns.  As many
  * batches as the context has scratch sets (2 or 3, option "scratch_sets") can be in flight; a further _submit completes
- * the oldest one first (its _collect then returns at once).  One thread per context, as for every other call; do not
- * mix other calls on the same context in between a _submit and its _collect. */
+ * the oldest one first (its _collect then returns at once).  One thread per context, as for every other call.  Any
+ * other batch call or mrgingham_amd_set_option on the same context completes the batches in flight first (they stay
+ * collectable), so mixing calls is safe but gives the overlap away; mrgingham_amd_destroy abandons what is in flight. */
 int mrgingham_amd_find_boards_submit(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* frames, int gridn,
                                      int image_pyramid_level, double* h_boards, signed char* h_found_level,
                                      int nthreads);

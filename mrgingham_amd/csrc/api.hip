@@ -686,6 +686,10 @@ static int queue_sparse_levels(mrgingham_amd_ctx* ctx, const mrgingham_amd_frame
 
 using namespace mrg;
 
+// find_boards_submit / _collect jobs in flight hold scratch sets between their device passes: every other call that
+// rotates through the sets or resizes them completes those jobs first (their results stay collectable)
+static void fb_drain(mrgingham_amd_ctx* ctx);
+
 extern "C" {
 
 int mrgingham_amd_abi_version(void) { return MRGINGHAM_AMD_ABI_VERSION; }
@@ -776,6 +780,11 @@ void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx) {
         for (int i = 0; i < 7; ++i) fprintf(stderr, "  [fb] %-56s %8.3f ms per batch\n", names[i], ctx->fb_prof[i] / ctx->fb_prof_n);
     }
 #endif
+    for (auto& j : ctx->jobs)  // batches still in flight are abandoned: only their host threads have to be out
+        if (j.grid_running) {
+            ctx->pool.wait();
+            j.grid_running = false;
+        }
     if (ctx->one) mrgingham_amd_destroy(ctx->one);
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
@@ -855,6 +864,7 @@ void mrgingham_amd_set_kernel_timing(mrgingham_amd_ctx* ctx, int enable) {
 /* tunables (not part of the reference surface) */
 int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value) {
     if (!ctx || !name) return MRGINGHAM_AMD_ERR_ARG;
+    fb_drain(ctx);
     if (!strcmp(name, "hot_capacity_shift")) {
         if (value < 0 || value > 10) return MRGINGHAM_AMD_ERR_ARG;
         ctx->cap_shift = value;
@@ -1108,6 +1118,7 @@ int mrgingham_amd_detect_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frame
                                int capacity_per_frame, int32_t* d_counts) {
     int rc = validate_frames(ctx, fr);
     if (rc) return rc;
+    fb_drain(ctx);
     int w, h;
     if (level_dims(fr->width, fr->height, level, &w, &h))
         return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "Got an unreasonable image_pyramid_level = %d", level);
@@ -1136,6 +1147,7 @@ int mrgingham_amd_refine_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frame
                                int32_t* d_nrefined) {
     int rc = validate_frames(ctx, fr);
     if (rc) return rc;
+    fb_drain(ctx);
     int w, h;
     if (level_dims(fr->width, fr->height, level, &w, &h))
         return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "Got an unreasonable image_pyramid_level = %d", level);
@@ -1169,6 +1181,7 @@ int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames
                               double* d_points, signed char* d_levels, int32_t* d_npoints, int points_pitch) {
     int rc = validate_frames(ctx, fr);
     if (rc) return rc;
+    fb_drain(ctx);
     int w, h;
     if (level_dims(fr->width, fr->height, start_level, &w, &h))
         return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "Got an unreasonable image_pyramid_level = %d", start_level);
@@ -1364,6 +1377,7 @@ int mrgingham_amd_cc_on_response_batch(mrgingham_amd_ctx* ctx, const int16_t* d_
                                        double* d_points, signed char* d_levels, const int32_t* d_npoints,
                                        int points_pitch, int32_t* d_nrefined) {
     if (!ctx) return MRGINGHAM_AMD_ERR_ARG;
+    fb_drain(ctx);
     const bool detect = d_xy != nullptr, refine = d_points != nullptr;
     if (detect == refine) return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "exactly one of d_xy (detect) and d_points (refine)");
     if (nframes < 0 || w < 0 || h < 0 || w > 32767 || h > 32767 || level < 0 || level > kMaxLevel ||
@@ -2628,6 +2642,16 @@ static int fb_complete(mrgingham_amd_ctx* ctx, mrgingham_amd_ctx::BoardsJob& job
     if (rc) return fb_abandon(ctx, job, rc);
     return fb_finish(ctx, job);
 }
+
+}  // extern "C"
+static void fb_drain(mrgingham_amd_ctx* ctx) {
+    for (auto& j : ctx->jobs)
+        if (j.state != 0) {
+            const int ticket = j.ticket;
+            ctx->done_tickets.emplace_back(ticket, fb_complete(ctx, j));
+        }
+}
+extern "C" {
 
 int mrgingham_amd_find_boards_submit(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int gridn,
                                      int image_pyramid_level, double* h_boards, signed char* h_found_level, int nthreads) {

@@ -239,3 +239,32 @@ def test_find_boards_fuzz_never_differs_from_the_synchronous_dense_schedule():
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " 0 mismatching" in r.stdout
+
+
+def test_other_calls_between_submit_and_collect_complete_the_batches_in_flight():
+    """A chain / detect / set_option on the same context while find_boards batches are in flight: the library completes
+    those batches first (they stay collectable, with the right boards), and a context destroyed with batches in flight
+    goes down cleanly."""
+    det, ref = mrgingham_amd.Detector(0), mrgingham_amd.Detector(0)
+    try:
+        ref.set_option("find_boards_pipeline", 0)
+        a, b = _mixed_batch(50), _mixed_batch(60, 1920, 1080)
+        wa, wb = ref.find_boards(a, gridn=10), ref.find_boards(b, gridn=10)
+        ja = det.find_boards_submit(a, gridn=10)
+        jb = det.find_boards_submit(b, gridn=10)
+        pts, lv, npts = det.chain(b, 3, 512)                    # rotates through the scratch sets: ja and jb are completed first
+        xy, cnt = det.detect(a, 2, capacity=1024)
+        det.set_option("scratch_sets", 2)
+        for job, (wbd, wf) in ((jb, wb), (ja, wa)):
+            gb, gf = det.find_boards_collect(job)
+            assert np.array_equal(gf, wf)
+            for f in range(len(wf)):
+                if wf[f] >= 0:
+                    assert np.array_equal(gb[f], wbd[f])
+        assert int(npts[0]) >= 100 and int(cnt[0]) >= 100
+        with pytest.raises(RuntimeError):
+            det.find_boards_collect(ja)                         # a ticket is collected once
+        det.find_boards_submit(a, gridn=10)                     # ... and left in flight
+        det.find_boards_submit(b, gridn=10)
+    finally:
+        det.close(); ref.close()
