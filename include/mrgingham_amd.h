@@ -326,7 +326,7 @@ int mrgingham_amd_process_image_ex(const void* image, int bits, int width, int h
 
 /* Batch form of the full detector (what find_chessboard_from_image_array_C does per frame, for
  * image_pyramid_level < 0 the reference's default "first level of 3,2,1,0 at which the grid finder
- * succeeds", mrgingham.cc:116-139): the GPU detects candidates for the whole batch (levels 3 and 2 in one pass; what
+ * succeeds", mrgingham.cc:116-139): the GPU detects candidates for the whole batch (levels 3, 2 and 1 in one pass; what
  * is still open after them level by level), up to `nthreads` host threads (<= 0: all cores, at most 32) run the grid
  * finder on the frames that have no board yet, and the boards found are refined to level 0 on the GPU.  Synchronous.
  * h_boards (HOST): nframes x gridn*gridn x 2 doubles, board order; h_found_level[f] (HOST): the
@@ -336,15 +336,15 @@ int mrgingham_amd_find_boards_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_
                                     int nthreads);
 
 /* The same in two halves, so that consecutive batches overlap: _submit queues the device passes of a batch (level
- * images, candidates of levels 3 and 2 -- or of the one level asked for) and returns a ticket (>= 0; < 0: an error code)
+ * images, candidates of levels 3, 2 and 1 -- or of the one level asked for) and returns a ticket (>= 0; < 0: an error code)
  * without waiting for them; _collect(ticket) returns when h_boards / h_found_level of that batch are complete (status as
  * mrgingham_amd_find_boards_batch, which is _submit + _collect).  Between the two, the library runs the host part of
- * a batch -- the grid finder on the candidates, level 3 first, then level 2 (mrgingham.cc:127-138) -- inside the NEXT
+ * a batch -- the grid finder on the candidates, level 3 first, then 2, then 1 (mrgingham.cc:127-138) -- inside the NEXT
  * _submit, after that call has queued its own device passes, and queues the refinement of the boards it found
  * (mrgingham.cc:81-99; with option "sparse_refine": the response only around the corners) on a stream of its own.  So
  *     t0 = submit(batch 0); t1 = submit(batch 1); loop: t(n+2) = submit(batch n+2); collect(t(n)); ...
  * keeps the device, the host threads and the refinement busy at the same time (64 frames of 4096x3072 on one
- * MI355X: see DESIGN.md 4.5).  Frames that show no board at levels 3 and 2 are finished level by level inside
+ * MI355X: see DESIGN.md 4.5).  Frames that show no board at levels 3, 2 and 1 are finished at level 0 inside
  * _collect.  Results do not depend on how calls are interleaved: they are the synchronous dense schedule's (option
  * "find_boards_pipeline" 0), double for double.
  * The frames, h_boards and h_found_level of a batch must stay valid and untouched until its _collect returns.  As many

@@ -2398,19 +2398,21 @@ static int find_boards_sync_levels(mrgingham_amd_ctx* ctx, const mrgingham_amd_f
 // finder ...) -> refinement of the found board level by level.  One batch at a time that leaves the device idle
 // while the host threads run the grid finder and the host idle during the device passes (round 3: 3.8 ms per 64
 // frames of 4096x3072 against 0.98 ms for the chain).  Here a batch is a JOB in three parts:
-//   A  (device, queued by submit)  all level images in one pass over the frames, the response + candidates of
-//      levels 3 AND 2 (level 2 speculatively: it is a quarter of level 3's neighbour in cost and where 12 MP boards
-//      are found), candidates to pinned host memory;
-//   H  (host, run by the NEXT submit or by collect)  grid finder per frame, level 3 first, then level 2
-//      (mrgingham.cc:127-138) on the context's host threads; the boards that were found go back to the device;
+//   A  (device, queued by submit)  all level images in one pass over the frames, the responses + candidates of
+//      levels 3, 2 AND 1 in one grid (levels 2 and 1 speculatively: together a third of a level-0 pass; 12 MP boards
+//      are found at level 2, and the one frame in fifty that needs level 1 would otherwise hold up its whole batch),
+//      candidates to pinned host memory;
+//   H  (host, run inside the NEXT submit or by collect)  grid finder per frame, level 3 first, then 2, then 1
+//      (mrgingham.cc:127-138) on the context's host threads -- started before that submit queues its own part A,
+//      joined after it; the boards that were found go back to the device;
 //   B  (device, queued by H on the job's component stream)  refinement of the found boards down to level 0
 //      (mrgingham.cc:81-99) with the sparse schedule -- response only in the cells around the corners, frames it
 //      cannot take repeated densely on the device (queue_sparse_levels) --, boards to pinned host memory.
-// A job owns one scratch set from A to the end of B (B reads A's level images), so up to `scratch sets` jobs are in
-// flight; submit(N+1) queues A(N+1) and THEN runs H(N), so the grid finder of batch N works while the device runs
-// the first pass of batch N+1, and B(N) runs on its own stream underneath that.  Frames without a board at levels 3
-// and 2 (no board in view, or one that needs level 1 / 0) finish through the synchronous level search above, after
-// the other jobs in flight have been completed.  Results are the synchronous dense schedule's, double for double.
+// A job owns one scratch set from A to the end of B (B reads A's level images; its level sizes stay with that set, so
+// jobs of different frame sizes can be in flight), so up to `scratch sets` jobs are in flight; submit completes the job
+// that still holds the set it is about to take.  Frames without a board at levels 3-1 (no board in view, or one that
+// only shows at full resolution) finish through the synchronous level search above on the single-frame context of the
+// same device, which leaves the jobs in flight alone.  Results are the synchronous dense schedule's, double for double.
 
 static int fb_complete(mrgingham_amd_ctx* ctx, mrgingham_amd_ctx::BoardsJob& job);
 #ifdef MRG_EXPERIMENT
