@@ -182,6 +182,8 @@ struct mrgingham_amd_ctx {
         int gridn = 0, level_arg = 0, nthreads = 0, nlev = 0, levs[3] = {0, 0, 0}, cap = 0;
         double* h_boards = nullptr;
         signed char* h_found = nullptr;
+        signed char* h_levels = nullptr;  // optional: the refinement level of every corner, [frame][gridn^2]
+        bool do_refine = true;
         hipEvent_t ev_a = nullptr, ev_b = nullptr;
         bool refine_queued = false;
         int top = 0;  // the highest level a board of the job was found at (levels below it are refined)
@@ -689,6 +691,8 @@ using namespace mrg;
 // find_boards_submit / _collect jobs in flight hold scratch sets between their device passes: every other call that
 // rotates through the sets or resizes them completes those jobs first (their results stay collectable)
 static void fb_drain(mrgingham_amd_ctx* ctx);
+static int fb_submit(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int gridn, int image_pyramid_level,
+                     double* h_boards, signed char* h_found_level, int nthreads, bool do_refine, signed char* h_levels);
 
 extern "C" {
 
@@ -1916,6 +1920,17 @@ static int find_board_on_device(mrgingham_amd_ctx* ctx, const char* who, const m
                                 const char* debug_image_filename = nullptr) {
     const int Nrows = fr->height, Ncols = fr->width;
     const int N = gridn * gridn;
+    if (!debug && ctx->fb_pipeline && image_pyramid_level <= kMaxLevel) {
+        // one frame through the pipelined batch detector (find_boards_submit / _collect below): the candidates of levels
+        // 3, 2 and 1 in ONE device pass instead of a round trip per level, the refinement of every level in one more --
+        // same boards (the pipelined detector equals the level-by-level schedule frame for frame, tests/test_gpu_board.py)
+        board.assign((size_t)N, PointD{0., 0.});
+        lv.assign((size_t)N, 0);
+        signed char found_level = -1;
+        const int ticket = fb_submit(ctx, fr, gridn, image_pyramid_level, &board[0].x, &found_level, 1, do_refine, lv.data());
+        if (ticket < 0 || mrgingham_amd_find_boards_collect(ctx, ticket) != 0) return -1;
+        return found_level;
+    }
     std::vector<int32_t> xy;
     bool found = false;
     // image_pyramid_level >= 0: that level only; < 0: 3, 2, 1, 0 until a grid is found (mrgingham.cc:116-139)
@@ -2217,8 +2232,11 @@ static int fb_threads(int nthreads) {
 // already), the grid finder on host threads, the boards found at the level refined densely level by level.  The
 // pipelined form (find_boards_submit / _collect below) uses it for what its first pass leaves open, and option
 // "find_boards_pipeline" 0 for everything.
+// `h_levels` (may be NULL): per frame the gridn^2 refinement levels of its corners (what the reference's
+// refinement_level array holds, mrgingham.cc:81-99); `do_refine` false: the boards stay as the grid finder made them.
 static int find_boards_sync_levels(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int gridn, int first, int last,
-                                   double* h_boards, signed char* h_found_level, int nthreads, std::vector<int> open) {
+                                   double* h_boards, signed char* h_found_level, int nthreads, std::vector<int> open,
+                                   bool do_refine = true, signed char* h_levels = nullptr) {
     int rc = 0;
     const int B = fr->nframes, N = gridn * gridn;
     const int cap = 4 * N + 64;  // candidates kept per frame for the grid finder
@@ -2319,7 +2337,11 @@ static int find_boards_sync_levels(mrgingham_amd_ctx* ctx, const mrgingham_amd_f
         ctx->pool.run(nthreads < nb ? nthreads : nb, worker);
         std::vector<int> found_pos;  // positions within the current batch
         for (int k = 0; k < nb; ++k)
-            if (found_now[k]) { h_found_level[cur_idx[k]] = (signed char)L; found_pos.push_back(k); }
+            if (found_now[k]) {
+                h_found_level[cur_idx[k]] = (signed char)L;
+                found_pos.push_back(k);
+                if (h_levels) memset(h_levels + (size_t)cur_idx[k] * N, L, (size_t)N);
+            }
         lap("grid finder", L, (int)found_pos.size());
         if (found_pos.empty()) continue;
         {
@@ -2328,7 +2350,7 @@ static int find_boards_sync_levels(mrgingham_amd_ctx* ctx, const mrgingham_amd_f
                 if (h_found_level[f] < 0) still.push_back(f);
             open.swap(still);
         }
-        if (L == 0) continue;
+        if (L == 0 || !do_refine) continue;
         // (c) refine the boards found at this level down to level 0 (mrgingham.cc:81-99): on the current
         // batch with zero points for the other frames, or on a dense copy of just those frames
         const mrgingham_amd_frames* rb = &cur;
@@ -2374,17 +2396,22 @@ static int find_boards_sync_levels(mrgingham_amd_ctx* ctx, const mrgingham_amd_f
                 std::vector<signed char> lv1((size_t)N, (signed char)L);
                 for (int l = L - 1; l >= 0; --l)
                     if (refine_on_device(one, &f1, bp, lv1.data(), N, l) <= 0) break;
+                if (h_levels) memcpy(h_levels + (size_t)ridx[k] * N, lv1.data(), (size_t)N);
             }
             lap("refine 1-by-1", L, nr);
             continue;
         }
         if (rc) break;
-        if (hipMemcpy(h_pts.data(), d_pts.p, (size_t)nr * N * 16, hipMemcpyDeviceToHost) != hipSuccess) {
+        if (hipMemcpy(h_pts.data(), d_pts.p, (size_t)nr * N * 16, hipMemcpyDeviceToHost) != hipSuccess ||
+            (h_levels && hipMemcpy(h_lv.data(), d_lv.p, (size_t)nr * N, hipMemcpyDeviceToHost) != hipSuccess)) {
             rc = fail(ctx, MRGINGHAM_AMD_ERR_DEVICE, "board download failed");
             break;
         }
         for (int k = 0; k < nr; ++k)
-            if (h_np[k]) memcpy(h_boards + (size_t)ridx[k] * N * 2, h_pts.data() + (size_t)k * N * 2, sizeof(double) * 2 * N);
+            if (h_np[k]) {
+                memcpy(h_boards + (size_t)ridx[k] * N * 2, h_pts.data() + (size_t)k * N * 2, sizeof(double) * 2 * N);
+                if (h_levels) memcpy(h_levels + (size_t)ridx[k] * N, h_lv.data() + (size_t)k * N, (size_t)N);
+            }
         lap("refine+D2H", L, nr);
     }
     return rc;
@@ -2460,6 +2487,7 @@ static void fb_grid_worker(mrgingham_amd_ctx::BoardsJob* job) {
             if (find_grid_from_points(board, cand, job->gridn) && (int)board.size() == N) {
                 memcpy(job->h_boards + (size_t)k * N * 2, board.data(), sizeof(double) * 2 * N);
                 job->h_found[k] = (signed char)job->levs[li];
+                if (job->h_levels) memset(job->h_levels + (size_t)k * N, job->levs[li], (size_t)N);
                 break;
             }
         }
@@ -2526,7 +2554,7 @@ static int fb_host_end(mrgingham_amd_ctx* ctx, mrgingham_amd_ctx::BoardsJob& job
     const FbPinned pin = fb_layout(job.pin, nlev, B, cap, N);
     int rc = 0;
     int top = 0, nref = 0;
-    for (int k = 0; k < B; ++k) {
+    for (int k = 0; k < B && job.do_refine; ++k) {
         const int L = job.h_found[k];
         pin.np[k] = L >= 1 ? N : 0;
         if (L < 1) continue;
@@ -2557,6 +2585,7 @@ static int fb_host_end(mrgingham_amd_ctx* ctx, mrgingham_amd_ctx::BoardsJob& job
             rc = queue_sparse_levels(ctx, fr, top, io, src, !sparse);
             job.top = top;
             e = hipMemcpyAsync(pin.pts, job.d_pts.p, pb, hipMemcpyDeviceToHost, cc);
+            if (e == hipSuccess && job.h_levels) e = hipMemcpyAsync(pin.lv, job.d_lv.p, lb, hipMemcpyDeviceToHost, cc);
             for (int L = 0; L < top && e == hipSuccess; ++L)  // (a frame whose tables overflowed at a level was not refined there)
                 e = hipMemcpyAsync(pin.st + (size_t)L * B, status_of(ctx, L), (size_t)B * 4, hipMemcpyDeviceToHost, cc);
             if (e == hipSuccess) e = hipEventRecord(job.ev_b, cc);
@@ -2588,6 +2617,7 @@ static int fb_finish(mrgingham_amd_ctx* ctx, mrgingham_amd_ctx::BoardsJob& job) 
             for (int L = 0; L < Lf; ++L) bad |= pin.st[(size_t)L * B + k] & (kStatusHotOverflow | kStatusCandOverflow);
             if (!bad) {
                 memcpy(job.h_boards + (size_t)k * N * 2, pin.pts + (size_t)k * N * 2, sizeof(double) * 2 * N);
+                if (job.h_levels) memcpy(job.h_levels + (size_t)k * N, pin.lv + (size_t)k * N, (size_t)N);
                 continue;
             }
             // The component tables of a level overflowed for this frame (dense texture): it was not refined there.  Its
@@ -2601,6 +2631,7 @@ static int fb_finish(mrgingham_amd_ctx* ctx, mrgingham_amd_ctx::BoardsJob& job) 
             std::vector<signed char> lv1((size_t)N, (signed char)Lf);
             for (int l = Lf - 1; l >= 0; --l)
                 if (refine_on_device(one, &f1, job.h_boards + (size_t)k * N * 2, lv1.data(), N, l) <= 0) break;
+            if (job.h_levels) memcpy(job.h_levels + (size_t)k * N, lv1.data(), (size_t)N);
         }
         if (overflowed)
             for (int L = 0; L < job.top; ++L) {
@@ -2621,7 +2652,8 @@ static int fb_finish(mrgingham_amd_ctx* ctx, mrgingham_amd_ctx::BoardsJob& job) 
         // the single-frame context of this device -- its own streams and scratch, so the jobs in flight here stay so
         mrgingham_amd_ctx* one = same_device_ctx(ctx);
         if (!one) return fail(ctx, MRGINGHAM_AMD_ERR_DEVICE, "no single-frame context");
-        rc = find_boards_sync_levels(one, &job.fr, job.gridn, lowest - 1, 0, job.h_boards, job.h_found, job.nthreads, open);
+        rc = find_boards_sync_levels(one, &job.fr, job.gridn, lowest - 1, 0, job.h_boards, job.h_found, job.nthreads, open,
+                                     job.do_refine, job.h_levels);
         if (rc) ctx->err = one->err;
     }
     return rc;
@@ -2655,8 +2687,10 @@ static void fb_drain(mrgingham_amd_ctx* ctx) {
 }
 extern "C" {
 
-int mrgingham_amd_find_boards_submit(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int gridn,
-                                     int image_pyramid_level, double* h_boards, signed char* h_found_level, int nthreads) {
+}  // extern "C"
+// (the public entry + what the single-image wrappers need on top of it: no refinement, the corners' refinement levels)
+static int fb_submit(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int gridn, int image_pyramid_level,
+                     double* h_boards, signed char* h_found_level, int nthreads, bool do_refine, signed char* h_levels) {
     int rc = validate_frames(ctx, fr);
     if (rc) return rc;
     if (gridn < 2 || image_pyramid_level > kMaxLevel || !h_boards || !h_found_level)
@@ -2677,7 +2711,8 @@ int mrgingham_amd_find_boards_submit(mrgingham_amd_ctx* ctx, const mrgingham_amd
         const int last = image_pyramid_level >= 0 ? image_pyramid_level : 0;
         std::vector<int> open(B);
         for (int f = 0; f < B; ++f) open[f] = f;
-        ctx->done_tickets.emplace_back(ticket, find_boards_sync_levels(ctx, fr, gridn, first, last, h_boards, h_found_level, nthreads, open));
+        ctx->done_tickets.emplace_back(ticket, find_boards_sync_levels(ctx, fr, gridn, first, last, h_boards, h_found_level, nthreads, open,
+                                                               do_refine, h_levels));
         return ticket;
     }
     // levels searched in the first pass: the one asked for, or 3, 2 and 1 (levels 2 and 1 speculatively: together they
@@ -2728,6 +2763,8 @@ int mrgingham_amd_find_boards_submit(mrgingham_amd_ctx* ctx, const mrgingham_amd
     job.cap = cap;
     job.h_boards = h_boards;
     job.h_found = h_found_level;
+    job.h_levels = h_levels;
+    job.do_refine = do_refine;
     job.refine_queued = false;
     if ((rc = ensure(ctx, job.d_xy, (size_t)nlev * B * cap * 8)) || (rc = ensure(ctx, job.d_cnt, (size_t)nlev * B * 4)) ||
         (rc = ensure(ctx, job.d_pts, (size_t)B * N * 16)) || (rc = ensure(ctx, job.d_lv, (size_t)B * N)) ||
@@ -2809,6 +2846,13 @@ int mrgingham_amd_find_boards_submit(mrgingham_amd_ctx* ctx, const mrgingham_amd
     }
     if (e != hipSuccess) return fail_hip(ctx, e, "find_boards first pass", __FILE__, __LINE__);
     return ticket;
+}
+
+extern "C" {
+
+int mrgingham_amd_find_boards_submit(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int gridn,
+                                     int image_pyramid_level, double* h_boards, signed char* h_found_level, int nthreads) {
+    return fb_submit(ctx, fr, gridn, image_pyramid_level, h_boards, h_found_level, nthreads, true, nullptr);
 }
 
 int mrgingham_amd_find_boards_collect(mrgingham_amd_ctx* ctx, int ticket) {
