@@ -63,6 +63,23 @@ __device__ __forceinline__ int hot_overflow_status(int hot_cnt) {
     const uint32_t units = ((uint32_t)hot_cnt + 63u) >> 6;
     return (int)((uint32_t)kStatusHotOverflow | ((units > 0x7fffffu ? 0x7fffffu : units) << 8));
 }
+// Reports it in the frame's status word: the flag bits are OR-ed, the demand field keeps the MAXIMUM -- status words
+// accumulate until the host looks at them, and pipelined calls that reuse a scratch set must not OR two demands into a
+// number neither frame asked for (the tables would over-grow by up to 2x).  One thread per frame calls this.
+__device__ __forceinline__ void report_hot_overflow(int32_t* word, int hot_cnt) {
+    const uint32_t want = (uint32_t)hot_overflow_status(hot_cnt);
+    uint32_t old = (uint32_t)aload(word);
+    while (true) {
+        const uint32_t demand = (old >> 8) > (want >> 8) ? (old >> 8) : (want >> 8);
+        const uint32_t merged = ((old | want) & 0xffu) | (demand << 8);
+        if (merged == old) return;
+        int32_t expected = (int32_t)old;
+        if (__hip_atomic_compare_exchange_strong(word, &expected, (int32_t)merged, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_WORKGROUP))
+            return;
+        old = (uint32_t)expected;  // somebody else's flag arrived in between: merge again
+    }
+}
 
 __device__ __forceinline__ int uf_root(const int32_t* parent, int i) {
     int p = aload(parent + i);
@@ -385,7 +402,7 @@ __global__ __launch_bounds__(CCG_THREADS, 4) void cc_detect_kernel(LevelBatch lb
     if (t.lds_path && t.path[frame] == 1) return;  // done out of LDS
     if (t.hot_cnt[frame] > t.cap) {  // table overflow: report (with what the frame asked for), produce nothing
         if (threadIdx.x == 0) {
-            wg_or(t.status + frame, hot_overflow_status(t.hot_cnt[frame]));
+            report_hot_overflow(t.status + frame, t.hot_cnt[frame]);
             out.counts[frame] = -1;
         }
         return;
@@ -481,7 +498,7 @@ __device__ __forceinline__ void cc_refine_frame(const LevelBatch& lb, const Comp
     if (t.lds_path && t.path[frame] == 1) return;  // done out of LDS
     if (t.hot_cnt[frame] > t.cap) {
         if (threadIdx.x == 0) {
-            wg_or(t.status + frame, hot_overflow_status(t.hot_cnt[frame]));
+            report_hot_overflow(t.status + frame, t.hot_cnt[frame]);
             if (io.nrefined) io.nrefined[frame] = -1;
         }
         return;
