@@ -527,7 +527,7 @@ class Detector:
             issue()
         return xy, counts
 
-    def cc_refine_on_response(self, resp, level_images, level, points, levels, npoints, sync=True):
+    def cc_refine_on_response(self, resp, level_images, level, points, levels, npoints, sync=True, retry=True):
         """In-place refinement of points f64 [B,P,2] / levels int8 [B,P] / npoints int32 [B] against
         caller-built responses; -> nrefined int32 [B]."""
         t = self.torch
@@ -536,7 +536,7 @@ class Detector:
         assert points.dtype == t.float64 and points.is_contiguous() and levels.dtype == t.int8
         B, h, w = resp.shape
         nref = t.empty((B,), dtype=t.int32, device=resp.device)
-        keep = (points.clone(), levels.clone()) if sync else None
+        keep = (points.clone(), levels.clone()) if (sync and retry) else None   # (what a capacity retry restores)
         t.cuda.current_stream(resp.device).synchronize()
 
         def issue():
@@ -549,7 +549,7 @@ class Detector:
             points.copy_(keep[0]); levels.copy_(keep[1])
             t.cuda.current_stream(resp.device).synchronize()
         if sync:
-            self._sync_retrying(issue, True, restore)
+            self._sync_retrying(issue, retry, restore if retry else None)
         else:
             issue()
         return nref
