@@ -10,8 +10,8 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py"                              # defaults: 200 steps, 20 warmup
-TRACEB="python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline"   # short run under the tracer
-PMCB="python $R/bench.py --distinct 4 --steps 3 --warmup 1 --no-cpu-baseline"
+TRACEB="python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-find-boards"   # short run under the tracer (the find_boards leg has its own tool)
+PMCB="python $R/bench.py --distinct 4 --steps 3 --warmup 1 --no-cpu-baseline --no-find-boards"
 # 1. the bench line itself
 timeout 600 $BENCH > $OUT/bench.json 2> $OUT/bench.err
 # 2. kernel trace of the same command (no CPU baseline: it only adds host time)
@@ -26,7 +26,7 @@ timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_IN
 timeout 600 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2 -o p -- python $R/tools/chess_l0_alone.py > /dev/null 2> $OUT/pmc_sq2.err
 # 4b. the same counters on the kernels exactly as bench.py launches them (chess_v1_pyr_kernel: 64 frames, hot list +
 #     level images; chess_v1_multi_kernel), separate passes of the bench command
-PMCQ="python $R/bench.py --distinct 4 --steps 3 --warmup 1 --prime 2 --no-cpu-baseline --no-end-to-end"
+PMCQ="python $R/bench.py --distinct 4 --steps 3 --warmup 1 --prime 2 --no-cpu-baseline --no-end-to-end --no-find-boards"
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_sqp1 -o p -- $PMCQ > /dev/null 2> $OUT/pmc_sqp1.err
 timeout 600 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $OUT/pmc_sqp2 -o p -- $PMCQ > /dev/null 2> $OUT/pmc_sqp2.err
 # 4c. kernel trace of the textured-background workload

@@ -16,7 +16,7 @@ strip = lambda t: re.sub(r"/tmp/[^ ]*?/gpurun_out/", "gpurun_out/", t)
 
 # 1. kernel trace of the bench command
 tb, b = json.loads(rd("trace_bench.json")), json.loads(rd("bench.json"))
-hdr = (f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 40 --warmup 5 --no-cpu-baseline   (round {RND[1:]}, final kernels; tools/collect_profiles.sh {tag})\n"
+hdr = (f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-find-boards   (round {RND[1:]}, final kernels; tools/collect_profiles.sh {tag})\n"
        f"# bench.py under the tracer: {tb['value']:.0f} frames/s, {tb['ms_per_step']:.3f} ms/step, level-0 ChESS launch {tb['roofline']['avg_launch_ms']*1e3:.1f} us by hipEvents (trace below: every launch of the process incl. set-up passes and warm-up; the quartile line is closer to the steady state)\n"
        f"# bench.py with its defaults (200 steps) without the tracer, same box, same build: {b['value']:.0f} frames/s, {b['ms_per_step']:.3f} ms/step, level-0 ChESS launch {b['roofline']['avg_launch_ms']*1e3:.1f} us -> {b['roofline']['achieved']:.0f} GB/s = {b['roofline']['frac']*100:.1f} % of 8 TB/s\n")
 open(os.path.join(P, f"{RND}_bench_kernel_trace.txt"), "w").write(hdr + strip(rd("bench_kernel_trace.txt")))
