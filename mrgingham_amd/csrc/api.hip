@@ -166,6 +166,9 @@ struct mrgingham_amd_ctx {
     int counters_nf = 0;
     struct PointScratch { mrg::DevBuf leader, need, nseeds, seeds, sroot, cand_xy, cand_counts, cell_list, cell_cnt, flag_list; } pts[kMaxSets];  // per scratch set
     mrg::DevBuf aux_img, io_frame, io_out, io_counts;
+    void* io_pin = nullptr;  // page-locked staging of mrgingham_ChESS_response_5's way back
+    size_t io_pin_bytes = 0;
+    hipEvent_t io_ev[4] = {};
     mrg::DevBuf pre_scratch, pre_tmp, pre_out, pre16_scratch, io_frame16, dbg_img, dbg_resp, blob_scratch, blob_nodes, blob_out;
     mrg::DevBuf fb_xy, fb_cnt, fb_pts, fb_lv, fb_np, fb_frames, fb_frames2;  // find_boards_batch: candidates, counts, boards, levels, point counts
     // find_boards_batch's frame-by-frame retries (full-capacity detect, 1-by-1 refine) run on a single-frame
@@ -801,6 +804,9 @@ void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx) {
     for (hipEvent_t e : ctx->ev_cc_done)
         if (e) hipEventDestroy(e);
     if (ctx->ev_ext) hipEventDestroy(ctx->ev_ext);
+    if (ctx->io_pin) hipHostFree(ctx->io_pin);
+    for (hipEvent_t e : ctx->io_ev)
+        if (e) hipEventDestroy(e);
     if (ctx->mg_done) hipEventDestroy(ctx->mg_done);
     if (ctx->mg_stream) hipStreamDestroy(ctx->mg_stream);
     for (auto& j : ctx->jobs) {
@@ -1752,10 +1758,67 @@ void mrgingham_ChESS_response_5(int16_t* response, const uint8_t* image, int w, 
     if (mrgingham_amd_chess_response_batch(ctx, &fr, 0, 0, (int16_t*)ctx->io_out.p, ctx->pix)) return;
     // interior only, like the reference: the 7-pixel frame of `response` is not touched
     const size_t off = (size_t)kMargin * w + kMargin;
-    hipError_t e = hipMemcpy2DAsync(response + off, (size_t)w * 2, (const int16_t*)ctx->io_out.p + off,
-                                    (size_t)w * 2, (size_t)(w - 2 * kMargin) * 2, h - 2 * kMargin,
-                                    hipMemcpyDeviceToHost, ctx->pix);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->pix);
+    hipError_t e = hipSuccess;
+    const size_t bytes = (size_t)w * h * 2;
+    if (bytes < (4u << 20)) {  // small frames: one strided copy
+        e = hipMemcpy2DAsync(response + off, (size_t)w * 2, (const int16_t*)ctx->io_out.p + off, (size_t)w * 2,
+                             (size_t)(w - 2 * kMargin) * 2, h - 2 * kMargin, hipMemcpyDeviceToHost, ctx->pix);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->pix);
+    } else {
+        // Large frames (12 MP: 25 MB back): the strided copy into pageable memory goes through a slow path of the
+        // runtime (2.4 ms per 12 MP frame, all of it this copy).  Instead: whole rows in four plain copies into
+        // page-locked staging of the context, at the speed of the link, and a few host threads that move the interior
+        // of each row block into the caller's array as soon as the copy that carries it has landed.
+        constexpr int kChunks = 4;
+        if (bytes > ctx->io_pin_bytes) {
+            if (ctx->io_pin) hipHostFree(ctx->io_pin);
+            ctx->io_pin = nullptr;
+            ctx->io_pin_bytes = 0;
+            if (hipHostMalloc(&ctx->io_pin, bytes + bytes / 8, hipHostMallocDefault) != hipSuccess) ctx->io_pin = nullptr;
+            else ctx->io_pin_bytes = bytes + bytes / 8;
+        }
+        for (int c = 0; c < kChunks && !ctx->io_ev[c]; ++c) hipEventCreateWithFlags(&ctx->io_ev[c], hipEventDisableTiming);
+        if (!ctx->io_pin || !ctx->io_ev[kChunks - 1]) {
+            fprintf(stderr, "mrgingham_amd: ChESS response failed: no page-locked staging\n");
+            return;
+        }
+        const int rows_per = (h + kChunks - 1) / kChunks;
+        for (int c = 0; c < kChunks && e == hipSuccess; ++c) {
+            const int y0 = c * rows_per, y1 = y0 + rows_per < h ? y0 + rows_per : h;
+            if (y1 > y0)
+                e = hipMemcpyAsync((char*)ctx->io_pin + (size_t)y0 * w * 2, (const char*)ctx->io_out.p + (size_t)y0 * w * 2,
+                                   (size_t)(y1 - y0) * w * 2, hipMemcpyDeviceToHost, ctx->pix);
+            if (e == hipSuccess) e = hipEventRecord(ctx->io_ev[c], ctx->pix);
+        }
+        if (e == hipSuccess) {
+            std::atomic<int> next{0};
+            std::atomic<int> failed{0};
+            const int16_t* pin = (const int16_t*)ctx->io_pin;
+            const int device = ctx->device;
+            hipEvent_t* evs = ctx->io_ev;
+            constexpr int kBlock = 32;  // rows per work item
+            const int nblocks = (h - 2 * kMargin + kBlock - 1) / kBlock;
+            auto mover = [&]() {
+                hipSetDevice(device);
+                int waited = -1;  // chunks known to have landed
+                for (int b; (b = next.fetch_add(1)) < nblocks;) {
+                    const int ya = kMargin + b * kBlock, yb = ya + kBlock < h - kMargin ? ya + kBlock : h - kMargin;
+                    const int need = (yb - 1) / rows_per;
+                    while (waited < need) {
+                        if (hipEventSynchronize(evs[waited + 1]) != hipSuccess) { failed.store(1); return; }
+                        ++waited;
+                    }
+                    for (int y = ya; y < yb; ++y)
+                        memcpy(response + (size_t)y * w + kMargin, pin + (size_t)y * w + kMargin, (size_t)(w - 2 * kMargin) * 2);
+                }
+            };
+            int nthreads = (int)std::thread::hardware_concurrency();
+            nthreads = nthreads > 8 ? 8 : (nthreads < 1 ? 1 : nthreads);
+            ctx->pool.run(nthreads, mover);
+            if (failed.load()) e = hipErrorUnknown;
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->pix);
+        }
+    }
     if (e != hipSuccess) fprintf(stderr, "mrgingham_amd: ChESS response failed: %s\n", hipGetErrorString(e));
 }
 
