@@ -566,10 +566,10 @@ static PyramidOut pyramid_out_of(mrgingham_amd_ctx* ctx, int max_level) {
 }
 // `levels_1_to_3` false: those come out of the level-0 response kernel (launch_chess_pyramid)
 static void queue_level_images(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int max_level,
-                               bool levels_1_to_3 = true) {
+                               bool levels_1_to_3 = true, bool gentle = false) {
     const FrameBatch fb{fr->frames, fr->frame_pitch, fr->width, fr->height, fr->stride};
     const int top = max_level < 3 ? max_level : 3;
-    if (top >= 1 && levels_1_to_3) launch_pyramid(fb, pyramid_out_of(ctx, max_level), top, fr->nframes, ctx->pix);
+    if (top >= 1 && levels_1_to_3) launch_pyramid(fb, pyramid_out_of(ctx, max_level), top, fr->nframes, ctx->pix, gentle);
     for (int L = 4; L <= max_level; ++L)
         launch_decimate(fb, L, (uint8_t*)cur_levels(ctx)[L].img.p, (long long)cur_levels(ctx)[L].w * cur_levels(ctx)[L].h,
                         cur_levels(ctx)[L].w, cur_levels(ctx)[L].h, 0, fr->nframes, ctx->pix);
@@ -891,6 +891,7 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
     if (!strcmp(name, "cc_schedule")) { ctx->cc_schedule = value; return 0; }
     if (!strcmp(name, "chess_multi_min_blocks")) { mrg::chess_multi_min_blocks = value; return 0; }
     if (!strcmp(name, "chess_stage")) { mrg::chess_stage_override = value; return 0; }
+    if (!strcmp(name, "pyramid_lds_pad")) { mrg::pyramid_lds_pad = value; return 0; }
 #endif
     if (!strcmp(name, "scratch_sets")) {
         if (value != 0 && (value < 2 || value > kMaxSets))
@@ -1246,7 +1247,7 @@ int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames
             e0 = timing_event(ctx);
             hipEventRecord(e0, ctx->pix);
         }
-        queue_level_images(ctx, fr, start_level, true);
+        queue_level_images(ctx, fr, start_level, true, true);
         if (e0) {
             hipEvent_t em = timing_event(ctx);
             hipEventRecord(em, ctx->pix);

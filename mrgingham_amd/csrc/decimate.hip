@@ -158,12 +158,20 @@ __global__ __launch_bounds__(256) void pyramid_fast_kernel(FrameBatch in, Pyrami
     }
 }
 
-void launch_pyramid(const FrameBatch& in, const PyramidOut& po, int top, int nframes, hipStream_t s) {
+int pyramid_lds_pad = -1;  // tuning hook "pyramid_lds_pad" (experiment builds): -1 = the rule below, else bytes
+
+// `gentle`: the pass runs beside latency-bound kernels (the component chains of sparse steps).  At full occupancy it
+// keeps ~6 TB/s of requests in flight and every global round trip of those kernels takes 2-3x as long (refinement 110 ->
+// 250 us per launch, cell responses 30 -> 125 us: rocprofv3 timeline of `bench.py --sparse-refine`); with two
+// workgroups per CU -- 80 KB of dynamic LDS nobody uses -- it is ~20 % slower itself and the step is 13 % shorter
+// (0.380 -> 0.330 ms per 64 x 4096x3072; 3 workgroups 0.350, 1 workgroup 0.383).
+void launch_pyramid(const FrameBatch& in, const PyramidOut& po, int top, int nframes, hipStream_t s, bool gentle) {
     if (nframes <= 0 || top < 1) return;
+    const int pad = pyramid_lds_pad >= 0 ? pyramid_lds_pad : (gentle ? 80000 : 0);
     const bool aligned16 = in.stride % 16 == 0 && in.frame_pitch % 16 == 0 && ((uintptr_t)in.frames & 15) == 0;
     if (in.width % 16 == 0 && in.height % 8 == 0 && in.width > 0 && in.height > 0 && aligned16) {
         dim3 grid((in.width / 16 + 63) / 64, (in.height / 8 + 3) / 4, nframes);
-        hipLaunchKernelGGL(pyramid_fast_kernel, grid, dim3(256), 0, s, in, po, top);
+        hipLaunchKernelGGL(pyramid_fast_kernel, grid, dim3(256), pad, s, in, po, top);
         return;
     }
     int gw = 0, gh = 0;  // thread grid in level-1 pixels, large enough for every requested level

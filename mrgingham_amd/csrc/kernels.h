@@ -34,6 +34,7 @@ bool launch_chess_multi(const LevelBatch* lbs, const CompTables* ts, int n, int 
 extern int chess_seg_override;
 extern int chess_stage_override;
 extern int chess_multi_min_blocks;
+extern int pyramid_lds_pad;
 
 // decimate.hip
 struct FrameBatch {
@@ -43,7 +44,7 @@ struct FrameBatch {
 };
 void launch_decimate(const FrameBatch& in, int level, uint8_t* out, long long out_pitch, int ow, int oh, int frame0,
                      int nframes, hipStream_t s);
-void launch_pyramid(const FrameBatch& in, const PyramidOut& po, int top, int nframes, hipStream_t s);
+void launch_pyramid(const FrameBatch& in, const PyramidOut& po, int top, int nframes, hipStream_t s, bool gentle = false);
 void launch_box_blur(const FrameBatch& in, int radius, uint8_t* out, int frame0, int nframes, hipStream_t s);
 
 // preprocess.hip: cv::normalize(0..255, NORM_MINMAX) + CLAHE (8x8 tiles), mrgingham-from-image.cc:71-79
