@@ -55,8 +55,7 @@ def main():
             for (w, h), (idx, frames) in batches.items():
                 for lo in range(0, len(idx), 64):                          # sub-batches of at most 64 frames
                     boards, found = det.find_boards(frames[lo:lo + 64], gridn=args.gridn)
-                    for k, f in enumerate(idx[lo:lo + 64]):
-                        recs.append((f, int(found[k]), boards[k]))
+                    recs.append((idx[lo:lo + 64], found, boards))
             return recs
     else:
         # Dynamic balance: every rank can reach every frame (here: has rendered it; in a deployment: reads it from
@@ -77,8 +76,7 @@ def main():
             def collect():
                 idx, job = jobs.pop(0)
                 boards, found = det.find_boards_collect(job)
-                for k, f in enumerate(idx):
-                    recs.append((f, int(found[k]), boards[k]))
+                recs.append((idx, found, boards))                          # (per unit: frame indices, found levels, boards)
             for u in q:
                 wh, idx = units[u]
                 jobs.append((idx, det.find_boards_submit(frames_of[idx[0]], gridn=args.gridn)))
@@ -97,10 +95,12 @@ def main():
     for _ in range(args.repeat):
         recs = run_once()
         # one gather of fixed-size records: [frame, level, 2N coordinates]
-        mine_n = len(recs)
+        mine_n = sum(len(idx) for idx, _, _ in recs)
         pack = torch.full((args.frames, 2 + 2 * N), -1.0, dtype=torch.float64, device=dev)
         if mine_n:
-            arr = np.array([[f, lv] + list(np.nan_to_num(b, nan=-1.0).ravel()) for f, lv, b in recs])
+            arr = np.concatenate([np.concatenate([np.asarray(idx, dtype=np.float64)[:, None], np.asarray(found, dtype=np.float64)[:, None],
+                                                  np.nan_to_num(np.asarray(boards, dtype=np.float64).reshape(len(idx), 2 * N), nan=-1.0)], axis=1)
+                                  for idx, found, boards in recs])
             pack[:mine_n] = torch.from_numpy(arr).to(dev)
         if world > 1:
             bufs = [torch.empty_like(pack) for _ in range(world)] if rank == 0 else None
