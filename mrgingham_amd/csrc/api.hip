@@ -2911,10 +2911,15 @@ static int fb_submit(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int
         for (int li = 0; li < job.nlev; ++li) lbs[li] = queue_level_chess(ctx, fr, job.levs[li]);
     hipStream_t cc = cur_cc(ctx);
     hipError_t e = hipStreamWaitEvent(cc, ctx->ev_pix[merged ? top : job.levs[job.nlev - 1]], 0);
-    for (int li = 0; li < job.nlev; ++li)
-        launch_cc_detect(lbs[li], tables_of(ctx, job.levs[li]), job.levs[li],
-                         DetectOut{(int32_t*)job.d_xy.p + (size_t)li * B * cap * 2, cap, (int32_t*)job.d_cnt.p + (size_t)li * B}, 0,
-                         B, cc);
+    {   // the candidates of every level searched in this pass: one grid per kernel, not one per level
+        CompTables dts[3];
+        DetectOut douts[3];
+        for (int li = 0; li < job.nlev; ++li) {
+            dts[li] = tables_of(ctx, job.levs[li]);
+            douts[li] = DetectOut{(int32_t*)job.d_xy.p + (size_t)li * B * cap * 2, cap, (int32_t*)job.d_cnt.p + (size_t)li * B};
+        }
+        launch_cc_detect_levels(lbs, dts, job.levs, douts, job.nlev, B, cc);
+    }
     const FbPinned pin = fb_layout(job.pin, job.nlev, B, cap, N);
     if (e == hipSuccess) e = hipMemcpyAsync(pin.cnt, job.d_cnt.p, (size_t)job.nlev * B * 4, hipMemcpyDeviceToHost, cc);
     if (e == hipSuccess) e = hipMemcpyAsync(pin.xy, job.d_xy.p, (size_t)job.nlev * B * cap * 8, hipMemcpyDeviceToHost, cc);

@@ -392,13 +392,13 @@ __device__ __forceinline__ void emit_detect_outputs(const FrameView& v, const un
 // ---------------------------------------------------------------------------
 // Detect: process_connected_components, points_scaled_out branch (:330-355)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(CCG_THREADS, 4) void cc_detect_kernel(LevelBatch lb, CompTables t, int level,
-                                                               DetectOut out, int frame0) {
+// (the body: cc_detect_kernel runs it for one level, cc_detect_levels_kernel for several levels in one grid)
+__device__ __forceinline__ void cc_detect_frame(const LevelBatch& lb, const CompTables& t, int level, const DetectOut& out,
+                                                int frame) {
     __shared__ int s_nroots, s_ncand, s_arena_full;
     __shared__ unsigned long long s_arena_top;
     // latency-bound and tiny next to the pixel kernels it shares CUs with: take issue priority
     __builtin_amdgcn_s_setprio(3);
-    const int frame = frame0 + blockIdx.x;
     if (t.lds_path && t.path[frame] == 1) return;  // done out of LDS
     if (t.hot_cnt[frame] > t.cap) {  // table overflow: report (with what the frame asked for), produce nothing
         if (threadIdx.x == 0) {
@@ -478,6 +478,17 @@ __global__ __launch_bounds__(CCG_THREADS, 4) void cc_detect_kernel(LevelBatch lb
     __syncthreads();
     bitonic_sort(v.sortkeys, n_pad);
     emit_detect_outputs(v, v.sortkeys, nvalid, level, out, frame);
+}
+__global__ __launch_bounds__(CCG_THREADS, 4) void cc_detect_kernel(LevelBatch lb, CompTables t, int level,
+                                                               DetectOut out, int frame0) {
+    cc_detect_frame(lb, t, level, out, frame0 + blockIdx.x);
+}
+// Several levels of the same frames in ONE grid (blockIdx.y = the level's slot): the first pass of the full detector
+// searches levels 3, 2 and 1 at once, and three launches of 64 workgroups one behind the other were three times the
+// latency of one of 192 (a single frame through find_chessboard: 165 -> 65 us).
+__global__ __launch_bounds__(CCG_THREADS, 4) void cc_detect_levels_kernel(DetectLevels a) {
+    const int k = blockIdx.y;
+    cc_detect_frame(a.lb[k], a.t[k], a.level[k], a.out[k], blockIdx.x);
 }
 
 void launch_cc_detect(const LevelBatch& lb, const CompTables& t, int level, const DetectOut& out, int frame0,
@@ -1557,15 +1568,15 @@ __device__ __forceinline__ void lds_decline_refine(const CompTables& t, int fram
 // (launch bounds: at most 128 VGPRs, so that a wave of these kernels fits into what ONE retiring wave of the pixel
 // kernels frees on a SIMD -- at 129 VGPRs the refine kernel waited for two, 80 -> 270 us per launch)
 template <int N>
-__global__ __launch_bounds__(CC_THREADS, 4) void cc_detect_lds_kernel(LevelBatch lb, CompTables t, int level,
-                                                                   DetectOut out, int frame0) {
+__device__ __forceinline__ void cc_detect_lds_frame(const LevelBatch& lb, const CompTables& t, int level, const DetectOut& out,
+                                                    int frame) {
     using LdsCC = LdsCCT<N>;
     constexpr int LROOTS = LdsCC::LROOTS, LEPT = LdsCC::LEPT;
     constexpr int LSTKD = LdsCC::LSTK - LdsCC::LN;  // LIFO words of the fills: the neighbour table takes the first LN
     extern __shared__ __attribute__((aligned(16))) char lds_cc_raw[];
     LdsCC& L = *reinterpret_cast<LdsCC*>(lds_cc_raw);
     if (!MRG_EXP(t.lds_path & 16)) __builtin_amdgcn_s_setprio(3);
-    const int frame = frame0 + blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int nraw = t.hot_cnt[frame];
     FrameView v = make_view(lb, t, frame);
     const int w = v.w, h = v.h;
@@ -1722,6 +1733,16 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_detect_lds_kernel(LevelBatch
     __syncthreads();
     bitonic_sort(keys, n_pad);
     emit_detect_outputs(v, keys, nvalid, level, out, frame);
+}
+template <int N>
+__global__ __launch_bounds__(CC_THREADS, 4) void cc_detect_lds_kernel(LevelBatch lb, CompTables t, int level,
+                                                                   DetectOut out, int frame0) {
+    cc_detect_lds_frame<N>(lb, t, level, out, frame0 + blockIdx.x);
+}
+template <int N>  // several levels in one grid: see cc_detect_levels_kernel
+__global__ __launch_bounds__(CC_THREADS, 4) void cc_detect_lds_levels_kernel(DetectLevels a) {
+    const int k = blockIdx.y;
+    cc_detect_lds_frame<N>(a.lb[k], a.t[k], a.level[k], a.out[k], blockIdx.x);
 }
 
 // SPARSE: the instantiation behind a level of a sparse chain (kLdsPathSparse).  Two kernels, so that what the sparse
@@ -2045,6 +2066,32 @@ void launch_cc_detect_lds(const LevelBatch& lb, const CompTables& t, int level, 
                           int nframes, hipStream_t s) {
     if (!t.lds_path || nframes <= 0) return;
     launch_lds<2048>(cc_detect_lds_kernel<2048>, nframes, s, lb, t, level, out, frame0);
+}
+
+void launch_cc_detect_levels(const LevelBatch* lbs, const CompTables* ts, const int* levels, const DetectOut* outs, int nlevels,
+                             int nframes, hipStream_t s) {
+    if (nframes <= 0 || nlevels <= 0) return;
+    if (nlevels == 1 || nlevels > kDetectLevelsMax) {
+        for (int k = 0; k < nlevels; ++k) launch_cc_detect(lbs[k], ts[k], levels[k], outs[k], 0, nframes, s);
+        return;
+    }
+    DetectLevels a;
+    bool lds = true;
+    for (int k = 0; k < kDetectLevelsMax; ++k) {
+        const int q = k < nlevels ? k : 0;
+        a.lb[k] = lbs[q];
+        a.t[k] = ts[q];
+        a.level[k] = levels[q];
+        a.out[k] = outs[q];
+        lds = lds && ts[q].lds_path;
+    }
+    if (lds) {
+        static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(cc_detect_lds_levels_kernel<2048>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LdsCCT<2048>)), true);
+        (void)once;
+        hipLaunchKernelGGL(cc_detect_lds_levels_kernel<2048>, dim3(nframes, nlevels), dim3(CC_THREADS), sizeof(LdsCCT<2048>), s, a);
+    }
+    hipLaunchKernelGGL(cc_detect_levels_kernel, dim3(nframes, nlevels), dim3(CCG_THREADS), 0, s, a);
 }
 
 void launch_sparse_cells(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io, uint32_t* cell_list,

@@ -102,6 +102,16 @@ struct RefineIO {
 };
 void launch_hot_from_response(const int16_t* src, const LevelBatch& lb, const CompTables& t, int frame0, int nframes,
                               hipStream_t s);
+// several levels of the same frames in one grid per kernel (the first pass of the full detector)
+constexpr int kDetectLevelsMax = 3;
+struct DetectLevels {
+    LevelBatch lb[kDetectLevelsMax];
+    CompTables t[kDetectLevelsMax];
+    DetectOut out[kDetectLevelsMax];
+    int level[kDetectLevelsMax];
+};
+void launch_cc_detect_levels(const LevelBatch* lbs, const CompTables* ts, const int* levels, const DetectOut* outs, int nlevels,
+                             int nframes, hipStream_t s);
 void launch_cc_detect(const LevelBatch& lb, const CompTables& t, int level, const DetectOut& out, int frame0,
                       int nframes, hipStream_t s);
 void launch_cc_refine(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io, int frame0,
