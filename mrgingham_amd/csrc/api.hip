@@ -191,7 +191,10 @@ struct mrgingham_amd_ctx {
         hipEvent_t ev_a = nullptr, ev_b = nullptr;
         bool refine_queued = false;
         int top = 0;  // the highest level a board of the job was found at (levels below it are refined)
-        mrg::DevBuf d_xy, d_cnt, d_pts, d_lv, d_np, d_pts0, d_lv0;
+        // device images of the pinned staging, laid out like it (fb_layout) so that each direction is ONE copy:
+        // d_cnt = counts | candidates (first pass), d_pts = boards | levels | point counts (refinement), d_pts0 = boards |
+        // levels as they went in (what the dense repeat of a sparse refinement starts from)
+        mrg::DevBuf d_cnt, d_pts, d_pts0;
         void* pin = nullptr;  // pinned host staging: counts, candidates | boards, levels, point counts
         size_t pin_bytes = 0;
         // the host part in progress (fb_host_begin .. fb_host_end): candidate lists of frames re-run at full capacity,
@@ -360,7 +363,7 @@ static std::vector<DevBuf*> all_buffers(mrgingham_amd_ctx* ctx) {
     v.push_back(&ctx->sparse_stat);
     for (DevBuf* b : {&ctx->mg_pts, &ctx->mg_lv, &ctx->mg_np}) v.push_back(b);
     for (auto& j : ctx->jobs)
-        for (DevBuf* b : {&j.d_xy, &j.d_cnt, &j.d_pts, &j.d_lv, &j.d_np, &j.d_pts0, &j.d_lv0}) v.push_back(b);
+        for (DevBuf* b : {&j.d_cnt, &j.d_pts, &j.d_pts0}) v.push_back(b);
     for (DevBuf* b : {&ctx->io_counts, &ctx->aux_img, &ctx->io_frame, &ctx->io_out, &ctx->pre_scratch, &ctx->pre_tmp,
                       &ctx->pre_out, &ctx->pre16_scratch, &ctx->io_frame16, &ctx->dbg_img, &ctx->dbg_resp, &ctx->blob_scratch, &ctx->blob_nodes, &ctx->blob_out,
                       &ctx->fb_xy, &ctx->fb_cnt, &ctx->fb_pts, &ctx->fb_lv, &ctx->fb_np, &ctx->fb_frames, &ctx->fb_frames2})
@@ -2656,26 +2659,29 @@ static int fb_host_end(mrgingham_amd_ctx* ctx, mrgingham_amd_ctx::BoardsJob& job
         ctx->cur = job.set;  // (the helpers below address the current set)
         hipStream_t cc = cur_cc(ctx);
         const size_t pb = (size_t)B * N * 16, lb = (size_t)B * N;
-        hipError_t e = hipMemcpyAsync(job.d_pts.p, pin.pts, pb, hipMemcpyHostToDevice, cc);
-        if (e == hipSuccess) e = hipMemcpyAsync(job.d_lv.p, pin.lv, lb, hipMemcpyHostToDevice, cc);
-        if (e == hipSuccess) e = hipMemcpyAsync(job.d_np.p, pin.np, (size_t)B * 4, hipMemcpyHostToDevice, cc);
-        if (e == hipSuccess) e = hipMemcpyAsync(job.d_pts0.p, job.d_pts.p, pb, hipMemcpyDeviceToDevice, cc);
-        if (e == hipSuccess) e = hipMemcpyAsync(job.d_lv0.p, job.d_lv.p, lb, hipMemcpyDeviceToDevice, cc);
+        // boards | levels | point counts: one block on both sides
+        char* const d_pts = (char*)job.d_pts.p;
+        char* const d_lv = d_pts + fb_align(pb);
+        char* const d_np = d_lv + fb_align(lb);
+        char* const d_pts0 = (char*)job.d_pts0.p;
+        const bool sparse = ctx->cc_lds && !ctx->use_v0 && top <= kRefineLevelsMax &&
+                            (ctx->sparse_refine == 2 ||
+                             (ctx->sparse_refine == 1 && (long long)fr->width * fr->height * B >= kSparsePaysPixels));
+        hipError_t e = hipMemcpyAsync(d_pts, pin.pts, fb_align(pb) + fb_align(lb) + (size_t)B * 4, hipMemcpyHostToDevice, cc);
+        if (e == hipSuccess && sparse)  // (only the dense repeat of a sparse refinement goes back to them)
+            e = hipMemcpyAsync(d_pts0, d_pts, fb_align(pb) + lb, hipMemcpyDeviceToDevice, cc);
         if (e == hipSuccess) {
             auto& ps = ctx->pts[job.set];
-            RefineIO io{(double*)job.d_pts.p, (signed char*)job.d_lv.p, (const int32_t*)job.d_np.p, N, nullptr,
+            RefineIO io{(double*)d_pts, (signed char*)d_lv, (const int32_t*)d_np, N, nullptr,
                         (int32_t*)ps.leader.p, (int32_t*)ps.need.p, (int32_t*)ps.nseeds.p, (uint32_t*)ps.seeds.p,
                         (int32_t*)ps.sroot.p};
-            const SparseRestore src{nullptr, 0, 0, (const double*)job.d_pts0.p, (const signed char*)job.d_lv0.p};
-            const bool sparse = ctx->cc_lds && !ctx->use_v0 && top <= kRefineLevelsMax &&
-                                (ctx->sparse_refine == 2 ||
-                                 (ctx->sparse_refine == 1 && (long long)fr->width * fr->height * B >= kSparsePaysPixels));
+            const SparseRestore src{nullptr, 0, 0, (const double*)d_pts0, (const signed char*)(d_pts0 + fb_align(pb))};
             rc = queue_sparse_levels(ctx, fr, top, io, src, !sparse);
             job.top = top;
-            e = hipMemcpyAsync(pin.pts, job.d_pts.p, pb, hipMemcpyDeviceToHost, cc);
-            if (e == hipSuccess && job.h_levels) e = hipMemcpyAsync(pin.lv, job.d_lv.p, lb, hipMemcpyDeviceToHost, cc);
-            for (int L = 0; L < top && e == hipSuccess; ++L)  // (a frame whose tables overflowed at a level was not refined there)
-                e = hipMemcpyAsync(pin.st + (size_t)L * B, status_of(ctx, L), (size_t)B * 4, hipMemcpyDeviceToHost, cc);
+            e = hipMemcpyAsync(pin.pts, d_pts, job.h_levels ? fb_align(pb) + lb : pb, hipMemcpyDeviceToHost, cc);
+            if (e == hipSuccess)  // (a frame whose tables overflowed at a level was not refined there): [level][frame]
+                e = hipMemcpy2DAsync(pin.st, (size_t)B * 4, status_of(ctx, 0), (size_t)ctx->counters_nf * 4, (size_t)B * 4, (size_t)top,
+                                     hipMemcpyDeviceToHost, cc);
             if (e == hipSuccess) e = hipEventRecord(job.ev_b, cc);
             end_op(ctx);
             job.refine_queued = true;
@@ -2854,10 +2860,9 @@ static int fb_submit(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int
     job.h_levels = h_levels;
     job.do_refine = do_refine;
     job.refine_queued = false;
-    if ((rc = ensure(ctx, job.d_xy, (size_t)nlev * B * cap * 8)) || (rc = ensure(ctx, job.d_cnt, (size_t)nlev * B * 4)) ||
-        (rc = ensure(ctx, job.d_pts, (size_t)B * N * 16)) || (rc = ensure(ctx, job.d_lv, (size_t)B * N)) ||
-        (rc = ensure(ctx, job.d_np, (size_t)B * 4)) || (rc = ensure(ctx, job.d_pts0, (size_t)B * N * 16)) ||
-        (rc = ensure(ctx, job.d_lv0, (size_t)B * N)))
+    if ((rc = ensure(ctx, job.d_cnt, fb_align((size_t)nlev * B * 4) + (size_t)nlev * B * cap * 8)) ||
+        (rc = ensure(ctx, job.d_pts, fb_align((size_t)B * N * 16) + fb_align((size_t)B * N) + (size_t)B * 4)) ||
+        (rc = ensure(ctx, job.d_pts0, fb_align((size_t)B * N * 16) + (size_t)B * N)))
         return rc;
     const size_t need = fb_layout(nullptr, nlev, B, cap, N).bytes;
     if (need > job.pin_bytes) {
@@ -2916,13 +2921,14 @@ static int fb_submit(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int
         DetectOut douts[3];
         for (int li = 0; li < job.nlev; ++li) {
             dts[li] = tables_of(ctx, job.levs[li]);
-            douts[li] = DetectOut{(int32_t*)job.d_xy.p + (size_t)li * B * cap * 2, cap, (int32_t*)job.d_cnt.p + (size_t)li * B};
+            douts[li] = DetectOut{(int32_t*)((char*)job.d_cnt.p + fb_align((size_t)job.nlev * B * 4)) + (size_t)li * B * cap * 2, cap,
+                                  (int32_t*)job.d_cnt.p + (size_t)li * B};
         }
         launch_cc_detect_levels(lbs, dts, job.levs, douts, job.nlev, B, cc);
     }
     const FbPinned pin = fb_layout(job.pin, job.nlev, B, cap, N);
-    if (e == hipSuccess) e = hipMemcpyAsync(pin.cnt, job.d_cnt.p, (size_t)job.nlev * B * 4, hipMemcpyDeviceToHost, cc);
-    if (e == hipSuccess) e = hipMemcpyAsync(pin.xy, job.d_xy.p, (size_t)job.nlev * B * cap * 8, hipMemcpyDeviceToHost, cc);
+    if (e == hipSuccess)  // counts | candidates: one block on both sides
+        e = hipMemcpyAsync(pin.cnt, job.d_cnt.p, fb_align((size_t)job.nlev * B * 4) + (size_t)job.nlev * B * cap * 8, hipMemcpyDeviceToHost, cc);
     if (e == hipSuccess) e = hipEventRecord(job.ev_a, cc);
     end_op(ctx);
     if (e == hipSuccess) e = hipGetLastError();
