@@ -2679,9 +2679,8 @@ static int fb_host_end(mrgingham_amd_ctx* ctx, mrgingham_amd_ctx::BoardsJob& job
             rc = queue_sparse_levels(ctx, fr, top, io, src, !sparse);
             job.top = top;
             e = hipMemcpyAsync(pin.pts, d_pts, job.h_levels ? fb_align(pb) + lb : pb, hipMemcpyDeviceToHost, cc);
-            if (e == hipSuccess)  // (a frame whose tables overflowed at a level was not refined there): [level][frame]
-                e = hipMemcpy2DAsync(pin.st, (size_t)B * 4, status_of(ctx, 0), (size_t)ctx->counters_nf * 4, (size_t)B * 4, (size_t)top,
-                                     hipMemcpyDeviceToHost, cc);
+            for (int L = 0; L < top && e == hipSuccess; ++L)  // (a frame whose tables overflowed at a level was not refined there)
+                e = hipMemcpyAsync(pin.st + (size_t)L * B, status_of(ctx, L), (size_t)B * 4, hipMemcpyDeviceToHost, cc);
             if (e == hipSuccess) e = hipEventRecord(job.ev_b, cc);
             end_op(ctx);
             job.refine_queued = true;
