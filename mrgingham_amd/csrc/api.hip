@@ -262,6 +262,14 @@ static int ensure(mrgingham_amd_ctx* ctx, DevBuf& b, size_t bytes) {
     return 0;
 }
 
+// Rows between host and device (or device and device): ONE plain copy whenever both sides are dense (every caller's usual case).  The 2-D copy
+// of the runtime is a slow path into pageable memory and serialises the threads of a process.
+static hipError_t copy_rows_async(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes, size_t rows,
+                                  hipMemcpyKind kind, hipStream_t s) {
+    if (dpitch == width_bytes && spitch == width_bytes) return hipMemcpyAsync(dst, src, width_bytes * rows, kind, s);
+    return hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, rows, kind, s);
+}
+
 static int level_dims(int W, int H, int level, int* w, int* h) {
     if (level < 0 || level > kMaxLevel) return -1;  // find_chessboard_corners.cc:433-441
     auto rnd = [level](int v) {                     // cvRound(v / 2^level): ties to even
@@ -1074,8 +1082,8 @@ int mrgingham_amd_decimate_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_fra
     hipStream_t s = (hipStream_t)stream;  // used as given: NULL is HIP's default stream
     if (level == 0) {
         for (int f = 0; f < fr->nframes; ++f)
-            MRG_HIP_CHECK(hipMemcpy2DAsync(d_out + (size_t)f * w * h, w, fr->frames + (size_t)f * fr->frame_pitch,
-                                           fr->stride, w, h, hipMemcpyDeviceToDevice, s));
+            MRG_HIP_CHECK(copy_rows_async(d_out + (size_t)f * w * h, w, fr->frames + (size_t)f * fr->frame_pitch,
+                                          fr->stride, w, h, hipMemcpyDeviceToDevice, s));
         return 0;
     }
     launch_one_level_image(fr, level, d_out, w, h, s);
@@ -1641,7 +1649,7 @@ static int upload_frame(mrgingham_amd_ctx* ctx, const void* host, int rows, int 
         if (stride == cols)
             MRG_HIP_CHECK(hipMemcpyAsync(ctx->io_frame.p, host, (size_t)rows * cols, hipMemcpyHostToDevice, ctx->pix));
         else
-            MRG_HIP_CHECK(hipMemcpy2DAsync(ctx->io_frame.p, cols, host, stride, cols, rows, hipMemcpyHostToDevice,
+            MRG_HIP_CHECK(copy_rows_async(ctx->io_frame.p, cols, host, stride, cols, rows, hipMemcpyHostToDevice,
                                            ctx->pix));
     }
     fr->frames = (const uint8_t*)ctx->io_frame.p;
@@ -1785,19 +1793,17 @@ void mrgingham_ChESS_response_5(int16_t* response, const uint8_t* image, int w, 
     if (ensure(ctx, ctx->io_out, (size_t)w * h * 2 + 64)) return;
     if (mrgingham_amd_chess_response_batch(ctx, &fr, 0, 0, (int16_t*)ctx->io_out.p, ctx->pix)) return;
     // interior only, like the reference: the 7-pixel frame of `response` is not touched
-    const size_t off = (size_t)kMargin * w + kMargin;
     hipError_t e = hipSuccess;
     const size_t bytes = (size_t)w * h * 2;
-    if (bytes < (4u << 20)) {  // small frames: one strided copy
-        e = hipMemcpy2DAsync(response + off, (size_t)w * 2, (const int16_t*)ctx->io_out.p + off, (size_t)w * 2,
-                             (size_t)(w - 2 * kMargin) * 2, h - 2 * kMargin, hipMemcpyDeviceToHost, ctx->pix);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->pix);
-    } else {
-        // Large frames (12 MP: 25 MB back): the strided copy into pageable memory goes through a slow path of the
-        // runtime (2.4 ms per 12 MP frame, all of it this copy).  Instead: whole rows in four plain copies into
-        // page-locked staging of the context, at the speed of the link, and a few host threads that move the interior
-        // of each row block into the caller's array as soon as the copy that carries it has landed.
-        constexpr int kChunks = 4;
+    {
+        // The strided copy of the interior into pageable memory goes through a slow path of the runtime (2.4 ms per 12 MP
+        // frame, all of it this copy) that also serialises the threads of a process (hipMemcpy2DAsync: sixteen workers
+        // of the command-line tool ran at an eighth of their rate behind one such copy per image).  Instead: whole rows
+        // in plain copies into page-locked staging of the context, at the speed of the link, and -- for large frames
+        // (12 MP: 25 MB back) in four chunks -- a few host threads that move the interior of each row block into the
+        // caller's array as soon as the copy that carries it has landed.
+        const bool small = bytes < (4u << 20);
+        const int kChunks = small ? 1 : 4;
         if (bytes > ctx->io_pin_bytes) {
             if (ctx->io_pin) hipHostFree(ctx->io_pin);
             ctx->io_pin = nullptr;
@@ -1805,7 +1811,8 @@ void mrgingham_ChESS_response_5(int16_t* response, const uint8_t* image, int w, 
             if (hipHostMalloc(&ctx->io_pin, bytes + bytes / 8, hipHostMallocDefault) != hipSuccess) ctx->io_pin = nullptr;
             else ctx->io_pin_bytes = bytes + bytes / 8;
         }
-        for (int c = 0; c < kChunks && !ctx->io_ev[c]; ++c) hipEventCreateWithFlags(&ctx->io_ev[c], hipEventDisableTiming);
+        for (int c = 0; c < kChunks; ++c)
+            if (!ctx->io_ev[c]) hipEventCreateWithFlags(&ctx->io_ev[c], hipEventDisableTiming);
         if (!ctx->io_pin || !ctx->io_ev[kChunks - 1]) {
             fprintf(stderr, "mrgingham_amd: ChESS response failed: no page-locked staging\n");
             return;
@@ -1842,7 +1849,8 @@ void mrgingham_ChESS_response_5(int16_t* response, const uint8_t* image, int w, 
             };
             int nthreads = (int)std::thread::hardware_concurrency();
             nthreads = nthreads > 8 ? 8 : (nthreads < 1 ? 1 : nthreads);
-            ctx->pool.run(nthreads, mover);
+            if (small) mover();  // (a few hundred KB: the calling thread)
+            else ctx->pool.run(nthreads, mover);
             if (failed.load()) e = hipErrorUnknown;
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->pix);
         }
@@ -2195,7 +2203,7 @@ int mrgingham_amd_preprocess_image16(const uint16_t* image, int width, int heigh
     if (ensure(ctx, ctx->io_frame16, npx * 2 + 64) || ensure(ctx, ctx->pre_tmp, npx + 64) || ensure(ctx, ctx->pre_out, npx + 64) ||
         ensure(ctx, ctx->pre16_scratch, preprocess16_scratch_bytes(1, width, height)))
         return -2;
-    if (hipMemcpy2DAsync(ctx->io_frame16.p, (size_t)width * 2, image, (size_t)stride * 2, (size_t)width * 2, height,
+    if (copy_rows_async(ctx->io_frame16.p, (size_t)width * 2, image, (size_t)stride * 2, (size_t)width * 2, height,
                          hipMemcpyHostToDevice, ctx->pix) != hipSuccess)
         return -2;
     uint8_t* eight = (uint8_t*)(blur_radius > 0 ? ctx->pre_tmp.p : ctx->pre_out.p);
@@ -2245,7 +2253,7 @@ int mrgingham_amd_process_image_ex(const void* image, int bits, int width, int h
             ensure(ctx, ctx->pre_out, npx + 64) ||
             ensure(ctx, ctx->pre16_scratch, preprocess16_scratch_bytes(1, width, height)))
             return -2;
-        if (hipMemcpy2DAsync(ctx->io_frame16.p, (size_t)width * 2, image, (size_t)stride * 2, (size_t)width * 2, height,
+        if (copy_rows_async(ctx->io_frame16.p, (size_t)width * 2, image, (size_t)stride * 2, (size_t)width * 2, height,
                              hipMemcpyHostToDevice, ctx->pix) != hipSuccess)
             return -2;
         uint8_t* eight = (uint8_t*)(o->blur_radius > 0 ? ctx->pre_tmp.p : ctx->pre_out.p);
@@ -2266,7 +2274,7 @@ int mrgingham_amd_process_image_ex(const void* image, int bits, int width, int h
         if (dot != std::string::npos) base.resize(dot);
         const std::string outname = "/tmp/" + base + "_preprocessed.png";
         std::vector<uint8_t> host(npx);
-        if (hipMemcpy2DAsync(host.data(), width, fr.frames, fr.stride, width, height, hipMemcpyDeviceToHost, ctx->pix) ==
+        if (copy_rows_async(host.data(), width, fr.frames, fr.stride, width, height, hipMemcpyDeviceToHost, ctx->pix) ==
                 hipSuccess &&
             hipStreamSynchronize(ctx->pix) == hipSuccess && write_png_gray8(outname.c_str(), host.data(), width, height))
             fprintf(stderr, "Wrote preprocessed image to %s\n", outname.c_str());
@@ -2277,7 +2285,7 @@ int mrgingham_amd_process_image_ex(const void* image, int bits, int width, int h
         // mrgingham-from-image.cc:153-160: find_circle_grid_from_image_array on the preprocessed image, "level" 0
         std::vector<uint8_t> host(npx);
         std::vector<int32_t> bxy;
-        if (hipMemcpy2DAsync(host.data(), width, fr.frames, fr.stride, width, height, hipMemcpyDeviceToHost, ctx->pix) !=
+        if (copy_rows_async(host.data(), width, fr.frames, fr.stride, width, height, hipMemcpyDeviceToHost, ctx->pix) !=
                 hipSuccess ||
             hipStreamSynchronize(ctx->pix) != hipSuccess || !blobs_on_device(ctx, &fr, host.data(), width, bxy))
             return -2;
@@ -2349,9 +2357,9 @@ static int find_boards_sync_levels(mrgingham_amd_ctx* ctx, const mrgingham_amd_f
         int r = ensure(ctx, buf, frame_bytes * idx.size() + 64);
         if (r) return r;
         for (size_t k = 0; k < idx.size(); ++k)
-            MRG_HIP_CHECK(hipMemcpy2DAsync((char*)buf.p + k * frame_bytes, fr->width,
-                                           fr->frames + (size_t)idx[k] * fr->frame_pitch, fr->stride, fr->width,
-                                           fr->height, hipMemcpyDeviceToDevice, ctx->pix));
+            MRG_HIP_CHECK(copy_rows_async((char*)buf.p + k * frame_bytes, fr->width,
+                                          fr->frames + (size_t)idx[k] * fr->frame_pitch, fr->stride, fr->width,
+                                          fr->height, hipMemcpyDeviceToDevice, ctx->pix));
         *sub = mrgingham_amd_frames{(const uint8_t*)buf.p, (int64_t)frame_bytes, (int)idx.size(), fr->width, fr->height,
                                     fr->width};
         return 0;
