@@ -172,6 +172,17 @@ void mrgingham_amd_host_free(void* p);
 int mrgingham_amd_host_register(void* p, size_t bytes);
 int mrgingham_amd_host_unregister(void* p);
 
+/* How the calling threads of this PROCESS wait for the device (hipSetDeviceFlags on every device): 0 = the runtime's
+ * choice, 1 = spin, 2 = yield the core while waiting, 3 = block.  The runtime's default spins, which is the lowest
+ * latency while every waiting thread has a core of its own -- and a cliff when it has not: a spinning thread burns the
+ * time slice the thread that feeds the device is waiting for (32 callers on 16 cores, 4096 small images: 10-13 s
+ * spinning, 4-6 s blocking, 1.4 s with four callers).  Better than any policy is FEWER callers per GPU -- the
+ * command-line tool hands the images of all its workers to eight device threads per GPU --; a host that cannot
+ * arrange that asks for 3.  Call it before the process creates its first context.  Returns 0, MRGINGHAM_AMD_ERR_ARG,
+ * or MRGINGHAM_AMD_ERR_DEVICE when a device refused (the HIP runtime of the process is already running with another
+ * policy: e.g. inside a PyTorch process). */
+int mrgingham_amd_set_wait_policy(int policy);
+
 /* Contiguous shards of `total` frames over n contexts / ranks: shard k = frames [*first, *first + *count), the first
  * total % n shards one frame longer (the split bench.py and mrgingham_amd/parallel.py use). */
 int mrgingham_amd_shard_range(int total, int k, int n, int* first, int* count);

@@ -38,7 +38,7 @@ EXPORTS = [
     "mrgingham_amd_find_boards_collect", "mrgingham_amd_device_for_thread", "mrgingham_amd_set_thread_device",
     "mrgingham_amd_thread_device", "mrgingham_amd_host_alloc", "mrgingham_amd_host_free", "mrgingham_amd_host_register",
     "mrgingham_amd_host_unregister", "mrgingham_amd_shard_range", "mrgingham_amd_chain_multi", "mrgingham_amd_sync_multi",
-    "mrgingham_amd_stream_wait_multi", "mrgingham_amd_kernel_id",
+    "mrgingham_amd_stream_wait_multi", "mrgingham_amd_kernel_id", "mrgingham_amd_set_wait_policy",
 ]
 
 
@@ -112,6 +112,7 @@ def lib():
     L.mrgingham_amd_host_free.restype = None
     L.mrgingham_amd_host_register.argtypes = [c_vp, ctypes.c_size_t]
     L.mrgingham_amd_host_unregister.argtypes = [c_vp]
+    L.mrgingham_amd_set_wait_policy.argtypes = [c_int]
     L.mrgingham_amd_shard_range.argtypes = [c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     L.mrgingham_amd_chain_multi.argtypes = [ctypes.POINTER(c_vp), c_int, FP, c_int, c_vp, c_vp, c_vp, c_int]
     L.mrgingham_amd_sync_multi.argtypes = [ctypes.POINTER(c_vp), c_int]

@@ -124,6 +124,13 @@ def read_image(filename, cli_scaling=False):
     return out
 
 
+def set_wait_policy(policy):
+    """How this process's threads wait for the device: 0 runtime default, 1 spin, 2 yield, 3 block
+    (mrgingham_amd_set_wait_policy; before the first context -- inside a PyTorch process the runtime is usually
+    running already and refuses)."""
+    return _lib.lib().mrgingham_amd_set_wait_policy(int(policy))
+
+
 def device_for_thread(thread_index, ndevices, env_value=None):
     """The library's policy for the device of the k-th thread that calls a reference symbol (include/mrgingham_amd.h,
     "several GPUs"): MRGINGHAM_AMD_DEVICE if set, else k modulo the number of devices.  Host only."""

@@ -68,13 +68,68 @@ const char* kUsage =
     "                  responses and the corner vnlogs to /tmp like the reference does\n"
     "  --debug-sequence x,y   accepted (the grid finder's own dumps are not produced)\n";
 
+// At most kDeviceSlots threads per GPU call into the library.  With --jobs up to that many per GPU the workers call it
+// themselves; with more, the workers only read, decode and print, and hand their images to kDeviceSlots DEVICE THREADS
+// per GPU, asleep on a condition variable while they wait.  More callers per GPU add no throughput (the device is one),
+// every caller costs a context (streams, scratch: ~20 ms of start-up each), and every waiting caller spins for the device:
+// once they outnumber the cores the spinners burn the time slices of the threads that feed the device (4096 small images
+// on 16 cores: 1.4 s with 4 workers, 2-4 s with 16, 10-13 s with 32 before this; decoding PNGs is what more workers are
+// for).
+constexpr int kDeviceSlots = 8;
+struct Request {
+    const void* px;
+    int depth, w, h;
+    const mrgingham_amd_cli_options* o;
+    double* xy;
+    signed char* lv;
+    int level;
+    bool done;
+    pthread_cond_t cv;
+};
+struct DeviceQueue {
+    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    pthread_cond_t work = PTHREAD_COND_INITIALIZER;
+    std::vector<Request*> q;  // (a handful of entries: at most one per worker)
+    bool stop = false;
+    int device = -1;  // -1: wherever the library puts the thread (MRGINGHAM_AMD_DEVICE)
+};
+std::vector<DeviceQueue> device_queues;  // one per GPU in use (main)
+bool hand_off = false;                   // more workers than device slots
+
+int process(const void* px, int depth, int w, int h, const mrgingham_amd_cli_options* o, double* xy, signed char* lv) {
+    return mrgingham_amd_process_image_ex(px, depth, w, h, w, o, xy, lv);
+}
+void* device_thread(void* arg) {
+    DeviceQueue& Q = *(DeviceQueue*)arg;
+    if (Q.device >= 0) mrgingham_amd_set_thread_device(Q.device);
+    pthread_mutex_lock(&Q.mu);
+    while (true) {
+        while (Q.q.empty() && !Q.stop) pthread_cond_wait(&Q.work, &Q.mu);
+        if (Q.q.empty()) break;
+        Request* r = Q.q.front();
+        Q.q.erase(Q.q.begin());
+        pthread_mutex_unlock(&Q.mu);
+        const int level = process(r->px, r->depth, r->w, r->h, r->o, r->xy, r->lv);
+        pthread_mutex_lock(&Q.mu);
+        r->level = level;
+        r->done = true;
+        pthread_cond_signal(&r->cv);
+    }
+    pthread_mutex_unlock(&Q.mu);
+    return nullptr;
+}
+
 void* worker(void* arg) {
     const int ijob = (int)(intptr_t)arg;
     const int N = opt.gridn * opt.gridn;
     std::vector<double> xy((size_t)N * 2);
     std::vector<signed char> lv((size_t)N);
     Image im;  // reused: its buffers keep their pages from image to image
-    if (opt.gpus > 0) mrgingham_amd_set_thread_device(ijob % opt.gpus);
+    // worker k works on device k mod N (N = --gpus, or every GPU of the node; MRGINGHAM_AMD_DEVICE pins all to one)
+    DeviceQueue& Q = device_queues[(size_t)ijob % device_queues.size()];
+    if (!hand_off && Q.device >= 0) mrgingham_amd_set_thread_device(Q.device);
+    Request req{};
+    if (hand_off) pthread_cond_init(&req.cv, nullptr);
     // the decoded pixels are page-locked where they lie, so that the upload runs at the speed of the link (re-done
     // when an image of another size moves the buffer)
     void* locked = nullptr;
@@ -114,9 +169,20 @@ void* worker(void* arg) {
         else lock_pixels(im.px8.data(), im.px8.capacity());
         const double t1 = now();
         // 8- and 16-bit images go to the device as they are (mrgingham-from-image.cc:71-92)
-        const int level = im.depth == 16
-                              ? mrgingham_amd_process_image_ex(im.px16.data(), 16, im.w, im.h, im.w, &o, xy.data(), lv.data())
-                              : mrgingham_amd_process_image_ex(im.px8.data(), 8, im.w, im.h, im.w, &o, xy.data(), lv.data());
+        const void* px = im.depth == 16 ? (const void*)im.px16.data() : (const void*)im.px8.data();
+        int level;
+        if (!hand_off) {
+            level = process(px, im.depth == 16 ? 16 : 8, im.w, im.h, &o, xy.data(), lv.data());
+        } else {
+            req.px = px; req.depth = im.depth == 16 ? 16 : 8; req.w = im.w; req.h = im.h;
+            req.o = &o; req.xy = xy.data(); req.lv = lv.data(); req.done = false;
+            pthread_mutex_lock(&Q.mu);
+            Q.q.push_back(&req);
+            pthread_cond_signal(&Q.work);
+            while (!req.done) pthread_cond_wait(&req.cv, &Q.mu);
+            pthread_mutex_unlock(&Q.mu);
+            level = req.level;
+        }
         const double t2 = now();
         flockfile(stdout);
         if (level >= 0)  // mrgingham-from-image.cc:174-183
@@ -131,6 +197,7 @@ void* worker(void* arg) {
         fprintf(stderr, "worker %d: %d images; per image: read + decode %.3f ms, upload + device + grid finder %.3f ms, output %.3f ms\n",
                 ijob, nimg, t_read / nimg, t_proc / nimg, t_out / nimg);
     if (locked) mrgingham_amd_host_unregister(locked);
+    if (hand_off) pthread_cond_destroy(&req.cv);
     return nullptr;
 }
 
@@ -232,9 +299,26 @@ int main(int argc, char* argv[]) {
     for (int i = 0; i < argc; ++i) printf(" %s", argv[i]);
     printf("\n# filename x y level\n");
     fflush(stdout);
+    const bool pinned_by_env = getenv("MRGINGHAM_AMD_DEVICE") != nullptr && opt.gpus <= 0;
+    const int ng = opt.gpus > 0 ? opt.gpus : (pinned_by_env ? 1 : ndev);
+    device_queues = std::vector<DeviceQueue>((size_t)ng);
+    for (int d = 0; d < ng; ++d) device_queues[(size_t)d].device = pinned_by_env ? -1 : d;
+    hand_off = opt.jobs > kDeviceSlots * ng;
+    std::vector<pthread_t> dth;
+    if (hand_off) {
+        dth.resize((size_t)kDeviceSlots * ng);
+        for (size_t i = 0; i < dth.size(); ++i) pthread_create(&dth[i], nullptr, device_thread, &device_queues[i % (size_t)ng]);
+    }
     std::vector<pthread_t> th((size_t)opt.jobs);
     for (int i = 0; i < opt.jobs; ++i) pthread_create(&th[i], nullptr, worker, (void*)(intptr_t)i);
     for (int i = 0; i < opt.jobs; ++i) pthread_join(th[i], nullptr);
+    for (DeviceQueue& Q : device_queues) {
+        pthread_mutex_lock(&Q.mu);
+        Q.stop = true;
+        pthread_cond_broadcast(&Q.work);
+        pthread_mutex_unlock(&Q.mu);
+    }
+    for (pthread_t& t : dth) pthread_join(t, nullptr);
     globfree(&opt.globbed);
     return 0;
 }

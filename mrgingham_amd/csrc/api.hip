@@ -1536,6 +1536,26 @@ int mrgingham_amd_host_unregister(void* p) {
     return hipHostUnregister(p) == hipSuccess ? MRGINGHAM_AMD_OK : MRGINGHAM_AMD_ERR_DEVICE;
 }
 
+int mrgingham_amd_set_wait_policy(int policy) {
+    unsigned flag;
+    switch (policy) {
+        case 0: flag = hipDeviceScheduleAuto; break;
+        case 1: flag = hipDeviceScheduleSpin; break;
+        case 2: flag = hipDeviceScheduleYield; break;
+        case 3: flag = hipDeviceScheduleBlockingSync; break;
+        default: return MRGINGHAM_AMD_ERR_ARG;
+    }
+    int ndev = 0, prev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return MRGINGHAM_AMD_ERR_DEVICE;
+    hipGetDevice(&prev);
+    int rc = MRGINGHAM_AMD_OK;
+    for (int d = 0; d < ndev; ++d)
+        if (hipSetDevice(d) != hipSuccess || hipSetDeviceFlags(flag) != hipSuccess) rc = MRGINGHAM_AMD_ERR_DEVICE;
+    hipSetDevice(prev);
+    (void)hipGetLastError();
+    return rc;
+}
+
 int mrgingham_amd_shard_range(int total, int k, int n, int* first, int* count) {
     if (total < 0 || n <= 0 || k < 0 || k >= n || !first || !count) return MRGINGHAM_AMD_ERR_ARG;
     const int q = total / n, r = total % n;  // the first r shards take one frame more

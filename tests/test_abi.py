@@ -162,3 +162,8 @@ def test_thread_to_device_policy_and_shard_ranges():
             assert max(c for _, c in got) - min(c for _, c in got) <= 1
     with pytest.raises(ValueError):
         api.shard_range(10, 3, 3)
+
+
+def test_wait_policy_rejects_unknown_values_without_touching_the_device():
+    from mrgingham_amd import _lib
+    assert _lib.lib().mrgingham_amd_set_wait_policy(9) == -1          # MRGINGHAM_AMD_ERR_ARG

@@ -162,6 +162,23 @@ def test_cli_vnlog_matches_composed_oracle(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_with_more_workers_than_device_slots_hands_its_images_to_device_threads(tmp_path):
+    """--jobs above eight per GPU: the workers decode and print, eight device threads per GPU call the library
+    (cli/mrgingham_from_image.cpp, kDeviceSlots).  Same lines per file as one worker gives, every file exactly once."""
+    from mrgingham_amd import synth
+    sizes = [(640, 480), (800, 600), (1280, 960)]
+    for i in range(30):
+        w, h = sizes[i % 3]
+        img = synth.board_frame(w, h, 10, i).numpy() if i % 7 else synth.noise_frame(w, h, i, smooth=1).numpy()
+        _write_pgm(str(tmp_path / f"img{i:02d}.pgm"), img)
+    one = _run("--jobs", "1", str(tmp_path / "img*.pgm"))
+    many = _run("--jobs", "40", "--gpus", "1", str(tmp_path / "img*.pgm"))
+    assert one.returncode == 0 and many.returncode == 0, (one.stderr, many.stderr)
+    a, b = _parse(one.stdout), _parse(many.stdout)
+    assert len(a) == 30 and a == b
+
+
+@pytest.mark.gpu
 def test_cli_rgb_png_16bit_pgm_and_unreadable_file(tmp_path):
     from mrgingham_amd import synth
     img = synth.board_frame(640, 480, 10, 7).numpy()
