@@ -155,3 +155,18 @@ def test_cli_gpus_option(tmp_path, gpus):
         assert "using 1" in r.stderr
     bad = subprocess.run([cli, "--gpus", "0", str(tmp_path / "f0.pgm")], capture_output=True, text=True, timeout=60)
     assert bad.returncode != 0 and "--gpus" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_wait_policy_is_accepted_or_refused_cleanly_and_changes_no_result():
+    """mrgingham_amd_set_wait_policy inside a process whose HIP runtime is already running (PyTorch's): 0, or
+    MRGINGHAM_AMD_ERR_DEVICE when the runtime refuses -- never a crash, and the detector answers as before."""
+    import mrgingham_amd
+    from mrgingham_amd import synth
+    img = synth.board_frame(640, 480, 10, 1).numpy()
+    before = mrgingham_amd.find_board(img, gridn=10)
+    for policy in (3, 2, 0):
+        assert api.set_wait_policy(policy) in (0, -2), policy
+    after = mrgingham_amd.find_board(img, gridn=10)
+    assert before is not None and np.array_equal(before, after)
+    assert api.set_wait_policy(7) == -1
