@@ -247,7 +247,8 @@ def end_to_end(det, frames, start_level, P, steps=12, warmup=3):
 
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script (one process per GPU,
-    rendezvous on a free local port) and wait for them; rank 0 prints the JSON line."""
+    rendezvous on a free local port) and wait for them; rank 0 prints the JSON line.  (`--rehearse`: the ranks
+    all use HIP device 0 -- main() ignores LOCAL_RANK for the device then.)"""
     import socket
     import subprocess
     with socket.socket() as sk:
@@ -317,6 +318,42 @@ def find_boards_leg(device_index, frames, gridn, batches=150, depth=3):
         det.close()
 
 
+def chess_pass_alone_leg(det, frames, launches=120, warm=10):
+    """north_star's sentence as a number: the plain ChESS pass -- mrgingham_amd_chess_response_batch(level 0, clamp 0),
+    the literal output of mrgingham_ChESS_response_5 (ChESS.c:56-106) for every frame of the batch: u8 read once, int16
+    written once, no clamp, no hot list, no level images -- alone on the device, every launch bracketed by hipEvents on
+    the stream it runs on (torch's current stream: that is the stream the call is given).  NOT `value`."""
+    B, H, W = frames.shape
+    out = torch.empty((B, H, W), dtype=torch.int16, device=frames.device)
+    det.sync()
+    torch.cuda.synchronize()
+    for _ in range(warm):
+        det.chess_response(frames, 0, clamp=False, out=out)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(launches + 1)]
+    ev[0].record()
+    for i in range(launches):
+        det.chess_response(frames, 0, clamp=False, out=out)
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    per = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(launches))
+    avg = ev[0].elapsed_time(ev[launches]) / launches        # back-to-back launches: includes the dispatch gaps
+    med = per[launches // 2]
+    alg = B * W * H * 3.0
+    del out
+    return {"kernel": "chess_v1_kernel<CLAMP 0, HOT 0> (plain ChESS response, the output of ChESS.c:56-106)",
+            "bytes_model": "3 B/px (u8 read once + int16 written once)", "bytes_per_launch": alg,
+            "launches_timed": launches, "avg_launch_ms": avg, "median_launch_ms": med,
+            "min_launch_ms": per[0], "p90_launch_ms": per[int(launches * 0.9)],
+            "achieved": alg / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "frac_median_launch": alg / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "frames_per_s": B / (avg * 1e-3),
+            "what": "the ChESS pass ALONE (nothing else on the device): `frac` from the average over back-to-back launches "
+                    "(first event to last / launches, dispatch gaps included), `frac_median_launch` from the median of the "
+                    "per-launch hipEvent intervals"}
+
+
 def sparse_leg(det, frames, start_level, P, steps):
     """The same workload with option "sparse_refine" (include/mrgingham_amd.h): level images and the start level's
     response for whole frames, the response below it only in the cells around the points.  NOT `value`: the judged
@@ -373,11 +410,18 @@ def main():
                     help="skip the leg that times the full detector (level search + host grid finder + refinement; N = 1 only)")
     ap.add_argument("--no-sparse-leg", action="store_true",
                     help="skip the extra leg that times the same workload with option sparse_refine (N = 1 only)")
+    ap.add_argument("--no-chess-alone", action="store_true",
+                    help="skip the leg that times the plain ChESS pass alone (level 0, no clamp; N = 1 only)")
     ap.add_argument("--scratch-sets", type=int, default=0,
                     help="option scratch_sets of the library (0 = its default: chosen from the batch shape): calls' component "
                          "searches in flight")
     ap.add_argument("--force-gather", action="store_true",
                     help="with one rank: still create the (one-rank) RCCL group and issue the gather every step")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="REHEARSAL of the N > 1 flow on ONE GPU: the N ranks share HIP device 0, the process group is "
+                         "gloo and the packed corner lists go through pinned host memory for the gather.  Exercises the "
+                         "launcher, per-rank shards, the cross-rank aggregation and the one-JSON-line rule; the line is "
+                         "marked `rehearsal: true, backend: gloo` and is NOT a scaling measurement")
     ap.add_argument("--bind-numa", action="store_true",
                     help="bind this process to the cores of its GPU's NUMA node (always done for --gpus > 1)")
     ap.add_argument("--prime", type=int, default=30,
@@ -385,7 +429,7 @@ def main():
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        if torch.cuda.device_count() < args.gpus:
+        if torch.cuda.device_count() < args.gpus and not (args.rehearse and torch.cuda.device_count() >= 1):
             raise SystemExit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} HIP device(s) here")
         sys.exit(launch_ranks(args.gpus))                    # no launcher: start the ranks ourselves
     # stdout carries ONE line, the JSON: keep a private handle to it and point file descriptor 1 at stderr for
@@ -399,6 +443,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: mrgingham_amd has no CPU path")
+    rehearse = bool(args.rehearse)
+    if rehearse:
+        local_rank = 0                                       # every rank of a rehearsal shares device 0
     torch.cuda.set_device(local_rank)
     binding = bind_rank_to_gpu_numa(local_rank) if (world > 1 or args.bind_numa) else None
     collective = world > 1 or args.force_gather
@@ -409,7 +456,10 @@ def main():
             with socket.socket() as sk:
                 sk.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
 
@@ -443,8 +493,11 @@ def main():
     NBUF = 3
     packs = [parallel.packed_outputs(batch, P, dev) for _ in range(NBUF)]   # (pack, points, levels, npoints)
     outs = [p[1:] for p in packs]
-    gathered = [torch.empty((world, packs[0][0].numel()), dtype=torch.uint8, device=dev) if (collective and rank == 0)
+    # where the collectives' tensors live: on the device for RCCL; a rehearsal (gloo) moves them through pinned host memory
+    cdev = torch.device("cpu") if rehearse else dev
+    gathered = [torch.empty((world, packs[0][0].numel()), dtype=torch.uint8, device=cdev) if (collective and rank == 0)
                 else None for _ in range(NBUF)]
+    hpack = [torch.empty(packs[0][0].numel(), dtype=torch.uint8, pin_memory=True) for _ in range(NBUF)] if (collective and rehearse) else None
     consumed = [None] * NBUF
     torch.cuda.synchronize()
     nstep = [0]
@@ -455,7 +508,12 @@ def main():
         if consumed[k] is not None:
             consumed[k].synchronize()                        # gather of three steps ago: long done
         pts, lv, npts = det.chain(frames, start_level=start_level, max_points=P, out=outs[k], sync=False)
-        if collective:
+        if collective and rehearse:
+            det.stream_wait()
+            hpack[k].copy_(packs[k][0], non_blocking=True)   # device -> pinned host behind the step ...
+            torch.cuda.current_stream().synchronize()        # ... which gloo needs on the host before it can send
+            parallel.gather_packed(hpack[k], dst=0, out=gathered[k], force=True)
+        elif collective:
             det.stream_wait()                                # torch's stream waits for this step on the device
             parallel.gather_packed(packs[k][0], dst=0, out=gathered[k], force=True)   # the ONE collective of the path
             consumed[k] = torch.cuda.Event()
@@ -474,7 +532,7 @@ def main():
     fence()
     ranks_seen = 1
     if collective:
-        seen = torch.ones(1, dtype=torch.int32, device=dev)
+        seen = torch.ones(1, dtype=torch.int32, device=cdev)
         dist.all_reduce(seen)
         ranks_seen = int(seen.item())
     for _ in range(args.warmup):
@@ -491,7 +549,7 @@ def main():
     kern_ms, nlaunch = det.chess_kernel_ms()
 
     if collective:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -504,7 +562,7 @@ def main():
             dist.barrier()
         e2e = end_to_end(det, frames, start_level, P)
         if collective:
-            mine = torch.tensor([e2e["h2d_GBs"], e2e["value"]], dtype=torch.float64, device=dev)
+            mine = torch.tensor([e2e["h2d_GBs"], e2e["value"]], dtype=torch.float64, device=cdev)
             allr = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(allr, mine)
             h2d = [float(t[0]) for t in allr]
@@ -513,6 +571,9 @@ def main():
                        what=e2e["what"] + "; all ranks at once, `value` = sum over ranks")
     fused, merged = det.chain_info()                         # (of the timed steps: before the sparse leg makes its calls)
     scratch_gib = det.scratch_bytes() / 2**30                # (likewise: a context that runs sparse chains keeps a third set)
+    alone = None
+    if world == 1 and not args.no_chess_alone:
+        alone = chess_pass_alone_leg(det, frames)
     sparse = None
     if world == 1 and start_level >= 1 and not args.no_sparse_leg and not args.sparse_refine:
         sparse = sparse_leg(det, frames, start_level, P, 100)   # (its own length: not the timed region of the contract)
@@ -528,8 +589,35 @@ def main():
     if collective and rank == 0:                             # what rank 0 received equals what the ranks produced
         last = (nstep[0] - 1) % NBUF
         gp, gl, gn = parallel.unpack_outputs(gathered[last], batch, P)
-        gather_ok = bool(torch.equal(gn[0], packs[last][3]) and torch.equal(gp[0], packs[last][1]))
+        gather_ok = bool(torch.equal(gn[0].to(dev), packs[last][3]) and torch.equal(gp[0].to(dev), packs[last][1]))
         assert gather_ok, "gathered corner lists differ from rank 0's own"
+    # which shard every rank worked on, as rank 0 received it: first global frame, corner count, a checksum of the corner
+    # bytes -- and (rehearsal) rank 0 renders every other rank's shard itself, runs the chain on it and compares
+    shards_seen, shards_differ, shards_verified = None, None, None
+    if collective and rank == 0:
+        last = (nstep[0] - 1) % NBUF
+        gp, gl, gn = parallel.unpack_outputs(gathered[last], batch, P)
+        shards_seen = []
+        for r in range(world):
+            rlo, _ = parallel.shard_range(world * batch, r, world)
+            live = gp[r].reshape(batch, P * 2).to(torch.float64)
+            shards_seen.append({"rank": r, "first_frame": rlo, "corners": int(gn[r].clamp(max=P).sum()),
+                                "corner_checksum": float(live.nan_to_num().sum())})
+        shards_differ = all(not torch.equal(gp[r], gp[0]) for r in range(1, world)) if world > 1 else None
+        if rehearse and world > 1 and not args.distinct:
+            shards_verified = True
+            for r in range(1, world):
+                rlo, _ = parallel.shard_range(world * batch, r, world)
+                fr_r = render(batch, W, H, gridn=gridn, seed0=rlo, device=dev)
+                wp, wl, wn = det.chain(fr_r, start_level=start_level, max_points=P)
+                n = wn.clamp(max=P).tolist()
+                ok = bool(torch.equal(gn[r].to(dev), wn))
+                for f in range(batch):
+                    ok = ok and bool(torch.equal(gp[r][f, :n[f]].to(dev), wp[f, :n[f]]) and
+                                     torch.equal(gl[r][f, :n[f]].to(dev), wl[f, :n[f]]))
+                shards_verified = shards_verified and ok
+                del fr_r
+            assert shards_verified, "a rank's gathered corner lists are not those of its shard of the global batch"
     if rank == 0:
         total_frames = world * batch * args.steps
         # level-0 ChESS launches per step = number of stream chunks; frames per launch follows
@@ -620,6 +708,17 @@ def main():
                          "launches_timed": nlaunch, "binding": valu},
         }
         res["gather_checked"] = gather_ok
+        if shards_seen is not None:
+            res["shards_seen"] = shards_seen
+            res["shards_differ"] = shards_differ
+            res["shards_verified_by_rerender"] = shards_verified
+        if rehearse:
+            res["rehearsal"] = True
+            res["backend"] = "gloo"
+            res["physical_gpus"] = 1
+            res["metric"] = "REHEARSAL (%d ranks share ONE GPU, gloo through pinned host memory; not a scaling measurement): " % world + res["metric"]
+        elif collective:
+            res["backend"] = "nccl"
         res["scratch_sets"] = args.scratch_sets or "auto"
         res["setup_prime_steps"] = args.prime
         res["timed_region_s"] = dt
@@ -632,6 +731,8 @@ def main():
         res["scratch_GiB"] = scratch_gib
         if e2e is not None:
             res["end_to_end"] = e2e
+        if alone is not None:
+            res["chess_pass_alone"] = alone
         if sparse is not None:
             res["sparse_refine"] = sparse
         if fboards is not None:

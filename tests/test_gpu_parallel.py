@@ -58,6 +58,30 @@ def test_bench_launches_its_own_two_ranks():
     assert res["scaling"] == "weak"
 
 
+def test_bench_rehearsal_two_ranks_on_one_gpu():
+    """The whole N > 1 flow of bench.py with world = 2 on the ONE GPU there is (`--rehearse`: both ranks on device 0,
+    gloo, the packed lists through pinned host memory): the self-launcher, per-rank shards of the global batch (seed =
+    global frame index), `ranks_seen`, the gather compared with rank 0's own lists AND with a re-render of rank 1's
+    shard, the per-rank host-fed leg aggregated over ranks, one JSON line on stdout -- marked so that it can never be
+    read as a scaling measurement."""
+    res = _bench("--gpus", "2", "--rehearse", "--workload", "c1_640x480_chain", "--steps", "6", "--warmup", "2",
+                 "--prime", "3", "--no-cpu-baseline")
+    assert res["rehearsal"] is True and res["backend"] == "gloo" and res["physical_gpus"] == 1
+    assert res["metric"].startswith("REHEARSAL")
+    assert res["n_gpus"] == 2 and res["ranks_seen"] == 2 and res["scaling"] == "weak"
+    assert res["gather_checked"] is True
+    sh = res["shards_seen"]
+    assert [x["rank"] for x in sh] == [0, 1] and [x["first_frame"] for x in sh] == [0, 64]
+    assert res["shards_differ"] is True                    # rank 1 did not work on rank 0's frames
+    assert sh[0]["corner_checksum"] != sh[1]["corner_checksum"] and min(x["corners"] for x in sh) >= 64 * 100
+    assert res["shards_verified_by_rerender"] is True       # ... but on frames 64..127 of the global batch
+    e = res["end_to_end"]
+    assert e["ranks"] == 2 and len(e["h2d_GBs_per_rank"]) == 2 and min(e["h2d_GBs_per_rank"]) > 0
+    assert res["config"]["frames_per_gpu"] == 64 and "gathered to rank 0" in res["config"]["workload"]
+    assert len(res["cpu_binding"]) == 2
+    assert "find_boards" not in res and "sparse_refine" not in res and "chess_pass_alone" not in res   # N = 1 legs
+
+
 def test_bench_refuses_more_ranks_than_devices():
     n = torch.cuda.device_count() + 1
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), *SMALL],
