@@ -73,7 +73,7 @@ def test_bench_rehearsal_two_ranks_on_one_gpu():
     sh = res["shards_seen"]
     assert [x["rank"] for x in sh] == [0, 1] and [x["first_frame"] for x in sh] == [0, 64]
     assert res["shards_differ"] is True                    # rank 1 did not work on rank 0's frames
-    assert sh[0]["corner_checksum"] != sh[1]["corner_checksum"] and min(x["corners"] for x in sh) >= 64 * 100
+    assert sh[0]["corner_checksum"] != sh[1]["corner_checksum"] and min(x["corners"] for x in sh) >= 64 * 50   # (640x480: ~63 candidates per frame at level 3)
     assert res["shards_verified_by_rerender"] is True       # ... but on frames 64..127 of the global batch
     e = res["end_to_end"]
     assert e["ranks"] == 2 and len(e["h2d_GBs_per_rank"]) == 2 and min(e["h2d_GBs_per_rank"]) > 0
