@@ -141,6 +141,7 @@ struct mrgingham_amd_ctx {
     int cap_shift = 7;
     int grown_shift[mrg::kMaxLevel + 1];
     bool use_v0 = false;  // reference-shaped ChESS kernel instead of the tuned one
+    int chess_variant = 0;  // 16: the plain response (no hot list) through chess_v16_kernel (chess16.hip)
     // levels 3..1 of a chain in one launch (set_option "multi_level_launch"): +1.5 % chain rate, but the
     // component chains then start later and overlap the level-0 launch more (+5 % on that launch): off
     // chain_batch: 0 = one ChESS launch per level; 1 = levels 3..1 in one launch (default: two kernel
@@ -497,7 +498,8 @@ static void launch_chess_any(mrgingham_amd_ctx* ctx, const LevelBatch& lb, const
         if (ctx->use_v0) launch_chess_v0(lb, t, 0, n, clamp, hot, s);
         else
 #endif
-            launch_chess(lb, t, 0, n, clamp, hot, s);
+        if (ctx->chess_variant == 16 && !hot && chess16_ok(lb)) launch_chess16(lb, 0, n, clamp, s);
+        else launch_chess(lb, t, 0, n, clamp, hot, s);
     }
     if (e0) {
         hipEventRecord(e1, s);
@@ -897,6 +899,11 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
 #ifdef MRG_EXPERIMENT
     if (!strcmp(name, "chess_v0")) { ctx->use_v0 = value != 0; return 0; }
 #endif
+    if (!strcmp(name, "chess_variant")) {
+        if (value != 0 && value != 16) return MRGINGHAM_AMD_ERR_ARG;
+        ctx->chess_variant = value;
+        return 0;
+    }
     if (!strcmp(name, "multi_level_launch")) { ctx->multi_level = value < 0 ? 0 : value > 2 ? 2 : value; return 0; }
 #ifdef MRG_EXPERIMENT
     if (!strcmp(name, "cc_schedule")) { ctx->cc_schedule = value; return 0; }

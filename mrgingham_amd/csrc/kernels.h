@@ -36,6 +36,10 @@ extern int chess_stage_override;
 extern int chess_multi_min_blocks;
 extern int pyramid_lds_pad;
 
+// chess16.hip: the response with sixteen pixels per lane (widths that are multiples of 16; no hot list)
+bool chess16_ok(const LevelBatch& lb);
+void launch_chess16(const LevelBatch& lb, int frame0, int nframes, bool clamp, hipStream_t s);
+
 // decimate.hip
 struct FrameBatch {
     const uint8_t* frames;
