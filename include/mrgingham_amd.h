@@ -368,6 +368,24 @@ int mrgingham_amd_find_boards_submit(mrgingham_amd_ctx* ctx, const mrgingham_amd
                                      int nthreads);
 int mrgingham_amd_find_boards_collect(mrgingham_amd_ctx* ctx, int ticket);
 
+/* Where the find_boards calls of this context spent their HOST time since the last reset, and what their grid-finder
+ * threads did (the reference's find_grid_from_points, mrgingham.cc:51, is the host part of the product call; on a busy
+ * batch it is what bounds it).  out[0 .. n) receives up to MRGINGHAM_AMD_FB_STATS doubles:
+ *   [0] batches submitted   [1] host threads of the most recent batch (grid-finder workers + the calling thread)
+ *   host milliseconds, totals over the batches:
+ *   [2] submit: checks + scratch   [3] submit: the previous batch's host part begun (waits for its first device pass)
+ *   [4] submit: this batch's device passes queued   [5] host part: grid finder joined (wall time the caller waits)
+ *   [6] host part: refinement queued   [7] collect: wait for the refinement   [8] collect: boards copied
+ *   grid finder, summed over the threads:
+ *   [9] calls   [10] calls that found a grid   microseconds in [11] neighbour graph (sort, Delaunay, site rings)
+ *   [12] adjacency lists   [13] sequence-candidate search   [14] outer edges, 4-cycles, rows
+ * Completes the batches in flight first (they stay collectable).  Returns MRGINGHAM_AMD_FB_STATS, or an error code. */
+#define MRGINGHAM_AMD_FB_STATS 15
+int mrgingham_amd_find_boards_stats(mrgingham_amd_ctx* ctx, double* out, int n, int reset);
+/* The same clock of the CALLING thread's own mrgingham_amd_find_grid_from_points* calls (host only, no device):
+ * out6 = calls, found, then the four microsecond sums. */
+int mrgingham_amd_grid_clock(double* out6, int reset);
+
 /* TEST HOOK: which implementation of the component search handled each frame of the most recent call at
  * `level`: h_paths[f] = 1 out of LDS, 0 the global-memory kernels (hot pixels that cannot be cut into bands
  * of at most 2048, more than 512 multi-pixel components per band / points, or more LIFO demand than the LDS

@@ -141,7 +141,7 @@ struct mrgingham_amd_ctx {
     int cap_shift = 7;
     int grown_shift[mrg::kMaxLevel + 1];
     bool use_v0 = false;  // reference-shaped ChESS kernel instead of the tuned one
-    int chess_variant = 0;  // 16: the plain response (no hot list) through chess_v16_kernel (chess16.hip)
+    int chess_variant = 0;  // the response without a hot list: 0 = chess_v16_kernel (chess16.hip) where it pays, 1 = chess_v1 always, 16 = chess_v16 wherever it can run
     // levels 3..1 of a chain in one launch (set_option "multi_level_launch"): +1.5 % chain rate, but the
     // component chains then start later and overlap the level-0 launch more (+5 % on that launch): off
     // chain_batch: 0 = one ChESS launch per level; 1 = levels 3..1 in one launch (default: two kernel
@@ -204,6 +204,7 @@ struct mrgingham_amd_ctx {
         std::atomic<int> next{0};
         bool grid_running = false;
         int nworkers = 0;
+        mrgingham_amd_ctx* owner = nullptr;
     } jobs[kMaxSets];
     // mrgingham_amd_chain_multi: this context's shard of the outputs before it travels to the first context's device
     mrg::DevBuf mg_pts, mg_lv, mg_np;
@@ -213,10 +214,13 @@ struct mrgingham_amd_ctx {
     int next_ticket = 0;
     std::vector<std::pair<int, int>> done_tickets;  // (ticket, status) of jobs completed before they were collected
     int fb_pipeline = 1;  // option "find_boards_pipeline"
-#ifdef MRG_EXPERIMENT
-    double fb_prof[10] = {};  // host milliseconds by phase of submit / collect (printed by destroy; tools/find_boards_bench.py)
+    // mrgingham_amd_find_boards_stats: host milliseconds by phase of submit / collect, batches, and what the grid-finder
+    // threads did (their thread-local clocks, grid.h, added up under the mutex when a worker leaves)
+    double fb_prof[10] = {};
     long fb_prof_n = 0;
-#endif
+    int fb_threads_used = 0;
+    std::mutex fb_stat_mu;
+    mrg::GridPhaseClock fb_grid{0, 0, 0, 0, 0, 0};
     int pts_nframes = 0, pts_pitch = 0;
     // levels (and frame counts) whose status words must be checked at the next sync
     int pending_frames[kMaxSets][mrg::kMaxLevel + 1] = {};
@@ -498,7 +502,7 @@ static void launch_chess_any(mrgingham_amd_ctx* ctx, const LevelBatch& lb, const
         if (ctx->use_v0) launch_chess_v0(lb, t, 0, n, clamp, hot, s);
         else
 #endif
-        if (ctx->chess_variant == 16 && !hot && chess16_ok(lb)) launch_chess16(lb, 0, n, clamp, s);
+        if (!hot && ((ctx->chess_variant == 0 && chess16_pays(lb, n)) || (ctx->chess_variant == 16 && chess16_ok(lb)))) launch_chess16(lb, 0, n, clamp, s);
         else launch_chess(lb, t, 0, n, clamp, hot, s);
     }
     if (e0) {
@@ -791,6 +795,36 @@ mrgingham_amd_ctx* mrgingham_amd_create(int device_ordinal) {
     return ctx;
 }
 
+int mrgingham_amd_find_boards_stats(mrgingham_amd_ctx* ctx, double* out, int n, int reset) {
+    if (!ctx || !out || n < 0) return MRGINGHAM_AMD_ERR_ARG;
+    fb_drain(ctx);
+    double v[MRGINGHAM_AMD_FB_STATS] = {};
+    {
+        std::lock_guard<std::mutex> lk(ctx->fb_stat_mu);
+        v[0] = (double)ctx->fb_prof_n;
+        v[1] = (double)ctx->fb_threads_used;
+        for (int i = 0; i < 7; ++i) v[2 + i] = ctx->fb_prof[i];
+        v[9] = (double)ctx->fb_grid.calls; v[10] = (double)ctx->fb_grid.found;
+        v[11] = ctx->fb_grid.graph_us; v[12] = ctx->fb_grid.adjacency_us; v[13] = ctx->fb_grid.sequences_us; v[14] = ctx->fb_grid.cycles_us;
+        if (reset) {
+            for (double& x : ctx->fb_prof) x = 0;
+            ctx->fb_prof_n = 0;
+            ctx->fb_grid = GridPhaseClock{0, 0, 0, 0, 0, 0};
+        }
+    }
+    for (int i = 0; i < n && i < MRGINGHAM_AMD_FB_STATS; ++i) out[i] = v[i];
+    return MRGINGHAM_AMD_FB_STATS;
+}
+
+int mrgingham_amd_grid_clock(double* out6, int reset) {
+    if (!out6) return MRGINGHAM_AMD_ERR_ARG;
+    GridPhaseClock& c = g_grid_clock;
+    out6[0] = (double)c.calls; out6[1] = (double)c.found; out6[2] = c.graph_us; out6[3] = c.adjacency_us;
+    out6[4] = c.sequences_us; out6[5] = c.cycles_us;
+    if (reset) c = GridPhaseClock{0, 0, 0, 0, 0, 0};
+    return 0;
+}
+
 void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx) {
     if (!ctx) return;
 #ifdef MRG_EXPERIMENT
@@ -900,10 +934,11 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
     if (!strcmp(name, "chess_v0")) { ctx->use_v0 = value != 0; return 0; }
 #endif
     if (!strcmp(name, "chess_variant")) {
-        if (value != 0 && value != 16) return MRGINGHAM_AMD_ERR_ARG;
+        if (value != 0 && value != 1 && value != 16) return MRGINGHAM_AMD_ERR_ARG;
         ctx->chess_variant = value;
         return 0;
     }
+    if (!strcmp(name, "chess16_seg")) { mrg::chess16_seg_override = value > 0 ? (value + 15) / 16 * 16 : 0; return 0; }
     if (!strcmp(name, "multi_level_launch")) { ctx->multi_level = value < 0 ? 0 : value > 2 ? 2 : value; return 0; }
 #ifdef MRG_EXPERIMENT
     if (!strcmp(name, "cc_schedule")) { ctx->cc_schedule = value; return 0; }
@@ -2568,14 +2603,10 @@ static int find_boards_sync_levels(mrgingham_amd_ctx* ctx, const mrgingham_amd_f
 // same device, which leaves the jobs in flight alone.  Results are the synchronous dense schedule's, double for double.
 
 static int fb_complete(mrgingham_amd_ctx* ctx, mrgingham_amd_ctx::BoardsJob& job);
-#ifdef MRG_EXPERIMENT
+// phase clock of the find_boards calls (a dozen clock reads per batch; mrgingham_amd_find_boards_stats)
 static double fb_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 #define FB_LAP(i) do { const double t_ = fb_now(); ctx->fb_prof[i] += t_ - fb_t; fb_t = t_; } while (0)
 #define FB_T0 double fb_t = fb_now()
-#else
-#define FB_LAP(i) do { } while (0)
-#define FB_T0 do { } while (0)
-#endif
 
 static size_t fb_align(size_t v) { return (v + 255) & ~(size_t)255; }
 struct FbPinned { int32_t *cnt, *xy; double* pts; signed char* lv; int32_t *np, *st; size_t bytes; };
@@ -2601,6 +2632,18 @@ static void fb_grid_worker(mrgingham_amd_ctx::BoardsJob* job) {
     const FbPinned pin = fb_layout(job->pin, nlev, B, cap, N);
     std::vector<PointI> cand;
     std::vector<PointD> board;
+    const GridPhaseClock c0 = g_grid_clock;
+    struct Leave {   // this thread's share of the batch's grid-finder time into the context's totals
+        mrgingham_amd_ctx* ctx; GridPhaseClock c0;
+        ~Leave() {
+            if (!ctx) return;
+            const GridPhaseClock& c = g_grid_clock;
+            std::lock_guard<std::mutex> lk(ctx->fb_stat_mu);
+            ctx->fb_grid.graph_us += c.graph_us - c0.graph_us; ctx->fb_grid.adjacency_us += c.adjacency_us - c0.adjacency_us;
+            ctx->fb_grid.sequences_us += c.sequences_us - c0.sequences_us; ctx->fb_grid.cycles_us += c.cycles_us - c0.cycles_us;
+            ctx->fb_grid.calls += c.calls - c0.calls; ctx->fb_grid.found += c.found - c0.found;
+        }
+    } leave{job->owner, c0};
     for (int k; (k = job->next.fetch_add(1)) < B;) {
         for (int li = 0; li < nlev; ++li) {
             const int n = pin.cnt[(size_t)li * B + k];
@@ -2657,6 +2700,8 @@ static int fb_host_begin(mrgingham_amd_ctx* ctx, mrgingham_amd_ctx::BoardsJob& j
     const int nthreads = fb_threads(job.nthreads);
     job.next.store(0);
     job.nworkers = (nthreads < B ? nthreads : B) - 1;  // + the calling thread, in fb_host_end
+    job.owner = ctx;
+    ctx->fb_threads_used = job.nworkers + 1;
     mrgingham_amd_ctx::BoardsJob* jp = &job;
     if (job.nworkers > 0) {
         ctx->pool.start(job.nworkers, [jp] { fb_grid_worker(jp); });

@@ -17,18 +17,18 @@
 #include "common.h"
 #include "kernels.h"
 
+
 namespace mrg {
 
 namespace v16 {
 
 constexpr int SW = 256;                 // strip width, output pixels
-constexpr int HL = 16;                  // left halo of the LDS window
-constexpr int WIN = SW + 2 * HL;        // 288
-constexpr int NCH = WIN / 16;           // 18 staging chunks per row
-constexpr int ROWB = WIN * 2 + 16;      // 592 bytes per row and plane
+constexpr int HL = 8;                   // halo of the LDS window on either side
+constexpr int WIN = SW + 2 * HL;        // 272
+constexpr int ROWB = WIN * 2 + 16;      // 560 bytes per row and plane: 35 sixteen-byte slots, an ODD number
 constexpr int NR = 44;                  // ring rows
 constexpr int RB = 16;                  // rows per iteration
-constexpr int PLANE = NR * ROWB;        // 26048
+constexpr int PLANE = NR * ROWB;        // 24640
 constexpr int RING = NR * ROWB;         // bytes of one plane's ring (wrap length)
 
 using u16x2 = unsigned short __attribute__((ext_vector_type(2)));
@@ -38,12 +38,20 @@ using u32x4 = uint32_t __attribute__((ext_vector_type(4)));
 
 __device__ u32x4 raw_buffer_load_b128(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4i32");
 __device__ unsigned char buffer_load_u8(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.i8");
+// two bytes -> one register of two u16 (the texture unit unpacks: 8_8 UINT elements, any byte address, 0 out of range)
+__device__ u16x2 buffer_load_u8x2_as_u16x2(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.format.v2i16");
 __device__ void raw_buffer_store_b128(u32x4 data, i32x4 rsrc, int voffset, int soffset, int aux)
     __asm("llvm.amdgcn.raw.buffer.store.v4i32");
 constexpr int kAuxNT = 2;
 __device__ __forceinline__ i32x4 raw_rsrc(const void* base, uint32_t bytes) {
     const uint64_t a = (uint64_t)base;
     return i32x4{(int)(uint32_t)a, (int)(uint32_t)(a >> 32), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ i32x4 typed88_rsrc(const void* base, uint32_t bytes) {
+    // word 3: dst_sel x, y = R, G (4, 5), z, w = 0; num_format UINT (4) << 12; data_format 8_8 (3) << 15
+    constexpr uint32_t w3 = (4u | (5u << 3)) | (4u << 12) | (3u << 15);
+    const uint64_t a = (uint64_t)base;
+    return i32x4{(int)(uint32_t)a, (int)(uint32_t)(a >> 32), (int)bytes, (int)w3};
 }
 
 __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
@@ -60,21 +68,13 @@ __device__ __forceinline__ uint32_t pk_sub_sat_u16(uint32_t a, uint32_t b) {
 }
 
 struct StageRegs {
-    uint4 g;
-    uint32_t next;
+    uint4 g;        // 16 pixels of the strip
+    uint32_t next;  // byte 0 = the pixel after them
+    uint32_t halo;  // one pair of the 8-pixel halo, already as two u16
 };
 
-__device__ __forceinline__ StageRegs stage_load_clamped(const uint8_t* img, int stride, int h, int r, int gx_c, int nx_c) {
-    StageRegs s;
-    const int rc = min(max(r, 0), h - 1);
-    const uint8_t* row = img + (long long)rc * stride;
-    __builtin_memcpy(&s.g, row + gx_c, 16);
-    s.next = row[nx_c];
-    return s;
-}
-
 // 16 bytes -> the P0 and P1 entries of the chunk (as chess_v1's stage_store), at byte offset `off` of plane P0
-__device__ __forceinline__ void stage_store(char* lds, uint32_t off, const StageRegs& s) {
+__device__ __forceinline__ void stage_store(char* lds, uint32_t off, uint32_t hoff, const StageRegs& s) {
     const uint32_t g0 = s.g.x, g1 = s.g.y, g2 = s.g.z, g3 = s.g.w;
     constexpr uint32_t S01 = 0x0c010c00u, S23 = 0x0c030c02u, S12 = 0x0c020c01u, S34 = 0x0c040c03u;
     uint4 a, b, c, d;
@@ -91,6 +91,7 @@ __device__ __forceinline__ void stage_store(char* lds, uint32_t off, const Stage
     *reinterpret_cast<uint4*>(p + 16) = b;
     *reinterpret_cast<uint4*>(p + PLANE) = c;
     *reinterpret_cast<uint4*>(p + PLANE + 16) = d;
+    *reinterpret_cast<uint32_t*>(lds + hoff) = s.halo;
 }
 
 __device__ __forceinline__ u32x4 lds_read_b128(const char* p) {
@@ -158,28 +159,39 @@ __global__ __launch_bounds__(256, 3) void chess_v16_kernel(LevelBatch lb, int fr
     const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, jx = lane & 15;
 
-    // staging tasks: task t = row t / 18 of the group, chunk t % 18; thread tid takes task tid, wave 0 also tasks 256..287
-    // (both of its half-waves the same 32: the branch is wave-uniform)
-    const int t0 = tid, t1 = 256 + (lane & 31);
-    const int r0 = t0 / NCH, c0 = t0 - r0 * NCH, r1 = t1 / NCH, c1 = t1 - r1 * NCH;
-    auto gxc = [&](int ch) { return min(max(strip_x - HL + 16 * ch, 0), max(w - 16, 0)); };
-    auto nxc = [&](int ch) { return min(max(strip_x - HL + 16 * ch + 16, 0), w - 1); };
-    const int g0x = gxc(c0), n0x = nxc(c0), g1x = gxc(c1), n1x = nxc(c1);
-    const i32x4 img_rsrc = raw_rsrc(img, (uint32_t)min((long long)(h - 1) * stride + w, 0xffffffffLL));
-    const int v0g = r0 * stride + g0x, v0n = r0 * stride + n0x, v1g = r1 * stride + g1x, v1n = r1 * stride + n1x;
-    // ring byte offset (plane P0) of the thread's task rows: row r of the frame lives in slot (r - ys) mod 44
+    // Staging, the same for every thread (16 rows per group):
+    //   one 16-pixel chunk of the strip: row tid / 16, chunk tid % 16 (a 16-byte load + the byte after it, v_perm into
+    //   the two planes, four ds_write_b128);
+    //   one pixel pair of the 8-pixel halo on either side: row tid / 16, then side | plane | pair in tid % 16 (a typed
+    //   two-byte load that arrives as two u16 = the plane's entry as it is, one ds_write_b32).  Out-of-range offsets
+    //   (columns left of the frame, rows above and below it) read 0: such pixels only reach outputs that are masked.
+    const int trow = tid >> 4, tch = tid & 15;
+    const int hside = (tid >> 3) & 1, hplane = (tid >> 2) & 1, hpair = tid & 3;
+    const uint32_t fbytes = (uint32_t)min((long long)(h - 1) * stride + w, 0x7fffffffLL);
+    const i32x4 img_rsrc = raw_rsrc(img, fbytes);
+    const i32x4 img88 = typed88_rsrc(img, fbytes);
+    const int vg = trow * stride + strip_x + 16 * tch;                       // + first row of the group * stride
+    const int vn = trow * stride + min(strip_x + 16 * tch + 16, w - 1);
+    const int vh = trow * stride + strip_x + (hside ? SW : -HL) + 2 * hpair + hplane;
+    const uint32_t chunk_col = (uint32_t)(2 * HL + 32 * tch);                // byte offset of the chunk within a row of P0
+    const uint32_t halo_col = (uint32_t)((hside ? 2 * (SW + HL) : 0) + 4 * hpair + hplane * PLANE);
+    auto stage_load = [&](int row0) {
+        StageRegs s;
+        const int rowoff = row0 * stride;
+        s.g = __builtin_bit_cast(uint4, raw_buffer_load_b128(img_rsrc, vg + rowoff, 0, 0));
+        s.next = buffer_load_u8(img_rsrc, vn + rowoff, 0, 0);
+        s.halo = __builtin_bit_cast(uint32_t, buffer_load_u8x2_as_u16x2(img88, vh + rowoff, 0, 0));
+        return s;
+    };
+    // ring byte offset (plane P0) of frame row ys + rel: slot (rel mod 44)
     auto slot_off = [&](int rel) { return (uint32_t)(((rel % NR) + NR) % NR) * ROWB; };
 
     // prologue: rows ys - 11 .. ys + 20 (two groups of 16; the first six are never read)
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const int rel = -11 + RB * g;
-        const StageRegs a = stage_load_clamped(img, stride, h, ys + rel + r0, g0x, n0x);
-        stage_store(lds, slot_off(rel + r0) + c0 * 32, a);
-        if (wvu == 0) {
-            const StageRegs b = stage_load_clamped(img, stride, h, ys + rel + r1, g1x, n1x);
-            stage_store(lds, slot_off(rel + r1) + c1 * 32, b);
-        }
+    {
+        const StageRegs a = stage_load(ys - 11), b = stage_load(ys + 5);
+        const uint32_t oa = slot_off(-11 + trow), ob = slot_off(5 + trow);
+        stage_store(lds, oa + chunk_col, oa + halo_col, a);
+        stage_store(lds, ob + chunk_col, ob + halo_col, b);
     }
     __syncthreads();
 
@@ -193,7 +205,7 @@ __global__ __launch_bounds__(256, 3) void chess_v16_kernel(LevelBatch lb, int fr
         if (CLAMP) xmask[k] = (ina ? 0x2000u : 0xffffu) | (inb ? 0x20000000u : 0xffff0000u);
         else xmask[k] = (ina ? 0xffffu : 0u) | (inb ? 0xffff0000u : 0u);
     }
-    const uint32_t lane_col = 16u + 32u * jx;  // D[-4] of the lane within a row
+    const uint32_t lane_col = 32u * jx;  // D[-4] of the lane within a row: pixel x0 - 8 = window pixel 16 jx
     // dy classes c = dy mod 4: the lane's row is row (c + q) & 3 of group B (c + q < 4) or of the group after it
     uint32_t LC[4], MK[4];
 #pragma unroll
@@ -204,22 +216,13 @@ __global__ __launch_bounds__(256, 3) void chess_v16_kernel(LevelBatch lb, int fr
     const bool seg_interior = ys >= kMargin && ye <= h - kMargin;
     const i32x4 resp_rsrc = raw_rsrc(resp, (uint32_t)min((long long)w * h * 2, 0xffffffffLL));
     const int st_resp_voff = (q * w + x0) * 2;
-    // running ring offsets of the staging tasks' rows (rows y + 21 + r of iteration y)
-    uint32_t so0 = slot_off(21 + r0) + c0 * 32, so1 = slot_off(21 + r1) + c1 * 32;
+    // running ring offset of the staging row (row y + 21 + trow of iteration y)
+    uint32_t so = slot_off(21 + trow);
 
     int am = 4 * wvu;  // (y - ys + 4 * wave) mod 44: the ring slot of the wave's first row, a multiple of 4
     for (int y = ys; y < ye; y += RB) {
         // prefetch rows y + 21 .. y + 36 (needed by the next iteration)
-        StageRegs pre0, pre1;
-        {
-            const int rowoff = (y + 21) * stride;
-            pre0.g = __builtin_bit_cast(uint4, raw_buffer_load_b128(img_rsrc, v0g + rowoff, 0, 0));
-            pre0.next = buffer_load_u8(img_rsrc, v0n + rowoff, 0, 0);
-            if (wvu == 0) {
-                pre1.g = __builtin_bit_cast(uint4, raw_buffer_load_b128(img_rsrc, v1g + rowoff, 0, 0));
-                pre1.next = buffer_load_u8(img_rsrc, v1n + rowoff, 0, 0);
-            }
-        }
+        const StageRegs pre = stage_load(y + 21);
 
         // window rows: wave-uniform group offsets (the aligned groups of four rows that start -8, -4, 0, +4, +8 rows from the
         // wave's own group), per-lane choice between a group and the next by mask
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(256, 3) void chess_v16_kernel(LevelBatch lb, int fr
             if (c == 0) return lds + (LC[0] + goff[gi] + (uint32_t)plane);
             return lds + (LC[c] + goff[gi] + (uint32_t)plane + (MK[c] & (goff[gi + 1] - goff[gi])));
         };
-        uint32_t m5[16], p5[16], m4[16], p4[16], m2[16], p2[16], z1[16];
+        uint32_t m5[16], p5[16], m4[16], p4[16], m2[16], p2[16], z1[16], z0[8];
         load16(m5, row_ptr(-5, 0));
         load16(p5, row_ptr(+5, 0));
         load16(m4, row_ptr(-4, 0));
@@ -245,16 +248,19 @@ __global__ __launch_bounds__(256, 3) void chess_v16_kernel(LevelBatch lb, int fr
         load16(m2, row_ptr(-2, PLANE));
         load16(p2, row_ptr(+2, PLANE));
         load16(z1, row_ptr(0, PLANE));
-        const char* rz = row_ptr(0, 0);
-        const u32x4 z0a = lds_read_b128(rz + 16), z0b = lds_read_b128(rz + 32);
-        const uint32_t z0[8] = {z0a.x, z0a.y, z0a.z, z0a.w, z0b.x, z0b.y, z0b.z, z0b.w};
+        {
+            const char* rz = row_ptr(0, 0);
+            const u32x4 z0a = lds_read_b128(rz + 16), z0b = lds_read_b128(rz + 32);
+            z0[0] = z0a.x; z0[1] = z0a.y; z0[2] = z0a.z; z0[3] = z0a.w;
+            z0[4] = z0b.x; z0[5] = z0b.y; z0[6] = z0b.z; z0[7] = z0b.w;
+        }
 
         const int yy = y + 4 * wvu + q;
         uint32_t out[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const uint32_t P = response_pair_biased(m5, p5, m4, p4, m2, p2, z1, z0, k);
-            if (CLAMP) out[k] = pk_sub_sat_u16(P, xmask[k]);
+            if (CLAMP) out[k] = pk_sub_sat_u16(P, xmask[k]);  // max(r, 0), 0 in the frame columns (chess.hip)
             else out[k] = pk_sub_i16(P, 0x20002000u) & xmask[k];
         }
         if (!seg_interior) {
@@ -264,14 +270,11 @@ __global__ __launch_bounds__(256, 3) void chess_v16_kernel(LevelBatch lb, int fr
         }
 
         // ring first, results second (chess.hip)
-        stage_store(lds, so0, pre0);
-        so0 += RB * ROWB;
-        if (so0 >= (uint32_t)RING) so0 -= RING;
-        if (wvu == 0) {
-            stage_store(lds, so1, pre1);
-            so1 += RB * ROWB;
-            if (so1 >= (uint32_t)RING) so1 -= RING;
-        }
+        __builtin_amdgcn_s_setprio(2);  // (-10 us of 636 on the launch, A/B)
+        stage_store(lds, so + chunk_col, so + halo_col, pre);
+        __builtin_amdgcn_s_setprio(0);
+        so += RB * ROWB;
+        if (so >= (uint32_t)RING) so -= RING;
         if (yy < ye && x0 < w) {
             const u32x4 va = {out[0], out[1], out[2], out[3]}, vb = {out[4], out[5], out[6], out[7]};
             const int soff = (int)((uint32_t)(y + 4 * wvu) * (uint32_t)w * 2u);
@@ -286,13 +289,40 @@ __global__ __launch_bounds__(256, 3) void chess_v16_kernel(LevelBatch lb, int fr
     }
 }
 
+int chess16_seg_override = 0;  // option "chess16_seg"
+
 bool chess16_ok(const LevelBatch& lb) {
-    return lb.w >= 16 && lb.w % 16 == 0 && lb.h > 0 && (long long)(lb.h + 64) * lb.img_stride < 0x7fffffffLL &&
+    return lb.w >= 16 && lb.w % 16 == 0 && lb.h > 0 && ((uintptr_t)lb.img & 3) == 0 && lb.img_stride % 4 == 0 && lb.img_pitch % 4 == 0 && (long long)(lb.h + 64) * lb.img_stride < 0x7fffffffLL &&
            (long long)lb.w * lb.h * 2 < 0x7fffffffLL;
 }
 
+// Rows per workgroup (multiples of 16).  Cost model fitted to measured launches (tools/chess16_sweep.py, 64 frames, 512x384 ..
+// 4096x3072): a segment costs its rows + ~22 rows for the 32-row prologue, the chip runs 768 workgroups at a time (three per
+// CU), and the launch drains over about 0.6 of half a workgroup's run time.
+static int pick_segment16(int w, int h, int nframes) {
+    if (chess16_seg_override > 0) return chess16_seg_override;
+    const long long strips = (w + v16::SW - 1) / v16::SW;
+    int best = 1024;
+    double best_cost = 0;
+    for (int seg : {1024, 512, 256, 128, 64}) {
+        const int nsegs = (h + seg - 1) / seg;
+        const double cost = (double)strips * nframes * (h + 22.0 * nsegs) / 768.0 + 0.6 * ((seg < h ? seg : h) + 22.0) / 2.0;
+        if (seg == 1024 || cost < 0.99 * best_cost) {
+            best = seg;
+            best_cost = cost;
+        }
+    }
+    return best;
+}
+
+// enough workgroups for the three-per-CU kernel to be worth it (below that chess_v1's shorter segments fill the chip better)
+bool chess16_pays(const LevelBatch& lb, int nframes) {
+    const long long strips = (lb.w + v16::SW - 1) / v16::SW;
+    return chess16_ok(lb) && strips * nframes * ((lb.h + 63) / 64) >= 256;
+}
+
 void launch_chess16(const LevelBatch& lb, int frame0, int nframes, bool clamp, hipStream_t s) {
-    const int seg = 256;
+    const int seg = pick_segment16(lb.w, lb.h, nframes);
     dim3 grid(((lb.w + v16::SW - 1) / v16::SW) * ((lb.h + seg - 1) / seg) * nframes);
     const size_t lds = 2 * v16::PLANE;
     if (clamp) hipLaunchKernelGGL(chess_v16_kernel<true>, grid, dim3(256), lds, s, lb, frame0, seg);

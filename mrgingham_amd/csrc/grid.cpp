@@ -24,6 +24,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include <sys/stat.h>
@@ -40,6 +41,7 @@ namespace mrg {
 thread_local GridDebugSequence g_grid_debug_sequence = {false, 0, 0};
 thread_local bool g_grid_debug = false;
 thread_local GridPerturbation g_grid_perturbation{0u, false};
+thread_local GridPhaseClock g_grid_clock = {0, 0, 0, 0, 0, 0};
 
 namespace {
 
@@ -670,14 +672,41 @@ void dump_sequences(const char* base, const std::vector<Sequence>& seq, const st
 
 }  // namespace
 
+static bool find_grid_impl(std::vector<PointD>& out, const std::vector<PointI>& pts, int gridn, double (&lap)[4]);
+
 bool find_grid_from_points(std::vector<PointD>& out, const std::vector<PointI>& pts, int gridn) {
+    double lap[4] = {0, 0, 0, 0};
+    const bool ok = find_grid_impl(out, pts, gridn, lap);
+    GridPhaseClock& c = g_grid_clock;
+    c.graph_us += lap[0]; c.adjacency_us += lap[1]; c.sequences_us += lap[2]; c.cycles_us += lap[3];
+    c.calls++;
+    c.found += ok;
+    return ok;
+}
+
+static bool find_grid_impl(std::vector<PointD>& out, const std::vector<PointI>& pts, int gridn, double (&lap)[4]) {
+    using clk = std::chrono::steady_clock;
+    struct Lap {   // adds the time since the last mark to lap[i]; the destructor closes the phase that was running
+        double (&lap)[4];
+        int cur = 0;
+        clk::time_point t = clk::now();
+        void to(int next) {
+            const clk::time_point n = clk::now();
+            lap[cur] += std::chrono::duration<double, std::micro>(n - t).count();
+            t = n;
+            cur = next;
+        }
+        ~Lap() { to(cur); }
+    } phase{lap};
     const bool debug = g_grid_debug;
     if (gridn < 2 || (int)pts.size() < gridn * gridn) return false;
     SiteGraph g;
     if (!build_site_graph(pts, g)) return false;
+    phase.to(1);
 
     // get_sequence_candidates, :502-569
     const AdjLists adj = build_adjacency(g, pts);
+    phase.to(2);
     if (debug) dump_graph(adj, g.order, pts);
     std::vector<Sequence> seq;
     // --debug-sequence (:515-539): the candidate nearest to the given pixel is traced
@@ -720,6 +749,7 @@ bool find_grid_from_points(std::vector<PointD>& out, const std::vector<PointI>& 
         fprintf(stderr, "got %zd points\n", pts.size());
         fprintf(stderr, "got %zd sequence candidates\n", seq.size());
     }
+    phase.to(3);
     // outer-edge candidates: sequences whose start site starts at least two sequences (:1246-1262)
     const int nsites = (int)pts.size();
     std::vector<int> started((size_t)nsites, 0);

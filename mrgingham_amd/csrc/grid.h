@@ -23,6 +23,13 @@ extern thread_local GridDebugSequence g_grid_debug_sequence;
 // on stderr what it found or why it gave up.  Thread-local: set around the call.
 extern thread_local bool g_grid_debug;
 
+// Where the calling thread's find_grid_from_points calls spent their time (a handful of clock reads per call): the
+// neighbour graph (sort + Delaunay sweep + site rings), the adjacency lists in the reference's visiting order, the
+// sequence-candidate search, and everything after it (outer edges, 4-cycles, rows).  Thread-local; the find_boards
+// calls add their workers' clocks up (mrgingham_amd_find_boards_stats).
+struct GridPhaseClock { double graph_us, adjacency_us, sequences_us, cycles_us; long calls, found; };
+extern thread_local GridPhaseClock g_grid_clock;
+
 // visiting-order perturbations for the insensitivity tests (see grid.cpp); thread-local, default off
 struct GridPerturbation { unsigned ring_seed; bool last_match; };
 extern thread_local GridPerturbation g_grid_perturbation;

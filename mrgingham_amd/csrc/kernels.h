@@ -38,7 +38,10 @@ extern int pyramid_lds_pad;
 
 // chess16.hip: the response with sixteen pixels per lane (widths that are multiples of 16; no hot list)
 bool chess16_ok(const LevelBatch& lb);
+bool chess16_pays(const LevelBatch& lb, int nframes);
 void launch_chess16(const LevelBatch& lb, int frame0, int nframes, bool clamp, hipStream_t s);
+
+extern int chess16_seg_override;
 
 // decimate.hip
 struct FrameBatch {

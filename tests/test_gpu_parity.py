@@ -82,6 +82,60 @@ def test_chess_batch_raw_and_clamped(det, shape):
         assert np.array_equal(cl[f], np.maximum(ref, 0)), (shape, f)
 
 
+@pytest.mark.parametrize("variant", [1, 16])
+@pytest.mark.parametrize("shape", [(16, 80), (40, 16), (48, 64), (300, 272), (480, 640), (777, 1008), (1080, 1920)])
+def test_chess_both_response_kernels(det, shape, variant):
+    """The response without a hot list has two kernels: chess_v1_kernel (8 pixels per lane, chess.hip) and, for widths
+    that are multiples of 16, chess_v16_kernel (16 pixels per lane, chess16.hip: the default where the batch is large
+    enough).  Each forced in turn (option chess_variant 1 / 16), raw and clamped, against the oracle; segment heights
+    from one iteration to more rows than the frame has."""
+    h, w = shape
+    rng = np.random.RandomState(h * 11 + w + variant)
+    frames = rng.randint(0, 256, size=(3, h, w)).astype(np.uint8)
+    if h >= 240:
+        frames[1] = synth.board_frame(w, h, 10, 1).numpy()
+    d = _cuda(frames)
+    ref = [oracle.chess_response_5(frames[f], fill=0) for f in range(3)]
+    det.set_option("chess_variant", variant)
+    try:
+        for seg in ((0,) if variant == 1 else (0, 16, 64, 2048)):
+            if variant == 16:
+                det.set_option("chess16_seg", seg)
+            raw = det.chess_response(d, 0, clamp=False).cpu().numpy()
+            cl = det.chess_response(d, 0, clamp=True).cpu().numpy()
+            for f in range(3):
+                assert np.array_equal(raw[f], ref[f]), (shape, variant, seg, f)
+                assert np.array_equal(cl[f], np.maximum(ref[f], 0)), (shape, variant, seg, f)
+    finally:
+        det.set_option("chess_variant", 0)
+        det.set_option("chess16_seg", 0)
+
+
+def test_chess_v16_is_the_default_on_a_large_batch_and_matches_v1(det):
+    """64 frames of 1920x1080 take chess_v16_kernel by default; its output equals chess_v1_kernel's on every pixel (and
+    the oracle's on a sample of frames); strided frames (rows and frames not dense) go through it as well."""
+    frames = synth.board_batch(4, 1920, 1080, 10, 0, device="cuda").repeat(16, 1, 1).contiguous()
+    frames[5] = synth.noise_frame(1920, 1080, seed=2, device="cuda")
+    a = det.chess_response(frames, 0)
+    det.set_option("chess_variant", 1)
+    try:
+        b = det.chess_response(frames, 0)
+    finally:
+        det.set_option("chess_variant", 0)
+    assert torch.equal(a, b)
+    for f in (0, 5, 63):
+        assert np.array_equal(a[f].cpu().numpy(), oracle.chess_response_5(frames[f].cpu().numpy(), fill=0))
+    big = torch.from_numpy(np.random.RandomState(9).randint(0, 256, size=(40, 300, 400)).astype(np.uint8)).cuda()
+    view = big[:, 20:280, 16:336]                       # 320 wide: rows 400 apart, frames 300 * 400 apart
+    det.set_option("chess_variant", 16)
+    try:
+        r = det.chess_response(view, 0).cpu().numpy()
+    finally:
+        det.set_option("chess_variant", 0)
+    for f in (0, 17, 39):
+        assert np.array_equal(r[f], oracle.chess_response_5(np.ascontiguousarray(big[f, 20:280, 16:336].cpu().numpy()), fill=0))
+
+
 def test_chess_strided_device_frames(det):
     rng = np.random.RandomState(5)
     big = rng.randint(0, 256, size=(2, 100, 200)).astype(np.uint8)
