@@ -295,12 +295,19 @@ def find_boards_leg(device_index, frames, gridn, batches=150, depth=3):
                     first = (last[0].copy(), last[1].copy())
         for _ in range(10):
             step()
+        while jobs:
+            det.find_boards_collect(jobs.pop(0))
+        det.find_boards_stats(reset=True)                    # the phase clock starts on an empty pipeline ...
+        for _ in range(depth - 1):                           # ... which is filled again before the timed batches
+            step()
         t0 = time.perf_counter()
         for _ in range(batches):
             step()
         while jobs:
             last = det.find_boards_collect(jobs.pop(0))
         dt = (time.perf_counter() - t0) / batches
+        st = det.find_boards_stats(reset=True)
+        nb = max(st["batches"], 1.0)
         ok = bool(np.array_equal(first[1], want[1]))
         for f in range(len(want[1])):
             if want[1][f] >= 0:
@@ -310,7 +317,25 @@ def find_boards_leg(device_index, frames, gridn, batches=150, depth=3):
                 "one_batch_at_a_time_synchronous_ms": sync_ms, "one_batch_at_a_time_synchronous_frames_per_s": B / (sync_ms / 1e3),
                 "boards_found": int((want[1] >= 0).sum()), "found_at_level": np.bincount(want[1][want[1] >= 0], minlength=4).tolist(),
                 "identical_to_synchronous_dense": ok, "repeated_densely_by_the_library": det.sparse_fallbacks(),
-                "host_threads": "one per core the process may use, at most 32",
+                # what the line is made of (mrgingham_amd_find_boards_stats; per batch of B frames, averaged over the timed batches)
+                "host_threads_used": int(st["host_threads"]),
+                "host_threads_rule": "one per core the process may use (std::thread::hardware_concurrency), at most 32; "
+                                     "cpu quota of this container: %s cores" % ("none" if cpu_quota_cores() is None else "%.0f" % cpu_quota_cores()),
+                "grid_finder_calls_per_frame": st["grid_calls"] / (nb * B),
+                "grid_finder_us_per_call": (st["grid_us_graph"] + st["grid_us_adjacency"] + st["grid_us_sequences"] + st["grid_us_cycles_rows"]) / max(st["grid_calls"], 1.0),
+                "grid_finder_us_per_frame": (st["grid_us_graph"] + st["grid_us_adjacency"] + st["grid_us_sequences"] + st["grid_us_cycles_rows"]) / (nb * B),
+                "grid_finder_us_per_call_by_phase": {"neighbour_graph": st["grid_us_graph"] / max(st["grid_calls"], 1.0),
+                                                     "adjacency": st["grid_us_adjacency"] / max(st["grid_calls"], 1.0),
+                                                     "sequences": st["grid_us_sequences"] / max(st["grid_calls"], 1.0),
+                                                     "cycles_rows": st["grid_us_cycles_rows"] / max(st["grid_calls"], 1.0)},
+                "host_part_ms_per_batch": (st["ms_submit_checks"] + st["ms_submit_prev_host_begin"] + st["ms_submit_device_queued"] +
+                                           st["ms_grid_finder_joined"] + st["ms_refinement_queued"] + st["ms_collect_wait_refinement"] +
+                                           st["ms_collect_boards_copied"]) / nb,
+                "host_part_ms_per_batch_by_phase": {k[3:]: st[k] / nb for k in st if k.startswith("ms_")},
+                "grid_finder_cpu_ms_per_batch_over_all_threads": (st["grid_us_graph"] + st["grid_us_adjacency"] + st["grid_us_sequences"] + st["grid_us_cycles_rows"]) / nb / 1e3,
+                "device_part_ms_per_batch": {"first_pass": st["device_ms_first_pass"] / nb, "refinement": st["device_ms_refinement"] / nb,
+                                             "note": "hipEvents; the two run on different streams and overlap each other and the host part"},
+                "bound_by": "host" if (st["ms_grid_finder_joined"] / nb) > 0.5 * dt * 1e3 else "device",
                 "what": "find_boards over the bench frames already in HBM, boards (gridn^2 refined corners per frame) on the host: "
                         "first pass (level images, responses + candidates of levels 3, 2, 1) on the device, grid finder on "
                         "the host threads under the next batch's first pass, refinement out of the cells around the corners"}
@@ -341,7 +366,8 @@ def chess_pass_alone_leg(det, frames, launches=120, warm=10):
     med = per[launches // 2]
     alg = B * W * H * 3.0
     del out
-    return {"kernel": "chess_v1_kernel<CLAMP 0, HOT 0> (plain ChESS response, the output of ChESS.c:56-106)",
+    return {"kernel": "chess_v16_kernel<CLAMP 0> (plain ChESS response, the output of ChESS.c:56-106; sixteen pixels per lane, "
+                      "mrgingham_amd/csrc/chess16.hip: the library's kernel for the response without a hot list)",
             "bytes_model": "3 B/px (u8 read once + int16 written once)", "bytes_per_launch": alg,
             "launches_timed": launches, "avg_launch_ms": avg, "median_launch_ms": med,
             "min_launch_ms": per[0], "p90_launch_ms": per[int(launches * 0.9)],

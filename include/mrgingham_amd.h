@@ -379,8 +379,11 @@ int mrgingham_amd_find_boards_collect(mrgingham_amd_ctx* ctx, int ticket);
  *   grid finder, summed over the threads:
  *   [9] calls   [10] calls that found a grid   microseconds in [11] neighbour graph (sort, Delaunay, site rings)
  *   [12] adjacency lists   [13] sequence-candidate search   [14] outer edges, 4-cycles, rows
+ *   device milliseconds (hipEvents), totals over the batches:
+ *   [15] first pass: from its first kernel on the pixel stream to the candidates on the host (runs behind the pass of the
+ *        batch before it, so in a full pipeline this is the pass's own time)   [16] refinement: boards up, levels, boards down
  * Completes the batches in flight first (they stay collectable).  Returns MRGINGHAM_AMD_FB_STATS, or an error code. */
-#define MRGINGHAM_AMD_FB_STATS 15
+#define MRGINGHAM_AMD_FB_STATS 17
 int mrgingham_amd_find_boards_stats(mrgingham_amd_ctx* ctx, double* out, int n, int reset);
 /* The same clock of the CALLING thread's own mrgingham_amd_find_grid_from_points* calls (host only, no device):
  * out6 = calls, found, then the four microsecond sums. */

@@ -594,6 +594,19 @@ class Detector:
         self._check(self.L.mrgingham_amd_find_boards_collect(self.ctx, job[0]))
         return job[1], job[2]
 
+    FB_STATS = ("batches", "host_threads", "ms_submit_checks", "ms_submit_prev_host_begin", "ms_submit_device_queued",
+                "ms_grid_finder_joined", "ms_refinement_queued", "ms_collect_wait_refinement", "ms_collect_boards_copied",
+                "grid_calls", "grid_found", "grid_us_graph", "grid_us_adjacency", "grid_us_sequences", "grid_us_cycles_rows",
+                "device_ms_first_pass", "device_ms_refinement")
+
+    def find_boards_stats(self, reset=True):
+        """mrgingham_amd_find_boards_stats as a dict (totals since the last reset; completes the batches in flight)."""
+        out = np.zeros(len(self.FB_STATS), dtype=np.float64)
+        n = self.L.mrgingham_amd_find_boards_stats(self.ctx, out.ctypes.data, len(out), int(bool(reset)))
+        if n < 0:
+            self._check(n)
+        return dict(zip(self.FB_STATS, out.tolist()))
+
     def sparse_fallbacks(self):
         """Frames the sparse refinement (option "sparse_refine") handed back to the dense kernels since the last
         call of this method; the library repeats them inside the call that met them.  Synchronises."""

@@ -190,6 +190,7 @@ struct mrgingham_amd_ctx {
         signed char* h_levels = nullptr;  // optional: the refinement level of every corner, [frame][gridn^2]
         bool do_refine = true;
         hipEvent_t ev_a = nullptr, ev_b = nullptr;
+        hipEvent_t ev_a0 = nullptr, ev_b0 = nullptr;  // where the two device parts begin (mrgingham_amd_find_boards_stats)
         bool refine_queued = false;
         int top = 0;  // the highest level a board of the job was found at (levels below it are refined)
         // device images of the pinned staging, laid out like it (fb_layout) so that each direction is ONE copy:
@@ -219,6 +220,7 @@ struct mrgingham_amd_ctx {
     double fb_prof[10] = {};
     long fb_prof_n = 0;
     int fb_threads_used = 0;
+    double fb_dev_ms[2] = {0, 0};  // device milliseconds: first passes (submit .. candidates on the host), refinements
     std::mutex fb_stat_mu;
     mrg::GridPhaseClock fb_grid{0, 0, 0, 0, 0, 0};
     int pts_nframes = 0, pts_pitch = 0;
@@ -806,10 +808,12 @@ int mrgingham_amd_find_boards_stats(mrgingham_amd_ctx* ctx, double* out, int n, 
         for (int i = 0; i < 7; ++i) v[2 + i] = ctx->fb_prof[i];
         v[9] = (double)ctx->fb_grid.calls; v[10] = (double)ctx->fb_grid.found;
         v[11] = ctx->fb_grid.graph_us; v[12] = ctx->fb_grid.adjacency_us; v[13] = ctx->fb_grid.sequences_us; v[14] = ctx->fb_grid.cycles_us;
+        v[15] = ctx->fb_dev_ms[0]; v[16] = ctx->fb_dev_ms[1];
         if (reset) {
             for (double& x : ctx->fb_prof) x = 0;
             ctx->fb_prof_n = 0;
             ctx->fb_grid = GridPhaseClock{0, 0, 0, 0, 0, 0};
+            ctx->fb_dev_ms[0] = ctx->fb_dev_ms[1] = 0;
         }
     }
     for (int i = 0; i < n && i < MRGINGHAM_AMD_FB_STATS; ++i) out[i] = v[i];
@@ -861,6 +865,8 @@ void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx) {
     for (auto& j : ctx->jobs) {
         if (j.ev_a) hipEventDestroy(j.ev_a);
         if (j.ev_b) hipEventDestroy(j.ev_b);
+        if (j.ev_a0) hipEventDestroy(j.ev_a0);
+        if (j.ev_b0) hipEventDestroy(j.ev_b0);
         if (j.pin) hipHostFree(j.pin);
     }
     if (ctx->pix) hipStreamDestroy(ctx->pix);
@@ -2669,6 +2675,10 @@ static int fb_host_begin(mrgingham_amd_ctx* ctx, mrgingham_amd_ctx::BoardsJob& j
     job.refine_queued = false;
     job.grid_running = false;
     MRG_HIP_CHECK(hipEventSynchronize(job.ev_a));
+    {
+        float ms = 0.f;
+        if (job.ev_a0 && hipEventElapsedTime(&ms, job.ev_a0, job.ev_a) == hipSuccess) ctx->fb_dev_ms[0] += ms;
+    }
     const FbPinned pin = fb_layout(job.pin, nlev, B, cap, N);
     int rc = 0;
     // Frames with more candidates than the batch buffer keeps (clutter), or whose component tables overflowed (dense
@@ -2747,6 +2757,7 @@ static int fb_host_end(mrgingham_amd_ctx* ctx, mrgingham_amd_ctx::BoardsJob& job
         const bool sparse = ctx->cc_lds && !ctx->use_v0 && top <= kRefineLevelsMax &&
                             (ctx->sparse_refine == 2 ||
                              (ctx->sparse_refine == 1 && (long long)fr->width * fr->height * B >= kSparsePaysPixels));
+        hipEventRecord(job.ev_b0, cc);
         hipError_t e = hipMemcpyAsync(d_pts, pin.pts, fb_align(pb) + fb_align(lb) + (size_t)B * 4, hipMemcpyHostToDevice, cc);
         if (e == hipSuccess && sparse)  // (only the dense repeat of a sparse refinement goes back to them)
             e = hipMemcpyAsync(d_pts0, d_pts, fb_align(pb) + lb, hipMemcpyDeviceToDevice, cc);
@@ -2781,6 +2792,10 @@ static int fb_finish(mrgingham_amd_ctx* ctx, mrgingham_amd_ctx::BoardsJob& job) 
     if (job.refine_queued) {
         MRG_HIP_CHECK(hipEventSynchronize(job.ev_b));
         FB_LAP(5);
+        {
+            float ms = 0.f;
+            if (job.ev_b0 && hipEventElapsedTime(&ms, job.ev_b0, job.ev_b) == hipSuccess) ctx->fb_dev_ms[1] += ms;
+        }
         const FbPinned pin = fb_layout(job.pin, job.nlev, B, job.cap, N);
         bool overflowed = false;
         for (int k = 0; k < B && !rc; ++k) {
@@ -2951,8 +2966,10 @@ static int fb_submit(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int
         MRG_HIP_CHECK(hipHostMalloc(&job.pin, need + need / 4, hipHostMallocDefault));
         job.pin_bytes = need + need / 4;
     }
-    if (!job.ev_a) MRG_HIP_CHECK(hipEventCreateWithFlags(&job.ev_a, hipEventDisableTiming));
-    if (!job.ev_b) MRG_HIP_CHECK(hipEventCreateWithFlags(&job.ev_b, hipEventDisableTiming));
+    if (!job.ev_a) MRG_HIP_CHECK(hipEventCreate(&job.ev_a));
+    if (!job.ev_b) MRG_HIP_CHECK(hipEventCreate(&job.ev_b));
+    if (!job.ev_a0) MRG_HIP_CHECK(hipEventCreate(&job.ev_a0));
+    if (!job.ev_b0) MRG_HIP_CHECK(hipEventCreate(&job.ev_b0));
     // The host part of the job before this one runs inside this call: its grid-finder threads are started first when
     // its candidates have already arrived (the steady state), so that they work while this thread queues the device
     // passes below; otherwise after them.
@@ -2971,6 +2988,7 @@ static int fb_submit(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int
     }
     FB_LAP(1);
     order_after_previous(ctx, {}, {});
+    hipEventRecord(job.ev_a0, ctx->pix);
     // part A: level images of every level up to the top in one pass (the refinement's variance windows and cells read
     // them too), the responses of the levels searched, their candidates
     queue_level_images(ctx, fr, top, true);
@@ -3013,9 +3031,7 @@ static int fb_submit(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) job.state = 1;
     FB_LAP(2);
-#ifdef MRG_EXPERIMENT
     ++ctx->fb_prof_n;
-#endif
     // ... and while the device works on that: the (rest of the) host part of the job before this one
     if (prev) {
         int r = prev_begun ? 0 : fb_host_begin(ctx, *prev);

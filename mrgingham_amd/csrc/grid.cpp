@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <string>
 #include <chrono>
+#include <x86intrin.h>
 #include <vector>
 
 #include <sys/stat.h>
@@ -674,6 +675,19 @@ void dump_sequences(const char* base, const std::vector<Sequence>& seq, const st
 
 static bool find_grid_impl(std::vector<PointD>& out, const std::vector<PointI>& pts, int gridn, double (&lap)[4]);
 
+// microseconds per time-stamp-counter tick, measured once per process against the steady clock
+static double tsc_us() {
+    static const double k = [] {
+        const auto c0 = std::chrono::steady_clock::now();
+        const unsigned long long t0 = __rdtsc();
+        while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c0).count() < 2000.0) {}
+        const unsigned long long t1 = __rdtsc();
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c0).count();
+        return us / (double)(t1 - t0);
+    }();
+    return k;
+}
+
 bool find_grid_from_points(std::vector<PointD>& out, const std::vector<PointI>& pts, int gridn) {
     double lap[4] = {0, 0, 0, 0};
     const bool ok = find_grid_impl(out, pts, gridn, lap);
@@ -685,14 +699,13 @@ bool find_grid_from_points(std::vector<PointD>& out, const std::vector<PointI>& 
 }
 
 static bool find_grid_impl(std::vector<PointD>& out, const std::vector<PointI>& pts, int gridn, double (&lap)[4]) {
-    using clk = std::chrono::steady_clock;
     struct Lap {   // adds the time since the last mark to lap[i]; the destructor closes the phase that was running
         double (&lap)[4];
         int cur = 0;
-        clk::time_point t = clk::now();
+        unsigned long long t = __rdtsc();   // (a clock_gettime per mark costs microseconds under some sandboxes)
         void to(int next) {
-            const clk::time_point n = clk::now();
-            lap[cur] += std::chrono::duration<double, std::micro>(n - t).count();
+            const unsigned long long n = __rdtsc();
+            lap[cur] += (double)(n - t) * tsc_us();
             t = n;
             cur = next;
         }
