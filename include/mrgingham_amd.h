@@ -201,6 +201,20 @@ int mrgingham_amd_chain_multi(mrgingham_amd_ctx* const* ctxs, int nctx, const mr
 int mrgingham_amd_sync_multi(mrgingham_amd_ctx* const* ctxs, int nctx);
 int mrgingham_amd_stream_wait_multi(mrgingham_amd_ctx* const* ctxs, int nctx, void* stream);
 
+/* ---- one process per GPU: the exchange over RCCL ---------------------------------------------------------------
+ * A host that runs one process (rank) per GPU calls mrgingham_amd_chain_batch on its shard with the three outputs laid
+ * out in ONE device block -- mrgingham_amd_packed_layout: points at offset 0, levels at *off_levels, counts at
+ * *off_npoints, *bytes in all (the layout of mrgingham_amd/parallel.py) -- and then mrgingham_amd_gather_rccl: ONE
+ * ncclGather (rccl.h:745) of that block to rank `root` on `stream` (a hipStream_t of the context's device), queued behind
+ * the chain on the device, asynchronous.  d_gathered (root only, may be NULL elsewhere): world x bytes, rank after rank,
+ * i.e. frame-major over the global batch when ranks own contiguous shards (mrgingham_amd_shard_range).  nccl_comm is the
+ * caller's ncclComm_t (this header names no RCCL type); the library does not link RCCL, it calls the ncclGather of the RCCL
+ * the process already runs on.  Returns 0, MRGINGHAM_AMD_ERR_ARG, or MRGINGHAM_AMD_ERR_DEVICE (no RCCL in the process / the
+ * collective failed: mrgingham_amd_last_error has RCCL's text). */
+int mrgingham_amd_packed_layout(int nframes, int points_pitch, size_t* off_levels, size_t* off_npoints, size_t* bytes);
+int mrgingham_amd_gather_rccl(mrgingham_amd_ctx* ctx, void* nccl_comm, int root, const void* d_packed, size_t bytes,
+                              void* d_gathered, void* stream);
+
 /* Size of pyramid level `level` of a width x height frame: what
  * cv::resize(.., 1/2^level, 1/2^level) produces (find_chessboard_corners.cc:449-450). */
 int mrgingham_amd_level_dims(int width, int height, int level, int* w, int* h);

@@ -26,7 +26,7 @@ class Frames(ctypes.Structure):
 EXPORTS = [
     "mrgingham_ChESS_response_5", "find_chessboard_corners_from_image_array_C",
     "refine_chessboard_corners_from_image_array_C", "find_chessboard_from_image_array_C",
-    "mrgingham_amd_find_grid_from_points", "mrgingham_amd_find_grid_from_points_traced", "mrgingham_amd_find_grid_from_points_perturbed", "mrgingham_amd_find_boards_stats", "mrgingham_amd_grid_clock", "mrgingham_amd_create", "mrgingham_amd_destroy",
+    "mrgingham_amd_find_grid_from_points", "mrgingham_amd_find_grid_from_points_traced", "mrgingham_amd_find_grid_from_points_perturbed", "mrgingham_amd_find_boards_stats", "mrgingham_amd_grid_clock", "mrgingham_amd_packed_layout", "mrgingham_amd_gather_rccl", "mrgingham_amd_create", "mrgingham_amd_destroy",
     "mrgingham_amd_last_error", "mrgingham_amd_abi_version", "mrgingham_amd_device_count", "mrgingham_amd_level_dims",
     "mrgingham_amd_chess_response_batch", "mrgingham_amd_decimate_batch", "mrgingham_amd_box_blur_batch",
     "mrgingham_amd_preprocess_batch", "mrgingham_amd_process_image", "mrgingham_amd_process_image_ex", "mrgingham_amd_preprocess_image16", "mrgingham_amd_preprocess_image",
@@ -86,6 +86,8 @@ def lib():
     L.mrgingham_amd_find_grid_from_points_perturbed.restype = c_bool
     L.mrgingham_amd_find_boards_stats.argtypes = [c_vp, c_vp, c_int, c_int]
     L.mrgingham_amd_grid_clock.argtypes = [c_vp, c_int]
+    L.mrgingham_amd_packed_layout.argtypes = [c_int, c_int, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+    L.mrgingham_amd_gather_rccl.argtypes = [c_vp, c_vp, c_int, c_vp, ctypes.c_size_t, c_vp, c_vp]
     L.mrgingham_amd_create.argtypes = [c_int]
     L.mrgingham_amd_create.restype = c_vp
     L.mrgingham_amd_destroy.argtypes = [c_vp]

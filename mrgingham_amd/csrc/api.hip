@@ -15,6 +15,9 @@
 #include <thread>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and the signature of ncclGather only: the function is looked up at run time (below)
+
 #include "../../include/mrgingham_amd.h"
 #include "common.h"
 #include "grid.h"
@@ -177,6 +180,7 @@ struct mrgingham_amd_ctx {
     // context of THIS context's device, created on first use -- not on the calling thread's default context, which
     // lives on MRGINGHAM_AMD_DEVICE / device 0 and cannot touch another GPU's frames
     mrgingham_amd_ctx* one = nullptr;
+    HostPool submit_pool;  // mrgingham_amd_chain_multi: the thread that queues this context's shard
     HostPool pool;  // preprocessing: extrema + tile histograms + LUTs, CLAHE output before the blur
     // mrgingham_amd_find_boards_submit / _collect: one job per scratch set (its level images stay in the set's scratch
     // between the first pass and the refinement)
@@ -1612,12 +1616,52 @@ int mrgingham_amd_shard_range(int total, int k, int n, int* first, int* count) {
     return MRGINGHAM_AMD_OK;
 }
 
+// One shard of mrgingham_amd_chain_multi: the chain on its context and, for a shard that is not on the root device, the
+// copy of its block to the root behind it.  Runs on the context's submit thread (or on the caller for a single shard).
+static int chain_multi_shard(mrgingham_amd_ctx* ctx, int root_device, const mrgingham_amd_frames* shard, int start_level,
+                             double* dst_p, signed char* dst_l, int32_t* dst_n, int points_pitch) {
+    const int B = shard->nframes;
+    const size_t np = (size_t)B * points_pitch;
+    int rc;
+    if (ctx->device == root_device) {
+        if ((rc = mrgingham_amd_chain_batch(ctx, shard, start_level, dst_p, dst_l, dst_n, points_pitch))) return rc;
+        ctx->mg_pending = false;
+        return MRGINGHAM_AMD_OK;
+    }
+    MRG_HIP_CHECK(hipSetDevice(ctx->device));
+    if (!ctx->mg_stream) {
+        MRG_HIP_CHECK(hipStreamCreateWithFlags(&ctx->mg_stream, hipStreamNonBlocking));
+        MRG_HIP_CHECK(hipEventCreateWithFlags(&ctx->mg_done, hipEventDisableTiming));
+        int can = 0;  // direct peer copies where the link allows them (otherwise HIP stages through the host)
+        if (hipDeviceCanAccessPeer(&can, ctx->device, root_device) == hipSuccess && can) {
+            hipError_t e = hipDeviceEnablePeerAccess(root_device, 0);
+            if (e != hipSuccess) (void)hipGetLastError();  // (already enabled, or refused: the copy still works)
+        }
+    }
+    if ((rc = ensure(ctx, ctx->mg_pts, np * 16)) || (rc = ensure(ctx, ctx->mg_lv, np)) || (rc = ensure(ctx, ctx->mg_np, (size_t)B * 4)))
+        return rc;
+    if (ctx->mg_pending) MRG_HIP_CHECK(hipStreamWaitEvent(ctx->pix, ctx->mg_done, 0));  // the gather before this one has read the buffers
+    if ((rc = mrgingham_amd_chain_batch(ctx, shard, start_level, (double*)ctx->mg_pts.p, (signed char*)ctx->mg_lv.p,
+                                        (int32_t*)ctx->mg_np.p, points_pitch)))
+        return rc;
+    if ((rc = mrgingham_amd_stream_wait(ctx, ctx->mg_stream))) return rc;
+    MRG_HIP_CHECK(hipMemcpyPeerAsync(dst_p, root_device, ctx->mg_pts.p, ctx->device, np * 16, ctx->mg_stream));
+    MRG_HIP_CHECK(hipMemcpyPeerAsync(dst_l, root_device, ctx->mg_lv.p, ctx->device, np, ctx->mg_stream));
+    MRG_HIP_CHECK(hipMemcpyPeerAsync(dst_n, root_device, ctx->mg_np.p, ctx->device, (size_t)B * 4, ctx->mg_stream));
+    MRG_HIP_CHECK(hipEventRecord(ctx->mg_done, ctx->mg_stream));
+    ctx->mg_pending = true;
+    return MRGINGHAM_AMD_OK;
+}
+
 /* chain_batch over several contexts -- one per device of a node, or several on one -- in ONE call: context k takes
  * shards[k] (frames in the memory of ITS device), and the corner lists of every shard arrive in d_points / d_levels /
  * d_npoints, buffers on the device of ctxs[0] laid out for the sum of the shards' frames in shard order (frame-major):
  * a shard on that device writes its block in place, a shard elsewhere writes into its own context's buffers and the
  * block travels device to device behind its chain (hipMemcpyPeerAsync: xGMI between the GPUs of a node) -- the ONE
- * exchange of the path.  Asynchronous; mrgingham_amd_sync_multi waits for everything. */
+ * exchange of the path.  Asynchronous; mrgingham_amd_sync_multi waits for everything.
+ * Every shard is queued by a submit thread of its own context, all at once (queueing one chain costs the host ~70 us:
+ * eight of them from one thread would be 0.56 ms per call, more than a sparse step takes on the device); the call returns
+ * when all of them are queued. */
 int mrgingham_amd_chain_multi(mrgingham_amd_ctx* const* ctxs, int nctx, const mrgingham_amd_frames* shards, int start_level,
                               double* d_points, signed char* d_levels, int32_t* d_npoints, int points_pitch) {
     if (!ctxs || nctx <= 0 || !shards || !ctxs[0]) return MRGINGHAM_AMD_ERR_ARG;
@@ -1629,46 +1673,86 @@ int mrgingham_amd_chain_multi(mrgingham_amd_ctx* const* ctxs, int nctx, const mr
         for (int j = 0; j < k; ++j)
             if (ctxs[j] == ctxs[k]) return fail(root, MRGINGHAM_AMD_ERR_ARG, "context %d is context %d again: one context per shard", k, j);
     }
+    int nwork = 0;
+    for (int k = 0; k < nctx; ++k) {
+        const int rc = validate_frames(ctxs[k], &shards[k]);
+        if (rc) return rc;
+        nwork += shards[k].nframes > 0;
+    }
+    std::vector<int> rcs((size_t)nctx, MRGINGHAM_AMD_OK);
+    std::vector<char> started((size_t)nctx, 0);
+    const int root_device = root->device;
     size_t off = 0;  // frames in front of shard k
     for (int k = 0; k < nctx; ++k) {
         mrgingham_amd_ctx* ctx = ctxs[k];
         const int B = shards[k].nframes;
-        int rc = validate_frames(ctx, &shards[k]);
-        if (rc) return rc;
         if (B == 0) continue;
-        const size_t np = (size_t)B * points_pitch;
         double* dst_p = d_points + off * points_pitch * 2;
         signed char* dst_l = d_levels + off * points_pitch;
         int32_t* dst_n = d_npoints + off;
         off += (size_t)B;
-        if (ctx->device == root->device) {
-            if ((rc = mrgingham_amd_chain_batch(ctx, &shards[k], start_level, dst_p, dst_l, dst_n, points_pitch))) return rc;
-            ctx->mg_pending = false;
-            continue;
+        const mrgingham_amd_frames* sh = &shards[k];
+        int* out = &rcs[(size_t)k];
+        if (nwork == 1) {
+            *out = chain_multi_shard(ctx, root_device, sh, start_level, dst_p, dst_l, dst_n, points_pitch);
+        } else {
+            ctx->submit_pool.start(1, [=] { *out = chain_multi_shard(ctx, root_device, sh, start_level, dst_p, dst_l, dst_n, points_pitch); });
+            started[(size_t)k] = 1;
         }
-        MRG_HIP_CHECK(hipSetDevice(ctx->device));
-        if (!ctx->mg_stream) {
-            MRG_HIP_CHECK(hipStreamCreateWithFlags(&ctx->mg_stream, hipStreamNonBlocking));
-            MRG_HIP_CHECK(hipEventCreateWithFlags(&ctx->mg_done, hipEventDisableTiming));
-            int can = 0;  // direct peer copies where the link allows them (otherwise HIP stages through the host)
-            if (hipDeviceCanAccessPeer(&can, ctx->device, root->device) == hipSuccess && can) {
-                hipError_t e = hipDeviceEnablePeerAccess(root->device, 0);
-                if (e != hipSuccess) (void)hipGetLastError();  // (already enabled, or refused: the copy still works)
+    }
+    int rc = MRGINGHAM_AMD_OK;
+    for (int k = 0; k < nctx; ++k) {
+        if (started[(size_t)k]) ctxs[k]->submit_pool.wait();
+        if (rcs[(size_t)k] && !rc) rc = rcs[(size_t)k];
+    }
+    (void)hipSetDevice(root_device);
+    return rc;
+}
+
+/* The one exchange of the path for a host that runs ONE PROCESS PER GPU (rccl.h:745): ncclGather of this
+ * rank's packed corner lists to `root`, on `stream`, behind the context's most recent call.  RCCL is not linked: the
+ * communicator was made by the RCCL the host process runs on, and its ncclGather is the one that has to be called -- looked
+ * up in the process (dlsym), then in librccl.so.1 / librccl.so. */
+int mrgingham_amd_packed_layout(int nframes, int points_pitch, size_t* off_levels, size_t* off_npoints, size_t* bytes) {
+    if (nframes < 0 || points_pitch <= 0) return MRGINGHAM_AMD_ERR_ARG;
+    const size_t np = (size_t)nframes * points_pitch;
+    const size_t o_lv = np * 16, o_np = (o_lv + np + 7) / 8 * 8;
+    if (off_levels) *off_levels = o_lv;
+    if (off_npoints) *off_npoints = o_np;
+    if (bytes) *bytes = o_np + (size_t)nframes * 4;
+    return MRGINGHAM_AMD_OK;
+}
+
+int mrgingham_amd_gather_rccl(mrgingham_amd_ctx* ctx, void* nccl_comm, int root, const void* d_packed, size_t bytes,
+                              void* d_gathered, void* stream) {
+    if (!ctx) return MRGINGHAM_AMD_ERR_ARG;
+    if (!nccl_comm || !d_packed || bytes == 0 || root < 0) return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "gather_rccl: NULL communicator / buffer, or nothing to send");
+    using gather_fn = ncclResult_t (*)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+    using errstr_fn = const char* (*)(ncclResult_t);
+    static gather_fn gather = nullptr;
+    static errstr_fn errstr = nullptr;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void* f = dlsym(RTLD_DEFAULT, "ncclGather");
+        void* h = nullptr;
+        if (!f) {
+            for (const char* name : {"librccl.so.1", "librccl.so"}) {
+                h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (h && (f = dlsym(h, "ncclGather"))) break;
             }
         }
-        if ((rc = ensure(ctx, ctx->mg_pts, np * 16)) || (rc = ensure(ctx, ctx->mg_lv, np)) || (rc = ensure(ctx, ctx->mg_np, (size_t)B * 4)))
-            return rc;
-        if (ctx->mg_pending) MRG_HIP_CHECK(hipStreamWaitEvent(ctx->pix, ctx->mg_done, 0));  // the gather before this one has read the buffers
-        if ((rc = mrgingham_amd_chain_batch(ctx, &shards[k], start_level, (double*)ctx->mg_pts.p, (signed char*)ctx->mg_lv.p,
-                                            (int32_t*)ctx->mg_np.p, points_pitch)))
-            return rc;
-        if ((rc = mrgingham_amd_stream_wait(ctx, ctx->mg_stream))) return rc;
-        MRG_HIP_CHECK(hipMemcpyPeerAsync(dst_p, root->device, ctx->mg_pts.p, ctx->device, np * 16, ctx->mg_stream));
-        MRG_HIP_CHECK(hipMemcpyPeerAsync(dst_l, root->device, ctx->mg_lv.p, ctx->device, np, ctx->mg_stream));
-        MRG_HIP_CHECK(hipMemcpyPeerAsync(dst_n, root->device, ctx->mg_np.p, ctx->device, (size_t)B * 4, ctx->mg_stream));
-        MRG_HIP_CHECK(hipEventRecord(ctx->mg_done, ctx->mg_stream));
-        ctx->mg_pending = true;
-    }
+        gather = (gather_fn)f;
+        void* e = dlsym(RTLD_DEFAULT, "ncclGetErrorString");
+        if (!e && h) e = dlsym(h, "ncclGetErrorString");
+        errstr = (errstr_fn)e;
+    });
+    if (!gather) return fail(ctx, MRGINGHAM_AMD_ERR_DEVICE, "gather_rccl: no ncclGather in this process and no librccl.so to load");
+    MRG_HIP_CHECK(hipSetDevice(ctx->device));
+    const int rc = mrgingham_amd_stream_wait(ctx, stream);  // the gather starts behind the chain that fills d_packed, on the device
+    if (rc) return rc;
+    const ncclResult_t r = gather(d_packed, d_gathered, bytes, ncclUint8, root, (ncclComm_t)nccl_comm, (hipStream_t)stream);
+    if (r != ncclSuccess)
+        return fail(ctx, MRGINGHAM_AMD_ERR_DEVICE, "ncclGather failed: %s", errstr ? errstr(r) : "(no error text)");
     return MRGINGHAM_AMD_OK;
 }
 

@@ -164,6 +164,21 @@ def test_thread_to_device_policy_and_shard_ranges():
         api.shard_range(10, 3, 3)
 
 
+def test_packed_layout_is_the_one_parallel_py_uses():
+    """mrgingham_amd_packed_layout (the block mrgingham_amd_gather_rccl moves) against parallel.packed_outputs, on the CPU."""
+    import ctypes
+    from mrgingham_amd import parallel
+    L = _lib.lib()
+    for B, P in [(1, 1), (5, 256), (64, 256), (3, 7), (256, 1024), (0, 16)]:
+        o_lv, o_np, nb = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+        assert L.mrgingham_amd_packed_layout(B, P, ctypes.byref(o_lv), ctypes.byref(o_np), ctypes.byref(nb)) == 0
+        pack, pts, lv, npts = parallel.packed_outputs(B, P, "cpu")
+        assert nb.value == pack.numel()
+        if B:
+            assert lv.data_ptr() - pack.data_ptr() == o_lv.value and npts.data_ptr() - pack.data_ptr() == o_np.value
+    assert L.mrgingham_amd_packed_layout(-1, 4, None, None, None) == -1 and L.mrgingham_amd_packed_layout(4, 0, None, None, None) == -1
+
+
 def test_wait_policy_rejects_unknown_values_without_touching_the_device():
     from mrgingham_amd import _lib
     assert _lib.lib().mrgingham_amd_set_wait_policy(9) == -1          # MRGINGHAM_AMD_ERR_ARG

@@ -66,6 +66,58 @@ def test_chain_multi_gathers_the_shards_in_frame_order(nctx, devices):
             d.close()
 
 
+def test_chain_multi_queues_eight_shards_in_the_time_of_one():
+    """Eight contexts (on the one device there is), eight shards: every shard is queued by its own context's submit
+    thread, so the CALL costs about what queueing one chain costs (~70 us of host time each: 0.56 ms from one thread);
+    the lists equal one chain over all the frames."""
+    import time
+    nctx, B, P = 8, 64, 256
+    frames = synth.board_batch(B, 640, 480, 10, 100, device="cuda:0")
+    one = mrgingham_amd.Detector(0)
+    dets = [mrgingham_amd.Detector(0) for _ in range(nctx)]
+    try:
+        want = one.chain(frames, 3, P)
+        ranges = [api.shard_range(B, k, nctx) for k in range(nctx)]
+        shards = [frames[a:a + c].contiguous() for a, c in ranges]
+        got = api.chain_multi(dets, shards, 3, P)                  # (also: first call, scratch allocation)
+        _same(want, got)
+        L = one.L
+        frs = (mrgingham_amd._lib.Frames * nctx)()
+        for k, (d, fr) in enumerate(zip(dets, shards)):
+            frs[k] = d._frames(fr)[0]
+        ctxs = (api.ctypes.c_void_p * nctx)(*[d.ctx for d in dets])
+        outs = [(torch.empty((B, P, 2), dtype=torch.float64, device="cuda:0"), torch.empty((B, P), dtype=torch.int8, device="cuda:0"),
+                 torch.empty((B,), dtype=torch.int32, device="cuda:0")) for _ in range(3)]
+        torch.cuda.synchronize()
+        issue = []
+        for i in range(30):
+            o = outs[i % 3]
+            t0 = time.perf_counter()
+            assert L.mrgingham_amd_chain_multi(ctxs, nctx, frs, 3, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), P) == 0
+            issue.append(time.perf_counter() - t0)
+            if i % 3 == 2:
+                assert L.mrgingham_amd_sync_multi(ctxs, nctx) == 0
+        assert L.mrgingham_amd_sync_multi(ctxs, nctx) == 0
+        for o in outs:
+            _same(want, o)
+        t_one = []
+        o = outs[0]
+        for i in range(30):                                        # the same frames as ONE chain on one context, for scale
+            t0 = time.perf_counter()
+            one.chain(frames, 3, P, out=o, sync=False)
+            t_one.append(time.perf_counter() - t0)
+            if i % 3 == 2:
+                one.sync()
+        one.sync()
+        med, med1 = sorted(issue[5:])[len(issue[5:]) // 2], sorted(t_one[5:])[len(t_one[5:]) // 2]
+        print(f"chain_multi over 8 contexts: {med * 1e6:.0f} us per call (one chain_batch through the Python mirror: {med1 * 1e6:.0f} us)")
+        assert med < 0.30e-3, (med, med1)                         # (0.10-0.15 ms measured; eight sequential submissions: ~0.6 ms)
+    finally:
+        one.close()
+        for d in dets:
+            d.close()
+
+
 def test_chain_multi_argument_errors():
     det = mrgingham_amd.Detector(0)
     try:

@@ -82,6 +82,74 @@ def test_bench_rehearsal_two_ranks_on_one_gpu():
     assert "find_boards" not in res and "sparse_refine" not in res and "chess_pass_alone" not in res   # N = 1 legs
 
 
+def _rccl():
+    """The RCCL of this process (PyTorch's), through ctypes: (library, communicator of ONE rank)."""
+    import ctypes
+    import glob
+    cands = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*")) + ["librccl.so.1", "librccl.so"]
+    lib = None
+    for c in cands:
+        try:
+            lib = ctypes.CDLL(c, mode=ctypes.RTLD_GLOBAL)
+            break
+        except OSError:
+            continue
+    if lib is None:
+        pytest.skip("no librccl in this environment")
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+    uid = UniqueId()
+    lib.ncclGetUniqueId.argtypes = [ctypes.POINTER(UniqueId)]
+    lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    assert lib.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    assert lib.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    return lib, comm
+
+
+def test_gather_rccl_c_entry_on_a_one_rank_communicator():
+    """mrgingham_amd_gather_rccl, the exchange of a C++ host that runs one process per GPU: chain_batch into ONE packed
+    block (mrgingham_amd_packed_layout = the layout of parallel.packed_outputs), ncclGather of it on a stream, queued
+    behind the chain on the device.  One rank here (a communicator made with RCCL's own C API, not torch.distributed);
+    what arrives is what the chain wrote."""
+    import ctypes
+    torch.cuda.set_device(0)
+    lib, comm = _rccl()
+    det = mrgingham_amd.Detector(0)
+    try:
+        B, P = 5, 256
+        L = det.L
+        o_lv, o_np, nbytes = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+        assert L.mrgingham_amd_packed_layout(B, P, ctypes.byref(o_lv), ctypes.byref(o_np), ctypes.byref(nbytes)) == 0
+        pack, pts, lv, npts = parallel.packed_outputs(B, P, "cuda:0")
+        assert nbytes.value == pack.numel() and o_lv.value == B * P * 16                      # one layout on both sides
+        assert lv.data_ptr() - pack.data_ptr() == o_lv.value and npts.data_ptr() - pack.data_ptr() == o_np.value
+        frames = synth.board_batch(B, 640, 480, 10, 40, device="cuda:0")
+        gathered = torch.zeros((1, pack.numel()), dtype=torch.uint8, device="cuda:0")
+        st = torch.cuda.Stream(torch.device("cuda", 0))
+        torch.cuda.synchronize()
+        for rep in range(3):                                       # asynchronous: chain -> gather, back to back
+            det.chain(frames, 3, P, out=(pts, lv, npts), sync=False)
+            rc = L.mrgingham_amd_gather_rccl(det.ctx, comm, 0, pack.data_ptr(), pack.numel(), gathered.data_ptr(), st.cuda_stream)
+            assert rc == 0, L.mrgingham_amd_last_error(det.ctx)
+        st.synchronize()
+        det.sync()
+        want = det.chain(frames, 3, P)
+        gp, gl, gn = parallel.unpack_outputs(gathered, B, P)
+        assert torch.equal(gn[0], want[2]) and int(gn[0].min()) >= 50
+        for f in range(B):
+            n = int(want[2][f])
+            assert torch.equal(gp[0][f, :n], want[0][f, :n]) and torch.equal(gl[0][f, :n], want[1][f, :n])
+        # argument errors come back as codes with a message, nothing is queued
+        assert L.mrgingham_amd_gather_rccl(det.ctx, None, 0, pack.data_ptr(), pack.numel(), gathered.data_ptr(), st.cuda_stream) == -1
+        assert b"gather_rccl" in L.mrgingham_amd_last_error(det.ctx)
+    finally:
+        det.close()
+        lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        lib.ncclCommDestroy(comm)
+
+
 def test_bench_refuses_more_ranks_than_devices():
     n = torch.cuda.device_count() + 1
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), *SMALL],

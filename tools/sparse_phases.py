@@ -7,7 +7,8 @@ import torch, time
 import mrgingham_amd
 from mrgingham_amd import synth
 W, H, B, P = 4096, 3072, 64, 256
-frames = synth.board_batch(B, W, H, 10, 0, device='cuda')
+gridn = int(sys.argv[1]) if len(sys.argv) > 1 else 10   # (a 5x5 board: what one of four workgroups per frame would see of a 10x10)
+frames = synth.board_batch(B, W, H, gridn, 0, device='cuda')
 det = mrgingham_amd.Detector(0)
 det.set_option("cc_lds", 1 | 512)
 det.set_option("sparse_refine", 2)
