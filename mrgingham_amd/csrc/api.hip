@@ -1719,7 +1719,7 @@ int mrgingham_amd_packed_layout(int nframes, int points_pitch, size_t* off_level
     const size_t o_lv = np * 16, o_np = (o_lv + np + 7) / 8 * 8;
     if (off_levels) *off_levels = o_lv;
     if (off_npoints) *off_npoints = o_np;
-    if (bytes) *bytes = o_np + (size_t)nframes * 4;
+    if (bytes) *bytes = (o_np + (size_t)nframes * 4 + 7) / 8 * 8;  // (a multiple of 8: rank blocks of the gathered buffer stay aligned)
     return MRGINGHAM_AMD_OK;
 }
 

@@ -46,7 +46,7 @@ def packed_outputs(nframes, max_points, device):
     B, P = int(nframes), int(max_points)
     o_lv = B * P * 16
     o_np = (o_lv + B * P + 7) // 8 * 8
-    pack = torch.zeros(o_np + 4 * B, dtype=torch.uint8, device=device)
+    pack = torch.zeros((o_np + 4 * B + 7) // 8 * 8, dtype=torch.uint8, device=device)   # (a multiple of 8: stacks of packs stay viewable as doubles)
     points = pack[:o_lv].view(torch.float64).view(B, P, 2)
     levels = pack[o_lv:o_lv + B * P].view(torch.int8).view(B, P)
     npoints = pack[o_np:o_np + 4 * B].view(torch.int32)
