@@ -25,7 +25,15 @@
 extern "C" {
 #endif
 
-#define MRGINGHAM_AMD_ABI_VERSION 1
+/* History of the boundary (mrgingham_amd_abi_version() reports what the LIBRARY was built as; compare with this macro):
+ *   1  rounds 1-3.
+ *   2  round 4: MRGINGHAM_AMD_ERR_SPARSE (-4) left the status enum -- value -4 stays RESERVED, it is never returned and
+ *      will not be reused --; option "sparse_refine" defaults to 1 (a context that runs sparse chains keeps a third scratch
+ *      set, up to 16 GB: INTEGRATION.md 5e); find_boards_submit / _collect, chain_multi, host_alloc / _register,
+ *      set_wait_policy, set_thread_device and the file entry points were added.
+ *   3  round 5: mrgingham_amd_find_boards_stats, _grid_clock, _packed_layout, _gather_rccl added; the packed corner block
+ *      is a multiple of 8 bytes; the reference-symbol wrappers restore the caller's current HIP device. */
+#define MRGINGHAM_AMD_ABI_VERSION 3
 
 /* ------------------------------------------------------------------------ */
 /* (1) Reference symbols                                                    */
@@ -130,6 +138,7 @@ enum {
     MRGINGHAM_AMD_ERR_ARG = -1,      /* bad argument (level, sizes, NULL) */
     MRGINGHAM_AMD_ERR_DEVICE = -2,   /* HIP error; see mrgingham_amd_last_error */
     MRGINGHAM_AMD_ERR_CAPACITY = -3, /* an output capacity given by the caller was too small */
+    /* -4 is reserved (MRGINGHAM_AMD_ERR_SPARSE of ABI 1: never returned since ABI 2) */
 };
 
 /* One context = one device, two HIP streams (the HBM-bound pixel kernels of a
@@ -443,7 +452,9 @@ int mrgingham_amd_chain_info(const mrgingham_amd_ctx* ctx, int* fused_pyramid, i
  *                         and levels, except on a LIFO overflow in the middle of a frame, where the points refined so
  *                         far stay refined) -- and the tables of that level GROW to what the frame asked for, so
  *                         the same call succeeds when it is made again (refinement is idempotent: points already at
- *                         the level are skipped).  Setting the option resets what has grown.
+ *                         the level are skipped).  Setting the option resets what has grown
+ *                         ("hot_capacity_shift_temporary": the same without that reset -- for a caller's own last-resort
+ *                         retry at shift 0 and the way back).
  *   "multi_level_launch"  chain_batch: 0 = one ChESS launch per pyramid level, 1 (default) = levels 3..1 in one
  *                         launch, 2 = all levels in one launch
  *   "cc_lds"              1 (default) = component search out of LDS: frames with at most 2048 hot pixels in one

@@ -339,11 +339,13 @@ class Detector:
         if not self.ctx:
             raise RuntimeError("mrgingham_amd_create failed")
         self._options = {}
+        self._fb_live = {}       # find_boards jobs in flight: ticket -> (boards, found, frames), see find_boards_submit
 
     def close(self):
         if getattr(self, "ctx", None):
-            self.L.mrgingham_amd_destroy(self.ctx)
+            self.L.mrgingham_amd_destroy(self.ctx)   # (joins the host threads of the jobs in flight: nothing writes after this)
             self.ctx = None
+        self._fb_live = {}
 
     def __del__(self):
         try:
@@ -382,11 +384,11 @@ class Detector:
                     if restore:
                         restore()
                     if attempt == 2:      # the last try takes a table entry for every pixel, like the C wrappers
-                        self.L.mrgingham_amd_set_option(self.ctx, b"hot_capacity_shift", 0)
+                        self.L.mrgingham_amd_set_option(self.ctx, b"hot_capacity_shift_temporary", 0)
                         full = True
         finally:
-            if full:                      # (back to the default; what has grown starts over)
-                self.L.mrgingham_amd_set_option(self.ctx, b"hot_capacity_shift", self._options.get("hot_capacity_shift", 7))
+            if full:                      # (back to the caller's choice; what the tables have grown to is KEPT)
+                self.L.mrgingham_amd_set_option(self.ctx, b"hot_capacity_shift_temporary", self._options.get("hot_capacity_shift", 7))
 
     def _frames(self, frames):
         t = self.torch
@@ -587,11 +589,22 @@ class Detector:
                                                          boards.ctypes.data, found.ctypes.data, int(nthreads))
         if ticket < 0:
             self._check(ticket)
-        return (ticket, boards, found, frames)                 # (the frames must outlive the job)
+        # The library writes into `boards` / `found` (and reads `frames`) until the job is complete -- from inside ANY later
+        # call on this context.  The Detector holds them until then, so a caller that drops the job tuple without
+        # collecting it cannot make the library write into freed memory.
+        self._fb_live[ticket] = (boards, found, frames)
+        if len(self._fb_live) > 64:            # jobs nobody collected: complete what is in flight, then let the old ones go
+            self.find_boards_stats(reset=False)   # (completes every batch in flight: their outputs are final)
+            for tk in sorted(self._fb_live)[:-8]:
+                del self._fb_live[tk]
+        return (ticket, boards, found, frames)
 
     def find_boards_collect(self, job):
         """Second half: waits for the job -> (boards float64 [B, gridn*gridn, 2], found_level int8 [B])."""
-        self._check(self.L.mrgingham_amd_find_boards_collect(self.ctx, job[0]))
+        try:
+            self._check(self.L.mrgingham_amd_find_boards_collect(self.ctx, job[0]))
+        finally:
+            self._fb_live.pop(job[0], None)
         return job[1], job[2]
 
     FB_STATS = ("batches", "host_threads", "ms_submit_checks", "ms_submit_prev_host_begin", "ms_submit_device_queued",

@@ -138,6 +138,14 @@ void* worker(void* arg) {
         if (locked) mrgingham_amd_host_unregister(locked);
         locked = mrgingham_amd_host_register(p, bytes) == 0 ? p : nullptr;
     };
+    // a larger image is about to move the pixel buffer: the registration goes first (registered memory must stay allocated
+    // until it is unregistered, include/mrgingham_amd.h), then the buffer grows with nothing locked in it
+    im.before_grow = [&](size_t n8, size_t n16) {
+        if (locked) mrgingham_amd_host_unregister(locked);
+        locked = nullptr;
+        if (n8 > im.px8.capacity()) im.px8.reserve(n8 + n8 / 8);
+        if (n16 > im.px16.capacity()) im.px16.reserve(n16 + n16 / 8);
+    };
     // MRGINGHAM_AMD_CLI_TIMING=1: where a worker's time goes (stderr, at its end)
     static const bool timing = getenv("MRGINGHAM_AMD_CLI_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };

@@ -940,6 +940,14 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
         for (int& g : ctx->grown_shift) g = 31;  // an explicit choice starts over
         return 0;
     }
+    if (!strcmp(name, "hot_capacity_shift_temporary")) {
+        // the retry of a caller (one table entry per pixel for one call, then back): the capacity changes, what the tables
+        // have GROWN to is kept -- a context that has met an adversarial frame does not forget it (the C wrappers do the
+        // same around their last attempt)
+        if (value < 0 || value > 10) return MRGINGHAM_AMD_ERR_ARG;
+        ctx->cap_shift = value;
+        return 0;
+    }
 #ifdef MRG_EXPERIMENT
     if (!strcmp(name, "chess_v0")) { ctx->use_v0 = value != 0; return 0; }
 #endif
@@ -1538,12 +1546,30 @@ static mrgingham_amd_ctx* thread_ctx() {
     ThreadCtxHolder& h = t_holder;
     if (!h.ctx) {
         int dev = h.requested;
-        if (dev < 0) dev = mrgingham_amd_device_for_thread(g_thread_counter.fetch_add(1), mrgingham_amd_device_count(),
+        const bool counted = dev < 0;
+        if (counted) dev = mrgingham_amd_device_for_thread(g_thread_counter.fetch_add(1), mrgingham_amd_device_count(),
                                                            getenv("MRGINGHAM_AMD_DEVICE"));
         h.ctx = mrgingham_amd_create(dev);
+        if (!h.ctx && counted) g_thread_counter.fetch_sub(1);  // a slot of the round-robin is used by a context, not by an attempt
     }
     return h.ctx;
 }
+
+// The reference-symbol wrappers work on the calling thread's context, which may live on another device than the one the
+// CALLER has current (the k-th thread's context is on device k % devices): they put the caller's device back when they
+// return -- a worker thread of a multi-GPU host (PyTorch, ...) keeps the current device it had.
+struct CallerDevice {
+    int prev = -1;
+    CallerDevice() {
+        if (hipGetDevice(&prev) != hipSuccess) {
+            prev = -1;
+            (void)hipGetLastError();
+        }
+    }
+    ~CallerDevice() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
 
 int mrgingham_amd_device_for_thread(int thread_index, int ndevices, const char* env_value) {
     if (env_value && *env_value) return atoi(env_value);
@@ -1567,6 +1593,7 @@ int mrgingham_amd_set_thread_device(int device_ordinal) {
 }
 
 int mrgingham_amd_thread_device(void) {
+    CallerDevice caller_device_;
     mrgingham_amd_ctx* ctx = thread_ctx();
     return ctx ? ctx->device : -1;
 }
@@ -1934,6 +1961,7 @@ static bool detect_one_frame_all(mrgingham_amd_ctx* ctx, const mrgingham_amd_fra
 
 void mrgingham_ChESS_response_5(int16_t* response, const uint8_t* image, int w, int h, int stride) {
     if (w < 15 || h < 15) return;  // no interior: the reference's loops do not execute (ChESS.c:62-63)
+    CallerDevice caller_device_;
     mrgingham_amd_ctx* ctx = thread_ctx();
     if (!ctx || !response || !image) {
         fprintf(stderr, "mrgingham_amd: mrgingham_ChESS_response_5: no device context; response not written\n");
@@ -2047,6 +2075,7 @@ bool find_chessboard_corners_from_image_array_C(int Nrows, int Ncols, int stride
     if (Nrows < 0 || Ncols < 0 || stride < Ncols || !imagebuffer || !add_points) return false;
     if (doblobs) {  // bridge.cc:50-55: the blob detector, level 0 only; always "found", possibly with 0 points
         if (image_pyramid_level != 0) return false;
+        CallerDevice caller_device_;
         mrgingham_amd_ctx* bctx = thread_ctx();
         if (!bctx) return false;
         hipSetDevice(bctx->device);
@@ -2059,6 +2088,7 @@ bool find_chessboard_corners_from_image_array_C(int Nrows, int Ncols, int stride
         return (*add_points)(bxy.empty() ? none : bxy.data(), (int)(bxy.size() / 2), 1. / kGridScale, cookie);
     }
     if (!check_level_and_layout(__func__, Nrows, Ncols, stride, image_pyramid_level)) return false;
+    CallerDevice caller_device_;
     mrgingham_amd_ctx* ctx = thread_ctx();
     if (!ctx) return false;
     hipSetDevice(ctx->device);
@@ -2123,6 +2153,7 @@ int refine_chessboard_corners_from_image_array_C(int Nrows, int Ncols, int strid
     if (Npoints > 0 && (!points_xy || !level)) return 0;
     if (!check_level_and_layout(__func__, Nrows, Ncols, stride, image_pyramid_level)) return 0;
     if (Npoints == 0) return 0;
+    CallerDevice caller_device_;
     mrgingham_amd_ctx* ctx = thread_ctx();
     if (!ctx) return 0;
     hipSetDevice(ctx->device);
@@ -2225,6 +2256,7 @@ bool find_chessboard_from_image_array_C(int Nrows, int Ncols, int stride, char* 
     if (Nrows < 0 || Ncols < 0 || stride < Ncols || !imagebuffer || !add_points || gridn < 2) return false;
     if (doblobs) {  // bridge.cc:104-113: find_circle_grid_from_image_array = blobs + grid finder, no refinement
         if (image_pyramid_level != 0) return false;
+        CallerDevice caller_device_;
         mrgingham_amd_ctx* bctx = thread_ctx();
         if (!bctx) return false;
         hipSetDevice(bctx->device);
@@ -2244,6 +2276,7 @@ bool find_chessboard_from_image_array_C(int Nrows, int Ncols, int stride, char* 
                 image_pyramid_level);
         return false;
     }
+    CallerDevice caller_device_;
     mrgingham_amd_ctx* ctx = thread_ctx();
     if (!ctx) return false;
     hipSetDevice(ctx->device);
@@ -2326,6 +2359,7 @@ bool find_chessboard_from_image_file_C(const char* filename, const int gridn, in
 int mrgingham_amd_preprocess_image(const uint8_t* image, int width, int height, int stride, int do_clahe,
                                    int blur_radius, uint8_t* out) {
     if (!image || !out || width <= 0 || height <= 0 || stride < width || blur_radius < 0) return -2;
+    CallerDevice caller_device_;
     mrgingham_amd_ctx* ctx = thread_ctx();
     if (!ctx) return -2;
     hipSetDevice(ctx->device);
@@ -2348,6 +2382,7 @@ int mrgingham_amd_preprocess_image16(const uint16_t* image, int width, int heigh
                                      int blur_radius, uint8_t* out) {
     if (!image || !out || width <= 0 || height <= 0 || stride < width || blur_radius < 0 || width > 32767 || height > 32767)
         return -2;
+    CallerDevice caller_device_;
     mrgingham_amd_ctx* ctx = thread_ctx();
     if (!ctx) return -2;
     hipSetDevice(ctx->device);
@@ -2386,6 +2421,7 @@ int mrgingham_amd_process_image_ex(const void* image, int bits, int width, int h
         TraceScope(int x, int y) { mrg::g_grid_debug_sequence = {x >= 0 && y >= 0, x, y}; }
         ~TraceScope() { mrg::g_grid_debug_sequence = {false, 0, 0}; }
     } trace_scope(o->debug_sequence_x, o->debug_sequence_y);
+    CallerDevice caller_device_;
     mrgingham_amd_ctx* ctx = thread_ctx();
     if (!ctx) return -2;
     hipSetDevice(ctx->device);
@@ -2693,6 +2729,13 @@ static int find_boards_sync_levels(mrgingham_amd_ctx* ctx, const mrgingham_amd_f
 // same device, which leaves the jobs in flight alone.  Results are the synchronous dense schedule's, double for double.
 
 static int fb_complete(mrgingham_amd_ctx* ctx, mrgingham_amd_ctx::BoardsJob& job);
+// Results of jobs that were completed before anybody collected them wait in done_tickets.  A caller that never collects
+// (it may: the outputs are complete by then) must not make the list grow for ever: beyond 1024 entries the oldest go, and
+// a _collect of such a ticket reports "no such ticket".
+static void fb_remember(mrgingham_amd_ctx* ctx, int ticket, int status) {
+    ctx->done_tickets.emplace_back(ticket, status);
+    if (ctx->done_tickets.size() > 1024) ctx->done_tickets.erase(ctx->done_tickets.begin(), ctx->done_tickets.begin() + 512);
+}
 // phase clock of the find_boards calls (a dozen clock reads per batch; mrgingham_amd_find_boards_stats)
 static double fb_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 #define FB_LAP(i) do { const double t_ = fb_now(); ctx->fb_prof[i] += t_ - fb_t; fb_t = t_; } while (0)
@@ -2954,7 +2997,7 @@ static void fb_drain(mrgingham_amd_ctx* ctx) {
     for (auto& j : ctx->jobs)
         if (j.state != 0) {
             const int ticket = j.ticket;
-            ctx->done_tickets.emplace_back(ticket, fb_complete(ctx, j));
+            fb_remember(ctx, ticket, fb_complete(ctx, j));
         }
 }
 extern "C" {
@@ -2972,18 +3015,18 @@ static int fb_submit(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int
     FB_T0;
     for (int f = 0; f < B; ++f) h_found_level[f] = -1;
     if (B == 0) {
-        ctx->done_tickets.emplace_back(ticket, 0);
+        fb_remember(ctx, ticket, 0);
         return ticket;
     }
     MRG_HIP_CHECK(hipSetDevice(ctx->device));
     if (!ctx->fb_pipeline) {  // option "find_boards_pipeline" 0: the synchronous dense schedule, at once
         for (auto& j : ctx->jobs)
-            if (j.state != 0) ctx->done_tickets.emplace_back(j.ticket, fb_complete(ctx, j));
+            if (j.state != 0) fb_remember(ctx, j.ticket, fb_complete(ctx, j));
         const int first = image_pyramid_level >= 0 ? image_pyramid_level : 3;
         const int last = image_pyramid_level >= 0 ? image_pyramid_level : 0;
         std::vector<int> open(B);
         for (int f = 0; f < B; ++f) open[f] = f;
-        ctx->done_tickets.emplace_back(ticket, find_boards_sync_levels(ctx, fr, gridn, first, last, h_boards, h_found_level, nthreads, open,
+        fb_remember(ctx, ticket, find_boards_sync_levels(ctx, fr, gridn, first, last, h_boards, h_found_level, nthreads, open,
                                                                do_refine, h_levels));
         return ticket;
     }
@@ -3001,13 +3044,13 @@ static int fb_submit(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int
         const int want = ctx->nsets_fixed ? ctx->nsets : (3.0 * mx <= (ctx->sparse_seen ? 16e9 : 8e9) ? 3 : 2);
         if (want != ctx->nsets)
             for (auto& j : ctx->jobs)
-                if (j.state != 0) ctx->done_tickets.emplace_back(j.ticket, fb_complete(ctx, j));
+                if (j.state != 0) fb_remember(ctx, j.ticket, fb_complete(ctx, j));
     }
     if ((rc = choose_sets(ctx, fr))) return rc;
     // the set this job is going to take may still belong to an earlier one: that one is completed first
     {
         auto& occupant = ctx->jobs[(ctx->cur + 1) % ctx->nsets];
-        if (occupant.state != 0) ctx->done_tickets.emplace_back(occupant.ticket, fb_complete(ctx, occupant));
+        if (occupant.state != 0) fb_remember(ctx, occupant.ticket, fb_complete(ctx, occupant));
     }
     // Level scratch of THAT set alone (the other sets belong to jobs in flight, possibly of another frame size: a stream
     // of mixed resolutions keeps every job's level sizes with its own set).  Buffers only ever grow; a buffer that has
@@ -3021,6 +3064,26 @@ static int fb_submit(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int
     if (!ctx->sparse_stat.p) {
         if ((rc = ensure(ctx, ctx->sparse_stat, 256))) return rc;
         MRG_HIP_CHECK(hipMemset(ctx->sparse_stat.p, 0, 256));
+    }
+    {   // everything the job allocates BEFORE the scratch rotation moves (begin_op): an allocation that fails returns with
+        // the context as it was -- no set taken, nothing queued -- and the call can simply be made again
+        auto& nj = ctx->jobs[(ctx->cur + 1) % ctx->nsets];
+        if ((rc = ensure(ctx, nj.d_cnt, fb_align((size_t)nlev * B * 4) + (size_t)nlev * B * cap * 8)) ||
+            (rc = ensure(ctx, nj.d_pts, fb_align((size_t)B * N * 16) + fb_align((size_t)B * N) + (size_t)B * 4)) ||
+            (rc = ensure(ctx, nj.d_pts0, fb_align((size_t)B * N * 16) + (size_t)B * N)))
+            return rc;
+        const size_t need = fb_layout(nullptr, nlev, B, cap, N).bytes;
+        if (need > nj.pin_bytes) {
+            if (nj.pin) hipHostFree(nj.pin);
+            nj.pin = nullptr;
+            nj.pin_bytes = 0;
+            MRG_HIP_CHECK(hipHostMalloc(&nj.pin, need + need / 4, hipHostMallocDefault));
+            nj.pin_bytes = need + need / 4;
+        }
+        if (!nj.ev_a) MRG_HIP_CHECK(hipEventCreate(&nj.ev_a));
+        if (!nj.ev_b) MRG_HIP_CHECK(hipEventCreate(&nj.ev_b));
+        if (!nj.ev_a0) MRG_HIP_CHECK(hipEventCreate(&nj.ev_a0));
+        if (!nj.ev_b0) MRG_HIP_CHECK(hipEventCreate(&nj.ev_b0));
     }
     begin_op(ctx, top);
     auto& job = ctx->jobs[ctx->cur];
@@ -3038,22 +3101,6 @@ static int fb_submit(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int
     job.h_levels = h_levels;
     job.do_refine = do_refine;
     job.refine_queued = false;
-    if ((rc = ensure(ctx, job.d_cnt, fb_align((size_t)nlev * B * 4) + (size_t)nlev * B * cap * 8)) ||
-        (rc = ensure(ctx, job.d_pts, fb_align((size_t)B * N * 16) + fb_align((size_t)B * N) + (size_t)B * 4)) ||
-        (rc = ensure(ctx, job.d_pts0, fb_align((size_t)B * N * 16) + (size_t)B * N)))
-        return rc;
-    const size_t need = fb_layout(nullptr, nlev, B, cap, N).bytes;
-    if (need > job.pin_bytes) {
-        if (job.pin) hipHostFree(job.pin);
-        job.pin = nullptr;
-        job.pin_bytes = 0;
-        MRG_HIP_CHECK(hipHostMalloc(&job.pin, need + need / 4, hipHostMallocDefault));
-        job.pin_bytes = need + need / 4;
-    }
-    if (!job.ev_a) MRG_HIP_CHECK(hipEventCreate(&job.ev_a));
-    if (!job.ev_b) MRG_HIP_CHECK(hipEventCreate(&job.ev_b));
-    if (!job.ev_a0) MRG_HIP_CHECK(hipEventCreate(&job.ev_a0));
-    if (!job.ev_b0) MRG_HIP_CHECK(hipEventCreate(&job.ev_b0));
     // The host part of the job before this one runs inside this call: its grid-finder threads are started first when
     // its candidates have already arrived (the steady state), so that they work while this thread queues the device
     // passes below; otherwise after them.
@@ -3065,7 +3112,7 @@ static int fb_submit(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int
     if (prev && hipEventQuery(prev->ev_a) == hipSuccess) {
         const int r = fb_host_begin(ctx, *prev);
         if (r) {
-            ctx->done_tickets.emplace_back(prev->ticket, fb_abandon(ctx, *prev, r));
+            fb_remember(ctx, prev->ticket, fb_abandon(ctx, *prev, r));
             prev = nullptr;
         }
         prev_begun = true;
@@ -3120,7 +3167,7 @@ static int fb_submit(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int
     if (prev) {
         int r = prev_begun ? 0 : fb_host_begin(ctx, *prev);
         if (!r) r = fb_host_end(ctx, *prev);
-        if (r) ctx->done_tickets.emplace_back(prev->ticket, fb_abandon(ctx, *prev, r));
+        if (r) fb_remember(ctx, prev->ticket, fb_abandon(ctx, *prev, r));
     }
     if (e != hipSuccess) return fail_hip(ctx, e, "find_boards first pass", __FILE__, __LINE__);
     return ticket;

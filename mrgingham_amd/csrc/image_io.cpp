@@ -27,6 +27,10 @@ static bool read_file(const char* path, std::vector<uint8_t>& buf) {
     return ok;
 }
 
+static void about_to_hold(Image& im, size_t n8, size_t n16) {
+    if (im.before_grow && (n8 > im.px8.capacity() || n16 > im.px16.capacity())) im.before_grow(n8, n16);
+}
+
 static bool decode_pgm(const std::vector<uint8_t>& b, Image& im) {
     size_t p = 2;
     auto next_int = [&](int& v) {
@@ -51,10 +55,12 @@ static bool decode_pgm(const std::vector<uint8_t>& b, Image& im) {
     if (maxval < 256) {
         if (b.size() - p < n) return false;
         im.depth = 8;
+        about_to_hold(im, n, 0);
         im.px8.assign(b.begin() + p, b.begin() + p + n);
     } else {
         if (b.size() - p < 2 * n) return false;
         im.depth = 16;
+        about_to_hold(im, 0, n);
         im.px16.resize(n);
         for (size_t i = 0; i < n; ++i) im.px16[i] = (uint16_t)((b[p + 2 * i] << 8) | b[p + 2 * i + 1]);
     }
@@ -131,6 +137,7 @@ static bool decode_png(const std::vector<uint8_t>& b, Image& im) {
     im.w = w; im.h = h; im.depth = bits;
     auto grey = [](uint32_t r, uint32_t g, uint32_t bl) { return (r * 4899u + g * 9617u + bl * 1868u + 8192u) >> 14; };
     if (bits == 8) {
+        about_to_hold(im, n, 0);
         im.px8.resize(n);
         for (size_t i = 0; i < n; ++i) {
             const uint8_t* q = &img[i * bpp];
@@ -141,6 +148,7 @@ static bool decode_png(const std::vector<uint8_t>& b, Image& im) {
             } else im.px8[i] = (uint8_t)grey(q[0], q[1], q[2]);
         }
     } else {
+        about_to_hold(im, 0, n);
         im.px16.resize(n);
         for (size_t i = 0; i < n; ++i) {
             const uint8_t* q = &img[i * bpp];
@@ -180,6 +188,7 @@ static int read_pgm8_direct(const char* path, Image& im) {
             ++p;  // the single whitespace after maxval
             const size_t n = (size_t)v[0] * v[1];
             im.w = v[0]; im.h = v[1]; im.depth = 8;
+            about_to_hold(im, n, 0);
             im.px8.resize(n);
             const size_t have = got - p < n ? got - p : n;
             memcpy(im.px8.data(), head + p, have);

@@ -7,6 +7,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <functional>
 #include <vector>
 
 namespace mrg {
@@ -16,6 +17,9 @@ struct Image {
     std::vector<uint8_t> px8;
     std::vector<uint16_t> px16;
     std::vector<uint8_t> file;  // the undecoded file; an Image that is reused keeps its buffers (and their warm pages)
+    // called by read_image right before px8 / px16 has to GROW beyond its capacity (arguments: the element counts about to
+    // be needed): an owner that has page-locked the old storage (hipHostRegister) must let go of it before it is freed
+    std::function<void(size_t n8, size_t n16)> before_grow;
 };
 
 bool read_image(const char* path, Image& im);

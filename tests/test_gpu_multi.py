@@ -138,10 +138,14 @@ def test_calling_threads_spread_over_the_devices():
     want = mrgingham_amd.find_points(img, 0)
     res = {}
 
+    current = {}
+
     def work(k, choose):
         if choose is not None:
             api.set_thread_device(choose)
+        torch.cuda.set_device(0)                                 # the caller's own current device ...
         res[k] = (api.thread_device(), mrgingham_amd.find_points(img, 0))
+        current[k] = torch.cuda.current_device()                 # ... is what it was when the wrappers return
 
     ths = [threading.Thread(target=work, args=(k, None)) for k in range(4)]
     for t in ths:
@@ -150,6 +154,7 @@ def test_calling_threads_spread_over_the_devices():
     assert all(0 <= d < NDEV for d in devs)
     assert [(d - devs[0]) % NDEV for d in devs] == [k % NDEV for k in range(4)], devs   # consecutive threads, consecutive devices
     assert all(np.array_equal(res[k][1], want) for k in range(4))
+    assert all(current[k] == 0 for k in range(4)), current      # (the contexts of threads 1, 3 live on device 1 when there is one)
     t = threading.Thread(target=work, args=(9, NDEV - 1)); t.start(); t.join()
     assert res[9][0] == NDEV - 1 and np.array_equal(res[9][1], want)
     with pytest.raises(ValueError):
