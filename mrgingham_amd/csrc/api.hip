@@ -144,6 +144,7 @@ struct mrgingham_amd_ctx {
     int cap_shift = 7;
     int grown_shift[mrg::kMaxLevel + 1];
     bool use_v0 = false;  // reference-shaped ChESS kernel instead of the tuned one
+    int chess_variant_hot = 0;  // the levels of a chain (clamp + hot list): 16 = chess_v16_hot_kernel / chess_v16_multi_kernel, 0 = chess_v1
     int chess_variant = 0;  // the response without a hot list: 0 = chess_v16_kernel (chess16.hip) where it pays, 1 = chess_v1 always, 16 = chess_v16 wherever it can run
     // levels 3..1 of a chain in one launch (set_option "multi_level_launch"): +1.5 % chain rate, but the
     // component chains then start later and overlap the level-0 launch more (+5 % on that launch): off
@@ -509,6 +510,7 @@ static void launch_chess_any(mrgingham_amd_ctx* ctx, const LevelBatch& lb, const
         else
 #endif
         if (!hot && ((ctx->chess_variant == 0 && chess16_pays(lb, n)) || (ctx->chess_variant == 16 && chess16_ok(lb)))) launch_chess16(lb, 0, n, clamp, s);
+        else if (hot && ctx->chess_variant_hot == 16 && !t.only && chess16_ok(lb)) launch_chess16_hot(lb, t, 0, n, s);
         else launch_chess(lb, t, 0, n, clamp, hot, s);
     }
     if (e0) {
@@ -956,6 +958,11 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
         ctx->chess_variant = value;
         return 0;
     }
+    if (!strcmp(name, "chess_variant_hot")) {
+        if (value != 0 && value != 16) return MRGINGHAM_AMD_ERR_ARG;
+        ctx->chess_variant_hot = value;
+        return 0;
+    }
     if (!strcmp(name, "chess16_seg")) { mrg::chess16_seg_override = value > 0 ? (value + 15) / 16 * 16 : 0; return 0; }
     if (!strcmp(name, "multi_level_launch")) { ctx->multi_level = value < 0 ? 0 : value > 2 ? 2 : value; return 0; }
 #ifdef MRG_EXPERIMENT
@@ -1389,7 +1396,8 @@ int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames
                 e0 = timing_event(ctx);
                 hipEventRecord(e0, ctx->pix);
             }
-            merged = launch_chess_multi(mlb, mt, n, fr->nframes, ctx->pix);
+            merged = (ctx->chess_variant_hot == 16 && launch_chess16_multi(mlb, mt, n, fr->nframes, ctx->pix)) ||
+                     launch_chess_multi(mlb, mt, n, fr->nframes, ctx->pix);
             if (merged) {
                 hipEvent_t em = (ctx->timing && !fused) ? timing_event(ctx) : ctx->ev_pix[top];
                 hipEventRecord(em, ctx->pix);
@@ -3132,7 +3140,8 @@ static int fb_submit(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int
             mlb[k] = level_batch_of(ctx, fr, job.levs[job.nlev - 1 - k]);
             mt[k] = tables_of(ctx, job.levs[job.nlev - 1 - k]);
         }
-        if (chess_multi_ok(mlb, job.nlev, B) && launch_chess_multi(mlb, mt, job.nlev, B, ctx->pix)) {
+        if (chess_multi_ok(mlb, job.nlev, B) && ((ctx->chess_variant_hot == 16 && launch_chess16_multi(mlb, mt, job.nlev, B, ctx->pix)) ||
+                                                  launch_chess_multi(mlb, mt, job.nlev, B, ctx->pix))) {
             merged = true;
             for (int k = 0; k < job.nlev; ++k) lbs[job.nlev - 1 - k] = mlb[k];
             hipEventRecord(ctx->ev_pix[top], ctx->pix);

@@ -15,6 +15,8 @@
 //     aligned group of four for dy = 0, +-4 and straddle two groups otherwise -- the group offsets are wave-uniform
 //     (SALU), the lane's choice between them a precomputed mask.
 #include "common.h"
+#include "hotlist.h"
+#include "chess_hot.h"
 #include "kernels.h"
 
 
@@ -65,6 +67,10 @@ __device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b) {
 }
 __device__ __forceinline__ uint32_t pk_sub_sat_u16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+
+__device__ __forceinline__ uint32_t dot2_u32_u16(uint32_t a, uint32_t b, uint32_t c) {  // a.lo * b.lo + a.hi * b.hi + c
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), c, false);
 }
 
 struct StageRegs {
@@ -135,14 +141,16 @@ __device__ __forceinline__ uint32_t response_pair_biased(const uint32_t (&m5)[16
 }  // namespace v16
 
 // Frames whose width is a multiple of 16 only (the staging loads are whole 16-byte chunks inside or outside the frame).
-template <bool CLAMP>
-__global__ __launch_bounds__(256, 3) void chess_v16_kernel(LevelBatch lb, int frame0, int seg) {
+// The body for workgroup `bid` of `nwg` of one level (the multi-level launch runs several levels in one grid).
+// HOT (implies CLAMP): the hot-pixel records of chess_hot.h, two aligned 8-pixel groups per lane.
+template <bool CLAMP, bool HOT>
+__device__ __forceinline__ void chess_v16_body(const LevelBatch& lb, const CompTables& t, int frame0, int seg, unsigned bid,
+                                               unsigned nwg_level, char* lds) {
     using namespace v16;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
     const int nstrips = (lb.w + SW - 1) / SW, nsegs = (lb.h + seg - 1) / seg;
     int work;
     {   // XCD-aware work order (chess.hip, chess_v1_body)
-        const unsigned b = blockIdx.x, nwg = gridDim.x, xcd = b & 7u, j = b >> 3;
+        const unsigned b = bid, nwg = nwg_level, xcd = b & 7u, j = b >> 3;
         const unsigned q = nwg >> 3, r = nwg & 7u;
         work = (int)((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j);
     }
@@ -158,6 +166,9 @@ __global__ __launch_bounds__(256, 3) void chess_v16_kernel(LevelBatch lb, int fr
     const int tid = threadIdx.x, lane = tid & 63;
     const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, jx = lane & 15;
+    uint32_t* hotbuf = reinterpret_cast<uint32_t*>(lds + 2 * PLANE);
+    int* hotcnt = reinterpret_cast<int*>(hotbuf + V1_HOTBUF);
+    HotSink hsink{hotbuf + (tid >> 6) * V1_HOTSEG, ys, strip_x, 0};
 
     // Staging, the same for every thread (16 rows per group):
     //   one 16-pixel chunk of the strip: row tid / 16, chunk tid % 16 (a 16-byte load + the byte after it, v_perm into
@@ -269,6 +280,25 @@ __global__ __launch_bounds__(256, 3) void chess_v16_kernel(LevelBatch lb, int fr
             for (int k = 0; k < 8; ++k) out[k] &= rm;
         }
 
+        if (HOT) {
+            // responses are clamped here, so "> 15" is "any bit above bit 3" (chess.hip); a lane has two aligned 8-pixel groups
+            const bool live = yy < ye;
+            const uint32_t any = (((out[0] | out[1]) | (out[2] | out[3])) | ((out[4] | out[5]) | (out[6] | out[7]))) & 0xfff0fff0u;
+            if (__ballot(any != 0 && live) != 0ull) {
+                uint32_t bits = 0;
+#pragma unroll
+                for (int k = 7; k >= 0; --k) {
+                    uint32_t m;
+                    asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(out[k] & 0xfff0fff0u), "v"(0x00010001u));
+                    bits = dot2_u32_u16(m, (1u << (2 * (k & 3))) | (2u << (2 * (k & 3) + 16)), k == 3 ? bits << 8 : bits);
+                }
+                // (pairs 7..4 were collected first and moved up by 8 in front of pair 3: bits 8..15 = the second group)
+                if (!live) bits = 0;
+                collect_hot(bits & 0xffu, yy, x0, hsink, t, frame);
+                collect_hot(bits >> 8, yy, x0 + 8, hsink, t, frame);
+            }
+        }
+
         // ring first, results second (chess.hip)
         __builtin_amdgcn_s_setprio(2);  // (-10 us of 636 on the launch, A/B)
         stage_store(lds, so + chunk_col, so + halo_col, pre);
@@ -287,6 +317,42 @@ __global__ __launch_bounds__(256, 3) void chess_v16_kernel(LevelBatch lb, int fr
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     }
+    if (HOT) flush_hot(hsink, hotcnt, wvu, t, frame);
+}
+
+// Frames whose width is a multiple of 16 only (the staging loads are whole 16-byte chunks inside or outside the frame).
+template <bool CLAMP>
+__global__ __launch_bounds__(256, 3) void chess_v16_kernel(LevelBatch lb, int frame0, int seg) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    chess_v16_body<CLAMP, false>(lb, CompTables{}, frame0, seg, blockIdx.x, gridDim.x, lds);
+}
+
+// clamp + hot list (the levels of a chain)
+__global__ __launch_bounds__(256, 3) void chess_v16_hot_kernel(LevelBatch lb, CompTables t, int frame0, int seg) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    chess_v16_body<true, true>(lb, t, frame0, seg, blockIdx.x, gridDim.x, lds);
+}
+
+// Several pyramid levels of the same batch in ONE grid (chess.hip, chess_v1_multi_kernel): clamp + hot list.
+constexpr int kMulti16Max = 4;
+struct ChessMulti16 {
+    LevelBatch lb[kMulti16Max];
+    CompTables t[kMulti16Max];
+    int first_wg[kMulti16Max];  // first workgroup of level slot k (a multiple of 8: the XCD-aware order counts from it)
+    int nwg[kMulti16Max];
+    int seg[kMulti16Max];
+    int n;
+};
+__global__ __launch_bounds__(256, 3) void chess_v16_multi_kernel(ChessMulti16 a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int b = blockIdx.x;
+    int k = 0;  // uniform
+#pragma unroll
+    for (int j = 1; j < kMulti16Max; ++j)
+        if (j < a.n && b >= a.first_wg[j]) k = j;
+    const int rel = b - a.first_wg[k];
+    if (rel >= a.nwg[k]) return;  // padding between slots
+    chess_v16_body<true, true>(a.lb[k], a.t[k], 0, a.seg[k], (unsigned)rel, (unsigned)a.nwg[k], lds);
 }
 
 int chess16_seg_override = 0;  // option "chess16_seg"
@@ -299,15 +365,16 @@ bool chess16_ok(const LevelBatch& lb) {
 // Rows per workgroup (multiples of 16).  Cost model fitted to measured launches (tools/chess16_sweep.py, 64 frames, 512x384 ..
 // 4096x3072): a segment costs its rows + ~22 rows for the 32-row prologue, the chip runs 768 workgroups at a time (three per
 // CU), and the launch drains over about 0.6 of half a workgroup's run time.
-static int pick_segment16(int w, int h, int nframes) {
+static int pick_segment16(int w, int h, int nframes, int max_seg = 1024) {   // (hot kernels: at most 512 rows -- record rows, records per wave)
     if (chess16_seg_override > 0) return chess16_seg_override;
     const long long strips = (w + v16::SW - 1) / v16::SW;
     int best = 1024;
     double best_cost = 0;
     for (int seg : {1024, 512, 256, 128, 64}) {
+        if (seg > max_seg) continue;
         const int nsegs = (h + seg - 1) / seg;
         const double cost = (double)strips * nframes * (h + 22.0 * nsegs) / 768.0 + 0.6 * ((seg < h ? seg : h) + 22.0) / 2.0;
-        if (seg == 1024 || cost < 0.99 * best_cost) {
+        if (best_cost == 0 || cost < 0.99 * best_cost) {
             best = seg;
             best_cost = cost;
         }
@@ -327,6 +394,40 @@ void launch_chess16(const LevelBatch& lb, int frame0, int nframes, bool clamp, h
     const size_t lds = 2 * v16::PLANE;
     if (clamp) hipLaunchKernelGGL(chess_v16_kernel<true>, grid, dim3(256), lds, s, lb, frame0, seg);
     else hipLaunchKernelGGL(chess_v16_kernel<false>, grid, dim3(256), lds, s, lb, frame0, seg);
+}
+
+// clamp + hot list of one level through chess_v16_hot_kernel
+void launch_chess16_hot(const LevelBatch& lb, const CompTables& t, int frame0, int nframes, hipStream_t s) {
+    const int seg = pick_segment16(lb.w, lb.h, nframes, 512);
+    dim3 grid(((lb.w + v16::SW - 1) / v16::SW) * ((lb.h + seg - 1) / seg) * nframes);
+    const size_t lds = 2 * v16::PLANE + (V1_HOTBUF + 12) * sizeof(int);
+    hipLaunchKernelGGL(chess_v16_hot_kernel, grid, dim3(256), lds, s, lb, t, frame0, seg);
+}
+
+// levels lbs[0 .. n) (largest first) of one batch in one launch; false when a shape does not qualify
+bool chess16_multi_ok(const LevelBatch* lbs, int n, int nframes) {
+    if (n < 2 || n > kMulti16Max || nframes <= 0) return false;
+    for (int k = 0; k < n; ++k)
+        if (!chess16_ok(lbs[k])) return false;
+    return true;
+}
+bool launch_chess16_multi(const LevelBatch* lbs, const CompTables* ts, int n, int nframes, hipStream_t s) {
+    if (!chess16_multi_ok(lbs, n, nframes) || ts[0].only) return false;  // (frame lists: the dense repeat stays on chess_v1)
+    ChessMulti16 a;
+    a.n = n;
+    int total = 0;
+    for (int k = 0; k < kMulti16Max; ++k) {
+        const int j = k < n ? k : 0;
+        a.lb[k] = lbs[j];
+        a.t[k] = ts[j];
+        a.seg[k] = pick_segment16(lbs[j].w, lbs[j].h, nframes, 512);
+        a.first_wg[k] = total;
+        a.nwg[k] = k < n ? ((lbs[j].w + v16::SW - 1) / v16::SW) * ((lbs[j].h + a.seg[k] - 1) / a.seg[k]) * nframes : 0;
+        total += (a.nwg[k] + 7) / 8 * 8;
+    }
+    const size_t lds = 2 * v16::PLANE + (V1_HOTBUF + 12) * sizeof(int);
+    hipLaunchKernelGGL(chess_v16_multi_kernel, dim3(total), dim3(256), lds, s, a);
+    return true;
 }
 
 }  // namespace mrg

@@ -49,9 +49,13 @@ j = json.load(open(os.path.join(P, "chess_l0_traffic.json")))
 j["kernel"] = ("mrg::chess_v1_pyr_kernel (CLAMP, HOT, STAGE_PERM16, + level images 1..3)" if fused else
                "mrg::chess_v1_kernel<true, true, 1> (CLAMP, HOT, STAGE_PERM16)")
 j["algorithmic_bytes_per_pixel"] = 3.328125 if fused else 3.0
-j["_comment"] = re.sub(r"mrg::chess_v1\w*(<true,true>)?", j["kernel"].split(" ")[0], j["_comment"])
 j["source"] = f"profiles/{RND}_bench_pmc_ea_traffic.txt"
-j["_comment"] = j["_comment"].replace("round 1, profiles/r01_bench_pmc_ea_traffic.txt", f"round {RND[1:]}, profiles/{RND}_bench_pmc_ea_traffic.txt")
+# (written from scratch every time: the round and the file it names are the ones in `source`)
+j["_comment"] = (f"HBM-side (L2 <-> EA fabric) traffic of ONE launch of the dominant kernel, {j['kernel'].split(' ')[0]} at level 0 over 64 "
+                 f"frames of 4096x3072, from rocprofv3 --pmc passes of `python bench.py --distinct 4 --steps 3 --warmup 1 --no-cpu-baseline` "
+                 f"(round {RND[1:]}, {j['source']}). Separate passes: {{TCC_EA0_RDREQ, _32B, _64B, _128B}}, {{TCC_EA0_WRREQ, _64B}}, "
+                 "{FETCH_SIZE}, {WRITE_SIZE}. Reads = 128*RDREQ_128B + 64*RDREQ_64B + 32*RDREQ_32B. FETCH_SIZE (KiB) reads exactly half of "
+                 "that on gfx950 (MI355X_MICROARCH.md, HBM section), so it is doubled; WRITE_SIZE (KiB) matches 64*WRREQ_64B to 0.1 %.")
 j["kernel_id"] = b.get("kernel_id")   # the library the passes ran on (bench.py prints it; mrgingham_amd_kernel_id)
 j.update(read_bytes=int(rdb), write_bytes=int(wrb), fetch_size_kib_raw=grab("pmc_fetch", kg, "FETCH_SIZE"),
          write_size_kib_raw=grab("pmc_write", kg, "WRITE_SIZE"), bytes_per_pixel=round((rdb + wrb) / px, 4))
