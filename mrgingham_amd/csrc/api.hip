@@ -510,7 +510,9 @@ static void launch_chess_any(mrgingham_amd_ctx* ctx, const LevelBatch& lb, const
         else
 #endif
         if (!hot && ((ctx->chess_variant == 0 && chess16_pays(lb, n)) || (ctx->chess_variant == 16 && chess16_ok(lb)))) launch_chess16(lb, 0, n, clamp, s);
-        else if (hot && ctx->chess_variant_hot == 16 && !t.only && chess16_ok(lb)) launch_chess16_hot(lb, t, 0, n, s);
+#ifdef MRG_EXPERIMENT
+        else if (hot && (ctx->chess_variant_hot & 16) && !t.only && chess16_ok(lb)) launch_chess16_hot(lb, t, 0, n, s);
+#endif
         else launch_chess(lb, t, 0, n, clamp, hot, s);
     }
     if (e0) {
@@ -958,11 +960,13 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
         ctx->chess_variant = value;
         return 0;
     }
+#ifdef MRG_EXPERIMENT
     if (!strcmp(name, "chess_variant_hot")) {
-        if (value != 0 && value != 16) return MRGINGHAM_AMD_ERR_ARG;
+        if (value & ~48) return MRGINGHAM_AMD_ERR_ARG;  // 16: levels below 0 on chess_v16, 32: level 0 with the level images on chess_v16
         ctx->chess_variant_hot = value;
         return 0;
     }
+#endif
     if (!strcmp(name, "chess16_seg")) { mrg::chess16_seg_override = value > 0 ? (value + 15) / 16 * 16 : 0; return 0; }
     if (!strcmp(name, "multi_level_launch")) { ctx->multi_level = value < 0 ? 0 : value > 2 ? 2 : value; return 0; }
 #ifdef MRG_EXPERIMENT
@@ -1360,7 +1364,10 @@ int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames
             e0 = timing_event(ctx);
             hipEventRecord(e0, ctx->pix);
         }
-        launch_chess_pyramid(lbs[0], tables_of(ctx, 0), pyramid_out_of(ctx, start_level), fr->nframes, ctx->pix);
+#ifdef MRG_EXPERIMENT
+        if (!((ctx->chess_variant_hot & 32) && launch_chess16_pyramid(lbs[0], tables_of(ctx, 0), pyramid_out_of(ctx, start_level), fr->nframes, ctx->pix)))
+#endif
+            launch_chess_pyramid(lbs[0], tables_of(ctx, 0), pyramid_out_of(ctx, start_level), fr->nframes, ctx->pix);
         if (e0) {
             hipEvent_t e1 = timing_event(ctx);
             hipEventRecord(e1, ctx->pix);
@@ -1396,8 +1403,11 @@ int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames
                 e0 = timing_event(ctx);
                 hipEventRecord(e0, ctx->pix);
             }
-            merged = (ctx->chess_variant_hot == 16 && launch_chess16_multi(mlb, mt, n, fr->nframes, ctx->pix)) ||
-                     launch_chess_multi(mlb, mt, n, fr->nframes, ctx->pix);
+            merged =
+#ifdef MRG_EXPERIMENT
+                ((ctx->chess_variant_hot & 16) && launch_chess16_multi(mlb, mt, n, fr->nframes, ctx->pix)) ||
+#endif
+                launch_chess_multi(mlb, mt, n, fr->nframes, ctx->pix);
             if (merged) {
                 hipEvent_t em = (ctx->timing && !fused) ? timing_event(ctx) : ctx->ev_pix[top];
                 hipEventRecord(em, ctx->pix);
@@ -3140,8 +3150,7 @@ static int fb_submit(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int
             mlb[k] = level_batch_of(ctx, fr, job.levs[job.nlev - 1 - k]);
             mt[k] = tables_of(ctx, job.levs[job.nlev - 1 - k]);
         }
-        if (chess_multi_ok(mlb, job.nlev, B) && ((ctx->chess_variant_hot == 16 && launch_chess16_multi(mlb, mt, job.nlev, B, ctx->pix)) ||
-                                                  launch_chess_multi(mlb, mt, job.nlev, B, ctx->pix))) {
+        if (chess_multi_ok(mlb, job.nlev, B) && launch_chess_multi(mlb, mt, job.nlev, B, ctx->pix)) {
             merged = true;
             for (int k = 0; k < job.nlev; ++k) lbs[job.nlev - 1 - k] = mlb[k];
             hipEventRecord(ctx->ev_pix[top], ctx->pix);

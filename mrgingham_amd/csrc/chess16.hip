@@ -1,5 +1,8 @@
-// ChESS response, second decomposition (round 5 experiment; option "chess_variant" 16 of experiment builds):
-// SIXTEEN pixels per lane.  Same algebra, same LDS format (two planes of packed u16 pixel pairs) and the same
+// ChESS response, second decomposition (round 5): SIXTEEN pixels per lane.  The library's kernel for the response WITHOUT a
+// hot list (mrgingham_amd_chess_response_batch, the literal output of ChESS.c:56-106) on widths that are multiples of 16:
+// 3.5-4.5 % faster than chess_v1_kernel at 4096x3072, 1-8 % at the smaller sizes (tools/chess16_sweep.py).  The variants with
+// the hot list, the level images and several levels per launch exist in experiment builds only: measured in the chain they
+// are NOT faster than chess_v1's.  Same algebra, same LDS format (two planes of packed u16 pixel pairs) and the same
 // rolling strip as chess_v1 (chess.hip); what changes is the shape of a lane's work:
 //
 //   * a lane owns 16 adjacent pixels (8 pairs) of one row; 16 lanes cover the 256-pixel strip, the four quarter-waves
@@ -7,10 +10,12 @@
 //   * the window of a (plane, row) is 16 dwords = 4 ds_read_b128 for 16 pixels (v1: 3 for 8): 30 reads and 120
 //     returned dwords per 16 pixels instead of 44 and 176; window addresses, masks and the barrier are paid per
 //     lane-iteration, i.e. half as often per pixel;
-//   * rows are 592 bytes apart (576 + 16), so that consecutive rows sit an ODD number of 16-byte slots apart: a
+//   * the window is 272 pixels (8 of halo on either side: v1 has 16) and rows are 560 bytes apart (544 + 16), so that consecutive rows sit an ODD number of 16-byte slots apart: a
 //     ds_read_b128 is serviced in groups of 16 lanes that here span two rows of 8 lanes at a 32-byte stride, and the
-//     odd pitch puts the second row on the slots the first leaves free (conflict-free; with 576 every read is 2-way);
-//   * the ring has 44 rows (16 computed + 10 halo + 16 arriving, rounded to a multiple of 4): 52 KB, three
+//     odd pitch puts the second row on the slots the first leaves free (conflict-free; with an even pitch every read is 2-way);
+//   * every thread stages the same: one 16-pixel chunk of the strip (16-byte load, v_perm into the two planes) and one pixel
+//     pair of the halo (a typed two-byte load that arrives as two u16): 256 + 256 tasks for 256 threads, no wave does more;
+//   * the ring has 44 rows (16 computed + 10 halo + 16 arriving, rounded to a multiple of 4): 49 KB, three
 //     workgroups per CU, and the kernel may use 168 VGPRs.  Slots are NOT a power of two: a wave's four rows are an
 //     aligned group of four for dy = 0, +-4 and straddle two groups otherwise -- the group offsets are wave-uniform
 //     (SALU), the lane's choice between them a precomputed mask.
@@ -138,14 +143,75 @@ __device__ __forceinline__ uint32_t response_pair_biased(const uint32_t (&m5)[16
     return (d1x + d1x) - dev;
 }
 
+#ifdef MRG_EXPERIMENT  // (the fused variants: measured, not faster than chess_v1's -- DESIGN.md section 9; experiment builds only)
+// ---------------------------------------------------------------------------
+// Level images 1..3 out of the ring (chess.hip, emit_pyramid_rows: frames of whole 16 x 8 blocks; every level pixel is
+// (a+b+c+d+2)>>2 of four FULL-RESOLUTION pixels, and a 2x2 cell is one packed pair of two consecutive rows).  Here an
+// iteration holds 16 frame rows = two blocks of 8: wave 2 emits the block y .. y+7, wave 3 the block y+8 .. y+15, each
+// exactly like chess_v1's wave 3 (level 1: eight pixels per lane, levels 2 and 3 on the two half-waves).  A block is two
+// aligned groups of four ring rows, whose offsets (gA, gB) are wave-uniform; the ring does not wrap inside a group.
+// ---------------------------------------------------------------------------
+__device__ void raw_buffer_store_b64(uint32_t __attribute__((ext_vector_type(2))) data, i32x4 rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.buffer.store.v2i32");
+__device__ void raw_buffer_store_b32(uint32_t data, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.i32");
+__device__ void raw_buffer_store_b8(unsigned char data, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.i8");
+
+__device__ __forceinline__ uint32_t cells4(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
+    const uint32_t lo01 = __builtin_amdgcn_perm(v1, v0, 0x05040100u), hi01 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const uint32_t lo23 = __builtin_amdgcn_perm(v3, v2, 0x05040100u), hi23 = __builtin_amdgcn_perm(v3, v2, 0x07060302u);
+    const uint32_t s01 = (lo01 + hi01 + 0x00020002u) >> 2, s23 = (lo23 + hi23 + 0x00020002u) >> 2;
+    return __builtin_amdgcn_perm(s23, s01, 0x06040200u);
+}
+// y8: first frame row of the block (a multiple of 8); gA / gB: ring byte offsets of rows y8 .. y8+3 / y8+4 .. y8+7
+__device__ __forceinline__ void emit_pyramid_block(const char* lds, uint32_t gA, uint32_t gB, int y8, int strip_x, int w, int frame,
+                                                   int lane, const PyramidOut& po) {
+    using u32x2 = uint32_t __attribute__((ext_vector_type(2)));
+    const int j = lane & 15, R = (lane >> 4) & 3;
+    const bool l3 = lane >= 32;
+    // level 1, output row R of the block's four: frame rows 2R, 2R+1 -- group A for R < 2, B otherwise
+    const uint32_t g1 = R < 2 ? gA : gB;
+    const char* r1 = lds + g1 + (uint32_t)(2 * HL + (R & 1) * (2 * ROWB) + 32 * j);
+    // levels 2 (lanes 0..31: output row R & 1, frame rows 4(R&1)+1, +2) and 3 (lanes 32..63: frame rows 3 and 4)
+    const uint32_t g2 = (R & 1) ? gB : gA;
+    const char* r2a = lds + PLANE + 2 * HL + (l3 ? gA + 3 * ROWB + 16 * (lane - 32) : g2 + ROWB + 32 * j);
+    const char* r2b = lds + PLANE + 2 * HL + (l3 ? gB + 16 * (lane - 32) : g2 + 2 * ROWB + 32 * j);
+    const u32x4 a0 = lds_read_b128(r1), a1 = lds_read_b128(r1 + 16);
+    const u32x4 b0 = lds_read_b128(r1 + ROWB), b1 = lds_read_b128(r1 + ROWB + 16);
+    const u32x4 c0 = lds_read_b128(r2a), c1 = lds_read_b128(r2a + 16);
+    const u32x4 d0 = lds_read_b128(r2b), d1 = lds_read_b128(r2b + 16);
+    if (po.out[0]) {
+        const i32x4 rs = raw_rsrc(po.out[0] + (long long)frame * po.h[0] * po.w[0], (uint32_t)(po.h[0] * po.w[0]));
+        u32x2 o;
+        o.x = cells4(a0.x + b0.x, a0.y + b0.y, a0.z + b0.z, a0.w + b0.w);
+        o.y = cells4(a1.x + b1.x, a1.y + b1.y, a1.z + b1.z, a1.w + b1.w);
+        if (strip_x + 16 * j < w)
+            raw_buffer_store_b64(o, rs, R * po.w[0] + 8 * j + (strip_x >> 1), (y8 >> 1) * po.w[0], 0);
+    }
+    if (po.out[1]) {
+        const uint32_t v0 = l3 ? c0.y + d0.y : c0.x + d0.x;
+        const uint32_t o = cells4(v0, c0.z + d0.z, c1.x + d1.x, c1.z + d1.z);
+        if (!l3) {
+            if (strip_x + 16 * j < w) {
+                const i32x4 rs = raw_rsrc(po.out[1] + (long long)frame * po.h[1] * po.w[1], (uint32_t)(po.h[1] * po.w[1]));
+                raw_buffer_store_b32(o, rs, (R & 1) * po.w[1] + 4 * j + (strip_x >> 2), (y8 >> 2) * po.w[1], 0);
+            }
+        } else if (po.out[2] && strip_x + 8 * (lane - 32) < w) {
+            const i32x4 rs = raw_rsrc(po.out[2] + (long long)frame * po.h[2] * po.w[2], (uint32_t)(po.h[2] * po.w[2]));
+            raw_buffer_store_b8((unsigned char)o, rs, lane - 32 + (strip_x >> 3), (y8 >> 3) * po.w[2], 0);
+        }
+    }
+}
+
+#endif  // MRG_EXPERIMENT
+
 }  // namespace v16
 
 // Frames whose width is a multiple of 16 only (the staging loads are whole 16-byte chunks inside or outside the frame).
 // The body for workgroup `bid` of `nwg` of one level (the multi-level launch runs several levels in one grid).
 // HOT (implies CLAMP): the hot-pixel records of chess_hot.h, two aligned 8-pixel groups per lane.
-template <bool CLAMP, bool HOT>
+template <bool CLAMP, bool HOT, bool PYR = false>
 __device__ __forceinline__ void chess_v16_body(const LevelBatch& lb, const CompTables& t, int frame0, int seg, unsigned bid,
-                                               unsigned nwg_level, char* lds) {
+                                               unsigned nwg_level, char* lds, const PyramidOut* po = nullptr) {
     using namespace v16;
     const int nstrips = (lb.w + SW - 1) / SW, nsegs = (lb.h + seg - 1) / seg;
     int work;
@@ -311,6 +377,22 @@ __device__ __forceinline__ void chess_v16_body(const LevelBatch& lb, const CompT
             raw_buffer_store_b128(va, resp_rsrc, st_resp_voff, soff, kAuxNT);
             raw_buffer_store_b128(vb, resp_rsrc, st_resp_voff + 16, soff, kAuxNT);
         }
+#ifdef MRG_EXPERIMENT
+        if (PYR && wvu >= 2) {
+            // behind the math, when the window registers are dead (chess.hip); rows y .. y+15 sit complete in the ring
+            __builtin_amdgcn_sched_barrier(0);
+            const int a0 = am - 4 * wvu;  // ring slot of row y (the wave's own group is 4 * wave further; may be negative)
+            auto goff_of = [&](int g) {   // aligned group g (0..3) of the iteration's sixteen rows
+                int b = a0 + 4 * g;
+                b = b < 0 ? b + NR : b;
+                b = b >= NR ? b - NR : b;
+                return (uint32_t)b * ROWB;
+            };
+            const int blk = wvu - 2;      // wave 2: rows y .. y+7, wave 3: rows y+8 .. y+15
+            emit_pyramid_block(lds, goff_of(2 * blk), goff_of(2 * blk + 1), y + 8 * blk, strip_x, w, frame, lane, *po);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
         am += RB;
         am = am >= NR ? am - NR : am;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -327,10 +409,17 @@ __global__ __launch_bounds__(256, 3) void chess_v16_kernel(LevelBatch lb, int fr
     chess_v16_body<CLAMP, false>(lb, CompTables{}, frame0, seg, blockIdx.x, gridDim.x, lds);
 }
 
+#ifdef MRG_EXPERIMENT
 // clamp + hot list (the levels of a chain)
 __global__ __launch_bounds__(256, 3) void chess_v16_hot_kernel(LevelBatch lb, CompTables t, int frame0, int seg) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     chess_v16_body<true, true>(lb, t, frame0, seg, blockIdx.x, gridDim.x, lds);
+}
+
+// level 0 of a chain: clamp + hot list + the level images 1..3
+__global__ __launch_bounds__(256, 3) void chess_v16_pyr_kernel(LevelBatch lb, CompTables t, int seg, PyramidOut po) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    chess_v16_body<true, true, true>(lb, t, 0, seg, blockIdx.x, gridDim.x, lds, &po);
 }
 
 // Several pyramid levels of the same batch in ONE grid (chess.hip, chess_v1_multi_kernel): clamp + hot list.
@@ -354,6 +443,8 @@ __global__ __launch_bounds__(256, 3) void chess_v16_multi_kernel(ChessMulti16 a)
     if (rel >= a.nwg[k]) return;  // padding between slots
     chess_v16_body<true, true>(a.lb[k], a.t[k], 0, a.seg[k], (unsigned)rel, (unsigned)a.nwg[k], lds);
 }
+
+#endif  // MRG_EXPERIMENT
 
 int chess16_seg_override = 0;  // option "chess16_seg"
 
@@ -396,12 +487,23 @@ void launch_chess16(const LevelBatch& lb, int frame0, int nframes, bool clamp, h
     else hipLaunchKernelGGL(chess_v16_kernel<false>, grid, dim3(256), lds, s, lb, frame0, seg);
 }
 
+#ifdef MRG_EXPERIMENT
 // clamp + hot list of one level through chess_v16_hot_kernel
 void launch_chess16_hot(const LevelBatch& lb, const CompTables& t, int frame0, int nframes, hipStream_t s) {
     const int seg = pick_segment16(lb.w, lb.h, nframes, 512);
     dim3 grid(((lb.w + v16::SW - 1) / v16::SW) * ((lb.h + seg - 1) / seg) * nframes);
     const size_t lds = 2 * v16::PLANE + (V1_HOTBUF + 12) * sizeof(int);
     hipLaunchKernelGGL(chess_v16_hot_kernel, grid, dim3(256), lds, s, lb, t, frame0, seg);
+}
+
+// level 0 with the level images fused in (shapes: chess_pyramid_ok of chess.hip, whole 16 x 8 blocks)
+bool launch_chess16_pyramid(const LevelBatch& lb, const CompTables& t, const PyramidOut& po, int nframes, hipStream_t s) {
+    if (!chess16_ok(lb) || !chess_pyramid_ok(lb, nframes) || lb.h % 16 != 0) return false;
+    const int seg = pick_segment16(lb.w, lb.h, nframes, 512);
+    dim3 grid(((lb.w + v16::SW - 1) / v16::SW) * ((lb.h + seg - 1) / seg) * nframes);
+    const size_t lds = 2 * v16::PLANE + (V1_HOTBUF + 12) * sizeof(int);
+    hipLaunchKernelGGL(chess_v16_pyr_kernel, grid, dim3(256), lds, s, lb, t, seg, po);
+    return true;
 }
 
 // levels lbs[0 .. n) (largest first) of one batch in one launch; false when a shape does not qualify
@@ -429,5 +531,7 @@ bool launch_chess16_multi(const LevelBatch* lbs, const CompTables* ts, int n, in
     hipLaunchKernelGGL(chess_v16_multi_kernel, dim3(total), dim3(256), lds, s, a);
     return true;
 }
+
+#endif  // MRG_EXPERIMENT
 
 }  // namespace mrg

@@ -136,6 +136,31 @@ def test_chess_v16_is_the_default_on_a_large_batch_and_matches_v1(det):
         assert np.array_equal(r[f], oracle.chess_response_5(np.ascontiguousarray(big[f, 20:280, 16:336].cpu().numpy()), fill=0))
 
 
+def test_chess_v16_fused_variants_give_the_same_chain(det):
+    """The sixteen-pixels-per-lane kernels WITH the hot list, the level images and several levels per launch (option
+    chess_variant_hot 16 | 32; experiment builds only: in the chain they are not faster than chess_v1's):
+    the chain's outputs are the shipped kernels'."""
+    try:
+        det.set_option("chess_variant_hot", 0)
+    except ValueError:
+        pytest.skip("the fused chess_v16 kernels exist in experiment builds only")
+    frames = synth.board_batch(3, 1024, 768, 10, 5, device="cuda")
+    frames[1] = synth.cluttered_board_frame(1024, 768, 10, seed=2, device="cuda")
+    det.set_option("sparse_refine", 0)
+    try:
+        want = det.chain(frames, 3, 1024)
+        for v in (16, 32, 48):
+            det.set_option("chess_variant_hot", v)
+            got = det.chain(frames, 3, 1024)
+            assert torch.equal(want[2], got[2]), v
+            for f in range(3):
+                n = int(want[2][f])
+                assert torch.equal(want[0][f, :n], got[0][f, :n]) and torch.equal(want[1][f, :n], got[1][f, :n]), (v, f)
+    finally:
+        det.set_option("chess_variant_hot", 0)
+        det.set_option("sparse_refine", 1)
+
+
 def test_chess_strided_device_frames(det):
     rng = np.random.RandomState(5)
     big = rng.randint(0, 256, size=(2, 100, 200)).astype(np.uint8)

@@ -1,6 +1,7 @@
-"""The dense chain (bench workload) with the levels' response kernels on chess_v1 (option chess_variant_hot 0) and on chess_v16
-(16: chess_v16_multi_kernel for levels 3..1; level 0 keeps chess_v1_pyr_kernel, which also writes the level images):
-outputs must be identical; interleaved timing of the pipelined step."""
+"""The dense chain (bench workload) with the levels' response kernels on chess_v1 (option chess_variant_hot 0) and on the
+sixteen-pixels-per-lane kernels (experiment build: MRGINGHAM_AMD_LIB=.../libmrgingham_amd_experiment.so; 32 = level 0 +
+level images on chess_v16_pyr_kernel, 16 = levels 3..1 on chess_v16_multi_kernel, 48 = both): outputs must be identical;
+interleaved timing of the pipelined step and of the level-0 launch inside it."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
@@ -14,9 +15,10 @@ det = mrgingham_amd.Detector(0)
 det.set_option("sparse_refine", 0)
 outs = [tuple(torch.empty(s, dtype=d, device="cuda") for s, d in (((B, P, 2), torch.float64), ((B, P), torch.int8), ((B,), torch.int32))) for _ in range(3)]
 want = None
-res = {0: [], 16: []}
+variants = (0, 32, 48)
+res = {v: [] for v in variants}
 for rnd in range(4):
-    for v in (0, 16):
+    for v in variants:
         det.set_option("chess_variant_hot", v)
         got = det.chain(frames, 3, P)
         if want is None:
@@ -36,7 +38,7 @@ for rnd in range(4):
         dt = (time.perf_counter() - t0) / 200
         ms, nl = det.chess_kernel_ms(); det.set_kernel_timing(False)
         res[v].append((dt * 1e3, ms * 1e3))
-for v in (0, 16):
+for v in variants:
     r = sorted(res[v])
     print(json.dumps({"chess_variant_hot": v, "step_ms_median": r[len(r) // 2][0], "step_ms_all": [round(x[0], 4) for x in r], "l0_us": [round(x[1], 1) for x in r]}))
 print("outputs identical")
