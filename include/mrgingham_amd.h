@@ -463,6 +463,10 @@ int mrgingham_amd_chain_info(const mrgingham_amd_ctx* ctx, int* fused_pyramid, i
  *                         the points (the global-memory kernels take what is left), 0 = global-memory kernels only;
  *                         1 | 256 = neither bands nor cells (test hook; results are the same).  Any other value is
  *                         refused.
+ *   "sparse_subsets"      1 .. 4 (default 2): workgroups per frame of the refinement kernel of a sparse level.  A frame with
+ *                         at least 128 points to refine at a level (a 14x14 board) is cut into that many subsets of points
+ *                         that are at least 64 pixels apart, refined side by side (64 x 4096x3072, 14x14: 0.55 -> 0.46 ms per
+ *                         sparse step; a 10x10 board stays with one workgroup, which is faster there).  Results do not depend on it.
  *   "sparse_refine"       1 (default), 0, 2: chain_batch computes the response of the levels BELOW the start level only in
  *                         the 16 x 16 cells around the points it refines there (all level images and the start level's
  *                         response stay whole-frame): 2 = always, 1 = for calls of at least 96 Mi frame pixels (smaller

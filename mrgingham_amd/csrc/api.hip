@@ -144,6 +144,7 @@ struct mrgingham_amd_ctx {
     int cap_shift = 7;
     int grown_shift[mrg::kMaxLevel + 1];
     bool use_v0 = false;  // reference-shaped ChESS kernel instead of the tuned one
+    int sparse_subsets = 2;  // option "sparse_subsets": workgroups per frame of the sparse refinement (1 .. 4; 4 measures like 2)
     int chess_variant_hot = 0;  // the levels of a chain (clamp + hot list): 16 = chess_v16_hot_kernel / chess_v16_multi_kernel, 0 = chess_v1
     int chess_variant = 0;  // the response without a hot list: 0 = chess_v16_kernel (chess16.hip) where it pays, 1 = chess_v1 always, 16 = chess_v16 wherever it can run
     // levels 3..1 of a chain in one launch (set_option "multi_level_launch"): +1.5 % chain rate, but the
@@ -442,7 +443,7 @@ static int ensure_points(mrgingham_amd_ctx* ctx, int nframes, int pitch) {
         if ((rc = ensure(ctx, ps.cand_xy, np * 8))) return rc;
         if ((rc = ensure(ctx, ps.cand_counts, (size_t)nframes * 4))) return rc;
         // sparse refinement: at most 4 cells per seed position of a point and 9 of those, of which at most 9 distinct
-        if ((rc = ensure(ctx, ps.cell_list, np * kCellsPerPoint * 4))) return rc;
+        if ((rc = ensure(ctx, ps.cell_list, 2 * np * kCellsPerPoint * 4))) return rc;  // two buffers: consecutive levels alternate
         if ((rc = ensure(ctx, ps.cell_cnt, (size_t)nframes * 4 * kCellHdr * (kMaxLevel + 1)))) return rc;  // per level and frame: the list's header
         if ((rc = ensure(ctx, ps.flag_list, ((size_t)nframes + 1) * 4))) return rc;  // the frames a sparse chain reported
     }
@@ -662,18 +663,21 @@ static int queue_sparse_levels(mrgingham_amd_ctx* ctx, const mrgingham_amd_frame
         return 0;
     }
     const int list_pitch = kCellsPerPoint * io.pitch;
-    io.cell_list = (uint32_t*)ps.cell_list.p;
+    io.subsets = ctx->sparse_subsets;
+    uint32_t* const lists[2] = {(uint32_t*)ps.cell_list.p, (uint32_t*)ps.cell_list.p + (size_t)nf * list_pitch};
     io.list_pitch = list_pitch;
     int32_t* cnt = (int32_t*)ps.cell_cnt.p;  // [level][frame][kCellHdr]
     for (int L = top - 1; L >= 0; --L) {
         lbs[L] = level_batch_of(ctx, fr, L);
         CompTables t = tables_of(ctx, L);
         t.lds_path |= kLdsPathSparse;
+        io.cell_list = lists[L & 1];
+        io.next_list = lists[(L & 1) ^ 1];
         io.cell_cnt = cnt + (size_t)L * nf * kCellHdr;
         // the cells of this level: listed by the refinement kernel of the level above, by a kernel of its own
         // for the first one (its points come out of the detection / from the caller)
         if (L == top - 1)
-            launch_sparse_cells(lbs[L], t, L, io, io.cell_list, cnt + (size_t)L * nf * kCellHdr, list_pitch, 0, nf, cc);
+            launch_sparse_cells(lbs[L], t, L, io, io.cell_list, cnt + (size_t)L * nf * kCellHdr, list_pitch, 0, nf, cc, cnt, nf);
         launch_chess_cells(lbs[L], t, io.cell_list, io.cell_cnt, list_pitch, 0, nf, cc);
         io.next_cnt = nullptr;
         if (L > 0) {
@@ -967,6 +971,11 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
         return 0;
     }
 #endif
+    if (!strcmp(name, "sparse_subsets")) {
+        if (value < 1 || value > 4) return MRGINGHAM_AMD_ERR_ARG;
+        ctx->sparse_subsets = value;
+        return 0;
+    }
     if (!strcmp(name, "chess16_seg")) { mrg::chess16_seg_override = value > 0 ? (value + 15) / 16 * 16 : 0; return 0; }
     if (!strcmp(name, "multi_level_launch")) { ctx->multi_level = value < 0 ? 0 : value > 2 ? 2 : value; return 0; }
 #ifdef MRG_EXPERIMENT

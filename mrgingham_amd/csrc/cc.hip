@@ -1324,7 +1324,12 @@ __device__ __forceinline__ bool lds_load_and_label(LdsCC& L, const FrameView& v,
 // seed's cell and its eight neighbours -- at most 2 x 2 per seed, a seed is then >= 2^(cs-1) pixels from the
 // edge of what is marked -- and the bitmap only spans the box around the points, which buys cells of 16 pixels
 // instead of 32 for a board that fills a quarter of a 12 MP frame (the response is computed in every marked cell).
-struct NoCellSink { __device__ __forceinline__ void operator()(int, int) const {} };
+struct NoCellSink { __device__ __forceinline__ void operator()(int, int, int) const {} };
+// A listed cell: (cell y << 16) | (subset << 12) | cell x -- cells are >= 16 pixels, a side is < 32768, so x and y are < 2048;
+// the subset (0 .. kSubsets - 1) is the workgroup of the refinement kernel that owns the cell (below: "Several workgroups").
+__device__ __forceinline__ int cell_x(uint32_t c) { return (int)(c & 0xfffu); }
+__device__ __forceinline__ int cell_y(uint32_t c) { return (int)(c >> 16); }
+__device__ __forceinline__ int cell_sub(uint32_t c) { return (int)((c >> 12) & 0xfu); }
 constexpr int kWinWords = 1280;  // cell bitmap: 40 960 cells (sizeof(LdsCCT<2048>::w) / 4)
 
 // the nine seed positions of point i exactly as the seeding loop forms them (int16 conversions of is_valid included)
@@ -1339,6 +1344,21 @@ __device__ __forceinline__ void for_each_seed(int w, int h, const double* pts, i
             const int sx = (int16_t)(x + sdx), sy = (int16_t)(y + sdy);
             if (sx >= 0 && sx < w && sy >= 0 && sy < h) f(sx, sy);
         }
+}
+
+// Cell size and span of the bitmap for the pixel box [x0, x1] x [y0, y1] that the seeds can reach.  cs = -1: the bitmap
+// cannot hold it.
+__device__ __forceinline__ void win_cells_of_box(WinSel& ws, int x0, int y0, int x1, int y1, int max_words, bool TIGHT) {
+    ws.cs = TIGHT ? 4 : 5;
+    while (true) {
+        const int half = TIGHT ? 1 << (ws.cs - 1) : 0;
+        ws.ox = max(x0 - half, 0) >> ws.cs;
+        ws.oy = max(y0 - half, 0) >> ws.cs;
+        ws.cw = ((x1 + half) >> ws.cs) - ws.ox + 1;
+        ws.chh = ((y1 + half) >> ws.cs) - ws.oy + 1;
+        if ((ws.cw * ws.chh + 31) / 32 <= max_words) break;
+        if (++ws.cs > 15) { ws.cs = -1; break; }
+    }
 }
 
 // Geometry: cell size and the span of the bitmap.  `box` = 4 words of LDS.  cs = -1: the bitmap cannot hold the frame.
@@ -1369,24 +1389,17 @@ __device__ __forceinline__ WinSel win_geometry(int w, int h, const double* pts, 
         if (b0 == 0xffffffffu) { x0 = y0 = 0; x1 = y1 = 0; }  // nothing to refine: one cell
         else { x0 = (int)b0; x1 = (int)b1; y0 = (int)b2; y1 = (int)b3; }
     }
-    ws.cs = TIGHT ? 4 : 5;
-    while (true) {
-        const int half = TIGHT ? 1 << (ws.cs - 1) : 0;
-        ws.ox = max(x0 - half, 0) >> ws.cs;
-        ws.oy = max(y0 - half, 0) >> ws.cs;
-        ws.cw = ((x1 + half) >> ws.cs) - ws.ox + 1;
-        ws.chh = ((y1 + half) >> ws.cs) - ws.oy + 1;
-        if ((ws.cw * ws.chh + 31) / 32 <= max_words) break;
-        if (++ws.cs > 15) { ws.cs = -1; break; }
-    }
+    win_cells_of_box(ws, x0, y0, x1, y1, max_words, TIGHT);
     return ws;
 }
 
 // Marking, with the geometry given: `bits` must hold (cw * chh + 31) / 32 words.  `sink(cell x, cell y)` (cells on
 // the frame's grid) is called by the thread that sets a cell's bit first.
+// `psub` != NULL: only the points of subset `sub` (psub[i] == sub) mark.
 template <int LNBITS, class Sink = NoCellSink>
 __device__ __forceinline__ void win_mark(WinSel& ws, int w, int h, const double* pts, const signed char* lv, int npts, int level,
-                                         uint32_t* bits, uint32_t* openbits, bool TIGHT, Sink sink = Sink()) {
+                                         uint32_t* bits, uint32_t* openbits, bool TIGHT, Sink sink = Sink(),
+                                         const int32_t* psub = nullptr, int sub = 0) {
     ws.bits = bits;
     ws.openbits = openbits;
     const int nw = (ws.cw * ws.chh + 31) / 32;
@@ -1396,6 +1409,7 @@ __device__ __forceinline__ void win_mark(WinSel& ws, int w, int h, const double*
     __syncthreads();
     for (int i = threadIdx.x; i < npts; i += CC_THREADS) {
         if (lv[i] != level + 1) continue;
+        if (psub && psub[i] != sub) continue;
         for_each_seed(w, h, pts, i, level, [&](int sx, int sy) {
             const int half = 1 << (ws.cs - 1);
             const int ax0 = TIGHT ? max(sx - half, 0) >> ws.cs : (sx >> ws.cs) - 1;
@@ -1408,27 +1422,123 @@ __device__ __forceinline__ void win_mark(WinSel& ws, int w, int h, const double*
                     if ((unsigned)cx >= (unsigned)ws.cw || (unsigned)cy >= (unsigned)ws.chh) continue;
                     const int c = cy * ws.cw + cx;
                     const uint32_t bit = 1u << (c & 31);
-                    if (!(bits[c >> 5] & bit) && !(atomicOr(&bits[c >> 5], bit) & bit)) sink(ax, ay);
+                    if (!(bits[c >> 5] & bit) && !(atomicOr(&bits[c >> 5], bit) & bit)) sink(ax, ay, i);
                 }
         });
     }
     __syncthreads();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Several workgroups per frame (round 5).  The refinement of a sparse level is a latency chain whose length grows with the
+// frame's hot pixels and points (tools/sparse_phases.py: a 5x5 board's frame takes 53 us, a 10x10's 95, a 14x14's 245), and
+// one workgroup per frame leaves the chip 94 % empty.  Points whose marked cells do not touch cannot share a
+// super-component (a fill never leaves the 4-connected hot region of its seeds, find_chessboard_corners.cc:356-397, and a
+// region that reaches an unmarked cell is "open": the frame is given up), so a frame's points are cut into up to kSubsets
+// SUBSETS that are far enough apart, every listed cell carries the subset of the point that marked it, and workgroup
+// (frame, s) of the refinement kernel loads the cells, seeds the points and fills the components of subset s alone --
+// outputs go to the points' own slots, so the order of the list is untouched.
+//   * The cut is made by a workgroup that owns the whole frame (sparse_cells_kernel for the first sparse level, the
+//     refinement kernel of the level above while it is not split): a point with no other point within kLinkDist pixels (at
+//     the level's coordinates, either axis) can go to any subset, all the others stay together in subset 0.  At 16-pixel
+//     cells the cells of a point lie within 24 pixels of it: points >= 64 apart have cells that do not even touch.
+//   * A split level hands ITS subsets on to the next level (nobody sees the whole frame any more) after checking that
+//     they stay apart: a point's refined position lies inside its marked cells, i.e. within 24 pixels of where it was;
+//     each workgroup compares its own refined points with every point of the other subsets (read while those workgroups
+//     may still be writing: old or new position) and asks for ONE workgroup at the next level (kFlagSingle) when any pair
+//     is closer than kKeepDist -- 48.5 for cells that stay disjoint whatever the other point does, a cell more to be sure.
+//   * Cells of more than 16 pixels (a box of more than 40 960 cells), fewer than kSplitMinPoints points, a single
+//     cluster: one workgroup, as before.  A subset whose cells hold more hot pixels than the tables gives the frame up
+//     (the dense repeat takes it), like every other case the LDS kernel cannot take.
+// Header of a level's list, kCellHdr words per frame: [0] cells (-1: given up), [1] log2 cell size, [2..5] span of the
+// bitmap, [6] subsets (<= 1: one workgroup), [7] flags.  sparse_cells_kernel zeroes [0], [6], [7] of every level below
+// the first; a split level ADDS its cells to [0].
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kSubsets = 4;
+constexpr int kHdrSub = 6, kHdrFlags = 7;
+constexpr int kFlagGivenUp = 1, kFlagSingle = 2;
+constexpr int kSplitMinPoints = 128;  // (a 10x10 board: one workgroup is faster -- more workgroups in flight slow the pixel stream by more than the shorter chain gains; 14x14: -15 %)
+constexpr float kLinkDist = 64.f, kKeepDist = 64.f;
+
+struct PartScratch {  // LDS of partition_points
+    float x[LPTS], y[LPTS];
+    int16_t lab[LPTS];
+    int nroots, nlive;
+};
+
+// Subsets of the points to refine at `level` (lv[i] == level + 1), from their positions now: psub[i] for every point of the
+// frame (0 for the others), returns how many subsets (uniform; 1 = no cut).  All threads of the workgroup.
+__device__ __forceinline__ int partition_points(const double* pts, const signed char* lv, int npts, int level, int32_t* psub,
+                                                PartScratch& S, int max_sub) {
+    const int tid = threadIdx.x;
+    if (npts > LPTS || max_sub < 2) {
+        for (int i = tid; i < npts; i += CC_THREADS) psub[i] = 0;
+        return 1;
+    }
+    const float inv = 1.0f / (float)(1 << level);
+    if (tid == 0) { S.nroots = 0; S.nlive = 0; }
+    __syncthreads();
+    for (int i = tid; i < npts; i += CC_THREADS) {
+        const bool live = lv[i] == level + 1;
+        S.x[i] = live ? ((float)pts[2 * i] + 0.5f) * inv : 1e30f;
+        S.y[i] = live ? ((float)pts[2 * i + 1] + 0.5f) * inv : 1e30f;
+        S.lab[i] = (int16_t)i;
+        if (live) atomicAdd(&S.nlive, 1);
+    }
+    __syncthreads();
+    const int nlive = S.nlive;
+    if (nlive < kSplitMinPoints) {  // (uniform)
+        for (int i = tid; i < npts; i += CC_THREADS) psub[i] = 0;
+        return 1;
+    }
+    // No clustering proper: a point with no other point within kLinkDist is a subset candidate of its own, ALL the others
+    // go together (several clusters in one subset are as good as one; label propagation over a board whose points are all
+    // linked -- a coarse level -- took 80 us of a 100-us kernel).  One pass over the pairs.
+    for (int i = tid; i < npts; i += CC_THREADS) {
+        const float xi = S.x[i], yi = S.y[i];
+        if (xi > 1e29f) { S.lab[i] = -1; continue; }
+        bool linked = false;
+        for (int j = 0; j < npts; ++j)
+            linked |= j != i && fabsf(S.x[j] - xi) < kLinkDist && fabsf(S.y[j] - yi) < kLinkDist;
+        S.lab[i] = linked ? 1 : 0;   // -1 not to be refined, 0 on its own, 1 with the rest
+        if (linked) atomicAdd(&S.nroots, 1);
+    }
+    __syncthreads();
+    const int nrest = S.nroots, niso = nlive - nrest;
+    int nsub = min(min(kSubsets, max_sub), niso + (nrest > 0 ? 1 : 0));
+    if (nsub < 2) nsub = 1;
+    // the rest is subset 0; the points on their own are dealt out so that the subsets come out even
+    const bool rest_full = nrest * nsub >= nlive;
+    for (int i = tid; i < npts; i += CC_THREADS) {
+        int sb = 0;
+        if (S.lab[i] == 0 && nsub > 1) {
+            int r = 0;
+            for (int j = 0; j < i; ++j) r += S.lab[j] == 0;
+            sb = rest_full ? 1 + r % (nsub - 1) : (r + nrest) % nsub;
+        }
+        psub[i] = sb;
+    }
+    __threadfence_block();
+    __syncthreads();
+    return nsub > 1 ? nsub : 1;
+}
+
 // Sparse refinement, step 1: the cells around the points of a frame to refine at `level`, as a list for the kernel
 // that computes the response there (chess_cells_kernel): cnt[0] = how many (-1: more than the list or the mask area
 // holds, the refinement kernel reports the frame), cnt[1] = their size (log2), cnt[2..5] = the span of the bitmap,
-// list = (cell y << 16) | cell x.  The refinement kernel marks exactly the listed cells for itself.  All threads of the
-// workgroup; `bits` = kWinWords words, `box` = 4 words, `n` = one word of LDS.
+// list = (cell y << 16) | (subset << 12) | cell x.  The refinement kernel marks exactly the listed cells for itself.  All
+// threads of the workgroup, which owns the WHOLE frame; `bits` = kWinWords words, `box` = 4 words, `n` = one word of LDS.
+// `psub` / `nsub`: the cut of partition_points (nsub <= 1: none); cells of more than 16 pixels are not cut.
 __device__ __forceinline__ void list_cells(int w, int h, const double* pts, const signed char* lv, int npts, int level,
                                            uint32_t* bits, uint32_t* box, int* n, uint32_t* list, int list_pitch,
-                                           long long max_items, int32_t* cnt) {
+                                           long long max_items, int32_t* cnt, const int32_t* psub = nullptr, int nsub = 1) {
     if (threadIdx.x == 0) *n = 0;
-    auto sink = [&](int ax, int ay) {
-        const int k = atomicAdd(n, 1);
-        if (k < list_pitch) list[k] = ((uint32_t)ay << 16) | (uint32_t)ax;
-    };
     WinSel ws = win_geometry(w, h, pts, lv, npts, level, kWinWords, true, box);  // (a barrier first: *n is 0 below)
+    const bool cut = nsub > 1 && ws.cs == 4;
+    auto sink = [&](int ax, int ay, int i) {
+        const int k = atomicAdd(n, 1);
+        if (k < list_pitch) list[k] = ((uint32_t)ay << 16) | (cut ? (uint32_t)psub[i] << 12 : 0u) | (uint32_t)ax;
+    };
     if (ws.cs >= 0) win_mark<2048>(ws, w, h, pts, lv, npts, level, bits, nullptr, true, sink);
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1437,21 +1547,94 @@ __device__ __forceinline__ void list_cells(int w, int h, const double* pts, cons
         cnt[0] = ok ? k : -1;
         cnt[1] = ws.cs;
         cnt[2] = ws.ox; cnt[3] = ws.oy; cnt[4] = ws.cw; cnt[5] = ws.chh;
+        cnt[kHdrSub] = cut ? nsub : 1;
+        cnt[kHdrFlags] = ok ? 0 : kFlagGivenUp;
     }
 }
 
+// The same by workgroup `sub` of a SPLIT level, for the next level down: the cells of its own points, ADDED to the list the
+// workgroups of the frame share (cnt[0], zero before the kernel); the geometry every workgroup must agree on comes from this
+// level's span (`hdr`: a refined point lies inside the cells that were marked for it, so twice the span holds every seed of
+// the next level); the subsets are kept if they stay apart (see above), else the next level runs as one workgroup.
+// `tmp`: LDS, `tmp_cap` words.
+__device__ __forceinline__ void list_cells_split(int w, int h, const double* pts, const signed char* lv, int npts, int level,
+                                                 uint32_t* bits, int* n, uint32_t* tmp, int tmp_cap, const int32_t* hdr,
+                                                 uint32_t* list, int list_pitch, long long max_items, int32_t* cnt,
+                                                 const int32_t* psub, int sub, int nsub) {
+    const int tid = threadIdx.x;
+    if (tid == 0) { n[0] = 0; n[1] = 0; }
+    WinSel ws;
+    ws.bits = nullptr;
+    ws.openbits = nullptr;
+    {
+        const int pcs = hdr[1], X0 = hdr[2] << pcs, Y0 = hdr[3] << pcs, X1 = ((hdr[2] + hdr[4]) << pcs) - 1, Y1 = ((hdr[3] + hdr[5]) << pcs) - 1;
+        win_cells_of_box(ws, max(2 * X0 - 2, 0), max(2 * Y0 - 2, 0), min(2 * X1 + 3, w - 1), min(2 * Y1 + 3, h - 1), kWinWords, true);
+    }
+    __syncthreads();
+    auto sink = [&](int ax, int ay, int) {
+        const int k = atomicAdd(&n[0], 1);
+        if (k < tmp_cap) tmp[k] = ((uint32_t)ay << 16) | ((uint32_t)sub << 12) | (uint32_t)ax;
+    };
+    if (ws.cs >= 0) win_mark<2048>(ws, w, h, pts, lv, npts, level, bits, nullptr, true, sink, psub, sub);
+    // do the subsets stay apart?  own points as they are now against every point of the others (level + 1 coordinates: the
+    // level this kernel has just refined)
+    {
+        const float inv = 1.0f / (float)(2 << level);
+        bool close = false;
+        for (int i = tid; i < npts; i += CC_THREADS) {
+            if (psub[i] != sub || lv[i] != level + 1) continue;
+            const float xi = ((float)pts[2 * i] + 0.5f) * inv, yi = ((float)pts[2 * i + 1] + 0.5f) * inv;
+            for (int j = 0; j < npts; ++j)
+                if (psub[j] != sub && lv[j] <= level + 2 && fabsf(((float)pts[2 * j] + 0.5f) * inv - xi) < kKeepDist &&  // (lv > level + 2: never refined again)
+                    fabsf(((float)pts[2 * j + 1] + 0.5f) * inv - yi) < kKeepDist)
+                    close = true;
+        }
+        if (close) n[1] = 1;
+    }
+    __syncthreads();
+    const int k = n[0];
+    __syncthreads();
+    if (tid == 0) {
+        int flags = (ws.cs != 4 || n[1]) ? kFlagSingle : 0;
+        int base = 0;
+        if (ws.cs < 0 || k > tmp_cap) {
+            flags |= kFlagGivenUp;
+        } else {
+            base = atomicAdd(&cnt[0], k);
+            if (base + k > list_pitch || ((long long)(base + k) << (2 * (ws.cs - 4))) > max_items) flags |= kFlagGivenUp;
+        }
+        if (flags) atomicOr(&cnt[kHdrFlags], flags);
+        cnt[1] = ws.cs;  // (the same values from every workgroup of the frame)
+        cnt[2] = ws.ox; cnt[3] = ws.oy; cnt[4] = ws.cw; cnt[5] = ws.chh;
+        cnt[kHdrSub] = nsub;
+        n[0] = (flags & kFlagGivenUp) ? -1 : base;
+    }
+    __syncthreads();
+    const int base = n[0];
+    if (base >= 0)
+        for (int q = tid; q < k; q += CC_THREADS) list[base + q] = tmp[q];
+}
+
 // One workgroup per frame: the cells of the first level below the start level (its points come from the detection;
-// below that the refinement kernel of a level lists the cells of the next one itself).
+// below that the refinement kernel of a level lists the cells of the next one itself), the cut of its points into
+// subsets, and the headers of the levels below it zeroed (cnt_all: [level][frame][kCellHdr]).
 __global__ __launch_bounds__(CC_THREADS) void sparse_cells_kernel(int w, int h, int level, RefineIO io, uint32_t* cell_list,
                                                                int32_t* cell_cnt, int list_pitch, long long max_items,
-                                                               int frame0) {
+                                                               int frame0, int32_t* cnt_all, int nframes_all) {
     __shared__ uint32_t bits[kWinWords];
     __shared__ uint32_t box[4];
     __shared__ int n;
+    __shared__ PartScratch part;
     const int frame = frame0 + blockIdx.x;
     const long long pb = (long long)frame * io.pitch;
-    list_cells(w, h, io.points + 2 * pb, io.levels + pb, min(io.npoints[frame], io.pitch), level, bits, box, &n,
-               cell_list + (long long)frame * list_pitch, list_pitch, max_items, cell_cnt + kCellHdr * frame);
+    if (cnt_all && threadIdx.x < level) {
+        int32_t* hd = cnt_all + ((size_t)threadIdx.x * nframes_all + frame) * kCellHdr;
+        hd[0] = 0; hd[kHdrSub] = 0; hd[kHdrFlags] = 0;
+    }
+    const int npts = min(io.npoints[frame], io.pitch);
+    const int nsub = partition_points(io.points + 2 * pb, io.levels + pb, npts, level, io.leader + pb, part, io.subsets);
+    list_cells(w, h, io.points + 2 * pb, io.levels + pb, npts, level, bits, box, &n,
+               cell_list + (long long)frame * list_pitch, list_pitch, max_items, cell_cnt + kCellHdr * frame, io.leader + pb, nsub);
 }
 
 // Sparse refinement, step 3a: the hot pixels of a frame out of the masks chess_cells_kernel left (32 bytes per 16 x 16
@@ -1460,8 +1643,10 @@ __global__ __launch_bounds__(CC_THREADS) void sparse_cells_kernel(int w, int h, 
 // lds_load_and_label's `preloaded`); only if there are more -- a frame that needs bands -- a second pass writes the
 // global list the band planner and the loader read, like a dense level's.  Returns the number of hot pixels
 // (uniform), -1 when the frame was given up by whoever listed the cells.  `cnt` = one word of LDS.
+// `only` >= 0: the cells of that subset alone (a split level).
 template <class Put>
-__device__ __forceinline__ void expand_masks(const uint32_t* masks, const uint32_t* list, int nwords, int cs, int* cnt, Put put) {
+__device__ __forceinline__ void expand_masks(const uint32_t* masks, const uint32_t* list, int nwords, int cs, int* cnt, Put put,
+                                             int only = -1) {
     const int sub = cs - 4;
     constexpr int U = 8;  // (a clean 10x10 board at 16-pixel cells: ~3800 words, two rounds of 256 x 8)
     for (int k0 = threadIdx.x; k0 < nwords; k0 += CC_THREADS * U) {
@@ -1469,7 +1654,7 @@ __device__ __forceinline__ void expand_masks(const uint32_t* masks, const uint32
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int k = k0 + u * CC_THREADS;
-            m[u] = k < nwords ? masks[k] : 0u;
+            m[u] = (k < nwords && (only < 0 || cell_sub(list[(k >> 3) >> (2 * sub)]) == only)) ? masks[k] : 0u;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1477,8 +1662,8 @@ __device__ __forceinline__ void expand_masks(const uint32_t* masks, const uint32
             const int k = k0 + u * CC_THREADS, it = k >> 3, j = k & 7;
             const uint32_t c = list[it >> (2 * sub)];
             const int si = it & ((1 << (2 * sub)) - 1);
-            const int xt = ((int)(c & 0xffffu) << cs) + 16 * (si & ((1 << sub) - 1));
-            const int yt = ((int)(c >> 16) << cs) + 16 * (si >> sub);
+            const int xt = (cell_x(c) << cs) + 16 * (si & ((1 << sub) - 1));
+            const int yt = (cell_y(c) << cs) + 16 * (si >> sub);
             int slot = atomicAdd(cnt, __popc(m[u]));
             uint32_t mm = m[u];
             while (mm) {
@@ -1492,14 +1677,15 @@ __device__ __forceinline__ void expand_masks(const uint32_t* masks, const uint32
 }
 // the cell bitmap of a frame straight from its list: what is marked IS what was computed
 __device__ __forceinline__ void mark_listed_cells(const WinSel& ws, const uint32_t* list, int ncell, uint32_t* bits,
-                                                  uint32_t* openbits, int nopen_words) {
+                                                  uint32_t* openbits, int nopen_words, int only = -1) {
     const int nw = (ws.cw * ws.chh + 31) / 32;
     for (int k = threadIdx.x; k < nw; k += CC_THREADS) bits[k] = 0;
     for (int k = threadIdx.x; k < nopen_words; k += CC_THREADS) openbits[k] = 0;
     __syncthreads();
     for (int k = threadIdx.x; k < ncell; k += CC_THREADS) {
         const uint32_t c = list[k];
-        const int cx = (int)(c & 0xffffu) - ws.ox, cy = (int)(c >> 16) - ws.oy;
+        if (only >= 0 && cell_sub(c) != only) continue;  // (another subset's cell: unmarked here, i.e. "not computed")
+        const int cx = cell_x(c) - ws.ox, cy = cell_y(c) - ws.oy;
         if ((unsigned)cx < (unsigned)ws.cw && (unsigned)cy < (unsigned)ws.chh) {
             const int b = cy * ws.cw + cx;
             atomicOr(&bits[b >> 5], 1u << (b & 31));
@@ -1508,11 +1694,13 @@ __device__ __forceinline__ void mark_listed_cells(const WinSel& ws, const uint32
     __syncthreads();
 }
 // -> number of hot pixels (uniform; -1: the frame was given up), `ws` = the selection (cells marked in `bits`)
+// `only` >= 0 (a split level): the cells of that subset; more hot pixels in them than the LDS list holds: -1 as well (the
+// global list is the frame's, not the subset's).
 __device__ __forceinline__ int hot_list_from_masks(const RefineIO& io, const CompTables& t, int frame, uint32_t* hot_xy, int* cnt,
                                                    uint32_t* lds_xy, int lds_cap, WinSel& ws, uint32_t* bits, uint32_t* openbits,
-                                                   int nopen_words) {
+                                                   int nopen_words, int only = -1) {
     const int32_t* hdr = io.cell_cnt + kCellHdr * frame;
-    const int ncell = hdr[0];
+    const int ncell = (hdr[kHdrFlags] & kFlagGivenUp) ? -1 : hdr[0];
     ws.cs = hdr[1]; ws.ox = hdr[2]; ws.oy = hdr[3]; ws.cw = hdr[4]; ws.chh = hdr[5];
     ws.bits = bits;
     ws.openbits = openbits;
@@ -1522,12 +1710,13 @@ __device__ __forceinline__ int hot_list_from_masks(const RefineIO& io, const Com
     const int nwords = (ncell << (2 * (ws.cs - 4))) * 8;
     const uint32_t* list = io.cell_list + (long long)frame * io.list_pitch;
     const uint32_t* masks = reinterpret_cast<const uint32_t*>(t.gidx + (long long)frame * t.gidx_pitch);
-    mark_listed_cells(ws, list, ncell, bits, openbits, nopen_words);
-    expand_masks(masks, list, nwords, ws.cs, cnt, [&](int slot, uint32_t e) { if (slot < lds_cap) lds_xy[slot] = e; });
+    mark_listed_cells(ws, list, ncell, bits, openbits, nopen_words, only);
+    expand_masks(masks, list, nwords, ws.cs, cnt, [&](int slot, uint32_t e) { if (slot < lds_cap) lds_xy[slot] = e; }, only);
     __syncthreads();
     const int n = *cnt;
     __syncthreads();
     if (n <= lds_cap) return n;
+    if (only >= 0) return -1;
     if (threadIdx.x == 0) *cnt = 0;
     __syncthreads();
     expand_masks(masks, list, nwords, ws.cs, cnt, [&](int slot, uint32_t e) { if (slot < t.cap) hot_xy[slot] = e; });
@@ -1544,11 +1733,13 @@ __device__ __forceinline__ int hot_list_from_masks(const RefineIO& io, const Com
 // only holds the cells around the points): the frame is reported instead (kStatusSparse -> the caller repeats the
 // call without the option).
 constexpr int kLdsSparse = kLdsPathSparse;
-__device__ __forceinline__ void lds_decline(const CompTables& t, int frame) {
+// (`next_hdr`: the header of the next level's cell list, or NULL -- nobody lists that level's cells now)
+__device__ __forceinline__ void lds_decline(const CompTables& t, int frame, int32_t* next_hdr = nullptr) {
     if (threadIdx.x != 0) return;
     if (t.lds_path & kLdsSparse) {
         t.path[frame] = 1;
-        wg_or(t.status + frame, kStatusSparse);
+        atomicOr(t.status + frame, kStatusSparse);  // (device scope: a frame may have several workgroups)
+        if (next_hdr) atomicOr(next_hdr + kHdrFlags, kFlagGivenUp);
     } else {
         t.path[frame] = 0;
     }
@@ -1558,7 +1749,8 @@ __device__ __forceinline__ void lds_decline_refine(const CompTables& t, int fram
     if (threadIdx.x != 0) return;
     if (t.lds_path & kLdsSparse) {
         t.path[frame] = 1;
-        wg_or(t.status + frame, kStatusSparse);
+        atomicOr(t.status + frame, kStatusSparse);
+        if (io.next_cnt) atomicOr(io.next_cnt + kCellHdr * frame + kHdrFlags, kFlagGivenUp);
         return;
     }
     t.path[frame] = band > 0 ? 2 : 0;
@@ -1765,7 +1957,19 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
     constexpr bool sparse = SPARSE;  // the response exists in the cells around the points only
     const int npts = min(io.npoints[frame], io.pitch);
     FrameView v = make_view(lb, t, frame);
-    if (sparse && io.next_cnt && tid == 0) io.next_cnt[kCellHdr * frame] = -1;  // until this kernel has listed the next level's cells
+    // several workgroups per frame ("Several workgroups" above): this one is subset `sub` of `nsub`
+    int nsub = 1;
+    const int sub = sparse ? (int)blockIdx.y : 0;
+    if (sparse) {
+        const int32_t* hdr = io.cell_cnt + kCellHdr * frame;
+        nsub = hdr[kHdrSub];
+        if (nsub < 1 || (hdr[kHdrFlags] & kFlagSingle)) nsub = 1;
+        if (sub >= nsub) return;  // (nothing of the frame is this workgroup's: no header, no status is touched)
+    }
+    const bool split = nsub > 1;
+    const int32_t* psub = io.leader + (long long)frame * io.pitch;  // (scratch of the global-memory kernel: here the points' subsets)
+    int32_t* const next_hdr = (sparse && io.next_cnt) ? io.next_cnt + kCellHdr * frame : nullptr;
+    if (split) v.arena += (long long)sub * (2 * LN);  // its own part of the frame's LIFO arena (lds_load_and_label parks there)
     // The cell bitmap lives in L.w (dead until the LIFO demands are written), the open flags behind the
     // accumulators in L.u (dead until the fills).
     WinSel ws;
@@ -1774,11 +1978,11 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
     uint32_t* const obits = reinterpret_cast<uint32_t*>(L.u.stk) + LN;
     static_assert(sizeof(L.u) >= (size_t)LN * 4 + (size_t)LN / 8, "open flags behind the accumulators");
     static_assert(sizeof(L.w) / 4 == kWinWords, "list_cells sizes the bitmap for kWinWords");
-    const int nraw = sparse ? hot_list_from_masks(io, t, frame, v.hot_xy, &L.nload, L.xy, LN, ws, wbits, obits, LN / 32)
+    const int nraw = sparse ? hot_list_from_masks(io, t, frame, v.hot_xy, &L.nload, L.xy, LN, ws, wbits, obits, LN / 32, split ? sub : -1)
                             : t.hot_cnt[frame];
     const bool preloaded = sparse && nraw <= LN;
     if (npts > LPTS || nraw < 0) {  // the LDS kernel does not take that many points (sparse: nor that many cells)
-        lds_decline(t, frame);
+        lds_decline(t, frame, next_hdr);
         return;
     }
     const int w = v.w, h = v.h;
@@ -1825,7 +2029,7 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
         __syncthreads();
     }
     if (nbands == 0) {
-        lds_decline(t, frame);
+        lds_decline(t, frame, next_hdr);
         return;
     }
     if (tid == 0) L.nref = 0;
@@ -1843,7 +2047,8 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
         int n;
         if (win_bands) {
             __syncthreads();
-            mark_listed_cells(ws, io.cell_list + (long long)frame * io.list_pitch, io.cell_cnt[kCellHdr * frame], wbits, obits, LN / 32);
+            mark_listed_cells(ws, io.cell_list + (long long)frame * io.list_pitch, io.cell_cnt[kCellHdr * frame], wbits, obits, LN / 32,
+                              split ? sub : -1);
         }
         if (!lds_load_and_label<SPARSE>(L, v, nraw, t.cap, nbands > 1, L.band_y[band], L.band_y[band + 1], n,
                                         windowed ? &ws : nullptr, preloaded)) {
@@ -1869,7 +2074,7 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
         for (int q = 0; q < LPPT; ++q) {
             const int i = tid + CC_THREADS * q;
             int ns = -1;  // -1: not refinable at this level (or no such point)
-            if (i < npts && lv[i] == level + 1) {
+            if (i < npts && lv[i] == level + 1 && (!split || psub[i] == sub)) {
                 ns = 0;
                 const double lx = rescale_coord(pts[2 * i + 0], 1.0 / coord_scale);  // :369
                 const double ly = rescale_coord(pts[2 * i + 1], 1.0 / coord_scale);
@@ -1900,7 +2105,7 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
         }
         __syncthreads();
         if (windowed && L.leak) {  // (uniform) nothing has been refined yet: the global-memory kernel takes the frame
-            lds_decline(t, frame);
+            lds_decline(t, frame, next_hdr);
             return;
         }
         if (band == 0) tick(3);
@@ -1943,7 +2148,7 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
 #pragma unroll
         for (int q = 0; q < LPPT; ++q) {
             const int i = tid + CC_THREADS * q;
-            if (i < npts) gneed[i] = 0;
+            if (i < npts && (!split || psub[i] == sub)) gneed[i] = 0;  // (a group's leader is one of the subset's own points)
         }
         __syncthreads();
 #pragma unroll
@@ -2033,13 +2238,27 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
     }
     if (tid == 0) {
         t.path[frame] = 1;
-        if (io.nrefined) io.nrefined[frame] = L.nref;
+        if (io.nrefined) {
+            if (split) atomicAdd(io.nrefined + frame, L.nref);  // (zeroed by the launcher)
+            else io.nrefined[frame] = L.nref;
+        }
     }
     if (sparse && io.next_cnt) {
         // the cells of the next level down, around the points as they are now (the barrier at the end of the last band
-        // has made them visible): saves a launch -- and its dependent round trips under a saturated HBM -- per level
-        list_cells(io.next_w, io.next_h, pts, lv, npts, level - 1, reinterpret_cast<uint32_t*>(&L.w), L.edge, &L.nload,
-                   io.cell_list + (long long)frame * io.list_pitch, io.list_pitch, io.next_max_items, io.next_cnt + kCellHdr * frame);
+        // has made them visible): saves a launch -- and its dependent round trips under a saturated HBM -- per level.
+        // They go into the OTHER list buffer: a workgroup of a split level may get here while the others still read
+        // this level's.  The tables are dead: the cut of the next level's points and the split list build in them.
+        uint32_t* const nlist = io.next_list + (long long)frame * io.list_pitch;
+        if (!split) {
+            static_assert(sizeof(L.u) >= sizeof(PartScratch), "partition_points works in the LIFO storage");
+            const int nnext = partition_points(pts, lv, npts, level - 1, io.leader + (long long)frame * io.pitch,
+                                               *reinterpret_cast<PartScratch*>(&L.u), io.subsets);
+            list_cells(io.next_w, io.next_h, pts, lv, npts, level - 1, reinterpret_cast<uint32_t*>(&L.w), L.edge, &L.nload,
+                       nlist, io.list_pitch, io.next_max_items, next_hdr, psub, nnext);
+        } else {
+            list_cells_split(io.next_w, io.next_h, pts, lv, npts, level - 1, reinterpret_cast<uint32_t*>(&L.w), &L.nload, L.xy, LN,
+                             io.cell_cnt + kCellHdr * frame, nlist, io.list_pitch, io.next_max_items, next_hdr, psub, sub, nsub);
+        }
     }
     if (clk) {
         tick(7);
@@ -2048,7 +2267,11 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
 }
 
 template <int N, class K, class... A>
-static void launch_lds(K kernel, int nframes, hipStream_t s, A... args) {
+static void launch_lds_grid(K kernel, dim3 grid, hipStream_t s, A... args);
+template <int N, class K, class... A>
+static void launch_lds(K kernel, int nframes, hipStream_t s, A... args) { launch_lds_grid<N>(kernel, dim3(nframes), s, args...); }
+template <int N, class K, class... A>
+static void launch_lds_grid(K kernel, dim3 grid, hipStream_t s, A... args) {
     // MRGINGHAM_AMD_CC_LDS_PAD: extra bytes of dynamic LDS per workgroup (experiment: where does the allocation
     // stop fitting into one slot of the pixel kernels?)
 #ifdef MRG_EXPERIMENT
@@ -2059,7 +2282,7 @@ static void launch_lds(K kernel, int nframes, hipStream_t s, A... args) {
     static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LdsCCT<N>) + pad), true);
     (void)once;
-    hipLaunchKernelGGL(kernel, dim3(nframes), dim3(CC_THREADS), sizeof(LdsCCT<N>) + pad, s, args...);
+    hipLaunchKernelGGL(kernel, grid, dim3(CC_THREADS), sizeof(LdsCCT<N>) + pad, s, args...);
 }
 
 void launch_cc_detect_lds(const LevelBatch& lb, const CompTables& t, int level, const DetectOut& out, int frame0,
@@ -2095,18 +2318,24 @@ void launch_cc_detect_levels(const LevelBatch* lbs, const CompTables* ts, const 
 }
 
 void launch_sparse_cells(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io, uint32_t* cell_list,
-                         int32_t* cell_cnt, int list_pitch, int frame0, int nframes, hipStream_t s) {
+                         int32_t* cell_cnt, int list_pitch, int frame0, int nframes, hipStream_t s, int32_t* cnt_all, int nframes_all) {
     if (nframes <= 0) return;
     // the masks of chess_cells_kernel (32 B per micro-tile) go where the pixel -> index map of a dense level is
     hipLaunchKernelGGL(sparse_cells_kernel, dim3(nframes), dim3(CC_THREADS), 0, s, lb.w, lb.h, level, io, cell_list, cell_cnt,
-                       list_pitch, t.gidx_pitch / 4, frame0);
+                       list_pitch, t.gidx_pitch / 4, frame0, cnt_all, nframes_all);
 }
 
 void launch_cc_refine_lds(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io, int frame0,
                           int nframes, hipStream_t s) {
     if (!t.lds_path || nframes <= 0) return;
-    if (t.lds_path & kLdsPathSparse) launch_lds<2048>(cc_refine_lds_kernel<2048, true>, nframes, s, lb, t, level, io, frame0);
-    else launch_lds<2048>(cc_refine_lds_kernel<2048, false>, nframes, s, lb, t, level, io, frame0);
+    if (t.lds_path & kLdsPathSparse) {
+        // up to kSubsets workgroups per frame (those that find no subset of theirs leave at once); they ADD to nrefined
+        if (io.nrefined) (void)hipMemsetAsync(io.nrefined + frame0, 0, (size_t)nframes * 4, s);
+        const int ky = io.subsets < 1 ? 1 : (io.subsets > kSubsets ? kSubsets : io.subsets);
+        launch_lds_grid<2048>(cc_refine_lds_kernel<2048, true>, dim3(nframes, ky), s, lb, t, level, io, frame0);
+    } else {
+        launch_lds<2048>(cc_refine_lds_kernel<2048, false>, nframes, s, lb, t, level, io, frame0);
+    }
 }
 
 }  // namespace mrg

@@ -724,7 +724,7 @@ __global__ __launch_bounds__(64) void chess_cells_kernel(LevelBatch lb, CompTabl
         const bool have = it < nitems;
         const uint32_t c = list[min(it, nitems - 1) >> (2 * sub)];
         const int si = it & ((1 << (2 * sub)) - 1);  // micro-tile within the cell, row-major
-        const int xt = ((int)(c & 0xffffu) << cs) + VC_T * (si & ((1 << sub) - 1));
+        const int xt = ((int)(c & 0xfffu) << cs) + VC_T * (si & ((1 << sub) - 1));  // (bits 12..15: the cell's subset, cc.hip)
         const int yt = ((int)(c >> 16) << cs) + VC_T * (si >> sub);
         __syncthreads();  // (one wave: orders the LDS reads of the pass before against these writes)
         for (int task = hl; task < VC_ROWS * 2; task += 32) {

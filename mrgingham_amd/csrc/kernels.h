@@ -107,9 +107,12 @@ struct RefineIO {
     uint32_t* cell_list = nullptr;        // [nframes*list_pitch]
     const int32_t* cell_cnt = nullptr;    // [nframes*kCellHdr] of this level (common.h)
     int list_pitch = 0;
-    // the refinement kernel of level L lists the cells of level L - 1 itself when it is done (the list is the same
-    // buffer: the kernel has read its own by then); next_cnt = NULL at level 0
+    // the refinement kernel of level L lists the cells of level L - 1 itself when it is done, into next_list (the OTHER of two
+    // buffers: a frame may have several workgroups, and one may be done while the others still read cell_list); next_cnt =
+    // NULL at level 0
     int32_t* next_cnt = nullptr;
+    uint32_t* next_list = nullptr;
+    int subsets = 1;  // workgroups per frame of the sparse refinement kernel (cc.hip, "Several workgroups"): 1 .. 4
     int next_w = 0, next_h = 0;
     long long next_max_items = 0;
 };
@@ -131,8 +134,9 @@ void launch_cc_refine(const LevelBatch& lb, const CompTables& t, int level, cons
                       int nframes, hipStream_t s);
 // sparse refinement: the cells (squares of 16 pixels; 32, 64 ... when the box around the points has more than 40 960 of them) around the points to refine at
 // `level`, per frame: cell_list[frame * list_pitch + k], k < cell_cnt[frame]
+// cnt_all / nframes_all: the cell-list headers of every level, [level][frame][kCellHdr]: those of the levels below `level` are zeroed
 void launch_sparse_cells(const LevelBatch& lb, const CompTables& t, int level, const RefineIO& io, uint32_t* cell_list,
-                         int32_t* cell_cnt, int list_pitch, int frame0, int nframes, hipStream_t s);
+                         int32_t* cell_cnt, int list_pitch, int frame0, int nframes, hipStream_t s, int32_t* cnt_all, int nframes_all);
 constexpr int kLdsPathSparse = 1024;  // CompTables::lds_path bit: the dense response only holds those cells
 // Sparse refinement, the frames it could not take (kStatusSparse in their level-0 status word): REPEATED DENSELY,
 // on the device, in three small launches (api.hip, queue_sparse_levels):

@@ -56,6 +56,32 @@ def test_sparse_chain_is_the_dense_chain(W, H, B, gridn, start):
         dense.close(); sparse.close()
 
 
+@pytest.mark.parametrize("W,H,gridn,start", [(4096, 3072, 14, 3), (2048, 1536, 14, 3), (3000, 3000, 12, 2), (4096, 3072, 16, 3)])
+def test_several_workgroups_per_frame_give_the_same_chain(W, H, gridn, start):
+    """A frame with at least 128 points to refine is cut into up to `sparse_subsets` subsets of points that are far enough
+    apart, one workgroup of the refinement kernel each (cc.hip, "Several workgroups"): 1, 2 and 4 give the dense chain's
+    doubles, levels and order; frames mixed (a 10x10 board's frame in the same batch stays with one workgroup), calls
+    pipelined without a sync, nothing repeated densely."""
+    dense, sparse = _pair()
+    try:
+        frames = synth.board_batch(3, W, H, gridn, 11, device="cuda")
+        frames[1] = synth.board_frame(W, H, 10, 5, device="cuda")
+        want = dense.chain(frames, start, 1024)
+        assert int(want[2].max()) >= 128
+        for k in (1, 2, 4, 3):
+            sparse.set_option("sparse_subsets", k)
+            _same(want, sparse.chain(frames, start, 1024))
+            outs = [sparse.chain(frames, start, 1024, sync=False) for _ in range(4)]
+            sparse.sync()
+            for o in outs:
+                _same(want, o)
+        assert sparse.sparse_fallbacks() == 0
+        with pytest.raises(ValueError):
+            sparse.set_option("sparse_subsets", 5)
+    finally:
+        dense.close(); sparse.close()
+
+
 def test_sparse_chain_on_textured_frames():
     dense, sparse = _pair()
     try:
