@@ -1694,9 +1694,8 @@ __device__ __forceinline__ void mark_listed_cells(const WinSel& ws, const uint32
     __syncthreads();
 }
 // -> number of hot pixels (uniform; -1: the frame was given up), `ws` = the selection (cells marked in `bits`)
-// `only` >= 0 (a split level): the cells of that subset; more hot pixels in them than the LDS list holds: -1 as well (the
-// global list is the frame's, not the subset's).
-__device__ __forceinline__ int hot_list_from_masks(const RefineIO& io, const CompTables& t, int frame, uint32_t* hot_xy, int* cnt,
+// `only` >= 0 (a split level): the cells of that subset; `hot_xy` / `cap` are then the subset's part of the frame's global list.
+__device__ __forceinline__ int hot_list_from_masks(const RefineIO& io, const CompTables& t, int frame, uint32_t* hot_xy, int cap, int* cnt,
                                                    uint32_t* lds_xy, int lds_cap, WinSel& ws, uint32_t* bits, uint32_t* openbits,
                                                    int nopen_words, int only = -1) {
     const int32_t* hdr = io.cell_cnt + kCellHdr * frame;
@@ -1716,10 +1715,9 @@ __device__ __forceinline__ int hot_list_from_masks(const RefineIO& io, const Com
     const int n = *cnt;
     __syncthreads();
     if (n <= lds_cap) return n;
-    if (only >= 0) return -1;
     if (threadIdx.x == 0) *cnt = 0;
     __syncthreads();
-    expand_masks(masks, list, nwords, ws.cs, cnt, [&](int slot, uint32_t e) { if (slot < t.cap) hot_xy[slot] = e; });
+    expand_masks(masks, list, nwords, ws.cs, cnt, [&](int slot, uint32_t e) { if (slot < cap) hot_xy[slot] = e; }, only);
     __threadfence();  // the list is read back by other waves of this workgroup
     __syncthreads();
     return n;
@@ -1969,7 +1967,13 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
     const bool split = nsub > 1;
     const int32_t* psub = io.leader + (long long)frame * io.pitch;  // (scratch of the global-memory kernel: here the points' subsets)
     int32_t* const next_hdr = (sparse && io.next_cnt) ? io.next_cnt + kCellHdr * frame : nullptr;
-    if (split) v.arena += (long long)sub * (2 * LN);  // its own part of the frame's LIFO arena (lds_load_and_label parks there)
+    // its own part of the frame's LIFO arena (lds_load_and_label parks there) and of its global hot list (a subset with more
+    // hot pixels than the LDS list holds goes band by band over it, like a whole frame does)
+    const int cap = split ? t.cap / kSubsets : t.cap;
+    if (split) {
+        v.arena += (long long)sub * (2 * LN);
+        v.hot_xy += (long long)sub * cap;
+    }
     // The cell bitmap lives in L.w (dead until the LIFO demands are written), the open flags behind the
     // accumulators in L.u (dead until the fills).
     WinSel ws;
@@ -1978,7 +1982,7 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
     uint32_t* const obits = reinterpret_cast<uint32_t*>(L.u.stk) + LN;
     static_assert(sizeof(L.u) >= (size_t)LN * 4 + (size_t)LN / 8, "open flags behind the accumulators");
     static_assert(sizeof(L.w) / 4 == kWinWords, "list_cells sizes the bitmap for kWinWords");
-    const int nraw = sparse ? hot_list_from_masks(io, t, frame, v.hot_xy, &L.nload, L.xy, LN, ws, wbits, obits, LN / 32, split ? sub : -1)
+    const int nraw = sparse ? hot_list_from_masks(io, t, frame, v.hot_xy, cap, &L.nload, L.xy, LN, ws, wbits, obits, LN / 32, split ? sub : -1)
                             : t.hot_cnt[frame];
     const bool preloaded = sparse && nraw <= LN;
     if (npts > LPTS || nraw < 0) {  // the LDS kernel does not take that many points (sparse: nor that many cells)
@@ -1990,7 +1994,7 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
     double* pts = io.points + 2 * pb;
     signed char* lv = io.levels + pb;
     int nbands = 0;  // cc_lds bit 256: no banding, no windows (test hook)
-    const bool may_select = nraw <= t.cap && !(nraw > LN && (t.lds_path & 256));
+    const bool may_select = nraw <= cap && !(nraw > LN && (t.lds_path & 256));
     // More hot pixels than the tables hold: first try to load only the cells around the points (one pass over the
     // list; a textured scene has 10^4 - 10^5 hot pixels of which the refinement needs ~10^3), then bands.
     // (sparse refinement: the selection is what was computed, marked above, and every listed pixel is in it)
@@ -2050,7 +2054,7 @@ __global__ __launch_bounds__(CC_THREADS, 4) void cc_refine_lds_kernel(LevelBatch
             mark_listed_cells(ws, io.cell_list + (long long)frame * io.list_pitch, io.cell_cnt[kCellHdr * frame], wbits, obits, LN / 32,
                               split ? sub : -1);
         }
-        if (!lds_load_and_label<SPARSE>(L, v, nraw, t.cap, nbands > 1, L.band_y[band], L.band_y[band + 1], n,
+        if (!lds_load_and_label<SPARSE>(L, v, nraw, cap, nbands > 1, L.band_y[band], L.band_y[band + 1], n,
                                         windowed ? &ws : nullptr, preloaded)) {
             // (window mode: the cells around the points hold more hot pixels than the tables do -- band 0, plain decline)
             lds_decline_refine(t, frame, band, io, L.nref);
