@@ -38,6 +38,20 @@ timeout 600 python $R/bench.py --workload c3_4096x3072_14x14_chain --no-cpu-base
 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace_sparse -o t -- python $R/bench.py --sparse-refine --steps 40 --warmup 5 --no-cpu-baseline --no-end-to-end > $OUT/trace_sparse_bench.json 2> $OUT/trace_sparse.err
 timeout 600 python $R/bench.py --sparse-refine --no-cpu-baseline --no-end-to-end > $OUT/bench_sparse.json 2> $OUT/bench_sparse.err
 timeout 900 python $R/bench.py --sparse-refine --workload c4_4096x3072_shard256 --steps 50 --warmup 5 --no-cpu-baseline --no-end-to-end > $OUT/bench_sparse_c4.json 2> $OUT/bench_sparse_c4.err
+# 4e. round 5: the plain ChESS pass alone (kernel trace + the script's own hipEvent line), BASELINE config 2 as a bench line +
+#     kernel trace, the two-rank rehearsal of the N > 1 flow, the sixteen-pixels-per-lane kernel's counters beside chess_v1's
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace_alone -o t -- python $R/tools/chess_pass_alone.py > $OUT/chess_alone.json 2> $OUT/trace_alone.err
+timeout 300 python $R/tools/chess_pass_alone.py > $OUT/chess_alone_untraced.json 2> $OUT/chess_alone_untraced.err
+timeout 300 python $R/tools/chess_pass_alone.py 1920 1080 64 > $OUT/chess_alone_c2_untraced.json 2>> $OUT/chess_alone_untraced.err
+timeout 600 python $R/bench.py --workload c2_1920x1080_level0 --no-cpu-baseline > $OUT/bench_c2.json 2> $OUT/bench_c2.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace_c2 -o t -- python $R/bench.py --workload c2_1920x1080_level0 --steps 40 --warmup 5 --no-cpu-baseline --no-find-boards --no-end-to-end > $OUT/trace_c2_bench.json 2> $OUT/trace_c2.err
+timeout 300 python $R/bench.py --gpus 2 --rehearse --workload c1_640x480_chain --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_rehearsal.json 2> $OUT/bench_rehearsal.err
+for v in 16 1; do
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_a$v -o p -- python $R/tools/chess16_pmc.py $v > /dev/null 2> $OUT/pmc_a$v.err
+timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $OUT/pmc_b$v -o p -- python $R/tools/chess16_pmc.py $v > /dev/null 2> $OUT/pmc_b$v.err
+done
+timeout 300 python $R/tools/chess16_sweep.py > $OUT/chess16_sweep.txt 2> $OUT/chess16_sweep.err
+timeout 300 python $R/tools/sparse_subsets_ab.py > $OUT/sparse_subsets_ab.txt 2> $OUT/sparse_subsets_ab.err
 # 5. preprocessing kernels (row (f)-2)
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/pre -o t -- python $R/tools/preprocess_bench.py > $OUT/prebench.txt 2> $OUT/pre.err
 # summaries on the box (the raw rocprofv3 output is too big to travel back), then drop the raw files
@@ -45,8 +59,10 @@ python $R/tools/rocprof_summary.py $OUT/trace/t_results.db > $OUT/bench_kernel_t
 python $R/tools/rocprof_summary.py $OUT/pre/t_results.db > $OUT/preprocess_kernel_trace.txt 2>> $OUT/pre.err
 python $R/tools/rocprof_summary.py $OUT/trace_clut/t_results.db > $OUT/cluttered_kernel_trace.txt 2>> $OUT/trace_clut.err
 python $R/tools/rocprof_summary.py $OUT/trace_sparse/t_results.db > $OUT/sparse_kernel_trace.txt 2>> $OUT/trace_sparse.err
-for d in pmc_rd pmc_wr pmc_fetch pmc_write pmc_sq1 pmc_sq2 pmc_sqp1 pmc_sqp2; do
+python $R/tools/rocprof_summary.py $OUT/trace_alone/t_results.db > $OUT/chess_alone_kernel_trace.txt 2>> $OUT/trace_alone.err
+python $R/tools/rocprof_summary.py $OUT/trace_c2/t_results.db > $OUT/c2_kernel_trace.txt 2>> $OUT/trace_c2.err
+for d in pmc_rd pmc_wr pmc_fetch pmc_write pmc_sq1 pmc_sq2 pmc_sqp1 pmc_sqp2 pmc_a16 pmc_b16 pmc_a1 pmc_b1; do
     python $R/tools/pmc_summary.py $OUT/$d/p_counter_collection.csv > $OUT/$d.txt 2>> $OUT/$d.err
 done
-rm -rf $OUT/trace $OUT/pre $OUT/trace_clut $OUT/trace_sparse $OUT/pmc_rd $OUT/pmc_wr $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sqp1 $OUT/pmc_sqp2
+rm -rf $OUT/trace_alone $OUT/trace_c2 $OUT/pmc_a16 $OUT/pmc_b16 $OUT/pmc_a1 $OUT/pmc_b1 $OUT/trace $OUT/pre $OUT/trace_clut $OUT/trace_sparse $OUT/pmc_rd $OUT/pmc_wr $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sqp1 $OUT/pmc_sqp2
 ls -la $OUT

@@ -104,3 +104,30 @@ if os.path.exists(os.path.join(R, "sparse_kernel_trace.txt")):
 for n in ("bench_cluttered.json", "bench_c4.json", "bench_14x14.json", "bench_sparse.json", "bench_sparse_c4.json"):
     if os.path.exists(os.path.join(R, n)) and rd(n).strip():
         open(os.path.join(P, f"{RND}_{n}"), "w").write(rd(n))
+
+# 6. round 5: the plain ChESS pass alone, config 2, the rehearsal, chess_v16 against chess_v1
+if os.path.exists(os.path.join(R, "chess_alone_kernel_trace.txt")):
+    ca = json.loads(rd("chess_alone.json").strip().splitlines()[-1])
+    cu = json.loads(rd("chess_alone_untraced.json").strip().splitlines()[-1])
+    open(os.path.join(P, f"{RND}_chess_alone_kernel_trace.txt"), "w").write(
+        "# rocprofv3 --kernel-trace --stats -- python tools/chess_pass_alone.py   (mrgingham_amd_chess_response_batch(level 0, clamp 0) = the output of ChESS.c:56-106,\n"
+        "# 64 frames of 4096x3072, 130 launches back to back, nothing else on the device; 3 B/px = 2 415 919 104 bytes per launch)\n"
+        f"# the script's own hipEvents under the tracer: avg {ca['avg_launch_ms']*1e3:.1f} us (first event to last / 120, dispatch gaps included) = {ca['frac']*100:.1f} % of 8 TB/s, median launch {ca['median_launch_ms']*1e3:.1f} us = {ca['frac_median_launch']*100:.1f} %\n"
+        f"# the same without the tracer, same box: avg {cu['avg_launch_ms']*1e3:.1f} us = {cu['frac']*100:.1f} %, median {cu['median_launch_ms']*1e3:.1f} us = {cu['frac_median_launch']*100:.1f} %\n"
+        + strip(rd("chess_alone_kernel_trace.txt")))
+if os.path.exists(os.path.join(R, "c2_kernel_trace.txt")):
+    c2 = json.loads(rd("bench_c2.json").strip().splitlines()[-1])
+    open(os.path.join(P, f"{RND}_c2_kernel_trace.txt"), "w").write(
+        "# rocprofv3 --kernel-trace --stats -- python bench.py --workload c2_1920x1080_level0 --steps 40 --warmup 5 --no-cpu-baseline --no-find-boards --no-end-to-end\n"
+        f"# BASELINE config 2 (64 x 1920x1080, level-0 detect).  bench.py with its defaults, untraced, same box: {c2['value']:.0f} frames/s, {c2['ms_per_step']:.4f} ms/step, level-0 launch "
+        f"{c2['roofline']['avg_launch_ms']*1e3:.1f} us = {c2['roofline']['frac']*100:.1f} % of 8 TB/s on 3 B/px; chess_pass_alone {c2['chess_pass_alone']['avg_launch_ms']*1e3:.1f} us = {c2['chess_pass_alone']['frac']*100:.1f} %\n"
+        + strip(rd("c2_kernel_trace.txt")))
+    open(os.path.join(P, f"{RND}_bench_c2.json"), "w").write(rd("bench_c2.json"))
+for n in ("bench_rehearsal.json", "chess16_sweep.txt", "sparse_subsets_ab.txt"):
+    if os.path.exists(os.path.join(R, n)) and rd(n).strip():
+        open(os.path.join(P, f"{RND}_{n}"), "w").write(strip(rd(n)))
+if os.path.exists(os.path.join(R, "pmc_a16.txt")):
+    open(os.path.join(P, f"{RND}_chess16_sq_counters.txt"), "w").write(
+        "# rocprofv3 --pmc <SQ counters> --kernel-trace --output-format csv -- python tools/chess16_pmc.py 16 | 1   (32 frames of 4096x3072, plain response, two passes each)\n"
+        "# chess_v16_kernel (16 pixels per lane, 3 waves per SIMD) beside chess_v1_kernel (8 pixels per lane, 4 waves per SIMD); per 512 px: divide by 786 432\n"
+        + rd("pmc_a16.txt") + rd("pmc_b16.txt") + rd("pmc_a1.txt") + rd("pmc_b1.txt"))
