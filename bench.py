@@ -344,6 +344,7 @@ def find_boards_leg(device_index, frames, gridn, batches=150, depth=3):
 
 
 def chess_pass_alone_leg(det, frames, launches=120, warm=10):
+    import mrgingham_amd
     """north_star's sentence as a number: the plain ChESS pass -- mrgingham_amd_chess_response_batch(level 0, clamp 0),
     the literal output of mrgingham_ChESS_response_5 (ChESS.c:56-106) for every frame of the batch: u8 read once, int16
     written once, no clamp, no hot list, no level images -- alone on the device, every launch bracketed by hipEvents on
@@ -366,7 +367,21 @@ def chess_pass_alone_leg(det, frames, launches=120, warm=10):
     med = per[launches // 2]
     alg = B * W * H * 3.0
     del out
-    return {"kernel": "chess_v16_kernel<CLAMP 0> (plain ChESS response, the output of ChESS.c:56-106; sixteen pixels per lane, "
+    # HBM-side bytes per launch: replayed from the committed rocprofv3 --pmc passes of this kernel alone
+    # (profiles/chess_alone_traffic.json), like `roofline.traffic`: only for a library built from the same kernel sources
+    traffic, traffic_src = None, None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "chess_alone_traffic.json")))
+        kid = mrgingham_amd._lib.lib().mrgingham_amd_kernel_id().decode()
+        if (tj["width"], tj["height"]) == (W, H):
+            if tj.get("kernel_id") == kid:
+                traffic, traffic_src = tj["bytes_per_pixel"] * B * W * H, tj["source"]
+            else:
+                traffic_src = f"none: {tj.get('source')} was collected on kernel sources {tj.get('kernel_id')}, this library is {kid}"
+    except (OSError, KeyError, ValueError):
+        pass
+    return {"traffic": traffic, "traffic_source": traffic_src,
+            "kernel": "chess_v16_kernel<CLAMP 0> (plain ChESS response, the output of ChESS.c:56-106; sixteen pixels per lane, "
                       "mrgingham_amd/csrc/chess16.hip: the library's kernel for the response without a hot list)",
             "bytes_model": "3 B/px (u8 read once + int16 written once)", "bytes_per_launch": alg,
             "launches_timed": launches, "avg_launch_ms": avg, "median_launch_ms": med,

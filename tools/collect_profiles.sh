@@ -50,6 +50,9 @@ for v in 16 1; do
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_a$v -o p -- python $R/tools/chess16_pmc.py $v > /dev/null 2> $OUT/pmc_a$v.err
 timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $OUT/pmc_b$v -o p -- python $R/tools/chess16_pmc.py $v > /dev/null 2> $OUT/pmc_b$v.err
 done
+# EA (fabric) traffic of the plain ChESS pass (chess_v16_kernel, 32 frames of 4096x3072): reads by size, writes
+timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_128B --kernel-trace --output-format csv -d $OUT/pmc_ard -o p -- python $R/tools/chess16_pmc.py 16 > /dev/null 2> $OUT/pmc_ard.err
+timeout 300 rocprofv3 --pmc TCC_EA0_WRREQ TCC_EA0_WRREQ_64B --kernel-trace --output-format csv -d $OUT/pmc_awr -o p -- python $R/tools/chess16_pmc.py 16 > /dev/null 2> $OUT/pmc_awr.err
 timeout 300 python $R/tools/chess16_sweep.py > $OUT/chess16_sweep.txt 2> $OUT/chess16_sweep.err
 timeout 300 python $R/tools/sparse_subsets_ab.py > $OUT/sparse_subsets_ab.txt 2> $OUT/sparse_subsets_ab.err
 # 5. preprocessing kernels (row (f)-2)
@@ -61,8 +64,8 @@ python $R/tools/rocprof_summary.py $OUT/trace_clut/t_results.db > $OUT/cluttered
 python $R/tools/rocprof_summary.py $OUT/trace_sparse/t_results.db > $OUT/sparse_kernel_trace.txt 2>> $OUT/trace_sparse.err
 python $R/tools/rocprof_summary.py $OUT/trace_alone/t_results.db > $OUT/chess_alone_kernel_trace.txt 2>> $OUT/trace_alone.err
 python $R/tools/rocprof_summary.py $OUT/trace_c2/t_results.db > $OUT/c2_kernel_trace.txt 2>> $OUT/trace_c2.err
-for d in pmc_rd pmc_wr pmc_fetch pmc_write pmc_sq1 pmc_sq2 pmc_sqp1 pmc_sqp2 pmc_a16 pmc_b16 pmc_a1 pmc_b1; do
+for d in pmc_rd pmc_wr pmc_fetch pmc_write pmc_sq1 pmc_sq2 pmc_sqp1 pmc_sqp2 pmc_a16 pmc_b16 pmc_a1 pmc_b1 pmc_ard pmc_awr; do
     python $R/tools/pmc_summary.py $OUT/$d/p_counter_collection.csv > $OUT/$d.txt 2>> $OUT/$d.err
 done
-rm -rf $OUT/trace_alone $OUT/trace_c2 $OUT/pmc_a16 $OUT/pmc_b16 $OUT/pmc_a1 $OUT/pmc_b1 $OUT/trace $OUT/pre $OUT/trace_clut $OUT/trace_sparse $OUT/pmc_rd $OUT/pmc_wr $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sqp1 $OUT/pmc_sqp2
+rm -rf $OUT/pmc_ard $OUT/pmc_awr $OUT/trace_alone $OUT/trace_c2 $OUT/pmc_a16 $OUT/pmc_b16 $OUT/pmc_a1 $OUT/pmc_b1 $OUT/trace $OUT/pre $OUT/trace_clut $OUT/trace_sparse $OUT/pmc_rd $OUT/pmc_wr $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sqp1 $OUT/pmc_sqp2
 ls -la $OUT

@@ -131,3 +131,22 @@ if os.path.exists(os.path.join(R, "pmc_a16.txt")):
         "# rocprofv3 --pmc <SQ counters> --kernel-trace --output-format csv -- python tools/chess16_pmc.py 16 | 1   (32 frames of 4096x3072, plain response, two passes each)\n"
         "# chess_v16_kernel (16 pixels per lane, 3 waves per SIMD) beside chess_v1_kernel (8 pixels per lane, 4 waves per SIMD); per 512 px: divide by 786 432\n"
         + rd("pmc_a16.txt") + rd("pmc_b16.txt") + rd("pmc_a1.txt") + rd("pmc_b1.txt"))
+
+# 7. EA traffic of the plain ChESS pass (chess_v16_kernel alone): what bench.py replays as chess_pass_alone.traffic
+if os.path.exists(os.path.join(R, "pmc_ard.txt")):
+    kga = "chess_v16_kernel<false>  grid=786432"
+    ardb = 128 * grab("pmc_ard", kga, "TCC_EA0_RDREQ_128B") + 64 * grab("pmc_ard", kga, "TCC_EA0_RDREQ_64B") + 32 * grab("pmc_ard", kga, "TCC_EA0_RDREQ_32B")
+    aw64, awall = grab("pmc_awr", kga, "TCC_EA0_WRREQ_64B"), grab("pmc_awr", kga, "TCC_EA0_WRREQ ")
+    awrb = 64 * aw64 + 32 * (awall - aw64)
+    apx = 32 * 4096 * 3072
+    open(os.path.join(P, f"{RND}_chess_alone_pmc_ea_traffic.txt"), "w").write(
+        "# rocprofv3 --pmc ... --kernel-trace --output-format csv -- python tools/chess16_pmc.py 16   (chess_v16_kernel alone, 32 frames of 4096x3072, plain response; two passes)\n"
+        "## pass 1: --pmc TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_128B\n" + rd("pmc_ard.txt") +
+        "## pass 2: --pmc TCC_EA0_WRREQ TCC_EA0_WRREQ_64B\n" + rd("pmc_awr.txt"))
+    json.dump({"_comment": f"HBM-side (L2 <-> EA fabric) traffic of ONE launch of mrg::chess_v16_kernel<false> (the plain ChESS pass, 32 frames of 4096x3072) from the rocprofv3 --pmc passes "
+                           f"of tools/chess16_pmc.py (round {RND[1:]}, profiles/{RND}_chess_alone_pmc_ea_traffic.txt).  Reads = 128*RDREQ_128B + 64*RDREQ_64B + 32*RDREQ_32B, writes = 64*WRREQ_64B + 32*(WRREQ - WRREQ_64B).",
+               "kernel": "mrg::chess_v16_kernel<false>", "frames": 32, "width": 4096, "height": 3072, "read_bytes": int(ardb), "write_bytes": int(awrb),
+               "bytes_per_pixel": round((ardb + awrb) / apx, 4), "algorithmic_bytes_per_pixel": 3.0,
+               "source": f"profiles/{RND}_chess_alone_pmc_ea_traffic.txt", "kernel_id": b.get("kernel_id")},
+              open(os.path.join(P, "chess_alone_traffic.json"), "w"), indent=1)
+    print(f"plain ChESS pass: read {ardb/1e6:.1f} MB + written {awrb/1e6:.1f} MB per 32-frame launch = {(ardb+awrb)/apx:.4f} B/px")
