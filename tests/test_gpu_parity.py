@@ -134,6 +134,16 @@ def test_chess_v16_is_the_default_on_a_large_batch_and_matches_v1(det):
         det.set_option("chess_variant", 0)
     for f in (0, 17, 39):
         assert np.array_equal(r[f], oracle.chess_response_5(np.ascontiguousarray(big[f, 20:280, 16:336].cpu().numpy()), fill=0))
+    # a view whose first pixel is not 4-byte aligned (its 16-byte staging loads would not be dword loads): the library
+    # takes chess_v1 for it whatever the option says, and the answer is the same
+    odd = big[:, 20:280, 3:323]
+    det.set_option("chess_variant", 16)
+    try:
+        r = det.chess_response(odd, 0).cpu().numpy()
+    finally:
+        det.set_option("chess_variant", 0)
+    for f in (1, 38):
+        assert np.array_equal(r[f], oracle.chess_response_5(np.ascontiguousarray(big[f, 20:280, 3:323].cpu().numpy()), fill=0))
 
 
 def test_chess_v16_fused_variants_give_the_same_chain(det):
