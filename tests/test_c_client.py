@@ -35,6 +35,18 @@ def test_header_is_c99_and_every_declared_function_links(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
 
 
+def test_rccl_host_example_compiles_as_c99():
+    """tests/boundary/rccl_host.c -- the rank of a one-process-per-GPU host of INTEGRATION.md 5d: shard, packed block,
+    chain_batch, ONE ncclGather through mrgingham_amd_gather_rccl -- against the header, the HIP runtime API and rccl.h
+    (syntax and types; ranks and GPUs are needed to run it)."""
+    if not os.path.exists("/opt/rocm/include/rccl/rccl.h"):
+        pytest.skip("no RCCL headers here")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-D__HIP_PLATFORM_AMD__",
+                        "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "boundary", "rccl_host.c")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
 @pytest.mark.gpu
 def test_c_caller_gets_what_the_python_mirror_gets(tmp_path):
     import mrgingham_amd
