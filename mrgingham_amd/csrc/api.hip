@@ -146,6 +146,7 @@ struct mrgingham_amd_ctx {
     bool use_v0 = false;  // reference-shaped ChESS kernel instead of the tuned one
     int sparse_subsets = 2;  // option "sparse_subsets": workgroups per frame of the sparse refinement (1 .. 4; 4 measures like 2)
     int chess_variant_hot = 0;  // the levels of a chain (clamp + hot list): 16 = chess_v16_hot_kernel / chess_v16_multi_kernel, 0 = chess_v1
+    int chess_seg = 0, chess16_seg = 0;  // options "chess_seg" / "chess16_seg": rows per workgroup of the response kernels, 0 = automatic
     int chess_variant = 0;  // the response without a hot list: 0 = chess_v16_kernel (chess16.hip) where it pays, 1 = chess_v1 always, 16 = chess_v16 wherever it can run
     // levels 3..1 of a chain in one launch (set_option "multi_level_launch"): +1.5 % chain rate, but the
     // component chains then start later and overlap the level-0 launch more (+5 % on that launch): off
@@ -510,11 +511,11 @@ static void launch_chess_any(mrgingham_amd_ctx* ctx, const LevelBatch& lb, const
         if (ctx->use_v0) launch_chess_v0(lb, t, 0, n, clamp, hot, s);
         else
 #endif
-        if (!hot && ((ctx->chess_variant == 0 && chess16_pays(lb, n)) || (ctx->chess_variant == 16 && chess16_ok(lb)))) launch_chess16(lb, 0, n, clamp, s);
+        if (!hot && ((ctx->chess_variant == 0 && chess16_pays(lb, n)) || (ctx->chess_variant == 16 && chess16_ok(lb)))) launch_chess16(lb, 0, n, clamp, s, ctx->chess16_seg);
 #ifdef MRG_EXPERIMENT
         else if (hot && (ctx->chess_variant_hot & 16) && !t.only && chess16_ok(lb)) launch_chess16_hot(lb, t, 0, n, s);
 #endif
-        else launch_chess(lb, t, 0, n, clamp, hot, s);
+        else launch_chess(lb, t, 0, n, clamp, hot, s, ctx->chess_seg);
     }
     if (e0) {
         hipEventRecord(e1, s);
@@ -712,9 +713,9 @@ static int queue_sparse_levels(mrgingham_amd_ctx* ctx, const mrgingham_amd_frame
         mt[L] = lt[L];
         mt[L].only = list;
     }
-    const bool merged = top >= 2 && chess_multi_ok(mlb, top, nf) && launch_chess_multi(mlb, mt, top, nf, cc);
+    const bool merged = top >= 2 && chess_multi_ok(mlb, top, nf) && launch_chess_multi(mlb, mt, top, nf, cc, ctx->chess_seg);
     if (!merged)
-        for (int L = top - 1; L >= 0; --L) launch_chess(lbs[L], mt[L], 0, nf, true, true, cc);
+        for (int L = top - 1; L >= 0; --L) launch_chess(lbs[L], mt[L], 0, nf, true, true, cc, ctx->chess_seg);
     launch_cc_refine_flagged_levels(lbs, lt, top, dio, restore, list, flags, ctx->counters_nf, (int32_t*)ctx->sparse_stat.p, cc);
     return 0;
 }
@@ -976,7 +977,13 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
         ctx->sparse_subsets = value;
         return 0;
     }
-    if (!strcmp(name, "chess16_seg")) { mrg::chess16_seg_override = value > 0 ? (value + 15) / 16 * 16 : 0; return 0; }
+    if (!strcmp(name, "chess16_seg") || !strcmp(name, "chess_seg")) {
+        // rows per workgroup of chess_v16_kernel / the chess_v1 kernels of THIS context (0 = automatic): the frame is cut into
+        // ceil(height / value) balanced segments (common.h, segment_rows)
+        if (value < 0 || value > 65536) return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "%s: 0 (automatic) or a row count", name);
+        (name[5] == '1' ? ctx->chess16_seg : ctx->chess_seg) = value;
+        return 0;
+    }
     if (!strcmp(name, "multi_level_launch")) { ctx->multi_level = value < 0 ? 0 : value > 2 ? 2 : value; return 0; }
 #ifdef MRG_EXPERIMENT
     if (!strcmp(name, "cc_schedule")) { ctx->cc_schedule = value; return 0; }
@@ -1009,7 +1016,6 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
         ctx->cc_lds = value;
         return 0;
     }
-    if (!strcmp(name, "chess_seg")) { mrg::chess_seg_override = value > 0 ? value : 0; return 0; }
     return MRGINGHAM_AMD_ERR_ARG;
 }
 
@@ -1376,7 +1382,7 @@ int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames
 #ifdef MRG_EXPERIMENT
         if (!((ctx->chess_variant_hot & 32) && launch_chess16_pyramid(lbs[0], tables_of(ctx, 0), pyramid_out_of(ctx, start_level), fr->nframes, ctx->pix)))
 #endif
-            launch_chess_pyramid(lbs[0], tables_of(ctx, 0), pyramid_out_of(ctx, start_level), fr->nframes, ctx->pix);
+            launch_chess_pyramid(lbs[0], tables_of(ctx, 0), pyramid_out_of(ctx, start_level), fr->nframes, ctx->pix, ctx->chess_seg);
         if (e0) {
             hipEvent_t e1 = timing_event(ctx);
             hipEventRecord(e1, ctx->pix);
@@ -1416,7 +1422,7 @@ int mrgingham_amd_chain_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames
 #ifdef MRG_EXPERIMENT
                 ((ctx->chess_variant_hot & 16) && launch_chess16_multi(mlb, mt, n, fr->nframes, ctx->pix)) ||
 #endif
-                launch_chess_multi(mlb, mt, n, fr->nframes, ctx->pix);
+                launch_chess_multi(mlb, mt, n, fr->nframes, ctx->pix, ctx->chess_seg);
             if (merged) {
                 hipEvent_t em = (ctx->timing && !fused) ? timing_event(ctx) : ctx->ev_pix[top];
                 hipEventRecord(em, ctx->pix);
@@ -3159,7 +3165,7 @@ static int fb_submit(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int
             mlb[k] = level_batch_of(ctx, fr, job.levs[job.nlev - 1 - k]);
             mt[k] = tables_of(ctx, job.levs[job.nlev - 1 - k]);
         }
-        if (chess_multi_ok(mlb, job.nlev, B) && launch_chess_multi(mlb, mt, job.nlev, B, ctx->pix)) {
+        if (chess_multi_ok(mlb, job.nlev, B) && launch_chess_multi(mlb, mt, job.nlev, B, ctx->pix, ctx->chess_seg)) {
             merged = true;
             for (int k = 0; k < job.nlev; ++k) lbs[job.nlev - 1 - k] = mlb[k];
             hipEventRecord(ctx->ev_pix[top], ctx->pix);

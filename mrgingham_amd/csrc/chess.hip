@@ -448,14 +448,14 @@ __device__ __forceinline__ uint32_t response_pair_biased(const uint32_t (&m5)[12
 }
 
 template <bool CLAMP, bool HOT, int STAGE, bool PYR = false, bool FILTER = false>
-__device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTables& t, int frame0, int seg, unsigned bid,
+__device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTables& t, int frame0, int nsegs, unsigned bid,
                                               unsigned nwg_level, char* lds, const PyramidOut* po = nullptr) {
     // XCD-aware work order: workgroup b is dispatched to XCD b % 8 (observed, used
     // for speed only).  Give each XCD a contiguous run of work items, strips
     // fastest, so the 32-pixel column halo and the 10-row segment halo a
     // workgroup shares with its neighbours is found in that XCD's L2 instead of
     // being fetched from HBM once per neighbour.
-    const int nstrips = (lb.w + V1_SW - 1) / V1_SW, nsegs = (lb.h + seg - 1) / seg;
+    const int nstrips = (lb.w + V1_SW - 1) / V1_SW;
     int work;
     {
         const unsigned b = bid, nwg = nwg_level, xcd = b & 7u, j = b >> 3;
@@ -473,8 +473,8 @@ __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTa
     const uint8_t* img = lb.img + (long long)frame * lb.img_pitch;
     int16_t* resp = lb.resp + (long long)frame * lb.resp_pitch;
     const int strip_x = strip * V1_SW;
-    const int ys = (rest % nsegs) * seg;
-    const int ye = min(ys + seg, h);
+    int ys, ye;  // the workgroup's rows: segment rest % nsegs of the frame's nsegs balanced segments (common.h)
+    segment_rows(h, nsegs, rest % nsegs, V1_RB, ys, ye);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6, half = lane >> 5, lx = lane & 31;
@@ -675,15 +675,15 @@ __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTa
 }
 
 template <bool CLAMP, bool HOT, int STAGE, bool FILTER = false>
-__global__ __launch_bounds__(256) void chess_v1_kernel(LevelBatch lb, CompTables t, int frame0, int seg) {
+__global__ __launch_bounds__(256) void chess_v1_kernel(LevelBatch lb, CompTables t, int frame0, int nsegs) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    chess_v1_body<CLAMP, HOT, STAGE, false, FILTER>(lb, t, frame0, seg, blockIdx.x, gridDim.x, lds);
+    chess_v1_body<CLAMP, HOT, STAGE, false, FILTER>(lb, t, frame0, nsegs, blockIdx.x, gridDim.x, lds);
 }
 
 // Level 0 of the chain: response + clamp + hot list + the level images 1..3 (see emit_pyramid_rows).
-__global__ __launch_bounds__(256, 4) void chess_v1_pyr_kernel(LevelBatch lb, CompTables t, int seg, PyramidOut po) {
+__global__ __launch_bounds__(256, 4) void chess_v1_pyr_kernel(LevelBatch lb, CompTables t, int nsegs, PyramidOut po) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    chess_v1_body<true, true, STAGE_PERM16, true>(lb, t, 0, seg, blockIdx.x, gridDim.x, lds, &po);
+    chess_v1_body<true, true, STAGE_PERM16, true>(lb, t, 0, nsegs, blockIdx.x, gridDim.x, lds, &po);
 }
 
 // ---------------------------------------------------------------------------
@@ -797,7 +797,7 @@ struct ChessMulti {
     CompTables t[kMultiMax];
     int first_wg[kMultiMax];  // first workgroup of level slot k (a multiple of 8: workgroup b runs on XCD b % 8,
     int nwg[kMultiMax];       // and the XCD-aware work order of the body counts from the slot's first workgroup)
-    int seg[kMultiMax];
+    int nsegs[kMultiMax];     // balanced row segments per frame (common.h, segment_rows)
     int n;
 };
 template <bool FILTER>  // FILTER: only the frames a sparse chain reported (CompTables::only, see chess_v1_body)
@@ -810,50 +810,42 @@ __global__ __launch_bounds__(256, 4) void chess_v1_multi_kernel(ChessMulti a) {
         if (j < a.n && b >= a.first_wg[j]) k = j;
     const int rel = b - a.first_wg[k];
     if (rel >= a.nwg[k]) return;  // padding between slots
-    chess_v1_body<true, true, STAGE_PERM16, false, FILTER>(a.lb[k], a.t[k], 0, a.seg[k], (unsigned)rel, (unsigned)a.nwg[k], lds);
+    chess_v1_body<true, true, STAGE_PERM16, false, FILTER>(a.lb[k], a.t[k], 0, a.nsegs[k], (unsigned)rel, (unsigned)a.nwg[k], lds);
 }
 
 
-int chess_seg_override = 0;  // tuning hook (mrgingham_amd_set_option "chess_seg"): 0 = automatic
 int chess_multi_min_blocks = 768;  // tuning hook "chess_multi_min_blocks": per-level block target inside a merged launch
 int chess_stage_override = 0;  // tuning hook "chess_stage": 0 = automatic, 2 / 3 = typed staging, -1 = generic
 
-// Rows per workgroup.  Tall segments amortise the three-group prologue (24 rows staged before the first response
-// row: worth ~13 rows of the steady state), short ones leave a smaller tail when the launch drains (the chip runs
-// 1024 workgroups at a time) and fill it when the batch is small.  Cost model fitted to measured launches
-// (tools/seg_ab.py; 64 frames): time ~ strips * frames * (h + segments * 13) / 1024 + 1.18 * (segment + 13) / 2.
-//   1920x1080: 256 -> 128 rows, 147 -> 137 us; 1280x960: 128 (89 us; 256: 99); 4096x3072 and 2560x1920: 256.
+// Row segments per frame (balanced: common.h, segment_rows).  Tall segments amortise the three-group prologue (24
+// rows staged before the first response row), short ones fill the chip when the batch is small and leave a shorter
+// drain; the model and its fit are in common.h (pick_balanced_segments).  Before round 6 the choice was among 256 / 128 /
+// 64 / 32 rows, cut from the top of the frame: 1080 rows became eight segments of 128 and one of 56, and the short one
+// every ninth workgroup put the tall ones on the same CUs (64 x 1920x1080, hot kernel: 132 -> 123 us with six of 180;
+// 2048x1536: 198 -> 166 us).
+// `seg_rows` > 0: the caller's segment height (option "chess_seg").
 // `min_blocks` > 0: the older rule for the levels inside a merged launch (tallest segment that still gives that
 // many workgroups), where the largest level fills the chip and the others only pack its tail.
-static int pick_segment(int w, int h, int nframes, int min_blocks = 0) {
-    if (chess_seg_override > 0) return (chess_seg_override + 7) / 8 * 8;
-    const long long strips = (w + V1_SW - 1) / V1_SW;
+static const SegModel kV1Model = {6.8, 0.57, 13.0, 32, 1024};      // plain response
+static const SegModel kV1HotModel = {12.0, 0.8, 13.0, 32, 1024};   // with the hot list (and the level images)
+static int pick_nsegs(int w, int h, int nframes, int seg_rows, bool hot, int min_blocks = 0) {
+    if (seg_rows > 0) return segments_for_rows(h, seg_rows, V1_RB);
+    const int strips = (w + V1_SW - 1) / V1_SW;
     if (min_blocks > 0) {
         for (int seg : {256, 128, 64, 32}) {
-            const long long blocks = strips * ((h + seg - 1) / seg) * nframes;
-            if (blocks >= min_blocks || seg == 32) return seg;
-        }
-        return 32;
-    }
-    int best = 256;
-    double best_cost = 0;
-    for (int seg : {256, 128, 64, 32}) {
-        const int nsegs = (h + seg - 1) / seg;
-        const double cost = (double)strips * nframes * (h + 13.0 * nsegs) / 1024.0 + 1.18 * ((seg < h ? seg : h) + 13.0) / 2.0;
-        if (seg == 256 || cost < 0.98 * best_cost) {  // a taller segment keeps the choice unless a shorter one gains 2 %
-            best = seg;
-            best_cost = cost;
+            const long long blocks = (long long)strips * ((h + seg - 1) / seg) * nframes;
+            if (blocks >= min_blocks || seg == 32) return segments_for_rows(h, seg, V1_RB);
         }
     }
-    return best;
+    return pick_balanced_segments(strips, h, nframes, V1_RB, hot ? kV1HotModel : kV1Model);
 }
 
 // Production entry point.
 void launch_chess(const LevelBatch& lb, const CompTables& t, int frame0, int nframes, bool clamp, bool hot,
-                  hipStream_t s) {
+                  hipStream_t s, int seg_rows) {
     if (hot && t.only) nframes = kOnlySlots;  // a frame list: the grid is laid out for that many frames (chess_v1_body)
-    const int seg = (hot && t.only) ? 256 : pick_segment(lb.w, lb.h, nframes);
-    dim3 grid(((lb.w + V1_SW - 1) / V1_SW) * ((lb.h + seg - 1) / seg) * nframes);
+    const int nsegs = pick_nsegs(lb.w, lb.h, nframes, (hot && t.only) ? 256 : seg_rows, hot);
+    dim3 grid(((lb.w + V1_SW - 1) / V1_SW) * nsegs * nframes);
     const size_t lds = 2 * V1_PLANE + (hot ? (V1_HOTBUF + 12) * sizeof(int) : 0);
     const bool w16 = lb.w >= 16 && lb.w % 16 == 0 && (long long)(lb.h + V1_RB) * lb.img_stride < 0x7fffffffLL;
     // staging path: chess_stage_override (tuning hook "chess_stage") 0 = automatic
@@ -873,7 +865,7 @@ void launch_chess(const LevelBatch& lb, const CompTables& t, int frame0, int nfr
 #else
 #define MRG_CASE_TYPED2(C, H)
 #endif
-#define MRG_LAUNCH(C, H, A) hipLaunchKernelGGL((chess_v1_kernel<C, H, A>), grid, dim3(256), lds, s, lb, t, frame0, seg)
+#define MRG_LAUNCH(C, H, A) hipLaunchKernelGGL((chess_v1_kernel<C, H, A>), grid, dim3(256), lds, s, lb, t, frame0, nsegs)
 #define MRG_LAUNCH_ST(C, H)                                             \
     switch (stage) {                                                    \
         case STAGE_PERM16: MRG_LAUNCH(C, H, STAGE_PERM16); break;       \
@@ -883,9 +875,9 @@ void launch_chess(const LevelBatch& lb, const CompTables& t, int frame0, int nfr
     }
     if (hot && t.only) {  // only the frames a sparse chain reported (see chess_v1_body)
         switch (stage) {
-            case STAGE_PERM16: hipLaunchKernelGGL((chess_v1_kernel<true, true, STAGE_PERM16, true>), grid, dim3(256), lds, s, lb, t, frame0, seg); break;
-            case STAGE_TYPED1: hipLaunchKernelGGL((chess_v1_kernel<true, true, STAGE_TYPED1, true>), grid, dim3(256), lds, s, lb, t, frame0, seg); break;
-            default: hipLaunchKernelGGL((chess_v1_kernel<true, true, STAGE_GENERIC, true>), grid, dim3(256), lds, s, lb, t, frame0, seg); break;
+            case STAGE_PERM16: hipLaunchKernelGGL((chess_v1_kernel<true, true, STAGE_PERM16, true>), grid, dim3(256), lds, s, lb, t, frame0, nsegs); break;
+            case STAGE_TYPED1: hipLaunchKernelGGL((chess_v1_kernel<true, true, STAGE_TYPED1, true>), grid, dim3(256), lds, s, lb, t, frame0, nsegs); break;
+            default: hipLaunchKernelGGL((chess_v1_kernel<true, true, STAGE_GENERIC, true>), grid, dim3(256), lds, s, lb, t, frame0, nsegs); break;
         }
     }
     else if (hot) { MRG_LAUNCH_ST(true, true) }
@@ -902,10 +894,11 @@ bool chess_pyramid_ok(const LevelBatch& lb, int nframes) {
            lb.img_pitch % 16 == 0 && ((uintptr_t)lb.img & 15) == 0 &&
            (long long)(lb.h + V1_RB) * lb.img_stride < 0x7fffffffLL;  // buffer offsets of the staging loads fit 31 bits
 }
-bool launch_chess_pyramid(const LevelBatch& lb, const CompTables& t, const PyramidOut& po, int nframes, hipStream_t s) {
+bool launch_chess_pyramid(const LevelBatch& lb, const CompTables& t, const PyramidOut& po, int nframes, hipStream_t s,
+                          int seg_rows) {
     if (!chess_pyramid_ok(lb, nframes)) return false;
-    const int seg = pick_segment(lb.w, lb.h, nframes);  // a multiple of 8: an iteration's rows are whole cells
-    dim3 grid(((lb.w + V1_SW - 1) / V1_SW) * ((lb.h + seg - 1) / seg) * nframes);
+    const int nsegs = pick_nsegs(lb.w, lb.h, nframes, seg_rows, true);  // segments of whole 8-row granules: an iteration's rows are whole cells
+    dim3 grid(((lb.w + V1_SW - 1) / V1_SW) * nsegs * nframes);
     const size_t lds = 2 * V1_PLANE + (V1_HOTBUF + 12) * sizeof(int);
     PyramidOut p2 = po;
 #ifdef MRG_EXPERIMENT
@@ -914,7 +907,7 @@ bool launch_chess_pyramid(const LevelBatch& lb, const CompTables& t, const Pyram
     for (int k = 0; k < 3; ++k)
         if (skip >> k & 1) p2.out[k] = nullptr;
 #endif
-    hipLaunchKernelGGL(chess_v1_pyr_kernel, grid, dim3(256), lds, s, lb, t, seg, p2);
+    hipLaunchKernelGGL(chess_v1_pyr_kernel, grid, dim3(256), lds, s, lb, t, nsegs, p2);
     return true;
 }
 
@@ -928,7 +921,7 @@ bool chess_multi_ok(const LevelBatch* lbs, int n, int nframes) {
     return true;
 }
 
-bool launch_chess_multi(const LevelBatch* lbs, const CompTables* ts, int n, int nframes, hipStream_t s) {
+bool launch_chess_multi(const LevelBatch* lbs, const CompTables* ts, int n, int nframes, hipStream_t s, int seg_rows) {
     if (!chess_multi_ok(lbs, n, nframes)) return false;
     if (ts[0].only) nframes = kOnlySlots;  // a frame list: the grid is laid out for that many frames (chess_v1_body)
     ChessMulti a;
@@ -941,9 +934,9 @@ bool launch_chess_multi(const LevelBatch* lbs, const CompTables* ts, int n, int 
         // inside a merged launch the largest level fills the chip; the smaller ones only need enough
         // workgroups to pack its tail, so they can afford taller segments than on their own
         // (a frame list: tall segments, i.e. as few workgroups as possible -- nearly always all of them leave at once)
-        a.seg[k] = ts[0].only ? 256 : pick_segment(lbs[j].w, lbs[j].h, nframes, k == 0 ? 2048 : chess_multi_min_blocks);
+        a.nsegs[k] = pick_nsegs(lbs[j].w, lbs[j].h, nframes, ts[0].only ? 256 : seg_rows, true, k == 0 ? 2048 : chess_multi_min_blocks);
         a.first_wg[k] = total;
-        a.nwg[k] = k < n ? ((lbs[j].w + V1_SW - 1) / V1_SW) * ((lbs[j].h + a.seg[k] - 1) / a.seg[k]) * nframes : 0;
+        a.nwg[k] = k < n ? ((lbs[j].w + V1_SW - 1) / V1_SW) * a.nsegs[k] * nframes : 0;
         total += (a.nwg[k] + 7) / 8 * 8;
     }
     const size_t lds = 2 * V1_PLANE + (V1_HOTBUF + 12) * sizeof(int);

@@ -210,10 +210,10 @@ __device__ __forceinline__ void emit_pyramid_block(const char* lds, uint32_t gA,
 // The body for workgroup `bid` of `nwg` of one level (the multi-level launch runs several levels in one grid).
 // HOT (implies CLAMP): the hot-pixel records of chess_hot.h, two aligned 8-pixel groups per lane.
 template <bool CLAMP, bool HOT, bool PYR = false>
-__device__ __forceinline__ void chess_v16_body(const LevelBatch& lb, const CompTables& t, int frame0, int seg, unsigned bid,
+__device__ __forceinline__ void chess_v16_body(const LevelBatch& lb, const CompTables& t, int frame0, int nsegs, unsigned bid,
                                                unsigned nwg_level, char* lds, const PyramidOut* po = nullptr) {
     using namespace v16;
-    const int nstrips = (lb.w + SW - 1) / SW, nsegs = (lb.h + seg - 1) / seg;
+    const int nstrips = (lb.w + SW - 1) / SW;
     int work;
     {   // XCD-aware work order (chess.hip, chess_v1_body)
         const unsigned b = bid, nwg = nwg_level, xcd = b & 7u, j = b >> 3;
@@ -226,8 +226,8 @@ __device__ __forceinline__ void chess_v16_body(const LevelBatch& lb, const CompT
     const uint8_t* img = lb.img + (long long)frame * lb.img_pitch;
     int16_t* resp = lb.resp + (long long)frame * lb.resp_pitch;
     const int strip_x = strip * SW;
-    const int ys = (rest % nsegs) * seg;
-    const int ye = min(ys + seg, h);
+    int ys, ye;  // segment rest % nsegs of the frame's nsegs balanced segments (common.h)
+    segment_rows(h, nsegs, rest % nsegs, RB, ys, ye);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -409,22 +409,22 @@ __device__ __forceinline__ void chess_v16_body(const LevelBatch& lb, const CompT
 
 // Frames whose width is a multiple of 16 only (the staging loads are whole 16-byte chunks inside or outside the frame).
 template <bool CLAMP>
-__global__ __launch_bounds__(256, 3) void chess_v16_kernel(LevelBatch lb, int frame0, int seg) {
+__global__ __launch_bounds__(256, 3) void chess_v16_kernel(LevelBatch lb, int frame0, int nsegs) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    chess_v16_body<CLAMP, false>(lb, CompTables{}, frame0, seg, blockIdx.x, gridDim.x, lds);
+    chess_v16_body<CLAMP, false>(lb, CompTables{}, frame0, nsegs, blockIdx.x, gridDim.x, lds);
 }
 
 #ifdef MRG_EXPERIMENT
 // clamp + hot list (the levels of a chain)
-__global__ __launch_bounds__(256, 3) void chess_v16_hot_kernel(LevelBatch lb, CompTables t, int frame0, int seg) {
+__global__ __launch_bounds__(256, 3) void chess_v16_hot_kernel(LevelBatch lb, CompTables t, int frame0, int nsegs) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    chess_v16_body<true, true>(lb, t, frame0, seg, blockIdx.x, gridDim.x, lds);
+    chess_v16_body<true, true>(lb, t, frame0, nsegs, blockIdx.x, gridDim.x, lds);
 }
 
 // level 0 of a chain: clamp + hot list + the level images 1..3
-__global__ __launch_bounds__(256, 3) void chess_v16_pyr_kernel(LevelBatch lb, CompTables t, int seg, PyramidOut po) {
+__global__ __launch_bounds__(256, 3) void chess_v16_pyr_kernel(LevelBatch lb, CompTables t, int nsegs, PyramidOut po) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    chess_v16_body<true, true, true>(lb, t, 0, seg, blockIdx.x, gridDim.x, lds, &po);
+    chess_v16_body<true, true, true>(lb, t, 0, nsegs, blockIdx.x, gridDim.x, lds, &po);
 }
 
 // Several pyramid levels of the same batch in ONE grid (chess.hip, chess_v1_multi_kernel): clamp + hot list.
@@ -434,7 +434,7 @@ struct ChessMulti16 {
     CompTables t[kMulti16Max];
     int first_wg[kMulti16Max];  // first workgroup of level slot k (a multiple of 8: the XCD-aware order counts from it)
     int nwg[kMulti16Max];
-    int seg[kMulti16Max];
+    int nsegs[kMulti16Max];
     int n;
 };
 __global__ __launch_bounds__(256, 3) void chess_v16_multi_kernel(ChessMulti16 a) {
@@ -446,36 +446,25 @@ __global__ __launch_bounds__(256, 3) void chess_v16_multi_kernel(ChessMulti16 a)
         if (j < a.n && b >= a.first_wg[j]) k = j;
     const int rel = b - a.first_wg[k];
     if (rel >= a.nwg[k]) return;  // padding between slots
-    chess_v16_body<true, true>(a.lb[k], a.t[k], 0, a.seg[k], (unsigned)rel, (unsigned)a.nwg[k], lds);
+    chess_v16_body<true, true>(a.lb[k], a.t[k], 0, a.nsegs[k], (unsigned)rel, (unsigned)a.nwg[k], lds);
 }
 
 #endif  // MRG_EXPERIMENT
-
-int chess16_seg_override = 0;  // option "chess16_seg"
 
 bool chess16_ok(const LevelBatch& lb) {
     return lb.w >= 16 && lb.w % 16 == 0 && lb.h > 0 && ((uintptr_t)lb.img & 3) == 0 && lb.img_stride % 4 == 0 && lb.img_pitch % 4 == 0 && (long long)(lb.h + 64) * lb.img_stride < 0x7fffffffLL &&
            (long long)lb.w * lb.h * 2 < 0x7fffffffLL;
 }
 
-// Rows per workgroup (multiples of 16).  Cost model fitted to measured launches (tools/chess16_sweep.py, 64 frames, 512x384 ..
-// 4096x3072): a segment costs its rows + ~22 rows for the 32-row prologue, the chip runs 768 workgroups at a time (three per
-// CU), and the launch drains over about 0.6 of half a workgroup's run time.
-static int pick_segment16(int w, int h, int nframes, int max_seg = 1024) {   // (hot kernels: at most 512 rows -- record rows, records per wave)
-    if (chess16_seg_override > 0) return chess16_seg_override;
-    const long long strips = (w + v16::SW - 1) / v16::SW;
-    int best = 1024;
-    double best_cost = 0;
-    for (int seg : {1024, 512, 256, 128, 64}) {
-        if (seg > max_seg) continue;
-        const int nsegs = (h + seg - 1) / seg;
-        const double cost = (double)strips * nframes * (h + 22.0 * nsegs) / 768.0 + 0.6 * ((seg < h ? seg : h) + 22.0) / 2.0;
-        if (best_cost == 0 || cost < 0.99 * best_cost) {
-            best = seg;
-            best_cost = cost;
-        }
-    }
-    return best;
+// Row segments per frame (balanced, whole 16-row granules: common.h, where the model and its fit are).  Before round 6:
+// 1024 / 512 / 256 / 128 / 64 rows cut from the top (1080 rows = 8 x 128 + 56: 119.8 us per 64 frames; five balanced
+// segments: 107.2 us).
+// `seg_rows` > 0: the caller's segment height (option "chess16_seg").
+static const SegModel kV16Model = {10.8, 0.34, 22.0, 32, 1024};
+static const SegModel kV16HotModel = {10.8, 0.34, 22.0, 32, 512};  // (hot kernels: at most 512 rows -- records per wave)
+static int pick_nsegs16(int w, int h, int nframes, int seg_rows, bool hot = false) {
+    if (seg_rows > 0) return segments_for_rows(h, seg_rows, v16::RB);
+    return pick_balanced_segments((w + v16::SW - 1) / v16::SW, h, nframes, v16::RB, hot ? kV16HotModel : kV16Model);
 }
 
 // enough workgroups for the three-per-CU kernel to be worth it (below that chess_v1's shorter segments fill the chip better)
@@ -484,30 +473,30 @@ bool chess16_pays(const LevelBatch& lb, int nframes) {
     return chess16_ok(lb) && strips * nframes * ((lb.h + 63) / 64) >= 256;
 }
 
-void launch_chess16(const LevelBatch& lb, int frame0, int nframes, bool clamp, hipStream_t s) {
-    const int seg = pick_segment16(lb.w, lb.h, nframes);
-    dim3 grid(((lb.w + v16::SW - 1) / v16::SW) * ((lb.h + seg - 1) / seg) * nframes);
+void launch_chess16(const LevelBatch& lb, int frame0, int nframes, bool clamp, hipStream_t s, int seg_rows) {
+    const int nsegs = pick_nsegs16(lb.w, lb.h, nframes, seg_rows);
+    dim3 grid(((lb.w + v16::SW - 1) / v16::SW) * nsegs * nframes);
     const size_t lds = 2 * v16::PLANE;
-    if (clamp) hipLaunchKernelGGL(chess_v16_kernel<true>, grid, dim3(256), lds, s, lb, frame0, seg);
-    else hipLaunchKernelGGL(chess_v16_kernel<false>, grid, dim3(256), lds, s, lb, frame0, seg);
+    if (clamp) hipLaunchKernelGGL(chess_v16_kernel<true>, grid, dim3(256), lds, s, lb, frame0, nsegs);
+    else hipLaunchKernelGGL(chess_v16_kernel<false>, grid, dim3(256), lds, s, lb, frame0, nsegs);
 }
 
 #ifdef MRG_EXPERIMENT
 // clamp + hot list of one level through chess_v16_hot_kernel
 void launch_chess16_hot(const LevelBatch& lb, const CompTables& t, int frame0, int nframes, hipStream_t s) {
-    const int seg = pick_segment16(lb.w, lb.h, nframes, 512);
-    dim3 grid(((lb.w + v16::SW - 1) / v16::SW) * ((lb.h + seg - 1) / seg) * nframes);
+    const int nsegs = pick_nsegs16(lb.w, lb.h, nframes, 0, true);
+    dim3 grid(((lb.w + v16::SW - 1) / v16::SW) * nsegs * nframes);
     const size_t lds = 2 * v16::PLANE + (V1_HOTBUF + 12) * sizeof(int);
-    hipLaunchKernelGGL(chess_v16_hot_kernel, grid, dim3(256), lds, s, lb, t, frame0, seg);
+    hipLaunchKernelGGL(chess_v16_hot_kernel, grid, dim3(256), lds, s, lb, t, frame0, nsegs);
 }
 
 // level 0 with the level images fused in (shapes: chess_pyramid_ok of chess.hip, whole 16 x 8 blocks)
 bool launch_chess16_pyramid(const LevelBatch& lb, const CompTables& t, const PyramidOut& po, int nframes, hipStream_t s) {
     if (!chess16_ok(lb) || !chess_pyramid_ok(lb, nframes) || lb.h % 16 != 0) return false;
-    const int seg = pick_segment16(lb.w, lb.h, nframes, 512);
-    dim3 grid(((lb.w + v16::SW - 1) / v16::SW) * ((lb.h + seg - 1) / seg) * nframes);
+    const int nsegs = pick_nsegs16(lb.w, lb.h, nframes, 0, true);
+    dim3 grid(((lb.w + v16::SW - 1) / v16::SW) * nsegs * nframes);
     const size_t lds = 2 * v16::PLANE + (V1_HOTBUF + 12) * sizeof(int);
-    hipLaunchKernelGGL(chess_v16_pyr_kernel, grid, dim3(256), lds, s, lb, t, seg, po);
+    hipLaunchKernelGGL(chess_v16_pyr_kernel, grid, dim3(256), lds, s, lb, t, nsegs, po);
     return true;
 }
 
@@ -527,9 +516,9 @@ bool launch_chess16_multi(const LevelBatch* lbs, const CompTables* ts, int n, in
         const int j = k < n ? k : 0;
         a.lb[k] = lbs[j];
         a.t[k] = ts[j];
-        a.seg[k] = pick_segment16(lbs[j].w, lbs[j].h, nframes, 512);
+        a.nsegs[k] = pick_nsegs16(lbs[j].w, lbs[j].h, nframes, 0, true);
         a.first_wg[k] = total;
-        a.nwg[k] = k < n ? ((lbs[j].w + v16::SW - 1) / v16::SW) * ((lbs[j].h + a.seg[k] - 1) / a.seg[k]) * nframes : 0;
+        a.nwg[k] = k < n ? ((lbs[j].w + v16::SW - 1) / v16::SW) * a.nsegs[k] * nframes : 0;
         total += (a.nwg[k] + 7) / 8 * 8;
     }
     const size_t lds = 2 * v16::PLANE + (V1_HOTBUF + 12) * sizeof(int);

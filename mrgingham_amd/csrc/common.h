@@ -30,6 +30,57 @@ struct LevelBatch {
     long long resp_pitch;     // elements between frames
 };
 
+// The response kernels cut a frame into `nsegs` row segments of whole granules (G rows: one loop iteration of the
+// kernel), as equal as whole granules allow: the first (granules % nsegs) segments have one granule more, the frame's
+// ragged last granule is in the last segment.  Equal segments matter: workgroups go to the CUs round robin, and a
+// periodic mix of tall and short ones (256 + 256 + 256 + 256 + 56 rows at 1080) puts the tall ones on the same CUs
+// -- measured 117 us against 107.5 us for 4 x 272 on 64 frames of 1920x1080.
+__host__ __device__ __forceinline__ void segment_rows(int h, int nsegs, int i, int G, int& ys, int& ye) {
+    const int granules = (h + G - 1) / G, q = granules / nsegs, r = granules - q * nsegs;
+    ys = (i * q + (i < r ? i : r)) * G;
+    const int y1 = ys + (q + (i < r ? 1 : 0)) * G;
+    ye = y1 < h ? y1 : h;
+}
+// how many segments a requested segment height (rows) makes of a frame: at least 1, at most one per granule
+inline int segments_for_rows(int h, int rows, int G) {
+    const int granules = (h + G - 1) / G;
+    int n = rows > 0 ? (h + rows - 1) / rows : 1;
+    return n < 1 ? 1 : (n > granules ? granules : n);
+}
+
+// How many segments: the cost model both response kernels share, fitted to tools/seg_rounds_sweep.py (64 frames of 640x480
+// .. 4096x3072, every k that leaves segments of 32 rows or more).  Workgroups are dealt to the 256
+// CUs round robin (to the XCDs first), and the kernels are VALU-bound with a CU's slots full, so a launch costs what the
+// BUSIEST CU computes -- its workgroups x (rows of a segment + `per_wg` rows' worth of prologue and epilogue that the
+// other resident workgroups do not hide) -- plus a drain while the last workgroups run with the CU half empty, a fraction
+// `drain` of one workgroup's own run time (its rows + `latency` rows: the staged prologue in full).  Picks within 1-2 %
+// of the measured best height at every size of the sweep; the curve is flat around the optimum.
+struct SegModel {
+    double per_wg;    // rows' worth of un-hidden time per workgroup
+    double drain;     // fraction of a workgroup's run time the launch drains over
+    double latency;   // rows' worth of time before a workgroup's first response row
+    int min_rows;     // shortest segment considered
+    int max_rows;     // tallest segment considered
+};
+inline int pick_balanced_segments(int strips, int h, int nframes, int G, const SegModel& m) {
+    const int granules = (h + G - 1) / G;
+    int best = 1;
+    double best_cost = 0;
+    for (int k = 1; k <= granules; ++k) {
+        const int rows = ((granules + k - 1) / k) * G;  // the tallest segment
+        if (rows > m.max_rows && k < granules) continue;
+        if (rows < m.min_rows && best_cost != 0) break;
+        const long long nwg = (long long)strips * k * nframes;
+        const long long per_cu = ((nwg + 7) / 8 + 31) / 32;
+        const double cost = (double)per_cu * ((double)granules * G / k + m.per_wg) + m.drain * (rows + m.latency);
+        if (best_cost == 0 || cost < 0.999 * best_cost) {  // (ties go to the taller segments)
+            best = k;
+            best_cost = cost;
+        }
+    }
+    return best;
+}
+
 // Per-frame tables of the component search, all of capacity `cap` entries per
 // frame unless noted.  "hot" pixels are those with response > kRespMin: the
 // only pixels that can seed, join or extend a component.

@@ -18,8 +18,10 @@ struct PyramidOut {
 void launch_chess_v0(const LevelBatch& lb, const CompTables& t, int frame0, int nframes, bool clamp, bool hot,
                      hipStream_t s);
 #endif
+// `seg_rows` (here and below): 0 = the launcher picks the row segments, > 0 = the caller's segment height (the
+// per-context options "chess_seg" / "chess16_seg")
 void launch_chess(const LevelBatch& lb, const CompTables& t, int frame0, int nframes, bool clamp, bool hot,
-                  hipStream_t s);
+                  hipStream_t s, int seg_rows = 0);
 
 // sparse refinement: the response + hot list in a per-frame list of cells only (cells listed by launch_sparse_cells, cc.hip)
 void launch_chess_cells(const LevelBatch& lb, const CompTables& t, const uint32_t* cell_list, const int32_t* cell_cnt,
@@ -27,11 +29,11 @@ void launch_chess_cells(const LevelBatch& lb, const CompTables& t, const uint32_
 
 // level 0 of a chain with the level images 1..3 produced by the same kernel (out of its LDS ring)
 bool chess_pyramid_ok(const LevelBatch& lb, int nframes);
-bool launch_chess_pyramid(const LevelBatch& lb, const CompTables& t, const PyramidOut& po, int nframes, hipStream_t s);
+bool launch_chess_pyramid(const LevelBatch& lb, const CompTables& t, const PyramidOut& po, int nframes, hipStream_t s,
+                          int seg_rows = 0);
 
 bool chess_multi_ok(const LevelBatch* lbs, int n, int nframes);
-bool launch_chess_multi(const LevelBatch* lbs, const CompTables* ts, int n, int nframes, hipStream_t s);
-extern int chess_seg_override;
+bool launch_chess_multi(const LevelBatch* lbs, const CompTables* ts, int n, int nframes, hipStream_t s, int seg_rows = 0);
 extern int chess_stage_override;
 extern int chess_multi_min_blocks;
 extern int pyramid_lds_pad;
@@ -39,15 +41,13 @@ extern int pyramid_lds_pad;
 // chess16.hip: the response with sixteen pixels per lane (widths that are multiples of 16; no hot list)
 bool chess16_ok(const LevelBatch& lb);
 bool chess16_pays(const LevelBatch& lb, int nframes);
-void launch_chess16(const LevelBatch& lb, int frame0, int nframes, bool clamp, hipStream_t s);
+void launch_chess16(const LevelBatch& lb, int frame0, int nframes, bool clamp, hipStream_t s, int seg_rows = 0);
 #ifdef MRG_EXPERIMENT
 void launch_chess16_hot(const LevelBatch& lb, const CompTables& t, int frame0, int nframes, hipStream_t s);
 bool launch_chess16_pyramid(const LevelBatch& lb, const CompTables& t, const PyramidOut& po, int nframes, hipStream_t s);
 bool chess16_multi_ok(const LevelBatch* lbs, int n, int nframes);
 bool launch_chess16_multi(const LevelBatch* lbs, const CompTables* ts, int n, int nframes, hipStream_t s);
 #endif
-
-extern int chess16_seg_override;
 
 // decimate.hip
 struct FrameBatch {
