@@ -32,8 +32,11 @@ extern "C" {
  *      set, up to 16 GB: INTEGRATION.md 5e); find_boards_submit / _collect, chain_multi, host_alloc / _register,
  *      set_wait_policy, set_thread_device and the file entry points were added.
  *   3  round 5: mrgingham_amd_find_boards_stats, _grid_clock, _packed_layout, _gather_rccl added; the packed corner block
- *      is a multiple of 8 bytes; the reference-symbol wrappers restore the caller's current HIP device. */
-#define MRGINGHAM_AMD_ABI_VERSION 3
+ *      is a multiple of 8 bytes; the reference-symbol wrappers restore the caller's current HIP device.
+ *   4  round 6: mrgingham_amd_sclk_mhz added; options "chess_seg" / "chess16_seg" are per context (they were process-wide) and
+ *      mean balanced segments, option "preprocess_fused"; _gather_rccl, _chain_multi, _sync_multi, _stream_wait_multi restore
+ *      the caller's current HIP device; _gather_rccl needs no RCCL header or library at build time and never loads a second RCCL. */
+#define MRGINGHAM_AMD_ABI_VERSION 4
 
 /* ------------------------------------------------------------------------ */
 /* (1) Reference symbols                                                    */
@@ -476,7 +479,14 @@ int mrgingham_amd_chain_info(const mrgingham_amd_ctx* ctx, int* fused_pyramid, i
  *                         by the library, on the device, inside the same call (mrgingham_amd_sparse_fallbacks counts them).
  *   "find_boards_pipeline" 1 (default): mrgingham_amd_find_boards_batch / _submit / _collect as described there; 0: the
  *                         synchronous schedule (one level at a time for the whole batch, dense refinement) -- same results
- *   "chess_seg"           rows per workgroup of the ChESS kernels (0 = cost model); results do not depend on it
+ *   "chess_seg", "chess16_seg"  rows per workgroup of the ChESS kernels of THIS context (chess_v1* / chess_v16; 0 = cost model,
+ *                         the default): the frame is cut into ceil(height / value) row segments of equal height (whole
+ *                         8- / 16-row groups); results do not depend on it
+ *   "chess_variant"       the response without a hot list: 0 (default) = chess_v16_kernel where it pays, 1 = chess_v1 always,
+ *                         16 = chess_v16 wherever it can run (widths that are multiples of 16); same results
+ *   "preprocess_fused"    1 (default): mrgingham_amd_preprocess_batch(do_clahe, blur_radius 1) -- the reference tool's default
+ *                         chain -- blends the CLAHE tile LUTs and blurs in ONE pass over the frame where the geometry allows
+ *                         (rows of 16-byte multiples, tiles at least 34 rows high); 0: always two kernels.  Same bytes.
  * Builds made with -DMRG_EXPERIMENT (make -C mrgingham_amd/csrc EXPERIMENT=1 -> libmrgingham_amd_experiment.so)
  * additionally accept the timing ablations and phase clocks of tools/ ("cc_lds" bits 2, 4, 8, 16, 128, 512,
  * "cc_schedule", "chess_stage", "chess_multi_min_blocks", "chess_v0" = the reference-shaped ChESS kernel as an on-device
@@ -512,6 +522,14 @@ int mrgingham_amd_after_stream(mrgingham_amd_ctx* ctx, void* stream);
  * mrgingham_amd_set_kernel_timing(ctx, 1). */
 void mrgingham_amd_set_kernel_timing(mrgingham_amd_ctx* ctx, int enable);
 double mrgingham_amd_chess_kernel_ms(mrgingham_amd_ctx* ctx, int* nlaunches);
+
+/* The engine clock the level-0 response kernels ACTUALLY ran at, in MHz, averaged over the launches issued since the last
+ * call while kernel timing was enabled: workgroup 0 of each launch reads the shader-cycle counter (s_memtime) and the
+ * constant-rate counter (s_memrealtime, hipDeviceAttributeWallClockRate) at its start and end and adds the two differences
+ * to a pair of device counters -- four scalar instructions in one workgroup of the launch.  A VALU-bound kernel scales with
+ * this clock, so a benchmark line that carries it can tell a slow box from a regression.  0 when nothing was probed.
+ * Synchronises the device. */
+double mrgingham_amd_sclk_mhz(mrgingham_amd_ctx* ctx);
 
 #ifdef __cplusplus
 }

@@ -34,7 +34,7 @@ EXPORTS = [
     "mrgingham_amd_detect_batch", "mrgingham_amd_refine_batch", "mrgingham_amd_chain_batch",
     "mrgingham_amd_find_boards_batch", "mrgingham_amd_cc_on_response_batch", "mrgingham_amd_scratch_bytes", "mrgingham_amd_chain_info", "mrgingham_amd_debug_refine_clock", "mrgingham_amd_debug_paths", "mrgingham_amd_read_image",
     "mrgingham_amd_set_option", "mrgingham_amd_sync", "mrgingham_amd_stream_wait", "mrgingham_amd_after_stream", "mrgingham_amd_set_kernel_timing",
-    "mrgingham_amd_chess_kernel_ms", "mrgingham_amd_sparse_fallbacks", "mrgingham_amd_find_boards_submit",
+    "mrgingham_amd_chess_kernel_ms", "mrgingham_amd_sclk_mhz", "mrgingham_amd_sparse_fallbacks", "mrgingham_amd_find_boards_submit",
     "mrgingham_amd_find_boards_collect", "mrgingham_amd_device_for_thread", "mrgingham_amd_set_thread_device",
     "mrgingham_amd_thread_device", "mrgingham_amd_host_alloc", "mrgingham_amd_host_free", "mrgingham_amd_host_register",
     "mrgingham_amd_host_unregister", "mrgingham_amd_shard_range", "mrgingham_amd_chain_multi", "mrgingham_amd_sync_multi",
@@ -139,5 +139,7 @@ def lib():
     L.mrgingham_amd_set_kernel_timing.restype = None
     L.mrgingham_amd_chess_kernel_ms.argtypes = [c_vp, ctypes.POINTER(c_int)]
     L.mrgingham_amd_chess_kernel_ms.restype = ctypes.c_double
+    L.mrgingham_amd_sclk_mhz.argtypes = [c_vp]
+    L.mrgingham_amd_sclk_mhz.restype = ctypes.c_double
     _lib = L
     return L

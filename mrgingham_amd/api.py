@@ -655,6 +655,10 @@ class Detector:
     def set_kernel_timing(self, enable):
         self.L.mrgingham_amd_set_kernel_timing(self.ctx, int(enable))
 
+    def sclk_mhz(self):
+        """Engine clock (MHz) the level-0 response launches since the last call ran at (kernel timing on); 0.0 = none probed."""
+        return float(self.L.mrgingham_amd_sclk_mhz(self.ctx))
+
     def chess_kernel_ms(self):
         n = ctypes.c_int()
         ms = self.L.mrgingham_amd_chess_kernel_ms(self.ctx, ctypes.byref(n))

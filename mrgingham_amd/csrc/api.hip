@@ -16,7 +16,6 @@
 #include <vector>
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>  // types and the signature of ncclGather only: the function is looked up at run time (below)
 
 #include "../../include/mrgingham_amd.h"
 #include "common.h"
@@ -146,6 +145,7 @@ struct mrgingham_amd_ctx {
     bool use_v0 = false;  // reference-shaped ChESS kernel instead of the tuned one
     int sparse_subsets = 2;  // option "sparse_subsets": workgroups per frame of the sparse refinement (1 .. 4; 4 measures like 2)
     int chess_variant_hot = 0;  // the levels of a chain (clamp + hot list): 16 = chess_v16_hot_kernel / chess_v16_multi_kernel, 0 = chess_v1
+    int pre_fused = 1;  // option "preprocess_fused": CLAHE blend + 3x3 blur in one kernel where the geometry allows (0: always two kernels, the A/B and test hook)
     int chess_seg = 0, chess16_seg = 0;  // options "chess_seg" / "chess16_seg": rows per workgroup of the response kernels, 0 = automatic
     int chess_variant = 0;  // the response without a hot list: 0 = chess_v16_kernel (chess16.hip) where it pays, 1 = chess_v1 always, 16 = chess_v16 wherever it can run
     // levels 3..1 of a chain in one launch (set_option "multi_level_launch"): +1.5 % chain rate, but the
@@ -177,6 +177,7 @@ struct mrgingham_amd_ctx {
     void* io_pin = nullptr;  // page-locked staging of mrgingham_ChESS_response_5's way back
     size_t io_pin_bytes = 0;
     hipEvent_t io_ev[4] = {};
+    mrg::DevBuf clk;  // two u64: shader cycles and constant-rate ticks of the probed workgroups (mrgingham_amd_sclk_mhz)
     mrg::DevBuf pre_scratch, pre_tmp, pre_out, pre16_scratch, io_frame16, dbg_img, dbg_resp, blob_scratch, blob_nodes, blob_out;
     mrg::DevBuf fb_xy, fb_cnt, fb_pts, fb_lv, fb_np, fb_frames, fb_frames2;  // find_boards_batch: candidates, counts, boards, levels, point counts
     // find_boards_batch's frame-by-frame retries (full-capacity detect, 1-by-1 refine) run on a single-frame
@@ -491,6 +492,23 @@ static CompTables tables_of(mrgingham_amd_ctx* ctx, int level) {
     return t;
 }
 
+// The reference-symbol wrappers (and the calls that span several devices: chain_multi, sync_multi, stream_wait_multi,
+// gather_rccl) work on the calling thread's context, which may live on another device than the one the
+// CALLER has current (the k-th thread's context is on device k % devices): they put the caller's device back when they
+// return -- a worker thread of a multi-GPU host (PyTorch, ...) keeps the current device it had.
+struct CallerDevice {
+    int prev = -1;
+    CallerDevice() {
+        if (hipGetDevice(&prev) != hipSuccess) {
+            prev = -1;
+            (void)hipGetLastError();
+        }
+    }
+    ~CallerDevice() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
 static hipEvent_t timing_event(mrgingham_amd_ctx* ctx) {
     hipEvent_t e;
     if (!ctx->event_pool.empty()) { e = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
@@ -623,6 +641,7 @@ static LevelBatch level_batch_of(mrgingham_amd_ctx* ctx, const mrgingham_amd_fra
     }
     lb.resp = (int16_t*)L.resp.p;
     lb.resp_pitch = (long long)L.w * L.h;
+    if (level == 0 && ctx->timing) lb.clk = (unsigned long long*)ctx->clk.p;  // (mrgingham_amd_sclk_mhz)
     return lb;
 }
 static LevelBatch queue_level_chess(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int level) {
@@ -936,7 +955,26 @@ int mrgingham_amd_sparse_fallbacks(mrgingham_amd_ctx* ctx) {
 }
 
 void mrgingham_amd_set_kernel_timing(mrgingham_amd_ctx* ctx, int enable) {
-    if (ctx) ctx->timing = enable != 0;
+    if (!ctx) return;
+    ctx->timing = enable != 0;
+    if (ctx->timing && !ctx->clk.p) {  // the engine-clock probe's two counters (without them the probe stays off)
+        const CallerDevice keep;
+        hipSetDevice(ctx->device);
+        if (ensure(ctx, ctx->clk, 2 * sizeof(unsigned long long)) == 0) hipMemset(ctx->clk.p, 0, 2 * sizeof(unsigned long long));
+    }
+}
+
+double mrgingham_amd_sclk_mhz(mrgingham_amd_ctx* ctx) {
+    if (!ctx || !ctx->clk.p) return 0.;
+    const CallerDevice keep;
+    hipSetDevice(ctx->device);
+    if (hipDeviceSynchronize() != hipSuccess) return 0.;
+    unsigned long long c[2] = {0, 0};
+    if (hipMemcpy(c, ctx->clk.p, sizeof(c), hipMemcpyDeviceToHost) != hipSuccess) return 0.;
+    hipMemset(ctx->clk.p, 0, sizeof(c));
+    int khz = 0;  // rate of s_memrealtime
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device) != hipSuccess || khz <= 0) khz = 100000;
+    return c[1] ? (double)c[0] / (double)c[1] * khz * 1e-3 : 0.;
 }
 
 /* tunables (not part of the reference surface) */
@@ -977,6 +1015,8 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
         ctx->sparse_subsets = value;
         return 0;
     }
+    if (!strcmp(name, "clahe_hist_copies")) { mrg::clahe_hist_copies = value; return 0; }
+    if (!strcmp(name, "preprocess_fused")) { ctx->pre_fused = value != 0; return 0; }
     if (!strcmp(name, "chess16_seg") || !strcmp(name, "chess_seg")) {
         // rows per workgroup of chess_v16_kernel / the chess_v1 kernels of THIS context (0 = automatic): the frame is cut into
         // ceil(height / value) balanced segments (common.h, segment_rows)
@@ -1151,6 +1191,7 @@ int mrgingham_amd_chess_response_batch(mrgingham_amd_ctx* ctx, const mrgingham_a
     }
     lb.resp = d_response;
     lb.resp_pitch = (long long)w * h;
+    if (level == 0 && ctx->timing) lb.clk = (unsigned long long*)ctx->clk.p;
     launch_chess_any(ctx, lb, CompTables{}, fr->nframes, clamp != 0, false, s, level == 0);
     MRG_HIP_CHECK(hipGetLastError());
     return 0;
@@ -1206,16 +1247,26 @@ int mrgingham_amd_preprocess_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_f
             return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "CLAHE needs a frame of at least 8x8 pixels");
         const size_t frame_bytes = (size_t)fr->width * fr->height;
         if ((rc = ensure(ctx, ctx->pre_scratch, clahe_scratch_bytes(fr->nframes)))) return rc;
-        uint8_t* clahe_out = d_out;
-        if (blur_radius > 0) {
-            if ((rc = ensure(ctx, ctx->pre_tmp, frame_bytes * fr->nframes))) return rc;
-            clahe_out = (uint8_t*)ctx->pre_tmp.p;
-        }
         // clip limit 8, default 8x8 tiles: mrgingham-from-image.cc:41-45
-        launch_clahe(fb, fr->nframes, 8.0, true, clahe_out, ctx->pre_scratch.p, s);
-        if (blur_radius > 0) {
-            const FrameBatch tb{clahe_out, (long long)frame_bytes, fr->width, fr->height, fr->width};
-            launch_box_blur(tb, blur_radius, d_out, 0, fr->nframes, s);
+        if (blur_radius == 1 && ctx->pre_fused) {
+            // the tool's default chain: blend + 3x3 blur in one pass over the frame where the geometry allows it
+            uint8_t* tmp = nullptr;
+            if (!clahe_blur3_fused(fb, d_out)) {
+                if ((rc = ensure(ctx, ctx->pre_tmp, frame_bytes * fr->nframes))) return rc;
+                tmp = (uint8_t*)ctx->pre_tmp.p;
+            }
+            launch_clahe(fb, fr->nframes, 8.0, true, d_out, ctx->pre_scratch.p, s, true, tmp);
+        } else {
+            uint8_t* clahe_out = d_out;
+            if (blur_radius > 0) {
+                if ((rc = ensure(ctx, ctx->pre_tmp, frame_bytes * fr->nframes))) return rc;
+                clahe_out = (uint8_t*)ctx->pre_tmp.p;
+            }
+            launch_clahe(fb, fr->nframes, 8.0, true, clahe_out, ctx->pre_scratch.p, s);
+            if (blur_radius > 0) {
+                const FrameBatch tb{clahe_out, (long long)frame_bytes, fr->width, fr->height, fr->width};
+                launch_box_blur(tb, blur_radius, d_out, 0, fr->nframes, s);
+            }
         }
     } else {
         launch_box_blur(fb, blur_radius, d_out, 0, fr->nframes, s);  // radius 0 = dense copy
@@ -1588,22 +1639,6 @@ static mrgingham_amd_ctx* thread_ctx() {
     return h.ctx;
 }
 
-// The reference-symbol wrappers work on the calling thread's context, which may live on another device than the one the
-// CALLER has current (the k-th thread's context is on device k % devices): they put the caller's device back when they
-// return -- a worker thread of a multi-GPU host (PyTorch, ...) keeps the current device it had.
-struct CallerDevice {
-    int prev = -1;
-    CallerDevice() {
-        if (hipGetDevice(&prev) != hipSuccess) {
-            prev = -1;
-            (void)hipGetLastError();
-        }
-    }
-    ~CallerDevice() {
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
-};
-
 int mrgingham_amd_device_for_thread(int thread_index, int ndevices, const char* env_value) {
     if (env_value && *env_value) return atoi(env_value);
     if (ndevices <= 0) return 0;
@@ -1725,6 +1760,7 @@ static int chain_multi_shard(mrgingham_amd_ctx* ctx, int root_device, const mrgi
 int mrgingham_amd_chain_multi(mrgingham_amd_ctx* const* ctxs, int nctx, const mrgingham_amd_frames* shards, int start_level,
                               double* d_points, signed char* d_levels, int32_t* d_npoints, int points_pitch) {
     if (!ctxs || nctx <= 0 || !shards || !ctxs[0]) return MRGINGHAM_AMD_ERR_ARG;
+    const CallerDevice keep;  // (the shards' contexts live on several devices: the caller's current one is put back)
     mrgingham_amd_ctx* root = ctxs[0];
     if (!d_points || !d_levels || !d_npoints || points_pitch <= 0)
         return fail(root, MRGINGHAM_AMD_ERR_ARG, "NULL point buffers");
@@ -1787,37 +1823,50 @@ int mrgingham_amd_gather_rccl(mrgingham_amd_ctx* ctx, void* nccl_comm, int root,
                               void* d_gathered, void* stream) {
     if (!ctx) return MRGINGHAM_AMD_ERR_ARG;
     if (!nccl_comm || !d_packed || bytes == 0 || root < 0) return fail(ctx, MRGINGHAM_AMD_ERR_ARG, "gather_rccl: NULL communicator / buffer, or nothing to send");
-    using gather_fn = ncclResult_t (*)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
-    using errstr_fn = const char* (*)(ncclResult_t);
-    static gather_fn gather = nullptr;
-    static errstr_fn errstr = nullptr;
-    static std::once_flag once;
-    std::call_once(once, [] {
+    // RCCL's ncclGather, looked up in the copy of RCCL the HOST has loaded (the one that made `nccl_comm`): no header and no
+    // link dependency, and never a second copy -- a communicator handed to another instance of the library is undefined
+    // behaviour.  First among the global symbols (a C host linked with -lrccl), then in an already-loaded librccl that was
+    // opened RTLD_LOCAL (Python / PyTorch's bundled copy): dlopen(RTLD_NOLOAD) finds it without loading anything.  A
+    // failed lookup is not remembered (the host may load RCCL later).
+    using gather_fn = int (*)(const void*, void*, size_t, int /* ncclDataType_t */, int, void* /* ncclComm_t */, hipStream_t);
+    using errstr_fn = const char* (*)(int);
+    constexpr int kNcclSuccess = 0, kNcclUint8 = 1;  // nccl.h: ncclSuccess, ncclUint8 (stable since NCCL 2.0)
+    static std::atomic<gather_fn> gather_cached{nullptr};
+    static std::atomic<errstr_fn> errstr_cached{nullptr};
+    gather_fn gather = gather_cached.load(std::memory_order_acquire);
+    if (!gather) {
         void* f = dlsym(RTLD_DEFAULT, "ncclGather");
-        void* h = nullptr;
-        if (!f) {
-            for (const char* name : {"librccl.so.1", "librccl.so"}) {
-                h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-                if (h && (f = dlsym(h, "ncclGather"))) break;
-            }
-        }
-        gather = (gather_fn)f;
         void* e = dlsym(RTLD_DEFAULT, "ncclGetErrorString");
-        if (!e && h) e = dlsym(h, "ncclGetErrorString");
-        errstr = (errstr_fn)e;
-    });
-    if (!gather) return fail(ctx, MRGINGHAM_AMD_ERR_DEVICE, "gather_rccl: no ncclGather in this process and no librccl.so to load");
+        if (!f)
+            for (const char* name : {"librccl.so.1", "librccl.so"}) {
+                void* h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+                if (h && (f = dlsym(h, "ncclGather"))) {
+                    e = dlsym(h, "ncclGetErrorString");
+                    break;  // (the handle is kept: the library stays mapped as long as this one uses its function)
+                }
+                if (h) dlclose(h);
+            }
+        if (!f)
+            return fail(ctx, MRGINGHAM_AMD_ERR_DEVICE, "gather_rccl: RCCL is not loaded in this process (no ncclGather among the global symbols, "
+                                                       "no librccl.so mapped): the host that made the communicator must have it loaded");
+        gather = (gather_fn)f;
+        errstr_cached.store((errstr_fn)e, std::memory_order_release);
+        gather_cached.store(gather, std::memory_order_release);
+    }
+    const errstr_fn errstr = errstr_cached.load(std::memory_order_acquire);
+    const CallerDevice keep;  // (the caller's current device is put back)
     MRG_HIP_CHECK(hipSetDevice(ctx->device));
     const int rc = mrgingham_amd_stream_wait(ctx, stream);  // the gather starts behind the chain that fills d_packed, on the device
     if (rc) return rc;
-    const ncclResult_t r = gather(d_packed, d_gathered, bytes, ncclUint8, root, (ncclComm_t)nccl_comm, (hipStream_t)stream);
-    if (r != ncclSuccess)
+    const int r = gather(d_packed, d_gathered, bytes, kNcclUint8, root, nccl_comm, (hipStream_t)stream);
+    if (r != kNcclSuccess)
         return fail(ctx, MRGINGHAM_AMD_ERR_DEVICE, "ncclGather failed: %s", errstr ? errstr(r) : "(no error text)");
     return MRGINGHAM_AMD_OK;
 }
 
 int mrgingham_amd_sync_multi(mrgingham_amd_ctx* const* ctxs, int nctx) {
     if (!ctxs || nctx <= 0) return MRGINGHAM_AMD_ERR_ARG;
+    const CallerDevice keep;  // (the contexts live on several devices: the caller's current one is put back)
     int rc = MRGINGHAM_AMD_OK;
     for (int k = 0; k < nctx; ++k) {
         mrgingham_amd_ctx* ctx = ctxs[k];
@@ -1837,6 +1886,7 @@ int mrgingham_amd_sync_multi(mrgingham_amd_ctx* const* ctxs, int nctx) {
  * context's) waits for the chains and the gathers of the most recent mrgingham_amd_chain_multi. */
 int mrgingham_amd_stream_wait_multi(mrgingham_amd_ctx* const* ctxs, int nctx, void* stream) {
     if (!ctxs || nctx <= 0) return MRGINGHAM_AMD_ERR_ARG;
+    const CallerDevice keep;
     for (int k = 0; k < nctx; ++k) {
         mrgingham_amd_ctx* ctx = ctxs[k];
         if (!ctx) return MRGINGHAM_AMD_ERR_ARG;

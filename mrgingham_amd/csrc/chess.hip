@@ -462,6 +462,8 @@ __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTa
         const unsigned q = nwg >> 3, r = nwg & 7u;
         work = (int)((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j);
     }
+    const bool probe = lb.clk != nullptr && bid == 0;  // (mrgingham_amd_sclk_mhz)
+    const ClockProbe clkp = clock_probe_begin(probe);
     const int strip = work % nstrips, rest = work / nstrips;
     // FILTER, the dense repeat of a sparse chain (CompTables::only): the grid is laid out for kOnlySlots frames and
     // the workgroup takes frames slot, slot + kOnlySlots, ... of the list (usually none: it leaves at once)
@@ -672,6 +674,7 @@ __device__ __forceinline__ void chess_v1_body(const LevelBatch& lb, const CompTa
     }
     if (HOT) flush_hot(hsink, hotcnt, wvu, t, frame);
   }
+    clock_probe_end(probe, clkp, lb.clk);
 }
 
 template <bool CLAMP, bool HOT, int STAGE, bool FILTER = false>

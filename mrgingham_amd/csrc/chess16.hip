@@ -220,6 +220,8 @@ __device__ __forceinline__ void chess_v16_body(const LevelBatch& lb, const CompT
         const unsigned q = nwg >> 3, r = nwg & 7u;
         work = (int)((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j);
     }
+    const bool probe = lb.clk != nullptr && bid == 0;  // (mrgingham_amd_sclk_mhz)
+    const ClockProbe clkp = clock_probe_begin(probe);
     const int strip = work % nstrips, rest = work / nstrips;
     const int frame = frame0 + rest / nsegs;
     const int w = lb.w, h = lb.h, stride = lb.img_stride;
@@ -405,6 +407,7 @@ __device__ __forceinline__ void chess_v16_body(const LevelBatch& lb, const CompT
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     }
     if (HOT) flush_hot(hsink, hotcnt, wvu, t, frame);
+    clock_probe_end(probe, clkp, lb.clk);
 }
 
 // Frames whose width is a multiple of 16 only (the staging loads are whole 16-byte chunks inside or outside the frame).

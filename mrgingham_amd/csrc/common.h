@@ -28,7 +28,29 @@ struct LevelBatch {
     int img_stride;           // bytes between rows
     int16_t* resp;            // dense w*h int16 per frame
     long long resp_pitch;     // elements between frames
+    // engine-clock probe of the response kernels (mrgingham_amd_sclk_mhz): when set, workgroup 0 of the launch adds the
+    // shader cycles (s_memtime) and the constant-rate ticks (s_memrealtime) of its own run to clk[0] / clk[1]
+    unsigned long long* clk = nullptr;
 };
+
+// the probe's two halves (all threads of the workgroup call them; `on` is workgroup-uniform)
+struct ClockProbe {
+    unsigned long long c0, r0;
+};
+__device__ __forceinline__ ClockProbe clock_probe_begin(bool on) {
+    ClockProbe p{0, 0};
+    if (on) {
+        p.c0 = __builtin_readcyclecounter();
+        p.r0 = __builtin_amdgcn_s_memrealtime();
+    }
+    return p;
+}
+__device__ __forceinline__ void clock_probe_end(bool on, const ClockProbe& p, unsigned long long* clk) {
+    if (on && threadIdx.x == 0) {
+        atomicAdd(clk, (unsigned long long)__builtin_readcyclecounter() - p.c0);
+        atomicAdd(clk + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime() - p.r0);
+    }
+}
 
 // The response kernels cut a frame into `nsegs` row segments of whole granules (G rows: one loop iteration of the
 // kernel), as equal as whole granules allow: the first (granules % nsegs) segments have one granule more, the frame's

@@ -62,8 +62,11 @@ void launch_box_blur(const FrameBatch& in, int radius, uint8_t* out, int frame0,
 
 // preprocess.hip: cv::normalize(0..255, NORM_MINMAX) + CLAHE (8x8 tiles), mrgingham-from-image.cc:71-79
 size_t clahe_scratch_bytes(int nframes);
+// `blur3`: followed by cv::blur(3x3), in the same pass where clahe_blur3_fused() says so, else through `tmp`
+extern int clahe_hist_copies;
+bool clahe_blur3_fused(const FrameBatch& in, const uint8_t* out);
 bool launch_clahe(const FrameBatch& in, int nframes, double clip_limit, bool do_normalize, uint8_t* out,
-                  void* scratch, hipStream_t s);
+                  void* scratch, hipStream_t s, bool blur3 = false, uint8_t* tmp = nullptr);
 
 // preprocess16.hip: the CLI's 16-bit branch (normalize to 0..65535, CLAHE on 16 bits, convertTo 8 bit)
 size_t preprocess16_scratch_bytes(int nframes, int w, int h);

@@ -83,7 +83,8 @@ struct ClaheGeom {
 // banks and only 4 lanes of a wave share a counter) and adds them to the frame's raw tile histogram.
 // cv::normalize is a per-frame value map, so it is applied to the BINS afterwards (clahe_lut_kernel)
 // and the frame extrema it needs are read off these histograms: one pass over the pixels.
-constexpr int kHistCopies = 16;
+int clahe_hist_copies = 16;  // tuning hook "clahe_hist_copies" (16 / 32 / 64)
+template <int kHistCopies>
 __global__ __launch_bounds__(256) void clahe_hist_kernel(FrameBatch in, ClaheGeom g, int* hist, int rows_per_block) {
     __shared__ int lh[kBins * kHistCopies];
     const int frame = blockIdx.z, tile = blockIdx.y, ty = tile / kTiles, tx = tile % kTiles;
@@ -96,19 +97,31 @@ __global__ __launch_bounds__(256) void clahe_hist_kernel(FrameBatch in, ClaheGeo
     const bool vec = g.ew == in.width && g.eh == in.height && g.tw % 16 == 0 && in.stride % 16 == 0 &&
                      in.frame_pitch % 16 == 0 && ((uintptr_t)in.frames & 15) == 0;
     if (vec) {
-        const int chunks = g.tw / 16;
-        for (int y = y0 + wv; y < y1; y += 4) {
-            const uint4* row = reinterpret_cast<const uint4*>(src + (long long)y * in.stride + x0);
-            for (int c = lane; c < chunks; c += 64) {
-                const u32x4n vv = __builtin_nontemporal_load(reinterpret_cast<const u32x4n*>(row + c));
-                const uint4 v = make_uint4(vv.x, vv.y, vv.z, vv.w);
-                const uint32_t q[4] = {v.x, v.y, v.z, v.w};
+        // the slab's 16-byte chunks, rows x chunks per row, dealt to the 256 threads in one flat sequence (a tile row of 512
+        // pixels is 32 chunks: a wave per row, as before round 6, left half the lanes idle), two loads in flight per thread
+        const int chunks = g.tw / 16, nchunks = (y1 - y0) * chunks;
+        const uint8_t* base = src + (long long)y0 * in.stride + x0;
+        auto load = [&](int i) {
+            const int r = i / chunks, c = i - r * chunks;
+            return __builtin_nontemporal_load(reinterpret_cast<const u32x4n*>(base + (long long)r * in.stride + 16 * c));
+        };
+        auto count = [&](const u32x4n& vv) {
+            const uint32_t q[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 4; ++k) {
 #pragma unroll
-                    for (int b = 0; b < 4; ++b)
-                        atomicAdd(&lh[((q[k] >> (8 * b)) & 0xffu) * kHistCopies + copy], 1);
-                }
+                for (int b = 0; b < 4; ++b)
+                    atomicAdd(&lh[((q[k] >> (8 * b)) & 0xffu) * kHistCopies + copy], 1);
+            }
+        };
+        for (int i = tid; i < nchunks; i += 512) {
+            const u32x4n a = load(i);
+            if (i + 256 < nchunks) {
+                const u32x4n b = load(i + 256);
+                count(a);
+                count(b);
+            } else {
+                count(a);
             }
         }
     } else {
@@ -291,16 +304,222 @@ __global__ __launch_bounds__(256) void clahe_apply_fast_kernel(FrameBatch in, Cl
     }
 }
 
-size_t clahe_scratch_bytes(int nframes) {
-    // extrema (2 ints) + 64 histograms + 64 LUTs per frame
-    return (size_t)nframes * (2 * sizeof(int) + (size_t)kTiles * kTiles * kBins * (sizeof(int) + 1)) + 256;
+// ---------------------------------------------------------------------------------------------------------------
+// CLAHE blend + 3x3 box blur in ONE pass (round 6): the reference tool's default chain ends clahe->apply(..);
+// cv::blur(.., Size(3, 3)) (mrgingham-from-image.cc:71-111), and as two kernels that was a read + a write of the
+// frame each -- 4 B/px where 2 suffice.  Here a thread owns a 16-pixel column chunk and rolls down a band of ROWS
+// output rows: per input row it loads its 16 raw pixels and the pixel on either side, blends all 18 (the neighbours'
+// two are recomputed: the same single-precision expression at the neighbour's own coordinates gives the same byte),
+// keeps the horizontal 3-sums of the last two rows as packed u16 pairs in registers and stores one blurred row.
+// The image border is BORDER_REFLECT_101 OF THE BLENDED IMAGE: column -1 is column 1 blended with column 1's weights,
+// row -1 is row 1.  A wave spans 1024 pixels of a row; the four waves of a workgroup take four consecutive bands.
+// The interpolation cells (rectangles between four neighbouring tile centres) such a workgroup meets -- at most
+// 9 across, 2 down when 4 * ROWS + 2 <= tile height -- come from a per-frame table clahe_quad_kernel makes once:
+// quad[cy][cx][v] = the four LUT values a pixel of value v needs in cell (cx - 1, cy - 1) as four HALF floats (8 bytes: one
+// ds_read_b64; integers up to 255 are exact in f16): v_fma_mix_f32 takes an f16 operand as it is, so l * weight is ONE
+// instruction per product -- round(l * w + 0) = the IEEE single product OpenCV computes -- where the byte table needed
+// a v_cvt_f32_ubyte per value and then the multiply (291 -> 246 VALU instructions per 16 pixels).
+// LDS layout [cx][cy][256] entries, so that the cell row is a constant offset.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kCells = kTiles + 1;  // interpolation cells per axis: tx1 = -1 .. 7
+
+// grid (81 cells, nframes), 256 threads = 256 pixel values
+using half2v = _Float16 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void clahe_quad_kernel(const uint8_t* lut, uint2* quad) {
+    const int frame = blockIdx.y, cell = blockIdx.x, cy = cell / kCells - 1, cx = cell % kCells - 1, v = threadIdx.x;
+    const uint8_t* fl = lut + (long long)frame * kTiles * kTiles * kBins;
+    const int txa = max(cx, 0), txb = min(cx + 1, kTiles - 1), tya = max(cy, 0), tyb = min(cy + 1, kTiles - 1);
+    const half2v top = {(_Float16)(int)fl[(tya * kTiles + txa) * kBins + v], (_Float16)(int)fl[(tya * kTiles + txb) * kBins + v]};
+    const half2v bot = {(_Float16)(int)fl[(tyb * kTiles + txa) * kBins + v], (_Float16)(int)fl[(tyb * kTiles + txb) * kBins + v]};
+    quad[((long long)frame * kCells * kCells + cell) * kBins + v] = make_uint2(__builtin_bit_cast(uint32_t, top), __builtin_bit_cast(uint32_t, bot));
 }
 
-// normalize + CLAHE(clip_limit) of every frame; `out` receives dense w x h bytes per frame.
-// `scratch` holds clahe_scratch_bytes(nframes).  Returns false when the frame is too small to tile.
-bool launch_clahe(const FrameBatch& in, int nframes, double clip_limit, bool do_normalize, uint8_t* out,
-                  void* scratch, hipStream_t s) {
-    if (nframes <= 0 || in.width <= 0 || in.height <= 0) return true;
+namespace fused {
+using f32x2 = float __attribute__((ext_vector_type(2)));
+using u32x2 = uint32_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t mad_u16lo(uint32_t a, uint32_t b, uint32_t c) {  // a.lo16 * b.lo16 + c
+    uint32_t r;
+    asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t mad_u16hi(uint32_t a, uint32_t b, uint32_t c) {  // a.hi16 * b.lo16 + c
+    uint32_t r;
+    asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+struct Raw18 {      // one input row of a thread: 16 pixels and the one on either side
+    uint4 g;
+    uint32_t left, right;
+};
+
+// f16 half of `h` (lo / hi) times the f32 `w`, as an f32: round(h * w + 0), one instruction
+__device__ __forceinline__ float mul_f16lo(uint32_t h, float w) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(w));
+    return r;
+}
+__device__ __forceinline__ float mul_f16hi(uint32_t h, float w) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(w));
+    return r;
+}
+
+// the horizontal 3-sums of the blended row, 16 outputs as 8 packed u16 pairs.  CY: the row's cell row inside the LDS table.
+template <int CY>
+__device__ __forceinline__ void blend_hsum(const char* q, const uint32_t (&cb)[18], const float (&xa)[18], const float (&xa1)[18],
+                                           float ya, const Raw18& r, uint32_t (&hs)[8]) {
+    const float ya1 = __fsub_rn(1.0f, ya);
+    const uint32_t gq[4] = {r.g.x, r.g.y, r.g.z, r.g.w};
+    uint32_t v[18];
+    v[0] = r.left;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[1 + j] = (gq[j >> 2] >> (8 * (j & 3))) & 0xffu;
+    v[17] = r.right;
+    uint32_t p[9];  // blended columns -1 .. 16 as packed u16 pairs: p[k] = (column 2k - 1, column 2k)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int i0 = 2 * k, i1 = 2 * k + 1;
+        const uint2 q0 = *reinterpret_cast<const uint2*>(q + CY * (kBins * 8) + cb[i0] + 8 * v[i0]);
+        const uint2 q1 = *reinterpret_cast<const uint2*>(q + CY * (kBins * 8) + cb[i1] + 8 * v[i1]);
+        const f32x2 p11 = {mul_f16lo(q0.x, xa1[i0]), mul_f16lo(q1.x, xa1[i1])};
+        const f32x2 p12 = {mul_f16hi(q0.x, xa[i0]), mul_f16hi(q1.x, xa[i1])};
+        const f32x2 p21 = {mul_f16lo(q0.y, xa1[i0]), mul_f16lo(q1.y, xa1[i1])};
+        const f32x2 p22 = {mul_f16hi(q0.y, xa[i0]), mul_f16hi(q1.y, xa[i1])};
+        const f32x2 top = (p11 + p12) * (f32x2){ya1, ya1};
+        const f32x2 bot = (p21 + p22) * (f32x2){ya, ya};
+        // saturate_cast<uchar>(cvRound(res)): the sum is in [0, 255.001], so adding 2^23 leaves rint(res) -- round half to
+        // even, the FPU's default mode -- in the low bits of the mantissa
+        const f32x2 rr = (top + bot) + (f32x2){8388608.0f, 8388608.0f};
+        // (the bits of the WHOLE vector: hipcc 7.2 compiles __builtin_bit_cast(uint32_t, rr.y) of a vector ELEMENT as the bits of rr.x)
+        const u32x2 rb = __builtin_bit_cast(u32x2, rr);
+        p[k] = __builtin_amdgcn_perm(rb.y, rb.x, 0x05040100u);
+    }
+    // output pixel pair (2k, 2k + 1) = columns (2k-1, 2k) + (2k, 2k+1) + (2k+1, 2k+2)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) hs[k] = p[k] + __builtin_amdgcn_alignbit(p[k + 1], p[k], 16) + p[k + 1];
+}
+}  // namespace fused
+
+template <int ROWS>
+__global__ __launch_bounds__(256) void clahe_blur3_kernel(FrameBatch in, ClaheGeom g, const uint2* quad, uint8_t* out,
+                                                          int ncx_max) {
+    using namespace fused;
+    extern __shared__ __attribute__((aligned(16))) char qlds[];  // [ncx][2][256] entries of 8 bytes
+    const int frame = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int W = in.width, H = in.height;
+    const int bx0 = blockIdx.x * 1024, by0 = blockIdx.y * 4 * ROWS;
+    const float inv_tw = __fdiv_rn(1.0f, (float)g.tw), inv_th = __fdiv_rn(1.0f, (float)g.th);
+    auto cell_x = [&](int x) { return (int)__builtin_floorf(__fsub_rn(__fmul_rn((float)x, inv_tw), 0.5f)); };
+    auto cell_y = [&](int y) { return (int)__builtin_floorf(__fsub_rn(__fmul_rn((float)y, inv_th), 0.5f)); };
+    // cells of the workgroup's samples: columns bx0 - 1 .. bx0 + 1024, rows by0 - 1 .. by0 + 4 ROWS (reflected ones are inside)
+    const int cxa = cell_x(max(bx0 - 1, 0)), ncx = min(cell_x(min(bx0 + 1024, W - 1)) - cxa + 1, ncx_max);
+    const int cya = cell_y(max(by0 - 1, 0));
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(quad + (long long)frame * kCells * kCells * kBins);
+        uint4* dst = reinterpret_cast<uint4*>(qlds);
+        constexpr int kPer = kBins / 2;  // 16-byte pieces of a cell's table
+        for (int i = tid; i < ncx * 2 * kPer; i += 256) {
+            const int c = i / (2 * kPer), rest = i - c * (2 * kPer), r = rest / kPer, e = rest % kPer;
+            const int cy = min(cya + r, kTiles - 1);
+            dst[i] = src[(((cy + 1) * kCells) + (cxa + c + 1)) * kPer + e];
+        }
+    }
+    __syncthreads();
+    const int x0 = bx0 + lane * 16;
+    const int y0 = by0 + wv * ROWS, y1 = min(y0 + ROWS, H);
+    if (x0 >= W || y0 >= H) return;
+    const uint8_t* src = in.frames + (long long)frame * in.frame_pitch;
+    uint8_t* dst = out + (long long)frame * W * H;
+    // per-column constants of the 18 samples: sample i is column x0 + i - 1, reflected at the frame's edge
+    uint32_t cb[18];
+    float xa[18], xa1[18];
+    const int xl = x0 > 0 ? x0 - 1 : 1, xr = x0 + 16 < W ? x0 + 16 : W - 2;
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+        const int x = i == 0 ? xl : (i == 17 ? xr : x0 + i - 1);
+        const float txf = __fsub_rn(__fmul_rn((float)x, inv_tw), 0.5f);
+        const int tx1 = (int)__builtin_floorf(txf);
+        xa[i] = __fsub_rn(txf, (float)tx1);
+        xa1[i] = __fsub_rn(1.0f, xa[i]);
+        cb[i] = (uint32_t)(tx1 - cxa) * (2 * kBins * 8);
+    }
+    auto load_row = [&](int y) {  // y in -1 .. H: the blended image's REFLECT_101 border
+        const int ys = y < 0 ? -y : (y >= H ? 2 * (H - 1) - y : y);
+        const uint8_t* row = src + (long long)ys * in.stride;
+        Raw18 r;
+        const u32x4n gv = __builtin_nontemporal_load(reinterpret_cast<const u32x4n*>(row + x0));
+        r.g = make_uint4(gv.x, gv.y, gv.z, gv.w);
+        r.left = row[xl];
+        r.right = row[xr];
+        return r;
+    };
+    auto hsum_row = [&](int y, const Raw18& r, uint32_t (&hs)[8]) {
+        const int ys = y < 0 ? -y : (y >= H ? 2 * (H - 1) - y : y);
+        const float tyf = __fsub_rn(__fmul_rn((float)ys, inv_th), 0.5f);
+        const int ty1 = (int)__builtin_floorf(tyf);
+        const float ya = __fsub_rn(tyf, (float)ty1);
+        if (ty1 == cya) blend_hsum<0>(qlds, cb, xa, xa1, ya, r, hs);  // (wave-uniform)
+        else blend_hsum<1>(qlds, cb, xa, xa1, ya, r, hs);
+    };
+    auto emit = [&](int y, const uint32_t (&a)[8], const uint32_t (&b)[8], const uint32_t (&c)[8]) {
+        uint32_t o[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            // (sum + 4) / 9 = ((sum + 4) * 7282) >> 16 exactly for sum <= 2295 (box_blur3_kernel, decimate.hip)
+            const uint32_t s0 = a[2 * m] + b[2 * m] + c[2 * m], s1 = a[2 * m + 1] + b[2 * m + 1] + c[2 * m + 1];
+            const uint32_t t0 = mad_u16lo(s0, 7282u, 29128u), t1 = mad_u16hi(s0, 7282u, 29128u);
+            const uint32_t t2 = mad_u16lo(s1, 7282u, 29128u), t3 = mad_u16hi(s1, 7282u, 29128u);
+            o[m] = __builtin_amdgcn_perm(t1, t0, 0x0c0c0602u) | __builtin_amdgcn_perm(t3, t2, 0x06020c0cu);
+        }
+        *reinterpret_cast<uint4*>(dst + (long long)y * W + x0) = make_uint4(o[0], o[1], o[2], o[3]);
+    };
+    // three row sums rotate through ha / hb / hc (the loop body is three rows, so nothing is copied); the raw row after
+    // the one being blended is always in flight
+    uint32_t ha[8], hb[8], hc[8];
+    Raw18 nx;
+    {
+        const Raw18 r0 = load_row(y0 - 1), r1 = load_row(y0);
+        nx = load_row(y0 + 1);
+        hsum_row(y0 - 1, r0, ha);
+        hsum_row(y0, r1, hb);
+    }
+#define MRG_ROW(Y, A, B, C)                          \
+    {                                                \
+        const Raw18 cur = nx;                        \
+        if ((Y) + 2 <= y1) nx = load_row((Y) + 2);   \
+        hsum_row((Y) + 1, cur, C);                   \
+        emit((Y), A, B, C);                          \
+    }
+    for (int y = y0; y < y1; y += 3) {
+        MRG_ROW(y, ha, hb, hc)
+        if (y + 1 >= y1) break;
+        MRG_ROW(y + 1, hb, hc, ha)
+        if (y + 2 >= y1) break;
+        MRG_ROW(y + 2, hc, ha, hb)
+    }
+#undef MRG_ROW
+}
+
+// rows per wave of the fused kernel for a geometry: the workgroup's 4 * rows + 2 sample rows must fit one tile height
+// (two cell rows); 0 = the frame is too small (or not 16-byte aligned): the two-kernel path takes it
+static int fused_rows(const FrameBatch& in, const ClaheGeom& g, const uint8_t* out) {
+    const bool aligned = in.width % 16 == 0 && in.width >= 32 && in.stride % 16 == 0 && in.frame_pitch % 16 == 0 &&
+                         ((uintptr_t)in.frames & 15) == 0 && ((uintptr_t)out & 15) == 0 && in.height >= 2;
+    if (!aligned) return 0;
+    for (int rows : {32, 16, 8})
+        if (4 * rows + 2 <= g.th) return rows;
+    return 0;
+}
+
+size_t clahe_scratch_bytes(int nframes) {
+    // extrema (2 ints) + 64 histograms + 64 LUTs + 81 cell tables per frame
+    return (size_t)nframes * (2 * sizeof(int) + (size_t)kTiles * kTiles * kBins * (sizeof(int) + 1) +
+                              (size_t)kCells * kCells * kBins * sizeof(uint2)) + 512;
+}
+
+static ClaheGeom clahe_geom(const FrameBatch& in) {
     ClaheGeom g;
     g.ew = in.width;
     g.eh = in.height;
@@ -310,6 +529,24 @@ bool launch_clahe(const FrameBatch& in, int nframes, double clip_limit, bool do_
     }
     g.tw = g.ew / kTiles;
     g.th = g.eh / kTiles;
+    return g;
+}
+
+// whether launch_clahe(.., blur3 = true) blends and blurs in one pass (then it needs no intermediate image)
+bool clahe_blur3_fused(const FrameBatch& in, const uint8_t* out) {
+    if (in.width <= 0 || in.height <= 0) return false;
+    const ClaheGeom g = clahe_geom(in);
+    return g.tw > 0 && g.th > 0 && fused_rows(in, g, out) > 0;
+}
+
+// normalize + CLAHE(clip_limit) of every frame; `out` receives dense w x h bytes per frame.
+// `scratch` holds clahe_scratch_bytes(nframes).  Returns false when the frame is too small to tile.
+// `blur3`: followed by cv::blur(3x3) -- in the same pass when clahe_blur3_fused(in, out), else through `tmp` (dense
+// w x h bytes per frame) and launch_box_blur.
+bool launch_clahe(const FrameBatch& in, int nframes, double clip_limit, bool do_normalize, uint8_t* out,
+                  void* scratch, hipStream_t s, bool blur3, uint8_t* tmp) {
+    if (nframes <= 0 || in.width <= 0 || in.height <= 0) return true;
+    const ClaheGeom g = clahe_geom(in);
     if (g.tw <= 0 || g.th <= 0) return false;
     const int area = g.tw * g.th;
     const float lut_scale = (float)(kBins - 1) / (float)area;
@@ -325,12 +562,32 @@ bool launch_clahe(const FrameBatch& in, int nframes, double clip_limit, bool do_
     hipMemsetAsync(hist, 0, (size_t)nframes * kTiles * kTiles * kBins * sizeof(int), s);
     {
         const int rpb = 64;
-        hipLaunchKernelGGL(clahe_hist_kernel, dim3((g.th + rpb - 1) / rpb, kTiles * kTiles, nframes), dim3(256), 0, s,
-                           in, g, hist, rpb);
+        const dim3 hg((g.th + rpb - 1) / rpb, kTiles * kTiles, nframes);
+        if (clahe_hist_copies == 8) hipLaunchKernelGGL(clahe_hist_kernel<8>, hg, dim3(256), 0, s, in, g, hist, rpb);
+        else if (clahe_hist_copies == 64) hipLaunchKernelGGL(clahe_hist_kernel<64>, hg, dim3(256), 0, s, in, g, hist, rpb);
+        else if (clahe_hist_copies == 32) hipLaunchKernelGGL(clahe_hist_kernel<32>, hg, dim3(256), 0, s, in, g, hist, rpb);
+        else hipLaunchKernelGGL(clahe_hist_kernel<16>, hg, dim3(256), 0, s, in, g, hist, rpb);
     }
     if (do_normalize) hipLaunchKernelGGL(minmax_from_hist_kernel, dim3(nframes), dim3(256), 0, s, hist, mm);
     hipLaunchKernelGGL(clahe_lut_kernel, dim3(kTiles * kTiles, nframes), dim3(256), 0, s, hist, mm, g, clip, lut_scale,
                        lut, do_normalize ? 1 : 0);
+    if (blur3) {
+        const int frows = fused_rows(in, g, out);
+        if (frows > 0) {
+            uint2* quad = (uint2*)(((uintptr_t)(lut + (size_t)nframes * kTiles * kTiles * kBins) + 255) & ~(uintptr_t)255);
+            hipLaunchKernelGGL(clahe_quad_kernel, dim3(kCells * kCells, nframes), dim3(256), 0, s, lut, quad);
+            int ncx_max = 1025 / g.tw + 2;  // cells a run of 1026 columns can meet
+            if (ncx_max > kCells) ncx_max = kCells;
+            const dim3 grid((in.width + 1023) / 1024, (in.height + 4 * frows - 1) / (4 * frows), nframes);
+            const size_t lds = (size_t)ncx_max * 2 * kBins * sizeof(uint2);
+            if (frows == 32) hipLaunchKernelGGL(clahe_blur3_kernel<32>, grid, dim3(256), lds, s, in, g, quad, out, ncx_max);
+            else if (frows == 16) hipLaunchKernelGGL(clahe_blur3_kernel<16>, grid, dim3(256), lds, s, in, g, quad, out, ncx_max);
+            else hipLaunchKernelGGL(clahe_blur3_kernel<8>, grid, dim3(256), lds, s, in, g, quad, out, ncx_max);
+            return true;
+        }
+    }
+    uint8_t* const final_out = out;
+    if (blur3) out = tmp;
     const int rows = 8;
     const bool fast = g.tw >= 256 && g.th >= 16 * rows && in.width % 16 == 0 && in.stride % 16 == 0 &&
                       in.frame_pitch % 16 == 0 && ((uintptr_t)in.frames & 15) == 0 && ((uintptr_t)out & 15) == 0;
@@ -342,6 +599,10 @@ bool launch_clahe(const FrameBatch& in, int nframes, double clip_limit, bool do_
         const int rpb = 32;
         hipLaunchKernelGGL(clahe_apply_kernel, dim3((in.width + 255) / 256, (in.height + rpb - 1) / rpb, nframes),
                            dim3(256), 0, s, in, g, lut, out, rpb);
+    }
+    if (blur3) {
+        const FrameBatch tb{out, (long long)in.width * in.height, in.width, in.height, in.width};
+        launch_box_blur(tb, 1, final_out, 0, nframes, s);
     }
     return true;
 }

@@ -31,6 +31,8 @@ def _frames(kind, H, W, n, seed):
     ("noise", 96, 131),      # only the width is ragged (OpenCV still pads the height by 8)
     ("noise", 101, 128),
     ("board", 1080, 1920),
+    ("noise", 600, 1296),    # the fused blend + blur kernel: two 1024-column workgroups, the second partial; 16 rows per wave
+    ("ramp", 272, 2064),     # ... three of them, 8 rows per wave, cells 162 px wide (nine across a workgroup)
 ])
 @pytest.mark.parametrize("clahe,blur", [(True, 1), (True, 0), (False, 1), (False, 2), (True, 3)])
 def test_preprocess_matches_oracle(kind, H, W, clahe, blur):
@@ -45,6 +47,28 @@ def test_preprocess_matches_oracle(kind, H, W, clahe, blur):
     for i in range(len(frames)):
         want = oracle.preprocess(frames[i], clahe=clahe, blur_radius=blur)
         assert np.array_equal(got[i], want), (kind, H, W, clahe, blur, i, int(np.abs(got[i].astype(int) - want).max()))
+
+
+@pytest.mark.parametrize("H,W", [(3072, 4096), (1080, 1920), (1536, 2048), (1440, 2560), (800, 1280), (2160, 4096), (1042, 1936), (274, 48)])
+def test_fused_blend_and_blur_equals_the_two_kernels(H, W):
+    """mrgingham-from-image.cc:71-111 as ONE pass (clahe_blur3_kernel) against the blend and the blur as two kernels
+    (option preprocess_fused 0), which the oracle pins at the small sizes above: identical bytes at full sizes, on
+    noise (every blend weight and every rounding case gets used) and on a board; batch of 3 with a strided view."""
+    import torch
+    import mrgingham_amd
+    from mrgingham_amd import synth
+    g = torch.Generator().manual_seed(H * 7 + W)
+    noise = (torch.rand((H, W + 16), generator=g) * torch.rand((H, 1), generator=g) * 255).to(torch.uint8)
+    frames = torch.stack([noise, torch.roll(noise, 5, 1), torch.zeros_like(noise)]).cuda()
+    frames[2, :, :W] = synth.board_frame(W, H, gridn=10, seed=3).cuda()
+    view = frames[:, :, :W]                                              # row stride W + 16
+    det = mrgingham_amd.Detector(0)
+    one = det.preprocess(view, clahe=True, blur_radius=1)
+    det.set_option("preprocess_fused", 0)
+    two = det.preprocess(view, clahe=True, blur_radius=1)
+    torch.cuda.synchronize()
+    assert torch.equal(one, two), (H, W, int((one.int() - two.int()).abs().max()), int((one != two).sum()))
+    det.close()
 
 
 def test_preprocess_strided_input_and_no_ops():
