@@ -26,6 +26,15 @@ frames.  Rank 0 prints ONE JSON line.
   end_to_end    (N = 1) the same step fed from PINNED HOST memory: H2D of the
                 batch on two copy streams (double-buffered device frames) ->
                 chain -> D2H of the packed corner lists; never `value`.
+  configs       (N = 1) every other BASELINE config that fits one GPU as a short
+                leg of its own, never `value`: c2_level0 (64 x 1920x1080, level-0
+                detect), preprocess (the reference tool's default CLAHE + blur on
+                the bench frames), c5_mixed_one_rank (1-12 MP stream through the
+                pipelined detector), c1_tool (the built tool on 640x480 files).
+  sclk_mhz      the engine clock the timed level-0 launches actually ran at
+                (mrgingham_amd_sclk_mhz: s_memtime / s_memrealtime inside the
+                kernel), and `frac_at_2400mhz` = frac * 2400 / sclk_mhz: the
+                kernels are VALU-bound, so a slow box shows here, not in the code.
 
 `python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment)
 starts the N ranks itself, one process per GPU, on a free local port.
@@ -356,6 +365,8 @@ def chess_pass_alone_leg(det, frames, launches=120, warm=10):
     for _ in range(warm):
         det.chess_response(frames, 0, clamp=False, out=out)
     torch.cuda.synchronize()
+    det.set_kernel_timing(2)                                 # the engine-clock probe alone: no events of the library on the stream
+    det.sclk_mhz()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(launches + 1)]
     ev[0].record()
     for i in range(launches):
@@ -366,6 +377,8 @@ def chess_pass_alone_leg(det, frames, launches=120, warm=10):
     avg = ev[0].elapsed_time(ev[launches]) / launches        # back-to-back launches: includes the dispatch gaps
     med = per[launches // 2]
     alg = B * W * H * 3.0
+    sclk = det.sclk_mhz()
+    det.set_kernel_timing(False)
     del out
     # HBM-side bytes per launch: replayed from the committed rocprofv3 --pmc passes of this kernel alone
     # (profiles/chess_alone_traffic.json), like `roofline.traffic`: only for a library built from the same kernel sources
@@ -380,7 +393,7 @@ def chess_pass_alone_leg(det, frames, launches=120, warm=10):
                 traffic_src = f"none: {tj.get('source')} was collected on kernel sources {tj.get('kernel_id')}, this library is {kid}"
     except (OSError, KeyError, ValueError):
         pass
-    return {"traffic": traffic, "traffic_source": traffic_src,
+    return dict(clock_fields(alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, sclk), **{"traffic": traffic, "traffic_source": traffic_src,
             "kernel": "chess_v16_kernel<CLAMP 0> (plain ChESS response, the output of ChESS.c:56-106; sixteen pixels per lane, "
                       "mrgingham_amd/csrc/chess16.hip: the library's kernel for the response without a hot list)",
             "bytes_model": "3 B/px (u8 read once + int16 written once)", "bytes_per_launch": alg,
@@ -392,7 +405,8 @@ def chess_pass_alone_leg(det, frames, launches=120, warm=10):
             "frames_per_s": B / (avg * 1e-3),
             "what": "the ChESS pass ALONE (nothing else on the device): `frac` from the average over back-to-back launches "
                     "(first event to last / launches, dispatch gaps included), `frac_median_launch` from the median of the "
-                    "per-launch hipEvent intervals"}
+                    "per-launch hipEvent intervals; `sclk_mhz` = the engine clock inside those launches, `frac_at_2400mhz` = "
+                    "frac * 2400 / sclk_mhz (the kernel is bound by VALU issue: its time goes with 1 / clock)"})
 
 
 def sparse_leg(det, frames, start_level, P, steps):
@@ -428,6 +442,236 @@ def sparse_leg(det, frames, start_level, P, steps):
         det.set_option("sparse_refine", 0)
 
 
+MAX_SCLK_MHZ = 2400.0  # MI355X peak engine clock (MI355X_MICROARCH.md)
+
+
+def clock_fields(frac, sclk_mhz):
+    """`sclk_mhz` + the fraction rescaled to the peak engine clock: the response kernels are bound by VALU issue, so
+    their time goes with 1 / sclk -- a box that holds 2.1 GHz under this load reads 12 % lower than one that holds 2.4."""
+    if not sclk_mhz or sclk_mhz <= 0:
+        return {"sclk_mhz": None, "frac_at_2400mhz": None}
+    return {"sclk_mhz": sclk_mhz, "frac_at_2400mhz": frac * MAX_SCLK_MHZ / sclk_mhz}
+
+
+def power_state(local_rank):
+    """Best effort, from sysfs (hwmon of the GPU's PCI device): power cap and the instantaneous average power in watts."""
+    out = {"power_cap_w": None, "power_w": None}
+    try:
+        import glob
+        bus = torch.cuda.get_device_properties(local_rank)
+        bdf = "%04x:%02x:%02x.0" % (getattr(bus, "pci_domain_id", 0), bus.pci_bus_id, bus.pci_device_id)
+        for hw in glob.glob("/sys/bus/pci/devices/" + bdf + "/hwmon/hwmon*"):
+            for key, name in (("power_cap_w", "power1_cap"), ("power_w", "power1_average"), ("power_w", "power1_input")):
+                try:
+                    out[key] = out[key] if out[key] is not None else int(open(os.path.join(hw, name)).read()) / 1e6
+                except (OSError, ValueError):
+                    pass
+    except Exception:
+        pass
+    return out
+
+
+def c2_level0_leg(device_index, steps=150, warm=30):
+    """BASELINE configs[1] as stated: 64 x 1920x1080, 10x10 board, image_pyramid_level = 0 -- one level-0 detect call per
+    step (response + clamp + hot list -> connected components -> candidate list), pipelined like the timed steps; the
+    level-0 launch on 3 B/px with its engine clock, and the plain ChESS pass alone at that size.  NOT `value`."""
+    import mrgingham_amd
+    from mrgingham_amd import synth
+    W, H, B, gridn = 1920, 1080, 64, 10
+    dev = torch.device("cuda", device_index)
+    frames = synth.board_batch(B, W, H, gridn=gridn, seed0=0, device=dev)
+    det = mrgingham_amd.Detector(device_index)
+    try:
+        for _ in range(warm):
+            xy, counts = det.detect(frames, 0, capacity=256, sync=False)
+        det.sync()
+        det.set_kernel_timing(True)
+        det.chess_kernel_ms()
+        det.sclk_mhz()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            xy, counts = det.detect(frames, 0, capacity=256, sync=False)
+        det.sync()
+        dt = time.perf_counter() - t0
+        kern_ms, nl = det.chess_kernel_ms()
+        sclk = det.sclk_mhz()
+        det.set_kernel_timing(False)
+        frac = B * W * H * 3.0 / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kern_ms > 0 else 0.0
+        alone = chess_pass_alone_leg(det, frames, launches=100, warm=10)
+        return dict({"workload": f"{B} x {W}x{H} u8, {gridn}x{gridn} board, level-0 detect (BASELINE configs[1])",
+                     "value": B * steps / dt, "unit": "frames/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
+                     "frames_with_all_candidates_last_step": int((counts >= gridn * gridn).sum().item()),
+                     "level0_launch_ms": kern_ms, "launches_timed": nl, "bytes_model": "3 B/px (u8 read once + int16 written once)",
+                     "frac": frac,
+                     "chess_pass_alone": {k: alone[k] for k in ("avg_launch_ms", "median_launch_ms", "frac", "frac_median_launch",
+                                                                "sclk_mhz", "frac_at_2400mhz")}},
+                    **clock_fields(frac, sclk))
+    finally:
+        det.close()
+
+
+def preprocess_leg(det, frames, runs=20):
+    """The reference tool's DEFAULT chain in front of the detector (mrgingham-from-image.cc:71-111: normalize + CLAHE(8) +
+    3x3 blur) on the bench frames, as the device runs it: tile histograms (1 B/px read), LUTs, then the blend and the blur
+    in one pass (1 B/px read + 1 B/px written).  Events on the stream the call is given; compared with the two-kernel
+    path (blend, then blur: what the oracle pins at test sizes) byte for byte on the whole batch.  NOT `value`."""
+    B, H, W = frames.shape
+    for _ in range(3):
+        out = det.preprocess(frames, clahe=True, blur_radius=1)
+    torch.cuda.synchronize()
+    det.set_kernel_timing(2)                                 # the engine-clock probe (here: in the blend + blur kernel)
+    det.sclk_mhz()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(runs + 1)]
+    ev[0].record()
+    for i in range(runs):
+        out = det.preprocess(frames, clahe=True, blur_radius=1)
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    sclk = det.sclk_mhz()
+    det.set_kernel_timing(False)
+    per = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(runs))
+    ms = ev[0].elapsed_time(ev[runs]) / runs
+    det.set_option("preprocess_fused", 0)
+    try:
+        two = det.preprocess(frames, clahe=True, blur_radius=1)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            two = det.preprocess(frames, clahe=True, blur_radius=1)
+        e1.record()
+        torch.cuda.synchronize()
+        two_ms = e0.elapsed_time(e1) / 3
+        same = bool(torch.equal(out, two))
+    finally:
+        det.set_option("preprocess_fused", 1)
+    del two, out
+    alg = B * W * H * 3.0
+    return {"workload": f"normalize + CLAHE(8) + 3x3 blur of {B} x {W}x{H} u8 (mrgingham-from-image.cc:71-111)",
+            "ms_per_batch": ms, "median_ms_per_batch": per[runs // 2], "runs": runs, "frames_per_s": B / (ms * 1e-3),
+            "bytes_model": "3 B/px (histograms: 1 read; blend + blur in one pass: 1 read + 1 written)", "bytes_per_batch": alg,
+            "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "sclk_mhz": sclk or None,
+            "ms_per_batch_at_2400mhz": ms * sclk / MAX_SCLK_MHZ if sclk else None,
+            "kernels": "clahe_hist_kernel (LDS-atomic bound: one ds_add per pixel at the unit's 8 lanes per clock), clahe_lut_kernel, "
+                       "clahe_quad_kernel, clahe_blur3_kernel (VALU-issue bound: ~15 instructions per pixel, scales with the engine clock)",
+            "two_kernel_path_ms_per_batch": two_ms, "identical_to_two_kernel_path": same}
+
+
+MIXED_RES = [(1280, 800), (1920, 1080), (2560, 1440), (4096, 2160), (4096, 3072)]   # SURVEY.md 8d: 1 .. 12 MP
+
+
+def c5_mixed_leg(device_index, nframes=400, gridn=10, unit=32, depth=3):
+    """BASELINE configs[4] on ONE rank: a stream of `nframes` frames of mixed resolution (1-12 MP, seeded draw) through the
+    full detector with per-frame adaptive pyramid depth (mrgingham.cc:106-140) -- per-resolution units of at most `unit`
+    frames, `depth` units in flight (mrgingham_amd_find_boards_submit / _collect), heaviest first as the multi-rank
+    work queue hands them out (mrgingham_amd.parallel.stream_units).  A sample of frames goes through the single-frame
+    entry point (find_board) and must give the same board, double for double.  NOT `value`."""
+    import random
+    import numpy as np
+    import mrgingham_amd
+    from mrgingham_amd import parallel, synth
+    dev = torch.device("cuda", device_index)
+    rnd = random.Random(5)
+    sizes = [MIXED_RES[rnd.randrange(len(MIXED_RES))] for _ in range(nframes)]
+    units = parallel.stream_units(sizes, unit_frames=unit)
+    frames_of = [torch.stack([synth.board_frame(wh[0], wh[1], gridn, seed=i, device=dev) for i in idx]) for wh, idx in units]
+    det = mrgingham_amd.Detector(device_index)
+    try:
+        def run_once():
+            recs, jobs = [], []
+            for u, (wh, idx) in enumerate(units):
+                jobs.append((u, det.find_boards_submit(frames_of[u], gridn=gridn)))
+                if len(jobs) >= depth:
+                    uu, job = jobs.pop(0)
+                    recs.append((uu,) + det.find_boards_collect(job))
+            while jobs:
+                uu, job = jobs.pop(0)
+                recs.append((uu,) + det.find_boards_collect(job))
+            return recs
+        run_once()                                           # allocations
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        recs = run_once()
+        dt = time.perf_counter() - t0
+        levels = np.concatenate([np.asarray(found, dtype=np.int64) for _, _, found in recs])
+        # a sample through the single-frame entry point
+        same, checked = True, 0
+        for u, boards, found in recs[:: max(1, len(recs) // 6)]:
+            img = frames_of[u][0].cpu().numpy()
+            single = mrgingham_amd.find_board(img, gridn=gridn)
+            checked += 1
+            if found[0] < 0:
+                same = same and single is None
+            else:
+                same = same and single is not None and bool(np.array_equal(single, boards[0]))
+        mpx = sum(w * h for w, h in sizes) / 1e6
+        return {"workload": f"{nframes} frames drawn from {MIXED_RES} (seed 5), {gridn}x{gridn} board, full detector "
+                            f"(level search + grid finder + refinement), units of <= {unit} frames of one resolution, {depth} in flight",
+                "value": nframes / dt, "unit": "frames/s", "seconds_per_pass": dt, "megapixels": mpx, "megapixels_per_s": mpx / dt,
+                "units": len(units), "boards_found": int((levels >= 0).sum()), "found_at_level": np.bincount(levels[levels >= 0], minlength=4).tolist(),
+                "single_frame_path_checked": checked, "identical_to_single_frame_path": same,
+                "what": "one rank's view of BASELINE configs[4]; on N ranks the same units are pulled off one shared counter "
+                        "(mrgingham_amd.parallel.WorkQueue, tools/mixed_stream_bench.py)"}
+    finally:
+        det.close()
+
+
+def c1_tool_leg(device_index, nfiles=256, jobs=4):
+    """BASELINE configs[0]: the command-line tool (mrgingham_amd/bin/mrgingham-amd-from-image, the reference's
+    mrgingham-from-image.cc) on `nfiles` 640x480 PGM files in a RAM-backed directory with its DEFAULT options (CLAHE + blur,
+    level search, refinement): wall time of the whole process (start + HIP initialisation + images), the steady-state rate
+    from the difference between a long and a short run, and the vnlog rows of one file against the Python mirror's
+    find_board on the preprocessed image.  NOT `value`."""
+    import shutil
+    import subprocess
+    import tempfile
+    import numpy as np
+    import mrgingham_amd
+    from mrgingham_amd import synth
+    cli = os.path.join(ROOT, "mrgingham_amd", "bin", "mrgingham-amd-from-image")
+    if not os.access(cli, os.X_OK):
+        return {"skipped": "the tool is not built (make -C mrgingham_amd/csrc)"}
+    W, H, gridn = 640, 480, 10
+    d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        frames = synth.board_batch(nfiles, W, H, gridn, 0, device=torch.device("cuda", device_index)).cpu().numpy()
+        names = []
+        for i in range(nfiles):
+            names.append(os.path.join(d, f"f{i:03d}.pgm"))
+            with open(names[-1], "wb") as f:
+                f.write(b"P5\n%d %d\n255\n" % (W, H))
+                f.write(frames[i].tobytes())
+        env = dict(os.environ, MRGINGHAM_AMD_DEVICE=str(device_index))
+
+        def run(n):
+            t0 = time.perf_counter()
+            r = subprocess.run([cli, "--jobs", str(jobs)] + names[:n], capture_output=True, text=True, env=env)
+            return time.perf_counter() - t0, r
+        small = max(nfiles // 8, 1)
+        t_small, _ = run(small)
+        t_all, r = run(nfiles)
+        rows = {}
+        for ln in r.stdout.splitlines():
+            if ln.startswith("#"):
+                continue
+            name, x, y, lv = ln.split()
+            rows.setdefault(name, []).append(None if x == "-" else (float(x), float(y)))
+        found = sum(1 for v in rows.values() if v and v[0] is not None)
+        want = mrgingham_amd.find_board(mrgingham_amd.preprocess(frames[0], clahe=True, blur_radius=1), gridn=gridn)
+        got = rows.get(names[0])
+        same = (want is None and got == [None]) or (want is not None and got is not None and len(got) == gridn * gridn and
+                                                     None not in got and bool(np.abs(np.array(got) - want).max() < 1e-6))
+        return {"workload": f"{nfiles} PGM files of {W}x{H} in {os.path.dirname(names[0])}, default options, --jobs {jobs} (BASELINE configs[0])",
+                "value": (nfiles - small) / max(t_all - t_small, 1e-9), "unit": "images/s",
+                "value_note": "steady state: (files of the long run - files of the short run) / (difference of their wall times)",
+                "wall_s": t_all, "wall_s_short_run": t_small, "files_short_run": small,
+                "images_per_s_with_process_start": nfiles / t_all, "returncode": r.returncode,
+                "boards_found": found, "vnlog_of_first_file_matches_find_board": bool(same)}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -453,6 +697,8 @@ def main():
                     help="skip the extra leg that times the same workload with option sparse_refine (N = 1 only)")
     ap.add_argument("--no-chess-alone", action="store_true",
                     help="skip the leg that times the plain ChESS pass alone (level 0, no clamp; N = 1 only)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` legs (BASELINE configs 1, 2, 5 and the preprocessing chain as short legs; N = 1 only)")
     ap.add_argument("--scratch-sets", type=int, default=0,
                     help="option scratch_sets of the library (0 = its default: chosen from the batch shape): calls' component "
                          "searches in flight")
@@ -580,14 +826,17 @@ def main():
         step()
     det.set_kernel_timing(True)
     det.chess_kernel_ms()
+    det.sclk_mhz()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         npts = step()
     fence()
     dt = time.perf_counter() - t0
+    power = power_state(local_rank)                          # (right behind the timed steps)
     det.set_kernel_timing(False)
     kern_ms, nlaunch = det.chess_kernel_ms()
+    sclk_mhz = det.sclk_mhz()                                # engine clock inside the timed level-0 launches
 
     if collective:
         tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
@@ -621,6 +870,16 @@ def main():
     fboards = None
     if world == 1 and not args.no_find_boards:
         fboards = find_boards_leg(local_rank, frames, gridn)
+    configs = None
+    if world == 1 and not args.no_configs:
+        configs = {"preprocess": preprocess_leg(det, frames)}
+        torch.cuda.empty_cache()
+        configs["c2_level0"] = c2_level0_leg(local_rank)
+        configs["c5_mixed_one_rank"] = c5_mixed_leg(local_rank)
+        torch.cuda.empty_cache()
+        configs["c1_tool"] = c1_tool_leg(local_rank)
+        configs["what"] = ("the other BASELINE configs that fit one GPU, and the reference tool's preprocessing chain, as short "
+                           "legs of the default command; none of them is `value`")
     bindings = None
     if collective and binding is not None:
         objs = [None] * world
@@ -748,6 +1007,12 @@ def main():
                                                       (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kern_ms > 0 else 0.0,
                          "launches_timed": nlaunch, "binding": valu},
         }
+        res["roofline"].update(clock_fields(achieved / HBM_PEAK_GBS, sclk_mhz))
+        res["roofline"].update(power)
+        res["roofline"]["clock_note"] = ("sclk_mhz: engine clock inside the timed level-0 launches (workgroup 0 of every launch reads "
+                                         "s_memtime and s_memrealtime: mrgingham_amd_sclk_mhz); frac_at_2400mhz = frac * 2400 / sclk_mhz: "
+                                         "what the same instructions give at the part's peak clock -- the kernel is VALU-issue bound "
+                                         "(`binding`), so a low sclk_mhz means a power- or thermally-limited box, not a slower kernel")
         res["gather_checked"] = gather_ok
         if shards_seen is not None:
             res["shards_seen"] = shards_seen
@@ -778,6 +1043,8 @@ def main():
             res["sparse_refine"] = sparse
         if fboards is not None:
             res["find_boards"] = fboards
+        if configs is not None:
+            res["configs"] = configs
         if bindings is not None or binding is not None:
             res["cpu_binding"] = bindings if bindings is not None else [binding]
         if world == 1 and not args.no_cpu_baseline:

@@ -519,12 +519,12 @@ int mrgingham_amd_after_stream(mrgingham_amd_ctx* ctx, void* stream);
  * response kernel) over the launches issued since the last call, measured with
  * hipEvents on the streams the kernel ran on; the number of launches is stored
  * in *nlaunches.  Timing is off by default: enable with
- * mrgingham_amd_set_kernel_timing(ctx, 1). */
+ * mrgingham_amd_set_kernel_timing(ctx, 1); 2 = only the engine-clock probe below (no events on the streams), 0 = off. */
 void mrgingham_amd_set_kernel_timing(mrgingham_amd_ctx* ctx, int enable);
 double mrgingham_amd_chess_kernel_ms(mrgingham_amd_ctx* ctx, int* nlaunches);
 
-/* The engine clock the level-0 response kernels ACTUALLY ran at, in MHz, averaged over the launches issued since the last
- * call while kernel timing was enabled: workgroup 0 of each launch reads the shader-cycle counter (s_memtime) and the
+/* The engine clock the level-0 response kernels (and the fused blend + blur kernel of mrgingham_amd_preprocess_batch) ACTUALLY ran at, in MHz, averaged over the launches issued since the last
+ * call while kernel timing was enabled (1 or 2): workgroup 0 of each launch reads the shader-cycle counter (s_memtime) and the
  * constant-rate counter (s_memrealtime, hipDeviceAttributeWallClockRate) at its start and end and adds the two differences
  * to a pair of device counters -- four scalar instructions in one workgroup of the launch.  A VALU-bound kernel scales with
  * this clock, so a benchmark line that carries it can tell a slow box from a regression.  0 when nothing was probed.

@@ -653,6 +653,7 @@ class Detector:
         return int(self.L.mrgingham_amd_scratch_bytes(self.ctx))
 
     def set_kernel_timing(self, enable):
+        """True / 1: hipEvents around the level-0 response launches + the engine-clock probe; 2: the probe alone; False: off."""
         self.L.mrgingham_amd_set_kernel_timing(self.ctx, int(enable))
 
     def sclk_mhz(self):

@@ -237,6 +237,7 @@ struct mrgingham_amd_ctx {
 
     // dominant-kernel timing
     bool timing = false;
+    bool clk_on = false;  // the engine-clock probe of the level-0 response launches (mrgingham_amd_sclk_mhz)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     std::vector<hipEvent_t> event_pool;
     std::vector<int32_t> host_status;
@@ -641,7 +642,7 @@ static LevelBatch level_batch_of(mrgingham_amd_ctx* ctx, const mrgingham_amd_fra
     }
     lb.resp = (int16_t*)L.resp.p;
     lb.resp_pitch = (long long)L.w * L.h;
-    if (level == 0 && ctx->timing) lb.clk = (unsigned long long*)ctx->clk.p;  // (mrgingham_amd_sclk_mhz)
+    if (level == 0 && ctx->clk_on) lb.clk = (unsigned long long*)ctx->clk.p;  // (mrgingham_amd_sclk_mhz)
     return lb;
 }
 static LevelBatch queue_level_chess(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* fr, int level) {
@@ -956,8 +957,9 @@ int mrgingham_amd_sparse_fallbacks(mrgingham_amd_ctx* ctx) {
 
 void mrgingham_amd_set_kernel_timing(mrgingham_amd_ctx* ctx, int enable) {
     if (!ctx) return;
-    ctx->timing = enable != 0;
-    if (ctx->timing && !ctx->clk.p) {  // the engine-clock probe's two counters (without them the probe stays off)
+    ctx->timing = (enable & 1) != 0;   // bit 0: hipEvents around the level-0 response launches
+    ctx->clk_on = enable != 0;         // any non-zero value: the engine-clock probe (2 = the probe alone, no events)
+    if (ctx->clk_on && !ctx->clk.p) {  // the engine-clock probe's two counters (without them the probe stays off)
         const CallerDevice keep;
         hipSetDevice(ctx->device);
         if (ensure(ctx, ctx->clk, 2 * sizeof(unsigned long long)) == 0) hipMemset(ctx->clk.p, 0, 2 * sizeof(unsigned long long));
@@ -1015,7 +1017,9 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
         ctx->sparse_subsets = value;
         return 0;
     }
+#ifdef MRG_EXPERIMENT
     if (!strcmp(name, "clahe_hist_copies")) { mrg::clahe_hist_copies = value; return 0; }
+#endif
     if (!strcmp(name, "preprocess_fused")) { ctx->pre_fused = value != 0; return 0; }
     if (!strcmp(name, "chess16_seg") || !strcmp(name, "chess_seg")) {
         // rows per workgroup of chess_v16_kernel / the chess_v1 kernels of THIS context (0 = automatic): the frame is cut into
@@ -1191,7 +1195,7 @@ int mrgingham_amd_chess_response_batch(mrgingham_amd_ctx* ctx, const mrgingham_a
     }
     lb.resp = d_response;
     lb.resp_pitch = (long long)w * h;
-    if (level == 0 && ctx->timing) lb.clk = (unsigned long long*)ctx->clk.p;
+    if (level == 0 && ctx->clk_on) lb.clk = (unsigned long long*)ctx->clk.p;
     launch_chess_any(ctx, lb, CompTables{}, fr->nframes, clamp != 0, false, s, level == 0);
     MRG_HIP_CHECK(hipGetLastError());
     return 0;
@@ -1255,7 +1259,7 @@ int mrgingham_amd_preprocess_batch(mrgingham_amd_ctx* ctx, const mrgingham_amd_f
                 if ((rc = ensure(ctx, ctx->pre_tmp, frame_bytes * fr->nframes))) return rc;
                 tmp = (uint8_t*)ctx->pre_tmp.p;
             }
-            launch_clahe(fb, fr->nframes, 8.0, true, d_out, ctx->pre_scratch.p, s, true, tmp);
+            launch_clahe(fb, fr->nframes, 8.0, true, d_out, ctx->pre_scratch.p, s, true, tmp, ctx->clk_on ? (unsigned long long*)ctx->clk.p : nullptr);
         } else {
             uint8_t* clahe_out = d_out;
             if (blur_radius > 0) {

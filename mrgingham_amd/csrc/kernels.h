@@ -66,7 +66,7 @@ size_t clahe_scratch_bytes(int nframes);
 extern int clahe_hist_copies;
 bool clahe_blur3_fused(const FrameBatch& in, const uint8_t* out);
 bool launch_clahe(const FrameBatch& in, int nframes, double clip_limit, bool do_normalize, uint8_t* out,
-                  void* scratch, hipStream_t s, bool blur3 = false, uint8_t* tmp = nullptr);
+                  void* scratch, hipStream_t s, bool blur3 = false, uint8_t* tmp = nullptr, unsigned long long* clk = nullptr);
 
 // preprocess16.hip: the CLI's 16-bit branch (normalize to 0..65535, CLAHE on 16 bits, convertTo 8 bit)
 size_t preprocess16_scratch_bytes(int nframes, int w, int h);

@@ -16,6 +16,7 @@
 //   apply          1 B/px read + 1 B/px written
 #include <hip/hip_runtime.h>
 
+#include "common.h"
 #include "kernels.h"
 
 namespace mrg {
@@ -83,7 +84,7 @@ struct ClaheGeom {
 // banks and only 4 lanes of a wave share a counter) and adds them to the frame's raw tile histogram.
 // cv::normalize is a per-frame value map, so it is applied to the BINS afterwards (clahe_lut_kernel)
 // and the frame extrema it needs are read off these histograms: one pass over the pixels.
-int clahe_hist_copies = 16;  // tuning hook "clahe_hist_copies" (16 / 32 / 64)
+int clahe_hist_copies = 16;  // tuning hook "clahe_hist_copies" (experiment builds: 8 / 16 / 32)
 template <int kHistCopies>
 __global__ __launch_bounds__(256) void clahe_hist_kernel(FrameBatch in, ClaheGeom g, int* hist, int rows_per_block) {
     __shared__ int lh[kBins * kHistCopies];
@@ -404,10 +405,13 @@ __device__ __forceinline__ void blend_hsum(const char* q, const uint32_t (&cb)[1
 
 template <int ROWS>
 __global__ __launch_bounds__(256) void clahe_blur3_kernel(FrameBatch in, ClaheGeom g, const uint2* quad, uint8_t* out,
-                                                          int ncx_max) {
+                                                          int ncx_max, unsigned long long* clk) {
     using namespace fused;
+    const bool probe = clk != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;  // (mrgingham_amd_sclk_mhz)
+    const ClockProbe clkp = clock_probe_begin(probe);
     extern __shared__ __attribute__((aligned(16))) char qlds[];  // [ncx][2][256] entries of 8 bytes
-    const int frame = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int frame = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // (a scalar: the row arithmetic below stays on the scalar unit)
     const int W = in.width, H = in.height;
     const int bx0 = blockIdx.x * 1024, by0 = blockIdx.y * 4 * ROWS;
     const float inv_tw = __fdiv_rn(1.0f, (float)g.tw), inv_th = __fdiv_rn(1.0f, (float)g.th);
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(256) void clahe_blur3_kernel(FrameBatch in, ClaheGe
     __syncthreads();
     const int x0 = bx0 + lane * 16;
     const int y0 = by0 + wv * ROWS, y1 = min(y0 + ROWS, H);
-    if (x0 >= W || y0 >= H) return;
+    if (x0 >= W || y0 >= H) return;  // (never thread 0 of workgroup 0: the probe's second half is reached)
     const uint8_t* src = in.frames + (long long)frame * in.frame_pitch;
     uint8_t* dst = out + (long long)frame * W * H;
     // per-column constants of the 18 samples: sample i is column x0 + i - 1, reflected at the frame's edge
@@ -500,6 +504,7 @@ __global__ __launch_bounds__(256) void clahe_blur3_kernel(FrameBatch in, ClaheGe
         MRG_ROW(y + 2, hc, ha, hb)
     }
 #undef MRG_ROW
+    clock_probe_end(probe, clkp, clk);
 }
 
 // rows per wave of the fused kernel for a geometry: the workgroup's 4 * rows + 2 sample rows must fit one tile height
@@ -539,12 +544,16 @@ bool clahe_blur3_fused(const FrameBatch& in, const uint8_t* out) {
     return g.tw > 0 && g.th > 0 && fused_rows(in, g, out) > 0;
 }
 
+// (Measured and dropped in round 6: the frame extrema folded into clahe_hist_kernel's epilogue -- two device-scope atomics per
+// workgroup on 128 words cost 181 -> 226 us, more than the 10 us kernel they replace --, and a two-stream pipeline over
+// chunks of frames, the table kernels of chunk k + 1 under the blend of chunk k: 0.686 against 0.653 ms per 64 x 4096x3072 and
+// +0.1 ms on small batches, the cross-stream waits cost more than the overlap gives.)
 // normalize + CLAHE(clip_limit) of every frame; `out` receives dense w x h bytes per frame.
 // `scratch` holds clahe_scratch_bytes(nframes).  Returns false when the frame is too small to tile.
 // `blur3`: followed by cv::blur(3x3) -- in the same pass when clahe_blur3_fused(in, out), else through `tmp` (dense
 // w x h bytes per frame) and launch_box_blur.
 bool launch_clahe(const FrameBatch& in, int nframes, double clip_limit, bool do_normalize, uint8_t* out,
-                  void* scratch, hipStream_t s, bool blur3, uint8_t* tmp) {
+                  void* scratch, hipStream_t s, bool blur3, uint8_t* tmp, unsigned long long* clk) {
     if (nframes <= 0 || in.width <= 0 || in.height <= 0) return true;
     const ClaheGeom g = clahe_geom(in);
     if (g.tw <= 0 || g.th <= 0) return false;
@@ -563,10 +572,14 @@ bool launch_clahe(const FrameBatch& in, int nframes, double clip_limit, bool do_
     {
         const int rpb = 64;
         const dim3 hg((g.th + rpb - 1) / rpb, kTiles * kTiles, nframes);
+        // (copies: 8 -> 262 us, 16 -> 181, 32 -> 190, 64 -> 358 per 64 x 4096x3072: it is the LDS atomic unit's rate, 8 lanes per
+        // clock, not bank conflicts, that bounds this kernel -- SQ_ACTIVE_INST_LDS covers the whole launch)
+#ifdef MRG_EXPERIMENT
         if (clahe_hist_copies == 8) hipLaunchKernelGGL(clahe_hist_kernel<8>, hg, dim3(256), 0, s, in, g, hist, rpb);
-        else if (clahe_hist_copies == 64) hipLaunchKernelGGL(clahe_hist_kernel<64>, hg, dim3(256), 0, s, in, g, hist, rpb);
         else if (clahe_hist_copies == 32) hipLaunchKernelGGL(clahe_hist_kernel<32>, hg, dim3(256), 0, s, in, g, hist, rpb);
-        else hipLaunchKernelGGL(clahe_hist_kernel<16>, hg, dim3(256), 0, s, in, g, hist, rpb);
+        else
+#endif
+        hipLaunchKernelGGL(clahe_hist_kernel<16>, hg, dim3(256), 0, s, in, g, hist, rpb);
     }
     if (do_normalize) hipLaunchKernelGGL(minmax_from_hist_kernel, dim3(nframes), dim3(256), 0, s, hist, mm);
     hipLaunchKernelGGL(clahe_lut_kernel, dim3(kTiles * kTiles, nframes), dim3(256), 0, s, hist, mm, g, clip, lut_scale,
@@ -580,9 +593,9 @@ bool launch_clahe(const FrameBatch& in, int nframes, double clip_limit, bool do_
             if (ncx_max > kCells) ncx_max = kCells;
             const dim3 grid((in.width + 1023) / 1024, (in.height + 4 * frows - 1) / (4 * frows), nframes);
             const size_t lds = (size_t)ncx_max * 2 * kBins * sizeof(uint2);
-            if (frows == 32) hipLaunchKernelGGL(clahe_blur3_kernel<32>, grid, dim3(256), lds, s, in, g, quad, out, ncx_max);
-            else if (frows == 16) hipLaunchKernelGGL(clahe_blur3_kernel<16>, grid, dim3(256), lds, s, in, g, quad, out, ncx_max);
-            else hipLaunchKernelGGL(clahe_blur3_kernel<8>, grid, dim3(256), lds, s, in, g, quad, out, ncx_max);
+            if (frows == 32) hipLaunchKernelGGL(clahe_blur3_kernel<32>, grid, dim3(256), lds, s, in, g, quad, out, ncx_max, clk);
+            else if (frows == 16) hipLaunchKernelGGL(clahe_blur3_kernel<16>, grid, dim3(256), lds, s, in, g, quad, out, ncx_max, clk);
+            else hipLaunchKernelGGL(clahe_blur3_kernel<8>, grid, dim3(256), lds, s, in, g, quad, out, ncx_max, clk);
             return true;
         }
     }
