@@ -840,7 +840,9 @@ int mrgingham_amd_find_boards_stats(mrgingham_amd_ctx* ctx, double* out, int n, 
         v[1] = (double)ctx->fb_threads_used;
         for (int i = 0; i < 7; ++i) v[2 + i] = ctx->fb_prof[i];
         v[9] = (double)ctx->fb_grid.calls; v[10] = (double)ctx->fb_grid.found;
-        v[11] = ctx->fb_grid.graph_us; v[12] = ctx->fb_grid.adjacency_us; v[13] = ctx->fb_grid.sequences_us; v[14] = ctx->fb_grid.cycles_us;
+        const double tick = grid_clock_tick_us();
+        v[11] = ctx->fb_grid.graph_t * tick; v[12] = ctx->fb_grid.adjacency_t * tick; v[13] = ctx->fb_grid.sequences_t * tick;
+        v[14] = ctx->fb_grid.cycles_t * tick;
         v[15] = ctx->fb_dev_ms[0]; v[16] = ctx->fb_dev_ms[1];
         if (reset) {
             for (double& x : ctx->fb_prof) x = 0;
@@ -856,8 +858,9 @@ int mrgingham_amd_find_boards_stats(mrgingham_amd_ctx* ctx, double* out, int n, 
 int mrgingham_amd_grid_clock(double* out6, int reset) {
     if (!out6) return MRGINGHAM_AMD_ERR_ARG;
     GridPhaseClock& c = g_grid_clock;
-    out6[0] = (double)c.calls; out6[1] = (double)c.found; out6[2] = c.graph_us; out6[3] = c.adjacency_us;
-    out6[4] = c.sequences_us; out6[5] = c.cycles_us;
+    const double tick = grid_clock_tick_us();
+    out6[0] = (double)c.calls; out6[1] = (double)c.found; out6[2] = c.graph_t * tick; out6[3] = c.adjacency_t * tick;
+    out6[4] = c.sequences_t * tick; out6[5] = c.cycles_t * tick;
     if (reset) c = GridPhaseClock{0, 0, 0, 0, 0, 0};
     return 0;
 }
@@ -2859,8 +2862,8 @@ static void fb_grid_worker(mrgingham_amd_ctx::BoardsJob* job) {
             if (!ctx) return;
             const GridPhaseClock& c = g_grid_clock;
             std::lock_guard<std::mutex> lk(ctx->fb_stat_mu);
-            ctx->fb_grid.graph_us += c.graph_us - c0.graph_us; ctx->fb_grid.adjacency_us += c.adjacency_us - c0.adjacency_us;
-            ctx->fb_grid.sequences_us += c.sequences_us - c0.sequences_us; ctx->fb_grid.cycles_us += c.cycles_us - c0.cycles_us;
+            ctx->fb_grid.graph_t += c.graph_t - c0.graph_t; ctx->fb_grid.adjacency_t += c.adjacency_t - c0.adjacency_t;
+            ctx->fb_grid.sequences_t += c.sequences_t - c0.sequences_t; ctx->fb_grid.cycles_t += c.cycles_t - c0.cycles_t;
             ctx->fb_grid.calls += c.calls - c0.calls; ctx->fb_grid.found += c.found - c0.found;
         }
     } leave{job->owner, c0};

@@ -1395,11 +1395,12 @@ __device__ __forceinline__ WinSel win_geometry(int w, int h, const double* pts, 
 
 // Marking, with the geometry given: `bits` must hold (cw * chh + 31) / 32 words.  `sink(cell x, cell y)` (cells on
 // the frame's grid) is called by the thread that sets a cell's bit first.
-// `psub` != NULL: only the points of subset `sub` (psub[i] == sub) mark.
+// `psub` != NULL: only the points of subset `sub` (psub[i] == sub) mark.  `outside` (one word of LDS, or NULL): bit 4 is set
+// when a cell a seed reaches lies outside the span.
 template <int LNBITS, class Sink = NoCellSink>
 __device__ __forceinline__ void win_mark(WinSel& ws, int w, int h, const double* pts, const signed char* lv, int npts, int level,
                                          uint32_t* bits, uint32_t* openbits, bool TIGHT, Sink sink = Sink(),
-                                         const int32_t* psub = nullptr, int sub = 0) {
+                                         const int32_t* psub = nullptr, int sub = 0, int* outside = nullptr) {
     ws.bits = bits;
     ws.openbits = openbits;
     const int nw = (ws.cw * ws.chh + 31) / 32;
@@ -1419,7 +1420,12 @@ __device__ __forceinline__ void win_mark(WinSel& ws, int w, int h, const double*
             for (int ay = ay0; ay <= ay1; ++ay)
                 for (int ax = ax0; ax <= ax1; ++ax) {
                     const int cx = TIGHT ? ax - ws.ox : ax, cy = TIGHT ? ay - ws.oy : ay;  // (not TIGHT: the span starts at cell (0, 0))
-                    if ((unsigned)cx >= (unsigned)ws.cw || (unsigned)cy >= (unsigned)ws.chh) continue;
+                    if ((unsigned)cx >= (unsigned)ws.cw || (unsigned)cy >= (unsigned)ws.chh) {
+                        // a span that was not made from these points (a split level's, list_cells_split): the cell cannot
+                        // be listed, the seeds in it would look "not hot" -- the caller gives the frame up instead
+                        if (outside) atomicOr(outside, 4);
+                        continue;
+                    }
                     const int c = cy * ws.cw + cx;
                     const uint32_t bit = 1u << (c & 31);
                     if (!(bits[c >> 5] & bit) && !(atomicOr(&bits[c >> 5], bit) & bit)) sink(ax, ay, i);
@@ -1575,29 +1581,37 @@ __device__ __forceinline__ void list_cells_split(int w, int h, const double* pts
         const int k = atomicAdd(&n[0], 1);
         if (k < tmp_cap) tmp[k] = ((uint32_t)ay << 16) | ((uint32_t)sub << 12) | (uint32_t)ax;
     };
-    if (ws.cs >= 0) win_mark<2048>(ws, w, h, pts, lv, npts, level, bits, nullptr, true, sink, psub, sub);
+    if (ws.cs >= 0) win_mark<2048>(ws, w, h, pts, lv, npts, level, bits, nullptr, true, sink, psub, sub, &n[1]);
     // do the subsets stay apart?  own points as they are now against every point of the others (level + 1 coordinates: the
-    // level this kernel has just refined)
+    // level this kernel has just refined).  n[1] bit 1: a pair closer than kKeepDist -> one workgroup at the next level;
+    // bit 2: a pair so close that both can mark the SAME cell (a cell of 2^cs pixels is marked by seeds up to half a cell
+    // beyond either edge: seeds less than 2 * 2^cs apart at this level, i.e. points less than 2^cs (+ rounding and the
+    // seed ring) apart at level + 1) -- every workgroup keeps a bitmap of its own, so the shared list would then hold the
+    // cell twice and the one workgroup of the next level would expand its hot pixels twice: the frame is given up (the
+    // dense repeat takes it); bit 4: a seed's cell outside the span the workgroups agreed on (win_mark).
     {
         const float inv = 1.0f / (float)(2 << level);
-        bool close = false;
+        const float dup = ws.cs >= 0 ? (float)(1 << min(ws.cs, 15)) + 2.f : 0.f;
+        bool close = false, twice = false;
         for (int i = tid; i < npts; i += CC_THREADS) {
             if (psub[i] != sub || lv[i] != level + 1) continue;
             const float xi = ((float)pts[2 * i] + 0.5f) * inv, yi = ((float)pts[2 * i + 1] + 0.5f) * inv;
             for (int j = 0; j < npts; ++j)
-                if (psub[j] != sub && lv[j] <= level + 2 && fabsf(((float)pts[2 * j] + 0.5f) * inv - xi) < kKeepDist &&  // (lv > level + 2: never refined again)
-                    fabsf(((float)pts[2 * j + 1] + 0.5f) * inv - yi) < kKeepDist)
-                    close = true;
+                if (psub[j] != sub && lv[j] <= level + 2) {  // (lv > level + 2: never refined again)
+                    const float dx = fabsf(((float)pts[2 * j] + 0.5f) * inv - xi), dy = fabsf(((float)pts[2 * j + 1] + 0.5f) * inv - yi);
+                    close |= dx < kKeepDist && dy < kKeepDist;
+                    twice |= dx < dup && dy < dup;
+                }
         }
-        if (close) n[1] = 1;
+        if (close || twice) atomicOr(&n[1], (close ? 1 : 0) | (twice ? 2 : 0));
     }
     __syncthreads();
     const int k = n[0];
     __syncthreads();
     if (tid == 0) {
-        int flags = (ws.cs != 4 || n[1]) ? kFlagSingle : 0;
+        int flags = (ws.cs != 4 || (n[1] & 1)) ? kFlagSingle : 0;
         int base = 0;
-        if (ws.cs < 0 || k > tmp_cap) {
+        if (ws.cs < 0 || k > tmp_cap || (n[1] & 6)) {
             flags |= kFlagGivenUp;
         } else {
             base = atomicAdd(&cnt[0], k);

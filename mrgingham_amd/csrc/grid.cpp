@@ -25,7 +25,9 @@
 #include <cstdio>
 #include <string>
 #include <chrono>
+#if defined(__x86_64__)
 #include <x86intrin.h>
+#endif
 #include <vector>
 
 #include <sys/stat.h>
@@ -675,24 +677,39 @@ void dump_sequences(const char* base, const std::vector<Sequence>& seq, const st
 
 static bool find_grid_impl(std::vector<PointD>& out, const std::vector<PointI>& pts, int gridn, double (&lap)[4]);
 
-// microseconds per time-stamp-counter tick, measured once per process against the steady clock
-static double tsc_us() {
-    static const double k = [] {
-        const auto c0 = std::chrono::steady_clock::now();
-        const unsigned long long t0 = __rdtsc();
-        while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c0).count() < 2000.0) {}
-        const unsigned long long t1 = __rdtsc();
-        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c0).count();
-        return us / (double)(t1 - t0);
-    }();
-    return k;
+// The phase clock: the time-stamp counter where there is one (a clock_gettime per mark costs microseconds under some
+// sandboxes), the steady clock in nanoseconds elsewhere.  What a tick is worth is worked out when somebody READS the totals:
+// from the anchor -- both clocks at the process's first grid-finder call -- to the moment of the question.
+#if defined(__x86_64__)
+static inline unsigned long long phase_ticks() { return __rdtsc(); }
+#else
+static inline unsigned long long phase_ticks() {
+    return (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+#endif
+namespace {
+struct ClockAnchor { std::chrono::steady_clock::time_point c; unsigned long long t; };
+const ClockAnchor& clock_anchor() {
+    static const ClockAnchor a{std::chrono::steady_clock::now(), phase_ticks()};
+    return a;
+}
+}  // namespace
+double grid_clock_tick_us() {
+    const ClockAnchor& a = clock_anchor();
+    double us;
+    unsigned long long t1;
+    do {   // (asked within 0.2 ms of the anchor -- only when nothing worth reading has been counted yet: wait that long)
+        t1 = phase_ticks();
+        us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a.c).count();
+    } while (us < 200.0 || t1 == a.t);
+    return us / (double)(t1 - a.t);
 }
 
 bool find_grid_from_points(std::vector<PointD>& out, const std::vector<PointI>& pts, int gridn) {
     double lap[4] = {0, 0, 0, 0};
     const bool ok = find_grid_impl(out, pts, gridn, lap);
     GridPhaseClock& c = g_grid_clock;
-    c.graph_us += lap[0]; c.adjacency_us += lap[1]; c.sequences_us += lap[2]; c.cycles_us += lap[3];
+    c.graph_t += lap[0]; c.adjacency_t += lap[1]; c.sequences_t += lap[2]; c.cycles_t += lap[3];
     c.calls++;
     c.found += ok;
     return ok;
@@ -702,10 +719,10 @@ static bool find_grid_impl(std::vector<PointD>& out, const std::vector<PointI>& 
     struct Lap {   // adds the time since the last mark to lap[i]; the destructor closes the phase that was running
         double (&lap)[4];
         int cur = 0;
-        unsigned long long t = __rdtsc();   // (a clock_gettime per mark costs microseconds under some sandboxes)
+        unsigned long long t = (clock_anchor(), phase_ticks());
         void to(int next) {
-            const unsigned long long n = __rdtsc();
-            lap[cur] += (double)(n - t) * tsc_us();
+            const unsigned long long n = phase_ticks();
+            lap[cur] += (double)(n - t);
             t = n;
             cur = next;
         }

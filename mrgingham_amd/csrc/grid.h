@@ -26,9 +26,12 @@ extern thread_local bool g_grid_debug;
 // Where the calling thread's find_grid_from_points calls spent their time (a handful of clock reads per call): the
 // neighbour graph (sort + Delaunay sweep + site rings), the adjacency lists in the reference's visiting order, the
 // sequence-candidate search, and everything after it (outer edges, 4-cycles, rows).  Thread-local; the find_boards
-// calls add their workers' clocks up (mrgingham_amd_find_boards_stats).
-struct GridPhaseClock { double graph_us, adjacency_us, sequences_us, cycles_us; long calls, found; };
+// calls add their workers' clocks up (mrgingham_amd_find_boards_stats).  The four phase fields count TICKS of the phase clock
+// (the time-stamp counter on x86-64, nanoseconds of the steady clock elsewhere); grid_clock_tick_us() is what one is worth,
+// applied where the totals are read out (no calibration loop on the path of a caller who never asks).
+struct GridPhaseClock { double graph_t, adjacency_t, sequences_t, cycles_t; long calls, found; };
 extern thread_local GridPhaseClock g_grid_clock;
+double grid_clock_tick_us();
 
 // visiting-order perturbations for the insensitivity tests (see grid.cpp); thread-local, default off
 struct GridPerturbation { unsigned ring_seed; bool last_match; };

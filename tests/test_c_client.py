@@ -70,3 +70,40 @@ def test_c_caller_gets_what_the_python_mirror_gets(tmp_path):
     got = np.array([[float(t) for t in l.split()[1:]] for l in lines if l.startswith("b ")])
     assert board is not None and "board found 1 n 100" in lines and np.array_equal(got, board)
     assert "bad_level 0 -1" in lines
+
+
+@pytest.mark.gpu
+def test_rccl_host_example_runs_one_rank(tmp_path):
+    """tests/boundary/rccl_host.c with its main(): a ONE-rank communicator from ncclGetUniqueId / ncclCommInitRank, the
+    rank's shard through chain_batch into the packed block, mrgingham_amd_gather_rccl -> the gathered block equals a
+    plain chain_batch of the same frames (checked in C, byte for byte) AND what the Python mirror returns here."""
+    import torch
+    import mrgingham_amd
+    from mrgingham_amd import parallel, synth
+    if not os.path.exists("/opt/rocm/include/rccl/rccl.h") or not os.path.exists("/opt/rocm/lib/librccl.so"):
+        pytest.skip("no RCCL development files here")
+    exe = str(tmp_path / "rccl_host")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                        "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "boundary", "rccl_host.c"),
+                        "-o", exe, "-L" + LIBDIR, "-lmrgingham_amd", "-L/opt/rocm/lib", "-lrccl", "-lamdhip64",
+                        "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    B, W, H, P = 6, 1280, 960, 256
+    frames = synth.board_batch(B, W, H, 10, 70, device="cuda:0")
+    (tmp_path / "frames.raw").write_bytes(frames.cpu().numpy().tobytes())
+    out = tmp_path / "gathered.bin"
+    r = subprocess.run([exe, str(tmp_path / "frames.raw"), str(B), str(W), str(H), str(P), str(out)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    assert "gathered_equals_chain 1" in r.stdout.splitlines()
+    gathered = torch.from_numpy(np.frombuffer(out.read_bytes(), dtype=np.uint8).copy())[None]
+    gp, gl, gn = parallel.unpack_outputs(gathered, B, P)
+    det = mrgingham_amd.Detector(0)
+    try:
+        want = [t.cpu() for t in det.chain(frames, 3, P)]
+    finally:
+        det.close()
+    assert torch.equal(gn[0], want[2]) and int(gn[0].min()) >= 50
+    for f in range(B):
+        n = int(want[2][f])
+        assert torch.equal(gp[0][f, :n], want[0][f, :n]) and torch.equal(gl[0][f, :n], want[1][f, :n])
