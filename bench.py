@@ -309,12 +309,17 @@ def find_boards_leg(device_index, frames, gridn, batches=150, depth=3):
         det.find_boards_stats(reset=True)                    # the phase clock starts on an empty pipeline ...
         for _ in range(depth - 1):                           # ... which is filled again before the timed batches
             step()
+        import resource
+        ru0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
         for _ in range(batches):
             step()
         while jobs:
             last = det.find_boards_collect(jobs.pop(0))
         dt = (time.perf_counter() - t0) / batches
+        ru1 = resource.getrusage(resource.RUSAGE_SELF)
+        cpu_ms = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / batches * 1e3   # all threads of the process
+        quota = cpu_quota_cores()
         st = det.find_boards_stats(reset=True)
         nb = max(st["batches"], 1.0)
         ok = bool(np.array_equal(first[1], want[1]))
@@ -342,6 +347,10 @@ def find_boards_leg(device_index, frames, gridn, batches=150, depth=3):
                                            st["ms_collect_boards_copied"]) / nb,
                 "host_part_ms_per_batch_by_phase": {k[3:]: st[k] / nb for k in st if k.startswith("ms_")},
                 "grid_finder_cpu_ms_per_batch_over_all_threads": (st["grid_us_graph"] + st["grid_us_adjacency"] + st["grid_us_sequences"] + st["grid_us_cycles_rows"]) / nb / 1e3,
+                # the container's CPU quota as a floor: a batch cannot take less wall time than its CPU time / the cores the
+                # process may use; `process_cpu_ms_per_batch` counts every thread (grid finder, submit / collect, the runtime's own)
+                "process_cpu_ms_per_batch": cpu_ms,
+                "cpu_quota_floor_ms_per_batch": (cpu_ms / quota) if quota else None,
                 "device_part_ms_per_batch": {"first_pass": st["device_ms_first_pass"] / nb, "refinement": st["device_ms_refinement"] / nb,
                                              "note": "hipEvents; the two run on different streams and overlap each other and the host part"},
                 "bound_by": "host" if (st["ms_grid_finder_joined"] / nb) > 0.5 * dt * 1e3 else "device",
@@ -644,29 +653,33 @@ def c1_tool_leg(device_index, nfiles=256, jobs=4):
                 f.write(frames[i].tobytes())
         env = dict(os.environ, MRGINGHAM_AMD_DEVICE=str(device_index))
 
-        def run(n):
+        def run(files):
             t0 = time.perf_counter()
-            r = subprocess.run([cli, "--jobs", str(jobs)] + names[:n], capture_output=True, text=True, env=env)
+            r = subprocess.run([cli, "--jobs", str(jobs)] + files, capture_output=True, text=True, env=env, timeout=120)
             return time.perf_counter() - t0, r
-        small = max(nfiles // 8, 1)
-        t_small, _ = run(small)
-        t_all, r = run(nfiles)
+        # a short run (process start + HIP initialisation + a few images) and a long one (every file `reps` times over: the
+        # difference of two sub-second wall times is the measurement, so it has to be a few tenths of a second)
+        small, reps = max(nfiles // 8, 1), 4
+        t_small, r_small = run(names[:small])
+        t_all, r = run(names * reps)
         rows = {}
-        for ln in r.stdout.splitlines():
+        for ln in r_small.stdout.splitlines():
             if ln.startswith("#"):
                 continue
             name, x, y, lv = ln.split()
             rows.setdefault(name, []).append(None if x == "-" else (float(x), float(y)))
-        found = sum(1 for v in rows.values() if v and v[0] is not None)
+        found = sum(1 for ln in r.stdout.splitlines() if not ln.startswith("#") and ln.split()[1] != "-") // (gridn * gridn)
         want = mrgingham_amd.find_board(mrgingham_amd.preprocess(frames[0], clahe=True, blur_radius=1), gridn=gridn)
         got = rows.get(names[0])
         same = (want is None and got == [None]) or (want is not None and got is not None and len(got) == gridn * gridn and
                                                      None not in got and bool(np.abs(np.array(got) - want).max() < 1e-6))
+        nlong = nfiles * reps
         return {"workload": f"{nfiles} PGM files of {W}x{H} in {os.path.dirname(names[0])}, default options, --jobs {jobs} (BASELINE configs[0])",
-                "value": (nfiles - small) / max(t_all - t_small, 1e-9), "unit": "images/s",
-                "value_note": "steady state: (files of the long run - files of the short run) / (difference of their wall times)",
-                "wall_s": t_all, "wall_s_short_run": t_small, "files_short_run": small,
-                "images_per_s_with_process_start": nfiles / t_all, "returncode": r.returncode,
+                "value": (nlong - small) / max(t_all - t_small, 1e-9), "unit": "images/s",
+                "value_note": "steady state: (images of the long run - images of the short run) / (difference of their wall times); "
+                              f"the long run names every file {reps} times",
+                "images_long_run": nlong, "wall_s": t_all, "wall_s_short_run": t_small, "files_short_run": small,
+                "images_per_s_with_process_start": nlong / t_all, "returncode": r.returncode,
                 "boards_found": found, "vnlog_of_first_file_matches_find_board": bool(same)}
     finally:
         shutil.rmtree(d, ignore_errors=True)
@@ -844,13 +857,26 @@ def main():
         dt = float(tmax.item())
 
     found = int((npts >= gridn * gridn).sum().item())
+    # Everything below is a LEG beside the timed region.  A leg that fails (a box without /dev/shm, a tool that was not
+    # built, ...) reports {"error": ...} in its place: it must never cost the run its JSON line.
+    def leg(fn, *a, **kw):
+        try:
+            return fn(*a, **kw)
+        except Exception as e:                               # noqa: BLE001 -- reported, not swallowed
+            import traceback
+            sys.stderr.write("bench.py: leg %s failed:\n%s" % (getattr(fn, "__name__", "?"), traceback.format_exc()))
+            try:
+                torch.cuda.synchronize()
+            except Exception:                                # noqa: BLE001
+                pass
+            return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     # the host-fed leg on EVERY rank (each rank feeds its own GPU from its own pinned buffer, all at once: what
     # the node's PCIe / memory topology gives when all GPUs are fed together); rank 0 reports min / max over ranks
     e2e = None
     if not args.no_end_to_end:
         if collective:
             dist.barrier()
-        e2e = end_to_end(det, frames, start_level, P)
+        e2e = end_to_end(det, frames, start_level, P) if collective else leg(end_to_end, det, frames, start_level, P)
         if collective:
             mine = torch.tensor([e2e["h2d_GBs"], e2e["value"]], dtype=torch.float64, device=cdev)
             allr = [torch.empty_like(mine) for _ in range(world)]
@@ -863,21 +889,21 @@ def main():
     scratch_gib = det.scratch_bytes() / 2**30                # (likewise: a context that runs sparse chains keeps a third set)
     alone = None
     if world == 1 and not args.no_chess_alone:
-        alone = chess_pass_alone_leg(det, frames)
+        alone = leg(chess_pass_alone_leg, det, frames)
     sparse = None
     if world == 1 and start_level >= 1 and not args.no_sparse_leg and not args.sparse_refine:
-        sparse = sparse_leg(det, frames, start_level, P, 100)   # (its own length: not the timed region of the contract)
+        sparse = leg(sparse_leg, det, frames, start_level, P, 100)   # (its own length: not the timed region of the contract)
     fboards = None
     if world == 1 and not args.no_find_boards:
-        fboards = find_boards_leg(local_rank, frames, gridn)
+        fboards = leg(find_boards_leg, local_rank, frames, gridn)
     configs = None
     if world == 1 and not args.no_configs:
-        configs = {"preprocess": preprocess_leg(det, frames)}
+        configs = {"preprocess": leg(preprocess_leg, det, frames)}
         torch.cuda.empty_cache()
-        configs["c2_level0"] = c2_level0_leg(local_rank)
-        configs["c5_mixed_one_rank"] = c5_mixed_leg(local_rank)
+        configs["c2_level0"] = leg(c2_level0_leg, local_rank)
+        configs["c5_mixed_one_rank"] = leg(c5_mixed_leg, local_rank)
         torch.cuda.empty_cache()
-        configs["c1_tool"] = c1_tool_leg(local_rank)
+        configs["c1_tool"] = leg(c1_tool_leg, local_rank)
         configs["what"] = ("the other BASELINE configs that fit one GPU, and the reference tool's preprocessing chain, as short "
                            "legs of the default command; none of them is `value`")
     bindings = None
@@ -1049,7 +1075,11 @@ def main():
             res["cpu_binding"] = bindings if bindings is not None else [binding]
         if world == 1 and not args.no_cpu_baseline:
             nhost = min(batch, 64)
-            res["cpu_baseline"] = cpu_baseline(frames[:nhost].cpu().numpy(), start_level)
+            try:
+                res["cpu_baseline"] = cpu_baseline(frames[:nhost].cpu().numpy(), start_level)
+            except Exception as e:                           # noqa: BLE001 -- the line must come out; the leg says what broke
+                res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": None, "kind": "port", "sample": None,
+                                       "error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         json_out.write(json.dumps(res) + "\n")
         json_out.flush()
     if collective:

@@ -830,8 +830,11 @@ int chess_stage_override = 0;  // tuning hook "chess_stage": 0 = automatic, 2 / 
 // `min_blocks` > 0: the older rule for the levels inside a merged launch (tallest segment that still gives that
 // many workgroups), where the largest level fills the chip and the others only pack its tail.
 static const SegModel kV1Model = {6.8, 0.57, 13.0, 32, 1024};      // plain response
-static const SegModel kV1HotModel = {12.0, 0.8, 13.0, 32, 1024};   // with the hot list (and the level images)
-static int pick_nsegs(int w, int h, int nframes, int seg_rows, bool hot, int min_blocks = 0) {
+static const SegModel kV1PyrModel = {12.0, 0.8, 13.0, 32, 1024};   // with the hot list and the level images (level 0 of a chain)
+// with the hot list alone: 10 rows' worth per workgroup, not 12 -- at 64 x 1920x1080 the two models differ by one segment
+// (six of 184 rows against five of 216) and the sweep has six to eight at 122 us, five at 125 (profiles/r06_seg_rounds_sweep.txt)
+static const SegModel kV1HotModel = {10.0, 0.8, 13.0, 32, 1024};
+static int pick_nsegs(int w, int h, int nframes, int seg_rows, bool hot, int min_blocks = 0, bool pyr = false) {
     if (seg_rows > 0) return segments_for_rows(h, seg_rows, V1_RB);
     const int strips = (w + V1_SW - 1) / V1_SW;
     if (min_blocks > 0) {
@@ -840,7 +843,7 @@ static int pick_nsegs(int w, int h, int nframes, int seg_rows, bool hot, int min
             if (blocks >= min_blocks || seg == 32) return segments_for_rows(h, seg, V1_RB);
         }
     }
-    return pick_balanced_segments(strips, h, nframes, V1_RB, hot ? kV1HotModel : kV1Model);
+    return pick_balanced_segments(strips, h, nframes, V1_RB, pyr ? kV1PyrModel : (hot ? kV1HotModel : kV1Model));
 }
 
 // Production entry point.
@@ -900,7 +903,7 @@ bool chess_pyramid_ok(const LevelBatch& lb, int nframes) {
 bool launch_chess_pyramid(const LevelBatch& lb, const CompTables& t, const PyramidOut& po, int nframes, hipStream_t s,
                           int seg_rows) {
     if (!chess_pyramid_ok(lb, nframes)) return false;
-    const int nsegs = pick_nsegs(lb.w, lb.h, nframes, seg_rows, true);  // segments of whole 8-row granules: an iteration's rows are whole cells
+    const int nsegs = pick_nsegs(lb.w, lb.h, nframes, seg_rows, true, 0, true);  // segments of whole 8-row granules: an iteration's rows are whole cells
     dim3 grid(((lb.w + V1_SW - 1) / V1_SW) * nsegs * nframes);
     const size_t lds = 2 * V1_PLANE + (V1_HOTBUF + 12) * sizeof(int);
     PyramidOut p2 = po;

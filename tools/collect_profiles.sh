@@ -11,24 +11,15 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py"                              # defaults: 200 steps, 20 warmup
 TRACEB="python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-find-boards"   # short run under the tracer (the find_boards leg has its own tool)
-PMCB="python $R/bench.py --distinct 4 --steps 3 --warmup 1 --no-cpu-baseline --no-find-boards"
 # 1. the bench line itself
 timeout 600 $BENCH > $OUT/bench.json 2> $OUT/bench.err
 # 2. kernel trace of the same command (no CPU baseline: it only adds host time)
 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- $TRACEB > $OUT/trace_bench.json 2> $OUT/trace.err
-# 3. EA (fabric) traffic: read requests by size, write requests, and the derived KiB counters
-timeout 900 rocprofv3 --pmc TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_128B --kernel-trace --output-format csv -d $OUT/pmc_rd -o p -- $PMCB > $OUT/pmc_rd.json 2> $OUT/pmc_rd.err
-timeout 900 rocprofv3 --pmc TCC_EA0_WRREQ TCC_EA0_WRREQ_64B --kernel-trace --output-format csv -d $OUT/pmc_wr -o p -- $PMCB > $OUT/pmc_wr.json 2> $OUT/pmc_wr.err
-timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o p -- $PMCB > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
-timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o p -- $PMCB > $OUT/pmc_write.json 2> $OUT/pmc_write.err
+# 3. + 4b. the counter passes of the bench command itself (their own script: they can be repeated alone)
+bash $R/tools/collect_pmc_bench.sh $TAG
 # 4. issue / wait / LDS counters of the level-0 response kernel alone
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_sq1 -o p -- python $R/tools/chess_l0_alone.py > /dev/null 2> $OUT/pmc_sq1.err
 timeout 600 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2 -o p -- python $R/tools/chess_l0_alone.py > /dev/null 2> $OUT/pmc_sq2.err
-# 4b. the same counters on the kernels exactly as bench.py launches them (chess_v1_pyr_kernel: 64 frames, hot list +
-#     level images; chess_v1_multi_kernel), separate passes of the bench command
-PMCQ="python $R/bench.py --distinct 4 --steps 3 --warmup 1 --prime 2 --no-cpu-baseline --no-end-to-end --no-find-boards"
-timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_sqp1 -o p -- $PMCQ > /dev/null 2> $OUT/pmc_sqp1.err
-timeout 600 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $OUT/pmc_sqp2 -o p -- $PMCQ > /dev/null 2> $OUT/pmc_sqp2.err
 # 4c. kernel trace of the textured-background workload
 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace_clut -o t -- python $R/bench.py --workload c3_cluttered --steps 40 --warmup 5 --no-cpu-baseline --no-end-to-end > $OUT/trace_clutter_bench.json 2> $OUT/trace_clut.err
 timeout 600 python $R/bench.py --workload c3_cluttered --no-cpu-baseline --no-end-to-end > $OUT/bench_cluttered.json 2> $OUT/bench_cluttered.err
@@ -55,6 +46,8 @@ timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TC
 timeout 300 rocprofv3 --pmc TCC_EA0_WRREQ TCC_EA0_WRREQ_64B --kernel-trace --output-format csv -d $OUT/pmc_awr -o p -- python $R/tools/chess16_pmc.py 16 > /dev/null 2> $OUT/pmc_awr.err
 timeout 300 python $R/tools/chess16_sweep.py > $OUT/chess16_sweep.txt 2> $OUT/chess16_sweep.err
 timeout 300 python $R/tools/sparse_subsets_ab.py > $OUT/sparse_subsets_ab.txt 2> $OUT/sparse_subsets_ab.err
+# 4f. round 6: balanced segment counts, every k against the automatic choice, at the sizes of configs 2 and 5
+timeout 900 python $R/tools/seg_rounds_sweep.py 1920x1080 1280x800 2560x1440 4096x2160 > $OUT/seg_rounds_sweep.txt 2> $OUT/seg_rounds_sweep.err
 # 5. preprocessing kernels (row (f)-2)
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/pre -o t -- python $R/tools/preprocess_bench.py > $OUT/prebench.txt 2> $OUT/pre.err
 # summaries on the box (the raw rocprofv3 output is too big to travel back), then drop the raw files
@@ -64,8 +57,8 @@ python $R/tools/rocprof_summary.py $OUT/trace_clut/t_results.db > $OUT/cluttered
 python $R/tools/rocprof_summary.py $OUT/trace_sparse/t_results.db > $OUT/sparse_kernel_trace.txt 2>> $OUT/trace_sparse.err
 python $R/tools/rocprof_summary.py $OUT/trace_alone/t_results.db > $OUT/chess_alone_kernel_trace.txt 2>> $OUT/trace_alone.err
 python $R/tools/rocprof_summary.py $OUT/trace_c2/t_results.db > $OUT/c2_kernel_trace.txt 2>> $OUT/trace_c2.err
-for d in pmc_rd pmc_wr pmc_fetch pmc_write pmc_sq1 pmc_sq2 pmc_sqp1 pmc_sqp2 pmc_a16 pmc_b16 pmc_a1 pmc_b1 pmc_ard pmc_awr; do
+for d in pmc_sq1 pmc_sq2 pmc_a16 pmc_b16 pmc_a1 pmc_b1 pmc_ard pmc_awr; do
     python $R/tools/pmc_summary.py $OUT/$d/p_counter_collection.csv > $OUT/$d.txt 2>> $OUT/$d.err
 done
-rm -rf $OUT/pmc_ard $OUT/pmc_awr $OUT/trace_alone $OUT/trace_c2 $OUT/pmc_a16 $OUT/pmc_b16 $OUT/pmc_a1 $OUT/pmc_b1 $OUT/trace $OUT/pre $OUT/trace_clut $OUT/trace_sparse $OUT/pmc_rd $OUT/pmc_wr $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_sqp1 $OUT/pmc_sqp2
+rm -rf $OUT/pmc_ard $OUT/pmc_awr $OUT/trace_alone $OUT/trace_c2 $OUT/pmc_a16 $OUT/pmc_b16 $OUT/pmc_a1 $OUT/pmc_b1 $OUT/trace $OUT/pre $OUT/trace_clut $OUT/trace_sparse $OUT/pmc_sq1 $OUT/pmc_sq2
 ls -la $OUT

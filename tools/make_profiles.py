@@ -29,7 +29,7 @@ for n, title in [("pmc_rd", "pass 1: --pmc TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_E
                  ("pmc_write", "pass 4: --pmc WRITE_SIZE")]:
     parts.append(f"## {title}\n" + rd(n + ".txt"))
 open(os.path.join(P, f"{RND}_bench_pmc_ea_traffic.txt"), "w").write(
-    "# rocprofv3 --pmc ... --kernel-trace --output-format csv -- python bench.py --distinct 4 --steps 3 --warmup 1 --no-cpu-baseline\n"
+    "# rocprofv3 --pmc ... --kernel-trace --output-format csv -- python bench.py --distinct 4 --steps 3 --warmup 1 --no-cpu-baseline (+ the legs beside the timed steps off: tools/collect_pmc_bench.sh)\n"
     f"# separate passes, counters only; means over the dispatches of each kernel (tools/pmc_summary.py); final round-{RND[1:]} kernels\n" + "\n".join(parts))
 
 
@@ -39,8 +39,15 @@ def grab(fn, kernel_grid, ctr):
     return float(re.search(re.escape(ctr) + r"\s+mean\s+([0-9.]+)", blk).group(1))
 
 
+def kernel_line(fn, name):
+    """'<name>  grid=N' of the kernel's block in a pmc summary (the grid follows the segment count the launcher picked)"""
+    m = re.search(re.escape(name) + r"  grid=\d+", rd(fn + ".txt"))
+    assert m, (fn, name)
+    return m.group(0)
+
+
 fused = "chess_v1_pyr_kernel" in rd("pmc_rd.txt")
-kg = "chess_v1_pyr_kernel  grid=3145728" if fused else "chess_v1_kernel<true, true, 1>  grid=3145728"
+kg = kernel_line("pmc_rd", "chess_v1_pyr_kernel" if fused else "chess_v1_kernel<true, true, 1>")
 rdb = 128 * grab("pmc_rd", kg, "TCC_EA0_RDREQ_128B") + 64 * grab("pmc_rd", kg, "TCC_EA0_RDREQ_64B") + 32 * grab("pmc_rd", kg, "TCC_EA0_RDREQ_32B")
 wr64, wrall = grab("pmc_wr", kg, "TCC_EA0_WRREQ_64B"), grab("pmc_wr", kg, "TCC_EA0_WRREQ ")
 wrb = 64 * wr64 + 32 * (wrall - wr64)
@@ -77,11 +84,11 @@ open(os.path.join(P, f"{RND}_preprocess_kernel_trace.txt"), "w").write(
 #    bench.py quotes next to the HBM roofline
 if os.path.exists(os.path.join(R, "pmc_sqp1.txt")):
     open(os.path.join(P, f"{RND}_bench_sq_counters.txt"), "w").write(
-        "# rocprofv3 --pmc <SQ counters> --kernel-trace --output-format csv -- python bench.py --distinct 4 --steps 3 --warmup 1 --prime 2 --no-cpu-baseline --no-end-to-end   (two passes)\n"
+        "# rocprofv3 --pmc <SQ counters> --kernel-trace --output-format csv -- python bench.py --distinct 4 --steps 3 --warmup 1 --prime 2 --no-cpu-baseline --no-end-to-end (+ the legs beside the timed steps off: tools/collect_pmc_bench.sh)   (two passes)\n"
         "# the kernels exactly as the bench launches them: chess_v1_pyr_kernel = 64 frames of 4096x3072, clamp + hot list + level images 1..3\n"
         "# per wave-iteration (512 px): divide by pixels / 512 = 1 572 864 for the level-0 launch; SQ_* cycle counters are in quad-cycles\n"
         + rd("pmc_sqp1.txt") + rd("pmc_sqp2.txt"))
-    kgq = "chess_v1_pyr_kernel  grid=3145728"
+    kgq = kernel_line("pmc_sqp1", "chess_v1_pyr_kernel")
     wi = 64 * 4096 * 3072 / 512
     insts, wavecyc = grab("pmc_sqp1", kgq, "SQ_INSTS_VALU"), grab("pmc_sqp1", kgq, "SQ_WAVE_CYCLES")
     waves = grab("pmc_sqp1", kgq, "SQ_WAVES")
@@ -123,7 +130,7 @@ if os.path.exists(os.path.join(R, "c2_kernel_trace.txt")):
         f"{c2['roofline']['avg_launch_ms']*1e3:.1f} us = {c2['roofline']['frac']*100:.1f} % of 8 TB/s on 3 B/px; chess_pass_alone {c2['chess_pass_alone']['avg_launch_ms']*1e3:.1f} us = {c2['chess_pass_alone']['frac']*100:.1f} %\n"
         + strip(rd("c2_kernel_trace.txt")))
     open(os.path.join(P, f"{RND}_bench_c2.json"), "w").write(rd("bench_c2.json"))
-for n in ("bench_rehearsal.json", "chess16_sweep.txt", "sparse_subsets_ab.txt"):
+for n in ("bench_rehearsal.json", "chess16_sweep.txt", "sparse_subsets_ab.txt", "seg_rounds_sweep.txt"):
     if os.path.exists(os.path.join(R, n)) and rd(n).strip():
         open(os.path.join(P, f"{RND}_{n}"), "w").write(strip(rd(n)))
 if os.path.exists(os.path.join(R, "pmc_a16.txt")):
@@ -134,7 +141,7 @@ if os.path.exists(os.path.join(R, "pmc_a16.txt")):
 
 # 7. EA traffic of the plain ChESS pass (chess_v16_kernel alone): what bench.py replays as chess_pass_alone.traffic
 if os.path.exists(os.path.join(R, "pmc_ard.txt")):
-    kga = "chess_v16_kernel<false>  grid=786432"
+    kga = kernel_line("pmc_ard", "chess_v16_kernel<false>")
     ardb = 128 * grab("pmc_ard", kga, "TCC_EA0_RDREQ_128B") + 64 * grab("pmc_ard", kga, "TCC_EA0_RDREQ_64B") + 32 * grab("pmc_ard", kga, "TCC_EA0_RDREQ_32B")
     aw64, awall = grab("pmc_awr", kga, "TCC_EA0_WRREQ_64B"), grab("pmc_awr", kga, "TCC_EA0_WRREQ ")
     awrb = 64 * aw64 + 32 * (awall - aw64)

@@ -7,11 +7,11 @@ det = mrgingham_amd.Detector(0)
 W,H,B = 4096,3072,64
 frames = synth.board_batch(4, W, H, 10, 0, device='cuda').repeat(B//4,1,1).contiguous()
 for clahe, blur in [(True,1),(True,0),(False,1)]:
-    for _ in range(2): out = det.preprocess(frames, clahe=clahe, blur_radius=blur)
+    for _ in range(30): out = det.preprocess(frames, clahe=clahe, blur_radius=blur)
     torch.cuda.synchronize()
     e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(5): out = det.preprocess(frames, clahe=clahe, blur_radius=blur)
+    for _ in range(40): out = det.preprocess(frames, clahe=clahe, blur_radius=blur)
     e1.record(); torch.cuda.synchronize()
-    ms=e0.elapsed_time(e1)/5
+    ms=e0.elapsed_time(e1)/40
     print(f"clahe={clahe} blur={blur}: {ms:.3f} ms per {B} frames -> {B/ms*1e3:.0f} frames/s, {B*W*H/ms/1e6:.0f} Mpx/ms-ish")
