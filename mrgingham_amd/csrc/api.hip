@@ -1009,6 +1009,7 @@ int mrgingham_amd_set_option(mrgingham_amd_ctx* ctx, const char* name, int value
         return 0;
     }
 #ifdef MRG_EXPERIMENT
+    if (!strcmp(name, "chess16_pair")) { mrg::chess16_pair = value != 0; return 0; }
     if (!strcmp(name, "chess_variant_hot")) {
         if (value & ~48) return MRGINGHAM_AMD_ERR_ARG;  // 16: levels below 0 on chess_v16, 32: level 0 with the level images on chess_v16
         ctx->chess_variant_hot = value;

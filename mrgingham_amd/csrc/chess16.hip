@@ -209,11 +209,17 @@ __device__ __forceinline__ void emit_pyramid_block(const char* lds, uint32_t gA,
 // Frames whose width is a multiple of 16 only (the staging loads are whole 16-byte chunks inside or outside the frame).
 // The body for workgroup `bid` of `nwg` of one level (the multi-level launch runs several levels in one grid).
 // HOT (implies CLAMP): the hot-pixel records of chess_hot.h, two aligned 8-pixel groups per lane.
-template <bool CLAMP, bool HOT, bool PYR = false>
+// PAIR (experiment builds; widths with w % 256 == 128, an even number of segments, no hot list): the half-empty last
+// strip's workgroups take TWO consecutive row segments at once -- lanes 0-7 of a quarter-wave on segment A, lanes 8-15 on
+// segment B, the window laid out [A's left halo 8 | A 128 | B's left halo 8 | B 128] = the 272 pixels it has (A's right
+// halo lies outside the frame and only feeds masked outputs).  The grid is nwg_level ordinary workgroups over the full
+// strips followed by (nsegs / 2) * frames paired ones; everything that differs is a per-lane constant set up front.
+template <bool CLAMP, bool HOT, bool PYR = false, bool PAIR = false>
 __device__ __forceinline__ void chess_v16_body(const LevelBatch& lb, const CompTables& t, int frame0, int nsegs, unsigned bid,
                                                unsigned nwg_level, char* lds, const PyramidOut* po = nullptr) {
     using namespace v16;
-    const int nstrips = (lb.w + SW - 1) / SW;
+    const int nstrips = PAIR ? lb.w / SW : (lb.w + SW - 1) / SW;
+    const bool paired = PAIR && bid >= nwg_level;  // (workgroup-uniform)
     int work;
     {   // XCD-aware work order (chess.hip, chess_v1_body)
         const unsigned b = bid, nwg = nwg_level, xcd = b & 7u, j = b >> 3;
@@ -222,7 +228,12 @@ __device__ __forceinline__ void chess_v16_body(const LevelBatch& lb, const CompT
     }
     const bool probe = lb.clk != nullptr && bid == 0;  // (mrgingham_amd_sclk_mhz)
     const ClockProbe clkp = clock_probe_begin(probe);
-    const int strip = work % nstrips, rest = work / nstrips;
+    int strip = work % nstrips, rest = work / nstrips;
+    if (paired) {  // the half strip, segments 2 i and 2 i + 1 of a frame
+        const int pw = (int)(bid - nwg_level), half_n = nsegs >> 1;
+        strip = nstrips;
+        rest = (pw / half_n) * nsegs + 2 * (pw % half_n);
+    }
     const int frame = frame0 + rest / nsegs;
     const int w = lb.w, h = lb.h, stride = lb.img_stride;
     const uint8_t* img = lb.img + (long long)frame * lb.img_pitch;
@@ -234,6 +245,15 @@ __device__ __forceinline__ void chess_v16_body(const LevelBatch& lb, const CompT
     const int tid = threadIdx.x, lane = tid & 63;
     const int wvu = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, jx = lane & 15;
+    // paired: this lane's segment (B for jx >= 8) starts dB rows below A's and ends at ye_lane; the loop runs to the longer one
+    int dB = 0, ye_lane = ye, ye_loop = ye;
+    const bool laneB = paired && jx >= 8;
+    if (paired) {
+        int ysB, yeB;
+        segment_rows(h, nsegs, rest % nsegs + 1, RB, ysB, yeB);
+        ye_loop = ys + max(ye - ys, yeB - ysB);
+        if (laneB) { dB = ysB - ys; ye_lane = yeB; }
+    }
     uint32_t* hotbuf = reinterpret_cast<uint32_t*>(lds + 2 * PLANE);
     int* hotcnt = reinterpret_cast<int*>(hotbuf + V1_HOTBUF);
     HotSink hsink{hotbuf + (tid >> 6) * V1_HOTSEG, ys, strip_x, 0};
@@ -249,11 +269,27 @@ __device__ __forceinline__ void chess_v16_body(const LevelBatch& lb, const CompT
     const uint32_t fbytes = (uint32_t)min((long long)(h - 1) * stride + w, 0x7fffffffLL);
     const i32x4 img_rsrc = raw_rsrc(img, fbytes);
     const i32x4 img88 = typed88_rsrc(img, fbytes);
-    const int vg = trow * stride + strip_x + 16 * tch;                       // + first row of the group * stride
-    const int vn = trow * stride + min(strip_x + 16 * tch + 16, w - 1);
-    const int vh = trow * stride + strip_x + (hside ? SW : -HL) + 2 * hpair + hplane;
-    const uint32_t chunk_col = (uint32_t)(2 * HL + 32 * tch);                // byte offset of the chunk within a row of P0
-    const uint32_t halo_col = (uint32_t)((hside ? 2 * (SW + HL) : 0) + 4 * hpair + hplane * PLANE);
+    int vg = trow * stride + strip_x + 16 * tch;                             // + first row of the group * stride
+    int vn = trow * stride + min(strip_x + 16 * tch + 16, w - 1);
+    int vh = trow * stride + strip_x + (hside ? SW : -HL) + 2 * hpair + hplane;
+    uint32_t chunk_col = (uint32_t)(2 * HL + 32 * tch);                      // byte offset of the chunk within a row of P0
+    uint32_t halo_col = (uint32_t)((hside ? 2 * (SW + HL) : 0) + 4 * hpair + hplane * PLANE);
+    if (paired) {
+        // chunks 8..15 are B's chunks 0..7 (B's rows, 8 window pixels further right than the ordinary layout puts them);
+        // "side 1" of the halo is B's LEFT halo, in front of B's pixels
+        int ysB, yeB;
+        segment_rows(h, nsegs, rest % nsegs + 1, RB, ysB, yeB);
+        const int rowsB = (ysB - ys) * stride;
+        if (tch >= 8) {
+            vg = trow * stride + strip_x + 16 * (tch - 8) + rowsB;
+            vn = trow * stride + min(strip_x + 16 * (tch - 8) + 16, w - 1) + rowsB;
+            chunk_col += 2 * HL;
+        }
+        if (hside) {
+            vh = trow * stride + strip_x - HL + 2 * hpair + hplane + rowsB;
+            halo_col = (uint32_t)(2 * (HL + SW / 2) + 4 * hpair + hplane * PLANE);
+        }
+    }
     auto stage_load = [&](int row0) {
         StageRegs s;
         const int rowoff = row0 * stride;
@@ -275,7 +311,7 @@ __device__ __forceinline__ void chess_v16_body(const LevelBatch& lb, const CompT
     __syncthreads();
 
     // per-lane constants
-    const int x0 = strip_x + 16 * jx;
+    const int x0 = strip_x + 16 * jx - (laneB ? SW / 2 : 0);
     uint32_t xmask[8], xadd[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -287,7 +323,7 @@ __device__ __forceinline__ void chess_v16_body(const LevelBatch& lb, const CompT
             xadd[k] = (ina ? 0xe000u : 0u) | (inb ? 0xe0000000u : 0u);      // -8192 * m per half
         }
     }
-    const uint32_t lane_col = 32u * jx;  // D[-4] of the lane within a row: pixel x0 - 8 = window pixel 16 jx
+    const uint32_t lane_col = 32u * jx + (laneB ? 2u * HL : 0u);  // D[-4] of the lane within a row: pixel x0 - 8 = window pixel 16 jx (paired, B: + 8)
     // dy classes c = dy mod 4: the lane's row is row (c + q) & 3 of group B (c + q < 4) or of the group after it
     uint32_t LC[4], MK[4];
 #pragma unroll
@@ -295,14 +331,14 @@ __device__ __forceinline__ void chess_v16_body(const LevelBatch& lb, const CompT
         LC[c] = lane_col + (uint32_t)((c + q) & 3) * ROWB;
         MK[c] = (c + q >= 4) ? 0xffffffffu : 0u;
     }
-    const bool seg_interior = ys >= kMargin && ye <= h - kMargin;
+    const bool seg_interior = !paired && ys >= kMargin && ye <= h - kMargin;
     const i32x4 resp_rsrc = raw_rsrc(resp, (uint32_t)min((long long)w * h * 2, 0xffffffffLL));
-    const int st_resp_voff = (q * w + x0) * 2;
+    const int st_resp_voff = ((q + dB) * w + x0) * 2;
     // running ring offset of the staging row (row y + 21 + trow of iteration y)
     uint32_t so = slot_off(21 + trow);
 
     int am = 4 * wvu;  // (y - ys + 4 * wave) mod 44: the ring slot of the wave's first row, a multiple of 4
-    for (int y = ys; y < ye; y += RB) {
+    for (int y = ys; y < ye_loop; y += RB) {
         // prefetch rows y + 21 .. y + 36 (needed by the next iteration)
         const StageRegs pre = stage_load(y + 21);
 
@@ -337,7 +373,7 @@ __device__ __forceinline__ void chess_v16_body(const LevelBatch& lb, const CompT
             z0[4] = z0b.x; z0[5] = z0b.y; z0[6] = z0b.z; z0[7] = z0b.w;
         }
 
-        const int yy = y + 4 * wvu + q;
+        const int yy = y + 4 * wvu + q + dB;
         uint32_t out[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -355,7 +391,7 @@ __device__ __forceinline__ void chess_v16_body(const LevelBatch& lb, const CompT
 
         if (HOT) {
             // responses are clamped here, so "> 15" is "any bit above bit 3" (chess.hip); a lane has two aligned 8-pixel groups
-            const bool live = yy < ye;
+            const bool live = yy < ye_lane;
             const uint32_t any = (((out[0] | out[1]) | (out[2] | out[3])) | ((out[4] | out[5]) | (out[6] | out[7]))) & 0xfff0fff0u;
             if (__ballot(any != 0 && live) != 0ull) {
                 uint32_t bits = 0;
@@ -378,7 +414,7 @@ __device__ __forceinline__ void chess_v16_body(const LevelBatch& lb, const CompT
         __builtin_amdgcn_s_setprio(0);
         so += RB * ROWB;
         if (so >= (uint32_t)RING) so -= RING;
-        if (yy < ye && x0 < w) {
+        if (yy < ye_lane && x0 < w) {
             const u32x4 va = {out[0], out[1], out[2], out[3]}, vb = {out[4], out[5], out[6], out[7]};
             const int soff = (int)((uint32_t)(y + 4 * wvu) * (uint32_t)w * 2u);
             raw_buffer_store_b128(va, resp_rsrc, st_resp_voff, soff, kAuxNT);
@@ -418,6 +454,13 @@ __global__ __launch_bounds__(256, 3) void chess_v16_kernel(LevelBatch lb, int fr
 }
 
 #ifdef MRG_EXPERIMENT
+// the plain response with the half strip's segments paired (chess_v16_body, PAIR): `nfull` ordinary workgroups first
+template <bool CLAMP>
+__global__ __launch_bounds__(256, 3) void chess_v16_pair_kernel(LevelBatch lb, int frame0, int nsegs, unsigned nfull) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    chess_v16_body<CLAMP, false, false, true>(lb, CompTables{}, frame0, nsegs, blockIdx.x, nfull, lds);
+}
+
 // clamp + hot list (the levels of a chain)
 __global__ __launch_bounds__(256, 3) void chess_v16_hot_kernel(LevelBatch lb, CompTables t, int frame0, int nsegs) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -476,8 +519,24 @@ bool chess16_pays(const LevelBatch& lb, int nframes) {
     return chess16_ok(lb) && strips * nframes * ((lb.h + 63) / 64) >= 256;
 }
 
+#ifdef MRG_EXPERIMENT
+int chess16_pair = 0;  // tuning hook "chess16_pair": 1 = pair the half strip's segments where the shape allows it
+#endif
 void launch_chess16(const LevelBatch& lb, int frame0, int nframes, bool clamp, hipStream_t s, int seg_rows) {
-    const int nsegs = pick_nsegs16(lb.w, lb.h, nframes, seg_rows);
+    int nsegs = pick_nsegs16(lb.w, lb.h, nframes, seg_rows);
+#ifdef MRG_EXPERIMENT
+    if (chess16_pair && lb.w % v16::SW == v16::SW / 2 && lb.w > v16::SW) {
+        nsegs += nsegs & 1;  // (an even number of segments)
+        if (nsegs <= (lb.h + v16::RB - 1) / v16::RB) {
+            const unsigned nfull = (unsigned)((lb.w / v16::SW) * nsegs * nframes);
+            dim3 grid(nfull + (unsigned)((nsegs / 2) * nframes));
+            const size_t lds = 2 * v16::PLANE;
+            if (clamp) hipLaunchKernelGGL(chess_v16_pair_kernel<true>, grid, dim3(256), lds, s, lb, frame0, nsegs, nfull);
+            else hipLaunchKernelGGL(chess_v16_pair_kernel<false>, grid, dim3(256), lds, s, lb, frame0, nsegs, nfull);
+            return;
+        }
+    }
+#endif
     dim3 grid(((lb.w + v16::SW - 1) / v16::SW) * nsegs * nframes);
     const size_t lds = 2 * v16::PLANE;
     if (clamp) hipLaunchKernelGGL(chess_v16_kernel<true>, grid, dim3(256), lds, s, lb, frame0, nsegs);

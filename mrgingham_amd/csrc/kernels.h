@@ -43,6 +43,7 @@ bool chess16_ok(const LevelBatch& lb);
 bool chess16_pays(const LevelBatch& lb, int nframes);
 void launch_chess16(const LevelBatch& lb, int frame0, int nframes, bool clamp, hipStream_t s, int seg_rows = 0);
 #ifdef MRG_EXPERIMENT
+extern int chess16_pair;
 void launch_chess16_hot(const LevelBatch& lb, const CompTables& t, int frame0, int nframes, hipStream_t s);
 bool launch_chess16_pyramid(const LevelBatch& lb, const CompTables& t, const PyramidOut& po, int nframes, hipStream_t s);
 bool chess16_multi_ok(const LevelBatch* lbs, int n, int nframes);

@@ -111,7 +111,7 @@ def test_shipped_library_has_no_experiment_hooks():
     blob = open(os.path.join(here, "mrgingham_amd", "libmrgingham_amd.so"), "rb").read()
     for name in (b"MRGINGHAM_AMD_PYR_SKIP", b"MRGINGHAM_AMD_CC_LDS_PAD", b"MRGINGHAM_AMD_CC_CUS",
                  b"MRGINGHAM_AMD_PIX_COMPLEMENT", b"MRGINGHAM_AMD_CHESS_V0", b"MRG_DBG_FB", b"chess_variant_hot",
-                 b"chess_v16_pyr_kernel", b"chess_v16_multi_kernel"):
+                 b"chess_v16_pyr_kernel", b"chess_v16_multi_kernel", b"chess_v16_pair_kernel", b"chess16_pair"):
         assert name not in blob, name
     assert b"MRGINGHAM_AMD_DEVICE" in blob                  # the one variable it does read
     for src in ("api.hip", "chess.hip", "cc.hip"):
