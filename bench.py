@@ -1058,7 +1058,7 @@ def main():
                         "run ~5-7 % below the steady state (clock ramp), which is why `setup_prime_steps` untimed "
                         "set-up passes precede the W warm-up steps.  The timed region is synchronised on both sides, so it "
                         "carries one pipeline fill and one drain (the last step's component chain runs with nothing "
-                        "beside it): measured time = 0.8 ms + K x 0.94 ms on the default workload, i.e. a 20-step "
+                        "beside it): measured time = 0.8 ms + K x 0.92 ms on the default workload, i.e. a 20-step "
                         "region reads ~4 % below a 200-step one")
         res["scratch_GiB"] = scratch_gib
         if e2e is not None:

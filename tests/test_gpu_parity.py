@@ -171,6 +171,34 @@ def test_chess_v16_fused_variants_give_the_same_chain(det):
         det.set_option("sparse_refine", 1)
 
 
+def test_chess_v16_paired_half_strip_matches_the_oracle(det):
+    """Widths with w % 256 = 128: the last strip's workgroups taking two row segments at once (chess_v16_pair_kernel,
+    option chess16_pair; experiment builds only -- +1.1 % at 64 x 1920x1080).  Raw and clamped against the
+    oracle on noise, for even and odd segment counts and a ragged last granule."""
+    try:
+        det.set_option("chess16_pair", 1)
+    except ValueError:
+        pytest.skip("the paired half-strip kernel exists in experiment builds only")
+    det.set_option("chess_variant", 16)
+    try:
+        for (h, w) in ((200, 384), (137, 640), (480, 1152)):
+            rng = np.random.RandomState(h + w)
+            frames = rng.randint(0, 256, size=(3, h, w)).astype(np.uint8)
+            d = _cuda(frames)
+            ref = [oracle.chess_response_5(frames[f], fill=0) for f in range(3)]
+            for seg in (0, 16, 48, 64, 4096):
+                det.set_option("chess16_seg", seg)
+                raw = det.chess_response(d, 0, clamp=False).cpu().numpy()
+                cl = det.chess_response(d, 0, clamp=True).cpu().numpy()
+                for f in range(3):
+                    assert np.array_equal(raw[f], ref[f]), (h, w, seg, f)
+                    assert np.array_equal(cl[f], np.maximum(ref[f], 0)), (h, w, seg, f)
+    finally:
+        det.set_option("chess16_pair", 0)
+        det.set_option("chess16_seg", 0)
+        det.set_option("chess_variant", 0)
+
+
 def test_chess_strided_device_frames(det):
     rng = np.random.RandomState(5)
     big = rng.randint(0, 256, size=(2, 100, 200)).astype(np.uint8)

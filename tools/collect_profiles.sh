@@ -21,21 +21,20 @@ bash $R/tools/collect_pmc_bench.sh $TAG
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_sq1 -o p -- python $R/tools/chess_l0_alone.py > /dev/null 2> $OUT/pmc_sq1.err
 timeout 600 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2 -o p -- python $R/tools/chess_l0_alone.py > /dev/null 2> $OUT/pmc_sq2.err
 # 4c. kernel trace of the textured-background workload
-timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace_clut -o t -- python $R/bench.py --workload c3_cluttered --steps 40 --warmup 5 --no-cpu-baseline --no-end-to-end > $OUT/trace_clutter_bench.json 2> $OUT/trace_clut.err
+timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace_clut -o t -- python $R/bench.py --workload c3_cluttered --steps 40 --warmup 5 --no-cpu-baseline --no-end-to-end > /dev/null 2> $OUT/trace_clut.err
 timeout 600 python $R/bench.py --workload c3_cluttered --no-cpu-baseline --no-end-to-end > $OUT/bench_cluttered.json 2> $OUT/bench_cluttered.err
 timeout 900 python $R/bench.py --workload c4_4096x3072_shard256 --force-gather --bind-numa --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_c4.json 2> $OUT/bench_c4.err
 timeout 600 python $R/bench.py --workload c3_4096x3072_14x14_chain --no-cpu-baseline --no-end-to-end > $OUT/bench_14x14.json 2> $OUT/bench_14x14.err
 # 4d. option sparse_refine as the timed schedule: kernel trace at 64 frames, bench lines at 64 and 256 frames
-timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace_sparse -o t -- python $R/bench.py --sparse-refine --steps 40 --warmup 5 --no-cpu-baseline --no-end-to-end > $OUT/trace_sparse_bench.json 2> $OUT/trace_sparse.err
+timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace_sparse -o t -- python $R/bench.py --sparse-refine --steps 40 --warmup 5 --no-cpu-baseline --no-end-to-end > /dev/null 2> $OUT/trace_sparse.err
 timeout 600 python $R/bench.py --sparse-refine --no-cpu-baseline --no-end-to-end > $OUT/bench_sparse.json 2> $OUT/bench_sparse.err
 timeout 900 python $R/bench.py --sparse-refine --workload c4_4096x3072_shard256 --steps 50 --warmup 5 --no-cpu-baseline --no-end-to-end > $OUT/bench_sparse_c4.json 2> $OUT/bench_sparse_c4.err
 # 4e. round 5: the plain ChESS pass alone (kernel trace + the script's own hipEvent line), BASELINE config 2 as a bench line +
 #     kernel trace, the two-rank rehearsal of the N > 1 flow, the sixteen-pixels-per-lane kernel's counters beside chess_v1's
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace_alone -o t -- python $R/tools/chess_pass_alone.py > $OUT/chess_alone.json 2> $OUT/trace_alone.err
 timeout 300 python $R/tools/chess_pass_alone.py > $OUT/chess_alone_untraced.json 2> $OUT/chess_alone_untraced.err
-timeout 300 python $R/tools/chess_pass_alone.py 1920 1080 64 > $OUT/chess_alone_c2_untraced.json 2>> $OUT/chess_alone_untraced.err
 timeout 600 python $R/bench.py --workload c2_1920x1080_level0 --no-cpu-baseline > $OUT/bench_c2.json 2> $OUT/bench_c2.err
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace_c2 -o t -- python $R/bench.py --workload c2_1920x1080_level0 --steps 40 --warmup 5 --no-cpu-baseline --no-find-boards --no-end-to-end > $OUT/trace_c2_bench.json 2> $OUT/trace_c2.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace_c2 -o t -- python $R/bench.py --workload c2_1920x1080_level0 --steps 40 --warmup 5 --no-cpu-baseline --no-find-boards --no-end-to-end > /dev/null 2> $OUT/trace_c2.err
 timeout 300 python $R/bench.py --gpus 2 --rehearse --workload c1_640x480_chain --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_rehearsal.json 2> $OUT/bench_rehearsal.err
 for v in 16 1; do
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_a$v -o p -- python $R/tools/chess16_pmc.py $v > /dev/null 2> $OUT/pmc_a$v.err
