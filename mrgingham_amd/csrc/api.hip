@@ -834,13 +834,13 @@ int mrgingham_amd_find_boards_stats(mrgingham_amd_ctx* ctx, double* out, int n, 
     if (!ctx || !out || n < 0) return MRGINGHAM_AMD_ERR_ARG;
     fb_drain(ctx);
     double v[MRGINGHAM_AMD_FB_STATS] = {};
+    const double tick = grid_clock_tick_us();  // (may wait 0.2 ms when the process has only just started: not under the lock)
     {
         std::lock_guard<std::mutex> lk(ctx->fb_stat_mu);
         v[0] = (double)ctx->fb_prof_n;
         v[1] = (double)ctx->fb_threads_used;
         for (int i = 0; i < 7; ++i) v[2 + i] = ctx->fb_prof[i];
         v[9] = (double)ctx->fb_grid.calls; v[10] = (double)ctx->fb_grid.found;
-        const double tick = grid_clock_tick_us();
         v[11] = ctx->fb_grid.graph_t * tick; v[12] = ctx->fb_grid.adjacency_t * tick; v[13] = ctx->fb_grid.sequences_t * tick;
         v[14] = ctx->fb_grid.cycles_t * tick;
         v[15] = ctx->fb_dev_ms[0]; v[16] = ctx->fb_dev_ms[1];
