@@ -861,6 +861,8 @@ def main():
     # built, ...) reports {"error": ...} in its place: it must never cost the run its JSON line.
     def leg(fn, *a, **kw):
         try:
+            if os.environ.get("MRG_BENCH_FAIL_LEG") == getattr(fn, "__name__", ""):   # (tests: a leg that breaks)
+                raise RuntimeError("forced by MRG_BENCH_FAIL_LEG")
             return fn(*a, **kw)
         except Exception as e:                               # noqa: BLE001 -- reported, not swallowed
             import traceback

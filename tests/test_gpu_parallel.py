@@ -51,6 +51,25 @@ def test_bench_under_a_launcher_environment():
     assert res["n_gpus"] == 1 and res["ranks_seen"] == 1
 
 
+def test_bench_line_survives_a_leg_that_breaks():
+    """The legs beside the timed region (chess_pass_alone, sparse_refine, find_boards, configs.*, end_to_end) run guarded: one that
+    throws is reported in its place and the ONE json line still comes out with every key of the contract."""
+    res = _bench("--gpus", "1", "--workload", "c1_640x480_chain", "--steps", "6", "--warmup", "2", "--prime", "3", "--no-cpu-baseline",
+                 "--no-find-boards", "--no-sparse-leg", env_extra={"MRG_BENCH_FAIL_LEG": "c5_mixed_leg"})
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline"):
+        assert key in res, key
+    assert res["config"]["workload"].startswith("c1_640x480_chain") and res["value"] > 0 and res["steps"] == 6
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "sclk_mhz", "frac_at_2400mhz"):
+        assert key in res["roofline"], key
+    cfg = res["configs"]
+    assert cfg["c5_mixed_one_rank"] == {"error": "RuntimeError: forced by MRG_BENCH_FAIL_LEG"}
+    assert cfg["c2_level0"]["value"] > 0 and cfg["c2_level0"]["frames_with_all_candidates_last_step"] == 64
+    assert cfg["preprocess"]["identical_to_two_kernel_path"] is True
+    assert cfg["c1_tool"].get("vnlog_of_first_file_matches_find_board", True) is True and "error" not in cfg["c1_tool"]
+    assert res["end_to_end"]["value"] > 0 and res["chess_pass_alone"]["frac"] > 0
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two HIP devices")
 def test_bench_launches_its_own_two_ranks():
     res = _bench("--gpus", "2", *SMALL)
