@@ -49,6 +49,9 @@ timeout 300 python $R/tools/sparse_subsets_ab.py > $OUT/sparse_subsets_ab.txt 2>
 timeout 900 python $R/tools/seg_rounds_sweep.py 1920x1080 1280x800 2560x1440 4096x2160 > $OUT/seg_rounds_sweep.txt 2> $OUT/seg_rounds_sweep.err
 # 5. preprocessing kernels (row (f)-2)
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/pre -o t -- python $R/tools/preprocess_bench.py > $OUT/prebench.txt 2> $OUT/pre.err
+# 5b. round 6: EA (fabric) traffic of the preprocessing kernels (3 B/px algorithmic: histogram read + fused read + write)
+timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_128B --kernel-trace --output-format csv -d $OUT/pmc_prd -o p -- python $R/tools/preprocess_bench.py 3 > /dev/null 2> $OUT/pmc_prd.err
+timeout 300 rocprofv3 --pmc TCC_EA0_WRREQ TCC_EA0_WRREQ_64B --kernel-trace --output-format csv -d $OUT/pmc_pwr -o p -- python $R/tools/preprocess_bench.py 3 > /dev/null 2> $OUT/pmc_pwr.err
 # summaries on the box (the raw rocprofv3 output is too big to travel back), then drop the raw files
 python $R/tools/rocprof_summary.py $OUT/trace/t_results.db > $OUT/bench_kernel_trace.txt 2>> $OUT/trace.err
 python $R/tools/rocprof_summary.py $OUT/pre/t_results.db > $OUT/preprocess_kernel_trace.txt 2>> $OUT/pre.err
@@ -56,8 +59,8 @@ python $R/tools/rocprof_summary.py $OUT/trace_clut/t_results.db > $OUT/cluttered
 python $R/tools/rocprof_summary.py $OUT/trace_sparse/t_results.db > $OUT/sparse_kernel_trace.txt 2>> $OUT/trace_sparse.err
 python $R/tools/rocprof_summary.py $OUT/trace_alone/t_results.db > $OUT/chess_alone_kernel_trace.txt 2>> $OUT/trace_alone.err
 python $R/tools/rocprof_summary.py $OUT/trace_c2/t_results.db > $OUT/c2_kernel_trace.txt 2>> $OUT/trace_c2.err
-for d in pmc_sq1 pmc_sq2 pmc_a16 pmc_b16 pmc_a1 pmc_b1 pmc_ard pmc_awr; do
+for d in pmc_prd pmc_pwr pmc_sq1 pmc_sq2 pmc_a16 pmc_b16 pmc_a1 pmc_b1 pmc_ard pmc_awr; do
     python $R/tools/pmc_summary.py $OUT/$d/p_counter_collection.csv > $OUT/$d.txt 2>> $OUT/$d.err
 done
-rm -rf $OUT/pmc_ard $OUT/pmc_awr $OUT/trace_alone $OUT/trace_c2 $OUT/pmc_a16 $OUT/pmc_b16 $OUT/pmc_a1 $OUT/pmc_b1 $OUT/trace $OUT/pre $OUT/trace_clut $OUT/trace_sparse $OUT/pmc_sq1 $OUT/pmc_sq2
+rm -rf $OUT/pmc_prd $OUT/pmc_pwr $OUT/pmc_ard $OUT/pmc_awr $OUT/trace_alone $OUT/trace_c2 $OUT/pmc_a16 $OUT/pmc_b16 $OUT/pmc_a1 $OUT/pmc_b1 $OUT/trace $OUT/pre $OUT/trace_clut $OUT/trace_sparse $OUT/pmc_sq1 $OUT/pmc_sq2
 ls -la $OUT

@@ -157,3 +157,12 @@ if os.path.exists(os.path.join(R, "pmc_ard.txt")):
                "source": f"profiles/{RND}_chess_alone_pmc_ea_traffic.txt", "kernel_id": b.get("kernel_id")},
               open(os.path.join(P, "chess_alone_traffic.json"), "w"), indent=1)
     print(f"plain ChESS pass: read {ardb/1e6:.1f} MB + written {awrb/1e6:.1f} MB per 32-frame launch = {(ardb+awrb)/apx:.4f} B/px")
+
+# 8. round 6: EA traffic of the preprocessing kernels
+if os.path.exists(os.path.join(R, "pmc_prd.txt")) and rd("pmc_prd.txt").strip():
+    open(os.path.join(P, f"{RND}_preprocess_pmc_ea_traffic.txt"), "w").write(
+        "# rocprofv3 --pmc ... --kernel-trace --output-format csv -- python tools/preprocess_bench.py 3   (64 frames of 4096x3072 = 805.3 Mpx per launch; two passes)\n"
+        "# bytes per launch = 128 * RDREQ_128B + 64 * RDREQ_64B + 32 * RDREQ_32B (reads), 64 * WRREQ_64B + 32 * (WRREQ - WRREQ_64B) (writes); algorithmic: clahe_hist 1 B/px read,\n"
+        "# clahe_blur3 1 B/px read + 1 B/px written (two-kernel path for comparison: clahe_apply_fast 1 + 1, box_blur3 1 + 1)\n"
+        "## pass 1: --pmc TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_128B\n" + rd("pmc_prd.txt") +
+        "## pass 2: --pmc TCC_EA0_WRREQ TCC_EA0_WRREQ_64B\n" + rd("pmc_pwr.txt"))
