@@ -347,8 +347,8 @@ def find_boards_leg(device_index, frames, gridn, batches=150, depth=3):
                                            st["ms_collect_boards_copied"]) / nb,
                 "host_part_ms_per_batch_by_phase": {k[3:]: st[k] / nb for k in st if k.startswith("ms_")},
                 "grid_finder_cpu_ms_per_batch_over_all_threads": (st["grid_us_graph"] + st["grid_us_adjacency"] + st["grid_us_sequences"] + st["grid_us_cycles_rows"]) / nb / 1e3,
-                # the container's CPU quota as a floor: a batch cannot take less wall time than its CPU time / the cores the
-                # process may use; `process_cpu_ms_per_batch` counts every thread (grid finder, submit / collect, the runtime's own)
+                # the container's CPU quota as a floor: a batch of a process that is held to its quota cannot take less wall time than its CPU time /
+                # the cores it may use (boxes that let a burst through come in a few per cent under it); `process_cpu_ms_per_batch` counts every thread (grid finder, submit / collect, the runtime's own)
                 "process_cpu_ms_per_batch": cpu_ms,
                 "cpu_quota_floor_ms_per_batch": (cpu_ms / quota) if quota else None,
                 "device_part_ms_per_batch": {"first_pass": st["device_ms_first_pass"] / nb, "refinement": st["device_ms_refinement"] / nb,
