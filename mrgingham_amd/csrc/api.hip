@@ -1085,24 +1085,17 @@ double mrgingham_amd_chess_kernel_ms(mrgingham_amd_ctx* ctx, int* nlaunches) {
     return n ? total / n : 0.;
 }
 
-// The status words of one (scratch set, level): inspected and cleared; a table overflow grows the tables of the level
-// to what the fullest frame asked for.  *rc keeps the first error.  Nothing of that set may be running at that level.
-static int harvest_status(mrgingham_amd_ctx* ctx, int set, int level, int* rc, bool quiet = false) {
-    const int nact = ctx->pending_frames[set][level];
-    ctx->pending_frames[set][level] = 0;
-    if (nact <= 0 || !ctx->counters2[set].p) return 0;
-    const int saved = ctx->cur;
-    ctx->cur = set;
-    int32_t* const words = status_of(ctx, level);
-    ctx->cur = saved;
-    ctx->host_status.resize(nact);
-    MRG_HIP_CHECK(hipMemcpy(ctx->host_status.data(), words, sizeof(int32_t) * nact, hipMemcpyDeviceToHost));
+// The status words of one (scratch set, level) as the host has them (`host`: nact words), inspected; `words` = where they
+// live on the device: cleared when any is set.  A table overflow grows the tables of the level to what the fullest frame
+// asked for.  *rc keeps the first error.  Nothing of that set may be running at that level.
+static int inspect_status(mrgingham_amd_ctx* ctx, int set, int level, const int32_t* host, int nact, int32_t* words, int* rc,
+                          bool quiet) {
     // every pending status block is inspected and cleared; only the first error is reported
     bool dirty = false;
     int flags = 0, first = -1;
     long long need = 0;  // hot pixels the fullest frame asked for (status words carry it in units of 64)
     for (int f = 0; f < nact; ++f) {
-        const int st = ctx->host_status[f];
+        const int st = host[f];
         if (!st) continue;
         dirty = true;
         if (first < 0) first = f;
@@ -1136,6 +1129,53 @@ static int harvest_status(mrgingham_amd_ctx* ctx, int set, int level, int* rc, b
     return 0;
 }
 
+static int32_t* status_words(mrgingham_amd_ctx* ctx, int set, int level) {
+    const int saved = ctx->cur;
+    ctx->cur = set;
+    int32_t* const words = status_of(ctx, level);
+    ctx->cur = saved;
+    return words;
+}
+
+// one (scratch set, level): its words copied, inspected, cleared
+static int harvest_status(mrgingham_amd_ctx* ctx, int set, int level, int* rc, bool quiet = false) {
+    const int nact = ctx->pending_frames[set][level];
+    ctx->pending_frames[set][level] = 0;
+    if (nact <= 0 || !ctx->counters2[set].p) return 0;
+    int32_t* const words = status_words(ctx, set, level);
+    ctx->host_status.resize(nact);
+    MRG_HIP_CHECK(hipMemcpy(ctx->host_status.data(), words, sizeof(int32_t) * nact, hipMemcpyDeviceToHost));
+    return inspect_status(ctx, set, level, ctx->host_status.data(), nact, words, rc, quiet);
+}
+
+// every level of a scratch set: the levels' status words are one block of the set's counter buffer, so ONE copy brings all
+// of them (a blocking 256-byte copy costs 15-30 us: a chain call's sync made four of them, a sync behind pipelined chain
+// calls up to eight)
+static int harvest_set(mrgingham_amd_ctx* ctx, int set, int* rc) {
+    int lo = -1, hi = -1;
+    for (int level = 0; level <= kMaxLevel; ++level)
+        if (ctx->pending_frames[set][level] > 0) {
+            if (lo < 0) lo = level;
+            hi = level;
+        }
+    if (lo < 0 || !ctx->counters2[set].p) {
+        for (int level = 0; level <= kMaxLevel; ++level) ctx->pending_frames[set][level] = 0;
+        return 0;
+    }
+    const size_t cnf = (size_t)ctx->counters_nf, nwords = (size_t)(hi - lo + 1) * cnf;
+    ctx->host_status.resize(nwords);
+    MRG_HIP_CHECK(hipMemcpy(ctx->host_status.data(), status_words(ctx, set, lo), sizeof(int32_t) * nwords, hipMemcpyDeviceToHost));
+    for (int level = lo; level <= hi; ++level) {
+        const int nact = ctx->pending_frames[set][level];
+        ctx->pending_frames[set][level] = 0;
+        if (nact <= 0) continue;
+        const int r = inspect_status(ctx, set, level, ctx->host_status.data() + (size_t)(level - lo) * cnf, nact,
+                                     status_words(ctx, set, level), rc, false);
+        if (r) return r;
+    }
+    return 0;
+}
+
 int mrgingham_amd_sync(mrgingham_amd_ctx* ctx) {
     if (!ctx) return MRGINGHAM_AMD_ERR_ARG;
     MRG_HIP_CHECK(hipSetDevice(ctx->device));
@@ -1146,11 +1186,10 @@ int mrgingham_amd_sync(mrgingham_amd_ctx* ctx) {
     }
     MRG_HIP_CHECK(hipGetLastError());
     int rc = MRGINGHAM_AMD_OK;
-    for (int set = 0; set < kMaxSets; ++set)
-        for (int level = 0; level <= kMaxLevel; ++level) {
-            const int r = harvest_status(ctx, set, level, &rc);
-            if (r) return r;
-        }
+    for (int set = 0; set < kMaxSets; ++set) {
+        const int r = harvest_set(ctx, set, &rc);
+        if (r) return r;
+    }
     return rc;
 }
 
