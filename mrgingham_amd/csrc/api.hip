@@ -241,6 +241,7 @@ struct mrgingham_amd_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     std::vector<hipEvent_t> event_pool;
     std::vector<int32_t> host_status;
+    std::vector<char> io_host_block;  // refine_on_device: the points block as it travels
 };
 
 namespace mrg {
@@ -2245,12 +2246,15 @@ static int refine_on_device(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* 
         const size_t o_lv = (size_t)Npoints * 16, o_np = o_lv + (((size_t)Npoints + 7) & ~(size_t)7), o_nr = o_np + 8;
         if (ensure(ctx, ctx->io_out, o_nr + 8)) break;
         char* base = (char*)ctx->io_out.p;
+        // ONE block up and ONE block down (points | levels | npoints | nrefined through a host copy of the same layout):
+        // every blocking copy of a few hundred bytes costs 15-20 us, and there were three each way
+        std::vector<char>& blk = ctx->io_host_block;
+        blk.assign(o_nr + 8, 0);
+        memcpy(blk.data(), points_xy, (size_t)Npoints * 16);
+        memcpy(blk.data() + o_lv, level, (size_t)Npoints);
         const int32_t np = Npoints;
-        hipStream_t s0 = ctx->pix;
-        if (hipMemcpyAsync(base, points_xy, (size_t)Npoints * 16, hipMemcpyHostToDevice, s0) != hipSuccess) break;
-        if (hipMemcpyAsync(base + o_lv, level, (size_t)Npoints, hipMemcpyHostToDevice, s0) != hipSuccess) break;
-        if (hipMemcpyAsync(base + o_np, &np, 4, hipMemcpyHostToDevice, s0) != hipSuccess) break;
-        if (hipStreamSynchronize(s0) != hipSuccess) break;  // `np` lives on this stack frame
+        memcpy(blk.data() + o_np, &np, 4);
+        if (hipMemcpy(base, blk.data(), o_nr + 8, hipMemcpyHostToDevice) != hipSuccess) break;
         if (mrgingham_amd_refine_batch(ctx, fr, image_pyramid_level, (double*)base, (signed char*)(base + o_lv),
                                        (const int32_t*)(base + o_np), Npoints, (int32_t*)(base + o_nr)))
             break;
@@ -2260,9 +2264,10 @@ static int refine_on_device(mrgingham_amd_ctx* ctx, const mrgingham_amd_frames* 
             continue;
         }
         if (rc) break;
-        if (hipMemcpy(&nrefined, base + o_nr, 4, hipMemcpyDeviceToHost) != hipSuccess) break;
-        if (hipMemcpy(points_xy, base, (size_t)Npoints * 16, hipMemcpyDeviceToHost) != hipSuccess) break;
-        if (hipMemcpy(level, base + o_lv, (size_t)Npoints, hipMemcpyDeviceToHost) != hipSuccess) break;
+        if (hipMemcpy(blk.data(), base, o_nr + 8, hipMemcpyDeviceToHost) != hipSuccess) break;
+        memcpy(&nrefined, blk.data() + o_nr, 4);
+        memcpy(points_xy, blk.data(), (size_t)Npoints * 16);
+        memcpy(level, blk.data() + o_lv, (size_t)Npoints);
         ok = true;
         break;
     }
