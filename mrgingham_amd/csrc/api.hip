@@ -174,6 +174,11 @@ struct mrgingham_amd_ctx {
     struct PointScratch { mrg::DevBuf leader, need, nseeds, seeds, sroot, cand_xy, cand_counts, cell_list, cell_cnt, flag_list; } pts[kMaxSets];  // per scratch set
     mrg::DevBuf aux_img, io_frame, io_out, io_counts;
     void* io_res_pin = nullptr;  // page-locked: count + first candidates of the single-frame detector
+    // page-locked copies of the sets' status words ([level][counters_nf], what mrgingham_amd_sync inspects): they follow every
+    // op on its component stream (end_op), so that the sync behind it reads host memory instead of making a blocking copy
+    int32_t* status_pin[kMaxSets] = {};
+    size_t status_pin_words[kMaxSets] = {};
+    bool status_copied[kMaxSets] = {};  // the LAST op on the set left its words in status_pin
     void* io_pin = nullptr;  // page-locked staging of mrgingham_ChESS_response_5's way back
     size_t io_pin_bytes = 0;
     hipEvent_t io_ev[4] = {};
@@ -348,6 +353,7 @@ static int ensure_level_set(mrgingham_amd_ctx* ctx, int set, int level, int nfra
         for (int k = 0; k < kMaxSets; ++k) {
             if ((rc = ensure(ctx, ctx->counters2[k], (size_t)(kMaxLevel + 1) * 3 * cnf * 4))) return rc;
             MRG_HIP_CHECK(hipMemset(ctx->counters2[k].p, 0, ctx->counters2[k].bytes));
+            ctx->status_copied[k] = false;  // (the layout of the words changes with counters_nf)
         }
         ctx->counters_nf = cnf;
     }
@@ -548,6 +554,7 @@ static void launch_chess_any(mrgingham_amd_ctx* ctx, const LevelBatch& lb, const
 static void begin_op(mrgingham_amd_ctx* ctx, int max_level) {
     (void)max_level;
     ctx->cur = (ctx->cur + 1) % ctx->nsets;  // this set was last used nsets calls ago
+    ctx->status_copied[ctx->cur] = false;    // (until this op's end_op has queued its copy)
     if (ctx->cc_pending[ctx->cur]) hipStreamWaitEvent(ctx->pix, ctx->ev_cc_done[ctx->cur], 0);
     // The hot-pixel counters of this set are zero here: they are zeroed at allocation and again by
     // end_op behind the component kernels that consumed them -- on the component stream, off the
@@ -583,6 +590,25 @@ static void end_op(mrgingham_amd_ctx* ctx) {
                    cur_cc(ctx));
     hipEventRecord(ctx->ev_cc_done[ctx->cur], cur_cc(ctx));
     ctx->cc_pending[ctx->cur] = true;
+    // the set's status words, behind everything of this op that can set one (behind the event too: whoever waits for
+    // the op does not wait for the copy; mrgingham_amd_sync waits for the stream)
+    const int set = ctx->cur;
+    const size_t words = (size_t)(kMaxLevel + 1) * (size_t)ctx->counters_nf;
+    if (ctx->status_pin_words[set] < words) {
+        if (ctx->status_pin[set]) hipHostFree(ctx->status_pin[set]);
+        ctx->status_pin[set] = nullptr;
+        ctx->status_pin_words[set] = 0;
+        void* p = nullptr;
+        if (hipHostMalloc(&p, words * sizeof(int32_t), hipHostMallocDefault) == hipSuccess) {
+            ctx->status_pin[set] = (int32_t*)p;
+            ctx->status_pin_words[set] = words;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    ctx->status_copied[set] = ctx->status_pin[set] != nullptr && words > 0 &&
+                              hipMemcpyAsync(ctx->status_pin[set], status_of(ctx, 0), words * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                             cur_cc(ctx)) == hipSuccess;
 }
 
 // Level images of levels [1, max_level] of the batch into the level scratch, on the pixel stream.
@@ -895,6 +921,8 @@ void mrgingham_amd_destroy(mrgingham_amd_ctx* ctx) {
     if (ctx->ev_ext) hipEventDestroy(ctx->ev_ext);
     if (ctx->io_pin) hipHostFree(ctx->io_pin);
     if (ctx->io_res_pin) hipHostFree(ctx->io_res_pin);
+    for (int k = 0; k < kMaxSets; ++k)
+        if (ctx->status_pin[k]) hipHostFree(ctx->status_pin[k]);
     for (hipEvent_t e : ctx->io_ev)
         if (e) hipEventDestroy(e);
     if (ctx->mg_done) hipEventDestroy(ctx->mg_done);
@@ -1164,15 +1192,25 @@ static int harvest_set(mrgingham_amd_ctx* ctx, int set, int* rc) {
         return 0;
     }
     const size_t cnf = (size_t)ctx->counters_nf, nwords = (size_t)(hi - lo + 1) * cnf;
-    ctx->host_status.resize(nwords);
-    MRG_HIP_CHECK(hipMemcpy(ctx->host_status.data(), status_words(ctx, set, lo), sizeof(int32_t) * nwords, hipMemcpyDeviceToHost));
+    const int32_t* host;
+    const bool pinned = ctx->status_copied[set] && ctx->status_pin[set] && ctx->status_pin_words[set] >= (size_t)(kMaxLevel + 1) * cnf;
+    if (pinned) {  // (the set's stream has been waited for: the copy end_op queued has landed)
+        host = ctx->status_pin[set] + (size_t)lo * cnf;
+    } else {
+        ctx->host_status.resize(nwords);
+        MRG_HIP_CHECK(hipMemcpy(ctx->host_status.data(), status_words(ctx, set, lo), sizeof(int32_t) * nwords, hipMemcpyDeviceToHost));
+        host = ctx->host_status.data();
+    }
     for (int level = lo; level <= hi; ++level) {
         const int nact = ctx->pending_frames[set][level];
         ctx->pending_frames[set][level] = 0;
         if (nact <= 0) continue;
-        const int r = inspect_status(ctx, set, level, ctx->host_status.data() + (size_t)(level - lo) * cnf, nact,
-                                     status_words(ctx, set, level), rc, false);
+        const int32_t* hw = host + (size_t)(level - lo) * cnf;
+        bool any = false;
+        for (int f = 0; f < nact && !any; ++f) any = hw[f] != 0;
+        const int r = inspect_status(ctx, set, level, hw, nact, status_words(ctx, set, level), rc, false);
         if (r) return r;
+        if (any && pinned) memset(ctx->status_pin[set] + (size_t)level * cnf, 0, (size_t)nact * sizeof(int32_t));  // (cleared on the device: here too)
     }
     return 0;
 }
