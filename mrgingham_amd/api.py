@@ -454,14 +454,20 @@ class Detector:
                                                           int(blur_radius), out.data_ptr(), stream))
         return out
 
-    def detect(self, frames, level, capacity=4096, sync=True, retry=True):
+    def detect(self, frames, level, capacity=4096, sync=True, retry=True, out=None):
         """-> (xy int32 [B,capacity,2], counts int32 [B]) on the device.  sync=True waits for the result and, with
-        retry, repeats the call when a frame overflowed the (self-growing) component tables."""
+        retry, repeats the call when a frame overflowed the (self-growing) component tables.  `out` = (xy, counts) of an
+        earlier call to write into (a pipelined caller rotates a few: no allocation, no stream synchronisation per call)."""
         t = self.torch
         fr, B, H, W = self._frames(frames)
-        xy = t.empty((B, capacity, 2), dtype=t.int32, device=frames.device)
-        counts = t.empty((B,), dtype=t.int32, device=frames.device)
-        t.cuda.current_stream(frames.device).synchronize()  # inputs/outputs ready before the ctx streams run
+        if out is None:
+            xy = t.empty((B, capacity, 2), dtype=t.int32, device=frames.device)
+            counts = t.empty((B,), dtype=t.int32, device=frames.device)
+            t.cuda.current_stream(frames.device).synchronize()  # inputs/outputs ready before the ctx streams run
+        else:
+            xy, counts = out
+            assert xy.dtype == t.int32 and counts.dtype == t.int32 and xy.is_contiguous() and xy.shape[0] == B and counts.shape[0] == B
+            capacity = xy.shape[1]
 
         def issue():
             self._check(self.L.mrgingham_amd_detect_batch(self.ctx, ctypes.byref(fr), level, xy.data_ptr(), capacity,
