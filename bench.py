@@ -1069,8 +1069,8 @@ def main():
                         "run ~5-7 % below the steady state (clock ramp), which is why `setup_prime_steps` untimed "
                         "set-up passes precede the W warm-up steps.  The timed region is synchronised on both sides, so it "
                         "carries one pipeline fill and one drain (the last step's component chain runs with nothing "
-                        "beside it): measured time = 0.8 ms + K x 0.92 ms on the default workload, i.e. a 20-step "
-                        "region reads ~4 % below a 200-step one")
+                        "beside it): measured time = ~0.45 ms + K x 0.93 ms on the default workload (a single step is 1.28 ms end to end), "
+                        "i.e. a 20-step region reads ~3 % below a 200-step one")
         res["scratch_GiB"] = scratch_gib
         if e2e is not None:
             res["end_to_end"] = e2e
