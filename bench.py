@@ -565,7 +565,22 @@ def preprocess_leg(det, frames, runs=60, prime=40):
         det.set_option("preprocess_fused", 1)
     del two, out
     alg = B * W * H * 3.0
-    return {"workload": f"normalize + CLAHE(8) + 3x3 blur of {B} x {W}x{H} u8 (mrgingham-from-image.cc:71-111)",
+    # HBM-side bytes of the chain: replayed from the committed counter passes (profiles/preprocess_traffic.json), only for the
+    # same frame shape and the same preprocess.hip
+    traffic, traffic_src = None, None
+    try:
+        import hashlib
+        tj = json.load(open(os.path.join(ROOT, "profiles", "preprocess_traffic.json")))
+        sha = hashlib.sha256(open(os.path.join(ROOT, "mrgingham_amd", "csrc", "preprocess.hip"), "rb").read()).hexdigest()[:16]
+        if (tj["frames"], tj["width"], tj["height"]) == (B, W, H):
+            if tj.get("preprocess_hip_sha16") == sha:
+                traffic, traffic_src = tj["bytes_per_call"], tj["source"]
+            else:
+                traffic_src = f"none: {tj.get('source')} was collected on another preprocess.hip"
+    except (OSError, KeyError, ValueError):
+        pass
+    return {"traffic": traffic, "traffic_source": traffic_src,
+            "workload": f"normalize + CLAHE(8) + 3x3 blur of {B} x {W}x{H} u8 (mrgingham-from-image.cc:71-111)",
             "ms_per_batch": ms, "median_ms_per_batch": per[runs // 2], "runs": runs, "frames_per_s": B / (ms * 1e-3),
             "bytes_model": "3 B/px (histograms: 1 read; blend + blur in one pass: 1 read + 1 written)", "bytes_per_batch": alg,
             "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

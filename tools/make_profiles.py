@@ -166,3 +166,25 @@ if os.path.exists(os.path.join(R, "pmc_prd.txt")) and rd("pmc_prd.txt").strip():
         "# clahe_blur3 1 B/px read + 1 B/px written (two-kernel path for comparison: clahe_apply_fast 1 + 1, box_blur3 1 + 1)\n"
         "## pass 1: --pmc TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_128B\n" + rd("pmc_prd.txt") +
         "## pass 2: --pmc TCC_EA0_WRREQ TCC_EA0_WRREQ_64B\n" + rd("pmc_pwr.txt"))
+    import hashlib
+    def g(fn, kern, ctr):
+        blk = rd(fn + ".txt")
+        blk = blk[blk.index(kern):]
+        return float(re.search(re.escape(ctr) + r"\s+mean\s+([0-9.]+)", blk).group(1))
+    def rdb(kern):
+        return 128 * g("pmc_prd", kern, "TCC_EA0_RDREQ_128B") + 64 * g("pmc_prd", kern, "TCC_EA0_RDREQ_64B") + 32 * g("pmc_prd", kern, "TCC_EA0_RDREQ_32B")
+    def wrb(kern):
+        w64, wall = g("pmc_pwr", kern, "TCC_EA0_WRREQ_64B"), g("pmc_pwr", kern, "TCC_EA0_WRREQ ")
+        return 64 * w64 + 32 * (wall - w64)
+    kernels = ["clahe_hist_kernel<16>", "minmax_from_hist_kernel", "clahe_lut_kernel", "clahe_quad_kernel", "clahe_blur3_kernel<32>"]
+    per = {k: {"read_bytes": int(rdb(k)), "write_bytes": int(wrb(k))} for k in kernels}
+    total = sum(v["read_bytes"] + v["write_bytes"] for v in per.values())
+    src = open(os.path.join(ROOT, "mrgingham_amd", "csrc", "preprocess.hip"), "rb").read()
+    json.dump({"_comment": "HBM-side (L2 <-> EA fabric) traffic of ONE call of the tool's default preprocessing chain (normalize + CLAHE(8) + 3x3 blur, fused path) on 64 frames "
+                           f"of 4096x3072, per kernel, from the rocprofv3 --pmc passes of tools/preprocess_bench.py (profiles/{RND}_preprocess_pmc_ea_traffic.txt); bench.py replays "
+                           "the total as configs.preprocess.traffic when preprocess.hip is the file these were collected on",
+               "frames": 64, "width": 4096, "height": 3072, "kernels": per, "bytes_per_call": int(total),
+               "bytes_per_pixel": round(total / (64 * 4096 * 3072), 4), "algorithmic_bytes_per_pixel": 3.0,
+               "preprocess_hip_sha16": hashlib.sha256(src).hexdigest()[:16], "source": f"profiles/{RND}_preprocess_pmc_ea_traffic.txt"},
+              open(os.path.join(P, "preprocess_traffic.json"), "w"), indent=1)
+    print(f"preprocessing chain: {total/1e6:.1f} MB per 64-frame call = {total/(64*4096*3072):.4f} B/px")
